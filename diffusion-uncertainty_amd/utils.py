@@ -1,0 +1,57 @@
+"""Small host-side helpers shared by bench, smoke and the tests (pure torch, no HIP).
+
+The reference ships no weights offline and ``zero_module`` zeroes every
+ResBlock's second conv, every attention ``proj_out`` and the output conv
+(reference ``guided_diffusion/nn.py:68-74``), so a freshly built ADM returns
+exactly 0.  ``seeded_state_dict`` re-randomises every parameter with a
+per-tensor seed derived from its *name*, so the same weights can be rebuilt on
+any box from (names, shapes, seed) alone - that is how the golden vectors of
+``tests/golden`` and the random-init weights of ``bench.py`` are defined.
+"""
+import math
+import random
+import zlib
+
+import numpy as np
+import torch
+
+
+def seeded_tensor(name, shape, seed=0):
+    g = torch.Generator(device="cpu").manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 62))
+    t = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    if "label_emb" in name or "pos_embed" in name:
+        return t * 0.3
+    if t.ndim >= 2:                                   # conv / linear weight: unit-gain fan-in init
+        return t / math.sqrt(max(1, int(np.prod(shape[1:]))))
+    if name.endswith("weight"):                       # norm gamma
+        return 1.0 + 0.1 * t
+    return 0.1 * t                                    # biases / norm beta
+
+
+def seeded_state_dict(shapes, seed=0):
+    """shapes: mapping name -> shape (e.g. ``{k: v.shape for k, v in model.state_dict().items()}``)."""
+    return {k: seeded_tensor(k, tuple(s), seed) for k, s in shapes.items()}
+
+
+def randomize_parameters_(module, seed=0):
+    sd = module.state_dict()
+    module.load_state_dict(seeded_state_dict({k: v.shape for k, v in sd.items()}, seed))
+    return module
+
+
+def seed_everything(seed):
+    """Counterpart of pytorch_lightning.seed_everything used by the reference script
+    (scripts/generate_dataset_score_uncertainty_imagenet.py:39)."""
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    return seed
+
+
+def starting_points(n, shape, num_classes=1000, dataset_index=0):
+    """X_T / y exactly as reference scripts/generate_diffusion_starting_data.py:27-49
+    (fresh generator seeded 49394 per dataset; ``dataset_index`` kept for bookkeeping only)."""
+    g = torch.Generator(device="cpu").manual_seed(49394)
+    x = torch.randn(n, *shape, generator=g)
+    y = torch.randint(0, num_classes, (n,), generator=g)
+    return x, y

@@ -1,0 +1,342 @@
+"""Generate the golden vectors of tests/golden/*.npz from the upstream reference.
+
+Runs ONLY in the build container (needs /root/reference); the fixtures it
+writes are committed and are the only thing the tests read.  Usage:
+
+    python tests/golden/make_golden.py            # all groups
+    python tests/golden/make_golden.py g3 g7      # selected groups
+
+Every fixture stores inputs + the reference's outputs (data only).  Weights are
+never stored: they are rebuilt from (state-dict names, shapes, seed) with
+``diffusion_uncertainty_amd.utils.seeded_state_dict``.
+"""
+import contextlib
+import io
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import refimport  # noqa: E402
+
+refimport.install()
+from diffusion_uncertainty_amd.utils import seeded_state_dict  # noqa: E402
+
+_quiet = contextlib.redirect_stdout(io.StringIO())
+with _quiet:
+    from diffusion_uncertainty.guided_diffusion import unet_openai as ref_unet
+    from diffusion_uncertainty.guided_diffusion.nn import timestep_embedding as ref_temb
+    from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_uncertainty_zigzag_centered import \
+        DDIMSchedulerUncertaintyImagenetClassConditioned as RefZigzag
+    from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_uncertainty_centered import \
+        DDIMSchedulerUncertaintyImagenetClassConditioned as RefCentered
+    from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_mc_dropout import \
+        DDIMSchedulerUncertaintyImagenetClassConditioned as RefMCDropout
+    from diffusion_uncertainty import generate_samples as ref_gs
+    from diffusion_uncertainty.uvit import uvit as ref_uvit
+    import diffusion_uncertainty.uncertainty_guidance as ref_ug
+
+sys.path.insert(0, ROOT)
+from oracle.schedule import cosine_trained_betas  # noqa: E402  (same formula as init_model.py:134-157; checked in g1)
+
+TINY_ADM = dict(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1,
+                attention_resolutions=(2,), dropout=0.0, channel_mult=(1, 2), num_classes=10,
+                use_checkpoint=False, use_fp16=False, num_heads=2, num_head_channels=-1, num_heads_upsample=-1,
+                use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=False)
+ADM128 = dict(image_size=128, in_channels=3, model_channels=256, out_channels=6, num_res_blocks=2,
+              attention_resolutions=(4, 8, 16), dropout=0.0, channel_mult=(1, 1, 2, 3, 4), num_classes=1000,
+              use_checkpoint=False, use_fp16=False, num_heads=4, num_head_channels=-1, num_heads_upsample=4,
+              use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=False)      # init_model.py:21
+ADM64 = dict(image_size=64, in_channels=3, model_channels=192, out_channels=6, num_res_blocks=3,
+             attention_resolutions=(2, 4, 8), dropout=0.1, channel_mult=(1, 2, 3, 4), num_classes=1000,
+             use_checkpoint=False, use_fp16=False, num_heads=4, num_head_channels=64, num_heads_upsample=4,
+             use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)        # init_model.py:45-47
+TINY_UVIT = dict(img_size=8, patch_size=2, in_chans=4, embed_dim=64, depth=4, num_heads=4, num_classes=11, conv=False)
+UVIT_H2 = dict(img_size=32, patch_size=2, in_chans=4, embed_dim=1152, depth=28, num_heads=16, num_classes=1001, conv=False)
+
+CONFIGS = {
+    "adm128": refimport.ddpm_base_config(),                                                       # init_model.py:38-40
+    "adm64": refimport.ddpm_base_config(trained_betas=None, beta_schedule="cosine"),              # init_model.py:134-137 (betas filled below)
+    "uvit": refimport.ddpm_base_config(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                       steps_offset=1, clip_sample=False),                        # load_pretrained_models.py:45-57
+}
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, len(out), "arrays")
+
+
+def build_adm(cfg, seed):
+    with _quiet:
+        m = ref_unet.UNetModel(**cfg)
+    m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed))
+    return m.eval()
+
+
+def randn(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def g1():
+    out = {}
+    CONFIGS["adm64"]["trained_betas"] = cosine_trained_betas()
+    for name, cfg in CONFIGS.items():
+        for n in (10, 20, 50):
+            after, num = (4, 3) if n == 10 else (n - 10, 10)
+            with _quiet:
+                s = RefZigzag.from_config(cfg, M=2, after_step=after, num_steps_uc=num)
+                s.set_timesteps(n)
+            out[f"{name}_betas"] = s.betas
+            out[f"{name}_alphas_cumprod"] = s.alphas_cumprod
+            out[f"{name}_timesteps_{n}"] = s.timesteps
+            out[f"{name}_window_{n}"] = np.array([after, num, s.timestep_after_step, s.timestep_end_step])
+    save("g1_schedules", **out)
+
+
+def g2():
+    out = {}
+    eps, x = randn(1, 2, 3, 16, 16), randn(2, 2, 3, 16, 16) * 1.5
+    out["eps"], out["x"] = eps, x
+    case = 0
+    for cfgname in ("adm128", "uvit"):
+        for t in (980, 500, 0):
+            for eta in (0.0, 0.5):
+                cfg = CONFIGS[cfgname]
+                with _quiet:
+                    s = RefZigzag.from_config(cfg, M=1, after_step=0, num_steps_uc=1, unet=None)
+                    s.set_timesteps(50)
+                    s.timestep_after_step, s.timestep_end_step = -1, -2          # keep the UC branch off
+                    tt = t + cfg["steps_offset"] if t + cfg["steps_offset"] < 1000 else t
+                    torch.manual_seed(100 + case)
+                    o = s.step(eps, tt, x, eta=eta)
+                out[f"c{case}_meta"] = np.array([["adm128", "uvit"].index(cfgname), tt, eta])
+                out[f"c{case}_prev"], out[f"c{case}_x0"] = o.prev_sample, o.pred_original_sample
+                case += 1
+    out["n_cases"] = case
+    save("g2_ddim_step", **out)
+
+
+class StubDenoiser(torch.nn.Module):
+    """eps = w * x + b(t, y): cheap class-conditional stand-in with 6 output channels."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, x, t, y=None):
+        b = (t.float() / 1000.0)[:, None, None, None] + 0.01 * y.float()[:, None, None, None]
+        h = 0.7 * x + 0.1 * torch.roll(x, 1, dims=-1) + b
+        return torch.cat([h, -h], dim=1)
+
+
+def g3():
+    out = {}
+    x, y = randn(3, 2, 3, 16, 16), torch.tensor([3, 7])
+    out["x"], out["y"] = x, y
+    tiny = build_adm(TINY_ADM, seed=5)
+    case = 0
+    for model_name, model in (("stub", StubDenoiser()), ("tiny_adm", tiny)):
+        for kind in ("zigzag_centered", "centered_next", "centered_x0"):
+            for M, nz in ((2, 1), (5, 3)):
+                if kind != "zigzag_centered" and nz != 1:
+                    continue
+                for t in (500, 400):
+                    with _quiet:
+                        if kind == "zigzag_centered":
+                            s = RefZigzag.from_config(CONFIGS["adm128"], M=M, after_step=4, num_steps_uc=3, unet=model, num_zigzag=nz)
+                        else:
+                            s = RefCentered.from_config(CONFIGS["adm128"], M=M, after_step=4, num_steps_uc=3, unet=model,
+                                                        predict_next=(kind == "centered_next"), y=None)
+                        s.set_timesteps(10)
+                        s.prompt_embeds = y
+                        with torch.no_grad():
+                            tv = torch.full((2,), t, dtype=torch.long)
+                            eps = model(x, tv, y=y)[:, :3]
+                            torch.manual_seed(1000 + case)
+                            o = s.step(eps, t, x)
+                    out[f"c{case}_meta"] = np.array([model_name, kind, str(M), str(nz), str(t), str(1000 + case)])
+                    out[f"c{case}_eps"] = eps
+                    out[f"c{case}_prev"], out[f"c{case}_unc"] = o.prev_sample, o.uncertainty
+                    case += 1
+    out["n_cases"] = case
+    save("g3_uc_estimators", **out)
+
+
+def g4():
+    out = {}
+    tiny = build_adm(TINY_ADM, seed=5)
+    X_T, y = randn(11, 4, 3, 16, 16), torch.tensor([1, 2, 3, 4])
+    out["X_T"], out["y"] = X_T, y
+    for kind, Cls, kw in (("zigzag_centered", RefZigzag, dict(num_zigzag=3)), ("centered", RefCentered, dict(predict_next=False))):
+        with _quiet:
+            s = Cls.from_config(CONFIGS["adm128"], M=2, after_step=4, num_steps_uc=3, unet=tiny, **kw)
+            s.set_timesteps(10)
+            torch.manual_seed(0)
+            r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, 3, torch.device("cpu"), tiny, s)
+        for k in ("gen_images", "uncertainty", "score"):
+            out[f"{kind}_{k}"] = r[k]
+    save("g4_driver", **out)
+
+
+def g5():
+    out = {}
+    # per-layer pieces
+    emb = randn(21, 2, 128)
+    cases = {"plain": (64, 64, {}), "chg": (64, 96, {}), "down": (64, 64, dict(down=True)), "up": (64, 64, dict(up=True))}
+    for name, (cin, cout, kw) in cases.items():
+        with _quiet:
+            rb = ref_unet.ResBlock(cin, 128, 0.0, out_channels=cout, use_scale_shift_norm=True, **kw)
+        rb.load_state_dict(seeded_state_dict({k: v.shape for k, v in rb.state_dict().items()}, 31))
+        x = randn(22, 2, cin, 8, 8)
+        with torch.no_grad():
+            out[f"res_{name}_out"] = rb.eval()(x, emb)
+        out[f"res_{name}_x"] = x
+    out["res_emb"] = emb
+    for name, (C, heads, new, T) in {"legacy_hd32": (128, 4, False, 64), "new_hd64": (128, 2, True, 16),
+                                     "legacy_hd96": (384, 4, False, 16)}.items():
+        with _quiet:
+            ab = ref_unet.AttentionBlock(C, num_heads=heads, use_new_attention_order=new)
+        ab.load_state_dict(seeded_state_dict({k: v.shape for k, v in ab.state_dict().items()}, 32))
+        s = int(T ** 0.5)
+        x = randn(23, 2, C, s, s)
+        with torch.no_grad():
+            out[f"attn_{name}_out"] = ab.eval()(x)
+        out[f"attn_{name}_x"] = x
+    out["temb_t"] = torch.tensor([0, 1, 500, 999])
+    out["temb_256"] = ref_temb(out["temb_t"], 256)
+    out["temb_193"] = ref_temb(out["temb_t"], 193)
+    # tiny full model
+    tiny = build_adm(TINY_ADM, seed=5)
+    x, t, y = randn(24, 3, 3, 16, 16), torch.tensor([999, 500, 0]), torch.tensor([0, 5, 9])
+    with torch.no_grad():
+        out["tiny_out"] = tiny(x, t, y=y)
+    out["tiny_x"], out["tiny_t"], out["tiny_y"] = x, t, y
+    save("g5_adm_blocks", **out)
+    # full-size models, B=1
+    for name, cfg, seed in (("adm64", ADM64, 64), ("adm128", ADM128, 128)):
+        m = build_adm(cfg, seed)
+        H = cfg["image_size"]
+        x, t, y = randn(25, 1, 3, H, H), torch.tensor([500]), torch.tensor([7])
+        with torch.no_grad():
+            o = m(x, t, y=y)
+        save(f"g5_{name}_full", x=x, t=t, y=y, out=o, seed=seed,
+             n_params=sum(p.numel() for p in m.parameters()), n_tensors=len(m.state_dict()))
+        del m
+
+
+def build_uvit(cfg, seed):
+    with _quiet:
+        m = ref_uvit.UViT(**cfg)
+    m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed))
+    return m.eval()
+
+
+def g6():
+    out = {}
+    m = build_uvit(TINY_UVIT, 6)
+    x, t, y = randn(61, 2, 4, 8, 8), torch.tensor([999, 3]), torch.tensor([10, 0])
+    with torch.no_grad():
+        out["tiny_out"] = m(x, t, y)
+        tok = randn(62, 2, 18, 64)
+        out["block_in"] = tok
+        out["block_noskip"] = m.in_blocks[0](tok)
+        out["block_skip"] = m.out_blocks[0](tok, randn(63, 2, 18, 64))
+        out["block_skip_in"] = randn(63, 2, 18, 64)
+    out["tiny_x"], out["tiny_t"], out["tiny_y"] = x, t, y
+    save("g6_uvit", **out)
+    m = build_uvit(UVIT_H2, 7)
+    x, t, y = randn(64, 1, 4, 32, 32), torch.tensor([501]), torch.tensor([7])
+    with torch.no_grad():
+        o = m(x, t, y)
+    save("g6_uvit_h2_full", x=x, t=t, y=y, out=o, seed=7, n_params=sum(p.numel() for p in m.parameters()))
+
+
+class FakeCFGUNet(torch.nn.Module):
+    """Conv 'UNet' with the diffusers call signature used at uncertainty_guidance.py:138-143."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = randn(71, 4, 4, 3, 3) * 0.2
+
+    def forward(self, sample, timestep, encoder_hidden_states, **kw):
+        h = torch.nn.functional.conv2d(sample, self.w, padding=1)
+        return (h + encoder_hidden_states.mean(dim=(1, 2))[:, None, None, None],)
+
+
+def g7():
+    out = {}
+    # pure function cases u -> (q, mask)
+    us = {"rand": randn(72, 3, 4, 16, 16).abs(), "ties": (randn(73, 2, 4, 16, 16) * 4).round().abs() / 4,
+          "const": torch.full((2, 4, 8, 8), 0.25), "adm128_like": randn(74, 1, 3, 128, 128) ** 2,
+          "odd_n": randn(75, 2, 3, 7, 5).abs()}
+    ps = (0.85, 0.9, 0.95, 0.99, 0.0, 1.0, 0.5)
+    for name, u in us.items():
+        out[f"u_{name}"] = u
+        for p in ps:
+            q = torch.quantile(u.to(torch.float32).flatten(1), p, dim=1, keepdim=True)
+            mask = u > q.view(u.shape[0], 1, 1, 1)
+            out[f"q_{name}_{p}"] = q[:, 0]
+            out[f"mask_{name}_{p}"] = mask.to(torch.uint8)
+    out["ps"] = np.array(ps)
+    # end-to-end posterior guidance with a fake CFG UNet, B=1 latents
+    ref_ug.use_posterior = True
+    model = FakeCFGUNet()
+    eps, lat = randn(76, 1, 4, 64, 64), randn(77, 1, 4, 64, 64)
+    inp = torch.cat([lat, lat])
+    ctx = randn(78, 2, 5, 8)
+    out["sd_eps"], out["sd_input"], out["sd_ctx"], out["sd_w"] = eps, inp, ctx, model.w
+    for i, p in enumerate((0.85, 0.9, 0.95, 0.99)):
+        torch.manual_seed(700 + i)
+        with _quiet, torch.no_grad():
+            fe = ref_ug.get_uncertainty_guided_score_with_percentile(
+                eps.clone(), inp, torch.tensor([500]), ctx, model, torch.tensor(0.3), p, "stable-diffusion",
+                num_uncertainty_samples=5, guidance_scale=7.5)
+        out[f"sd_final_{p}"] = fe
+    out["sd_alpha"] = np.float32(0.3)
+    save("g7_guidance", **out)
+
+
+def g8():
+    out = {}
+    cfg = dict(TINY_ADM, dropout=0.1)
+    tiny = build_adm(cfg, seed=5)
+    x, y = randn(3, 2, 3, 16, 16), torch.tensor([3, 7])
+    with _quiet, torch.no_grad():
+        s = RefMCDropout.from_config(CONFIGS["adm128"], M=3, after_step=4, num_steps_uc=3, unet=tiny, y=None)
+        s.set_timesteps(10)
+        s.prompt_embeds = y
+        eps = tiny(x, torch.full((2,), 500, dtype=torch.long), y=y)[:, :3]
+        torch.manual_seed(808)
+        o = s.step(eps, 500, x)
+    out.update(x=x, y=y, eps=eps, prev=o.prev_sample, unc=o.uncertainty, x0=o.pred_original_sample)
+    # F.dropout == x * bernoulli_(1-p) / (1-p) under the same seed
+    h = randn(81, 2, 8, 4, 4)
+    torch.manual_seed(9)
+    a = torch.nn.functional.dropout(h, 0.1, True)
+    torch.manual_seed(9)
+    b = h * torch.empty_like(h).bernoulli_(0.9) / 0.9
+    out["dropout_equiv_maxdiff"] = (a - b).abs().max()
+    # driver with mc_dropout
+    X_T, yy = randn(11, 4, 3, 16, 16), torch.tensor([1, 2, 3, 4])
+    with _quiet:
+        s = RefMCDropout.from_config(CONFIGS["adm128"], M=2, after_step=4, num_steps_uc=3, unet=tiny, y=None)
+        s.set_timesteps(10)
+        torch.manual_seed(0)
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, yy, 3, torch.device("cpu"), tiny, s)
+    out.update(drv_X_T=X_T, drv_y=yy, drv_gen_images=r["gen_images"], drv_uncertainty=r["uncertainty"], drv_score=r["score"])
+    save("g8_mc_dropout", **out)
+
+
+if __name__ == "__main__":
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8)
+    for g in (sys.argv[1:] or list(groups)):
+        groups[g]()
