@@ -1,0 +1,80 @@
+"""ctypes binding of libdua_hip.so (the C ABI declared in include/dua_hip.h).
+
+The library is the product: if it is missing, or a tensor is not a contiguous fp32 CUDA(HIP) tensor,
+the call raises - there is no eager/CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdua_hip.so")
+
+_c = ctypes
+_P, _I, _F, _Z, _L, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_long, _c.c_uint64
+
+
+class GemmArgs(_c.Structure):
+    _fields_ = [("A1", _P), ("A2", _P), ("B", _P), ("bias", _P), ("residual", _P), ("C", _P),
+                ("M", _I), ("N", _I), ("K1", _I), ("K2", _I),
+                ("lda1", _L), ("lda2", _L), ("ldb", _L), ("ldc", _L), ("ldr", _L),
+                ("sA1", _L), ("sA2", _L), ("sB", _L), ("sC", _L), ("sR", _L),
+                ("batch", _I), ("batch_inner", _I),
+                ("sA1i", _L), ("sBi", _L), ("sCi", _L),
+                ("transB", _I), ("act_in", _I), ("act_out", _I), ("alpha", _F)]
+
+
+# name -> (restype, argtypes); every symbol include/dua_hip.h declares
+SIGNATURES = {
+    "dua_version": (_I, []),
+    "dua_last_error": (_c.c_char_p, []),
+    "dua_ddim_step": (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "dua_axpby": (_I, [_P, _P, _P, _Z, _F, _F, _P]),
+    "dua_mc_centered_accum": (_I, [_P, _P, _P, _Z, _I, _I, _P]),
+    "dua_mc_reduce_centered": (_I, [_P, _P, _P, _Z, _I, _P]),
+    "dua_mc_reduce_var": (_I, [_P, _P, _Z, _I, _P]),
+    "dua_quantile_mask": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "dua_posterior_blend": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "dua_to_uint8": (_I, [_P, _P, _Z, _P]),
+    "dua_randn": (_I, [_P, _Z, _U64, _U64, _P]),
+    "dua_dropout_mask": (_I, [_P, _Z, _F, _U64, _U64, _P]),
+    "dua_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dua_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dua_groupnorm_ws_floats": (_Z, [_I, _I, _I, _I]),
+    "dua_groupnorm_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "dua_groupnorm_apply": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dua_resample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dua_conv3x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dua_conv3x3_packed_floats": (_Z, [_I, _I]),
+    "dua_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _P]),
+    "dua_gemm": (_I, [_c.POINTER(GemmArgs), _P]),
+    "dua_softmax_rows": (_I, [_P, _L, _I, _P]),
+    "dua_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "dua_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
+    "dua_embedding_add": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().dua_last_error().decode()}")

@@ -1,0 +1,42 @@
+"""Build libdua_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libdua_hip.so")
+SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", [])]
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "dua_hip.h")]
+    objs = []
+    for src, extra in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,386 @@
+// Memory-bound denoiser kernels: GroupNorm32 (+SiLU, FiLM, dropout mask, 2x resampling), row softmax,
+// LayerNorm, timestep / label embeddings.  NHWC fp32, 16 B per lane, wave64 shuffles for reductions.
+#include "common.h"
+
+#define BLK 256
+
+// =================================== GroupNorm statistics ======================================
+// Pass 1: one workgroup per (image, pixel chunk) streams its contiguous NHWC slab once with float4 loads;
+// every thread owns fixed channel quads, so per-channel sums stay in registers.  Per-group partials are
+// combined in double and written to ws[N][chunks][G][2].  Pass 2 (k_gn_finalize) folds the chunks.
+__global__ __launch_bounds__(BLK) void k_gn_partial(const float* __restrict__ x1, int C1, const float* __restrict__ x2,
+                                                    int C2, int HW, int G, int chunk_px, int nchunks,
+                                                    double* __restrict__ ws) {
+    extern __shared__ float sm[];   // [rowsPerIter][C] sums, then [rowsPerIter][C] sumsq
+    const int C = C1 + C2, cpg = C / G;
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int p0 = chunk * chunk_px, p1 = min(HW, p0 + chunk_px);
+    int rows_per_iter = 1;
+    for (int s = 0; s < 2; ++s) {
+        const float* x = s == 0 ? x1 : x2;
+        const int Cs = s == 0 ? C1 : C2, coff = s == 0 ? 0 : C1;
+        if (Cs == 0) continue;
+        const int Q = Cs / 4;
+        const float* base = x + ((size_t)n * HW) * Cs;
+        if (Q <= BLK) {
+            const int PP = BLK / Q, pl = tid / Q, q = tid % Q;
+            float4 su = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+            if (pl < PP)
+                for (int p = p0 + pl; p < p1; p += PP) {
+                    float4 v = *(const float4*)(base + (size_t)p * Cs + 4 * q);
+                    su.x += v.x; su.y += v.y; su.z += v.z; su.w += v.w;
+                    sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+                }
+            // fold the PP pixel lanes through LDS (deterministic order)
+            float* S = sm;              // [PP][Cs]
+            float* SS = sm + BLK * 4;   // PP*Cs <= 1024
+            if (pl < PP) {
+                *(float4*)(S + pl * Cs + 4 * q) = su;
+                *(float4*)(SS + pl * Cs + 4 * q) = sq;
+            }
+            __syncthreads();
+            // one thread per group whose channels live in this source
+            for (int g = tid; g < G; g += BLK) {
+                int c_lo = max(g * cpg, coff) - coff, c_hi = min((g + 1) * cpg, coff + Cs) - coff;
+                if (c_lo < c_hi) {
+                    double a = 0, b = 0;
+                    for (int pp = 0; pp < PP; ++pp)
+                        for (int c = c_lo; c < c_hi; ++c) { a += S[pp * Cs + c]; b += SS[pp * Cs + c]; }
+                    double* o = ws + (((size_t)n * nchunks + chunk) * G + g) * 2;
+                    if (s == 0 || g * cpg >= coff) { o[0] = a; o[1] = b; } else { o[0] += a; o[1] += b; }
+                }
+            }
+            __syncthreads();
+        } else {
+            // wide sources (Q > 256, at most 512): each thread owns quads tid and tid+256
+            float4 su[2], sq[2];
+            for (int j = 0; j < 2; ++j) { su[j] = make_float4(0, 0, 0, 0); sq[j] = make_float4(0, 0, 0, 0); }
+            for (int p = p0; p < p1; ++p)
+                for (int j = 0; j < 2; ++j) {
+                    int q = tid + j * BLK;
+                    if (q < Q) {
+                        float4 v = *(const float4*)(base + (size_t)p * Cs + 4 * q);
+                        su[j].x += v.x; su[j].y += v.y; su[j].z += v.z; su[j].w += v.w;
+                        sq[j].x += v.x * v.x; sq[j].y += v.y * v.y; sq[j].z += v.z * v.z; sq[j].w += v.w * v.w;
+                    }
+                }
+            float* S = sm;
+            float* SS = sm + 2048;
+            for (int j = 0; j < 2; ++j) {
+                int q = tid + j * BLK;
+                if (q < Q) { *(float4*)(S + 4 * q) = su[j]; *(float4*)(SS + 4 * q) = sq[j]; }
+            }
+            __syncthreads();
+            for (int g = tid; g < G; g += BLK) {
+                int c_lo = max(g * cpg, coff) - coff, c_hi = min((g + 1) * cpg, coff + Cs) - coff;
+                if (c_lo < c_hi) {
+                    double a = 0, b = 0;
+                    for (int c = c_lo; c < c_hi; ++c) { a += S[c]; b += SS[c]; }
+                    double* o = ws + (((size_t)n * nchunks + chunk) * G + g) * 2;
+                    if (s == 0 || g * cpg >= coff) { o[0] = a; o[1] = b; } else { o[0] += a; o[1] += b; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    (void)rows_per_iter;
+}
+
+__global__ void k_gn_finalize(const double* __restrict__ ws, int NG, int G, int nchunks, double count, float eps,
+                              float* __restrict__ stats) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NG) return;
+    int n = i / G, g = i % G;
+    double a = 0, b = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const double* o = ws + (((size_t)n * nchunks + c) * G + g) * 2;
+        a += o[0];
+        b += o[1];
+    }
+    double mean = a / count, var = b / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+static void gn_chunking(int N, int HW, int* chunk_px, int* nchunks) {
+    // aim for >= ~2048 workgroups, at least 16 pixels per chunk
+    int want = (2048 + N - 1) / N;
+    int cp = (HW + want - 1) / want;
+    if (cp < 16) cp = 16;
+    if (cp > HW) cp = HW;
+    *chunk_px = cp;
+    *nchunks = (HW + cp - 1) / cp;
+}
+
+extern "C" size_t dua_groupnorm_ws_floats(int N, int HW, int C, int G) {
+    int cp, nc;
+    gn_chunking(N, HW, &cp, &nc);
+    (void)C;
+    return (size_t)N * nc * G * 2 * 2 + 4;   // doubles, expressed in floats
+}
+
+extern "C" int dua_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int G, float eps,
+                                   float* ws, float* stats, void* stream) {
+    int C = C1 + C2;
+    DUA_REQUIRE(x1 && ws && stats && N > 0 && HW > 0 && G > 0, "dua_groupnorm_stats: bad arguments");
+    DUA_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0 && C1 <= 2048 && C2 <= 2048, "dua_groupnorm_stats: unsupported channels C1=%d C2=%d G=%d", C1, C2, G);
+    DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_stats: x2/C2 mismatch");
+    DUA_REQUIRE(((uintptr_t)ws & 7) == 0, "dua_groupnorm_stats: ws must be 8-byte aligned");
+    int cp, nc;
+    gn_chunking(N, HW, &cp, &nc);
+    hipLaunchKernelGGL(k_gn_partial, dim3(nc, N), BLK, 4096 * sizeof(float), as_stream(stream), x1, C1, x2, C2, HW, G, cp, nc, (double*)ws);
+    int NG = N * G;
+    hipLaunchKernelGGL(k_gn_finalize, (NG + 255) / 256, 256, 0, as_stream(stream), (const double*)ws, NG, G, nc,
+                       (double)HW * (double)(C / G), eps, stats);
+    return dua_check_launch("dua_groupnorm_stats");
+}
+
+// =================================== GroupNorm apply ===========================================
+// One float4 of the (virtually concatenated) input per lane-iteration.  resample: 0 none, +1 nearest x2
+// (each value written 4x), -1 2x2 average of the ACTIVATED values (unet_openai.py:238-243: h_upd after in_rest).
+struct GnApplyP {
+    const float *x1, *x2, *stats, *gamma, *beta, *film, *drop;
+    float* y;
+    int C1, C2, N, H, W, G, act, resample;
+};
+
+__device__ __forceinline__ float4 gn_xform(const GnApplyP& p, int n, size_t pix, int c) {
+    const int C = p.C1 + p.C2, cpg = C / p.G;
+    float4 v = c < p.C1 ? *(const float4*)(p.x1 + pix * p.C1 + c) : *(const float4*)(p.x2 + pix * p.C2 + (c - p.C1));
+    float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
+    float r[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    int g0 = c / cpg;
+    float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + g0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if ((cpg & 3) && (c + j) / cpg != g0) st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + (c + j) / cpg));
+        float t = (r[j] - st.x) * st.y * gg[j] + bb[j];
+        if (p.film) t = t * (1.0f + p.film[(size_t)n * 2 * C + c + j]) + p.film[(size_t)n * 2 * C + C + c + j];
+        if (p.act == 1) t = silu_f(t);
+        r[j] = t;
+    }
+    if (p.drop) {
+        float4 d = *(const float4*)(p.drop + pix * C + c);
+        r[0] *= d.x; r[1] *= d.y; r[2] *= d.z; r[3] *= d.w;
+    }
+    return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+__global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p) {
+    const int C = p.C1 + p.C2, Q = C / 4;
+    const int Ho = p.resample < 0 ? p.H / 2 : p.H, Wo = p.resample < 0 ? p.W / 2 : p.W;   // iteration space
+    size_t total = (size_t)p.N * Ho * Wo * Q, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % Q) * 4;
+        size_t pp = i / Q;
+        int xo = (int)(pp % Wo);
+        size_t t2 = pp / Wo;
+        int yo = (int)(t2 % Ho), n = (int)(t2 / Ho);
+        if (p.resample == 0) {
+            size_t pix = ((size_t)n * p.H + yo) * p.W + xo;
+            *(float4*)(p.y + pix * C + c) = gn_xform(p, n, pix, c);
+        } else if (p.resample > 0) {
+            size_t pix = ((size_t)n * p.H + yo) * p.W + xo;
+            float4 v = gn_xform(p, n, pix, c);
+            int W2 = 2 * p.W;
+            size_t o = (((size_t)n * 2 * p.H + 2 * yo) * W2 + 2 * xo) * C + c;
+            *(float4*)(p.y + o) = v;
+            *(float4*)(p.y + o + C) = v;
+            *(float4*)(p.y + o + (size_t)W2 * C) = v;
+            *(float4*)(p.y + o + (size_t)W2 * C + C) = v;
+        } else {
+            size_t pix = ((size_t)n * p.H + 2 * yo) * p.W + 2 * xo;
+            float4 a = gn_xform(p, n, pix, c), b = gn_xform(p, n, pix + 1, c);
+            float4 d = gn_xform(p, n, pix + p.W, c), e = gn_xform(p, n, pix + p.W + 1, c);
+            float4 o = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f,
+                                   (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f);
+            *(float4*)(p.y + (((size_t)n * Ho + yo) * Wo + xo) * C + c) = o;
+        }
+    }
+}
+
+extern "C" int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                   const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                   int resample, const float* dropmask, float* y, void* stream) {
+    int C = C1 + C2;
+    DUA_REQUIRE(x1 && stats && gamma && beta && y, "dua_groupnorm_apply: null pointer");
+    DUA_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0, "dua_groupnorm_apply: unsupported channels");
+    DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply: x2/C2 mismatch");
+    DUA_REQUIRE(resample >= 0 || (H % 2 == 0 && W % 2 == 0), "dua_groupnorm_apply: pooling needs even H, W");
+    DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply: dropout mask with resampling unsupported");
+    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample};
+    int Ho = resample < 0 ? H / 2 : H, Wo = resample < 0 ? W / 2 : W;
+    size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_gn_apply, stream_grid(total, BLK), BLK, 0, as_stream(stream), p);
+    return dua_check_launch("dua_groupnorm_apply");
+}
+
+// =================================== 2x resampling of the skip path ============================
+__global__ __launch_bounds__(BLK) void k_resample2x(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int mode) {
+    const int Q = C / 4;
+    const int Ho = mode < 0 ? H / 2 : H, Wo = mode < 0 ? W / 2 : W;
+    size_t total = (size_t)N * Ho * Wo * Q, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % Q) * 4;
+        size_t pp = i / Q;
+        int xo = (int)(pp % Wo);
+        size_t t2 = pp / Wo;
+        int yo = (int)(t2 % Ho), n = (int)(t2 / Ho);
+        if (mode > 0) {
+            float4 v = *(const float4*)(x + (((size_t)n * H + yo) * W + xo) * C + c);
+            int W2 = 2 * W;
+            size_t o = (((size_t)n * 2 * H + 2 * yo) * W2 + 2 * xo) * C + c;
+            *(float4*)(y + o) = v;
+            *(float4*)(y + o + C) = v;
+            *(float4*)(y + o + (size_t)W2 * C) = v;
+            *(float4*)(y + o + (size_t)W2 * C + C) = v;
+        } else {
+            size_t pix = ((size_t)n * H + 2 * yo) * W + 2 * xo;
+            float4 a = *(const float4*)(x + pix * C + c), b = *(const float4*)(x + (pix + 1) * C + c);
+            float4 d = *(const float4*)(x + (pix + W) * C + c), e = *(const float4*)(x + (pix + W + 1) * C + c);
+            *(float4*)(y + (((size_t)n * Ho + yo) * Wo + xo) * C + c) =
+                make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f,
+                            (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f);
+        }
+    }
+}
+extern "C" int dua_resample2x(const float* x, float* y, int N, int H, int W, int C, int resample, void* stream) {
+    DUA_REQUIRE(x && y && C % 4 == 0 && resample != 0, "dua_resample2x: bad arguments");
+    DUA_REQUIRE(resample > 0 || (H % 2 == 0 && W % 2 == 0), "dua_resample2x: pooling needs even H, W");
+    int Ho = resample < 0 ? H / 2 : H, Wo = resample < 0 ? W / 2 : W;
+    size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_resample2x, stream_grid(total, BLK), BLK, 0, as_stream(stream), x, y, N, H, W, C, resample);
+    return dua_check_launch("dua_resample2x");
+}
+
+// =================================== row softmax ===============================================
+// One wave per row; the row lives in registers (cols <= 64*32).
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int PER>
+__global__ __launch_bounds__(BLK) void k_softmax_rows(float* __restrict__ S, long rows, int cols) {
+    long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float* r = S + row * (long)cols;
+    float v[PER];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int c = lane + 64 * j;
+        v[j] = c < cols ? r[c] : -INFINITY;
+        m = fmaxf(m, v[j]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] = expf(v[j] - m);
+        s += (lane + 64 * j < cols) ? v[j] : 0.f;
+    }
+    s = wave_sum(s);
+    float inv = 1.0f / s;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int c = lane + 64 * j;
+        if (c < cols) r[c] = v[j] * inv;
+    }
+}
+extern "C" int dua_softmax_rows(float* S, long rows, int cols, void* stream) {
+    DUA_REQUIRE(S && rows >= 0 && cols >= 1 && cols <= 2048, "dua_softmax_rows: cols must be in [1, 2048]");
+    if (rows == 0) return DUA_OK;
+    unsigned grid = (unsigned)((rows + 3) / 4);
+    if (cols <= 64) hipLaunchKernelGGL(k_softmax_rows<1>, grid, BLK, 0, as_stream(stream), S, rows, cols);
+    else if (cols <= 256) hipLaunchKernelGGL(k_softmax_rows<4>, grid, BLK, 0, as_stream(stream), S, rows, cols);
+    else if (cols <= 512) hipLaunchKernelGGL(k_softmax_rows<8>, grid, BLK, 0, as_stream(stream), S, rows, cols);
+    else if (cols <= 1024) hipLaunchKernelGGL(k_softmax_rows<16>, grid, BLK, 0, as_stream(stream), S, rows, cols);
+    else hipLaunchKernelGGL(k_softmax_rows<32>, grid, BLK, 0, as_stream(stream), S, rows, cols);
+    return dua_check_launch("dua_softmax_rows");
+}
+
+// =================================== LayerNorm =================================================
+template <int PER>
+__global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, const float* __restrict__ ga,
+                                                   const float* __restrict__ be, float* __restrict__ y, long rows, int D, float eps) {
+    long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    const float* r = x + row * (long)D;
+    float v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int c = lane + 64 * j;
+        v[j] = c < D ? r[c] : 0.f;
+        s += v[j];
+    }
+    float mean = wave_sum(s) / (float)D, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        float d = (lane + 64 * j < D) ? v[j] - mean : 0.f;
+        q += d * d;
+    }
+    float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int c = lane + 64 * j;
+        if (c < D) y[row * (long)D + c] = (v[j] - mean) * rstd * ga[c] + be[c];
+    }
+}
+extern "C" int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, void* stream) {
+    DUA_REQUIRE(x && gamma && beta && y && D >= 1 && D <= 2048, "dua_layernorm: D must be in [1, 2048]");
+    if (rows == 0) return DUA_OK;
+    unsigned grid = (unsigned)((rows + 3) / 4);
+    if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps);
+    else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps);
+    return dua_check_launch("dua_layernorm");
+}
+
+// =================================== embeddings ================================================
+__global__ void k_timestep_embedding(const int64_t* __restrict__ t, float* __restrict__ emb, int N, int dim) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * dim) return;
+    int n = i / dim, d = i % dim, half = dim / 2;
+    float out = 0.f;
+    if (d < 2 * half) {
+        int j = d < half ? d : d - half;
+        // nn.py:112-116: freqs = exp(-log(10000) * j / half) in fp32, args = t.float() * freqs
+        float freq = expf(-9.210340371976184f * (float)j / (float)half);
+        float a = (float)t[n] * freq;
+        out = d < half ? cosf(a) : sinf(a);
+    }
+    emb[i] = out;
+}
+extern "C" int dua_timestep_embedding(const int64_t* t, float* emb, int N, int dim, void* stream) {
+    DUA_REQUIRE(t && emb && N >= 0 && dim >= 2, "dua_timestep_embedding: bad arguments");
+    if (N == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_timestep_embedding, (N * dim + 255) / 256, 256, 0, as_stream(stream), t, emb, N, dim);
+    return dua_check_launch("dua_timestep_embedding");
+}
+
+__global__ void k_embedding_add(const float* __restrict__ a, const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                float* __restrict__ out, int N, int D) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    int n = i / D, d = i % D;
+    float v = table[(size_t)idx[n] * D + d];
+    out[i] = a ? a[i] + v : v;
+}
+extern "C" int dua_embedding_add(const float* a, const float* table, const int64_t* idx, float* out, int N, int D, void* stream) {
+    DUA_REQUIRE(table && idx && out && N >= 0 && D >= 1, "dua_embedding_add: bad arguments");
+    if (N == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_embedding_add, (N * D + 255) / 256, 256, 0, as_stream(stream), a, table, idx, out, N, D);
+    return dua_check_launch("dua_embedding_add");
+}

@@ -1,0 +1,357 @@
+// Sampler-side kernels: DDIM update, re-noising, Monte-Carlo reductions, exact quantile mask,
+// posterior blend, uint8 conversion, Philox normal generator.  All HBM-bound; vectorised 16 B/lane.
+// Built with -ffp-contract=off so the elementwise arithmetic rounds like the reference's separate ATen ops.
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+extern "C" void dua_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dua_last_error(void) { return g_err; }
+extern "C" int dua_version(void) { return 100; }
+
+#define BLK 256
+
+// ---- DDIM update: zigzag_centered.py:473,490-493,507-510,523-525 -------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(BLK) void k_ddim_step(const float* __restrict__ eps, const float* __restrict__ x,
+                                                   const float* __restrict__ noise, float* __restrict__ prev,
+                                                   float* __restrict__ x0o, size_t n, float sb, float sa, float sap,
+                                                   float dc, float sigma, int clip, float cr) {
+    auto one = [&](float e, float xv, float nz) -> float2 {
+        float x0 = (xv - sb * e) / sa;
+        if (clip) x0 = fminf(fmaxf(x0, -cr), cr);
+        float p = sap * x0 + dc * e;
+        if (noise) p = p + sigma * nz;
+        return make_float2(p, x0);
+    };
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {
+        size_t n4 = n / 4;
+        for (; i < n4; i += stride) {
+            float4 e = ((const float4*)eps)[i], xv = ((const float4*)x)[i];
+            float4 nz = noise ? ((const float4*)noise)[i] : make_float4(0, 0, 0, 0);
+            float2 a = one(e.x, xv.x, nz.x), b = one(e.y, xv.y, nz.y), c = one(e.z, xv.z, nz.z), d = one(e.w, xv.w, nz.w);
+            ((float4*)prev)[i] = make_float4(a.x, b.x, c.x, d.x);
+            ((float4*)x0o)[i] = make_float4(a.y, b.y, c.y, d.y);
+        }
+    } else {
+        for (; i < n; i += stride) {
+            float2 a = one(eps[i], x[i], noise ? noise[i] : 0.f);
+            prev[i] = a.x;
+            x0o[i] = a.y;
+        }
+    }
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int dua_ddim_step(const float* eps, const float* x, const float* noise, float* prev, float* x0, size_t n,
+                             float sb, float sa, float sap, float dc, float sigma, int clip, float cr, void* stream) {
+    DUA_REQUIRE(eps && x && prev && x0, "dua_ddim_step: null pointer");
+    if (n == 0) return DUA_OK;
+    if (sigma == 0.f) noise = nullptr;
+    bool vec = (n % 4 == 0) && aligned16(eps) && aligned16(x) && aligned16(prev) && aligned16(x0) && (!noise || aligned16(noise));
+    if (vec)
+        hipLaunchKernelGGL(k_ddim_step<true>, stream_grid(n / 4, BLK), BLK, 0, as_stream(stream), eps, x, noise, prev, x0, n, sb, sa, sap, dc, sigma, clip, cr);
+    else
+        hipLaunchKernelGGL(k_ddim_step<false>, stream_grid(n, BLK), BLK, 0, as_stream(stream), eps, x, noise, prev, x0, n, sb, sa, sap, dc, sigma, clip, cr);
+    return dua_check_launch("dua_ddim_step");
+}
+
+// ---- out = a*src + b*noise ---------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_axpby(const float* __restrict__ s, const float* __restrict__ z,
+                                               float* __restrict__ o, size_t n, float a, float b, int vec) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t n4 = n / 4; i < n4; i += stride) {
+            float4 sv = ((const float4*)s)[i], zv = ((const float4*)z)[i];
+            ((float4*)o)[i] = make_float4(a * sv.x + b * zv.x, a * sv.y + b * zv.y, a * sv.z + b * zv.z, a * sv.w + b * zv.w);
+        }
+    } else {
+        for (; i < n; i += stride) o[i] = a * s[i] + b * z[i];
+    }
+}
+extern "C" int dua_axpby(const float* src, const float* noise, float* out, size_t n, float a, float b, void* stream) {
+    DUA_REQUIRE(src && noise && out, "dua_axpby: null pointer");
+    if (n == 0) return DUA_OK;
+    int vec = (n % 4 == 0) && aligned16(src) && aligned16(noise) && aligned16(out);
+    hipLaunchKernelGGL(k_axpby, stream_grid(vec ? n / 4 : n, BLK), BLK, 0, as_stream(stream), src, noise, out, n, a, b, vec);
+    return dua_check_launch("dua_axpby");
+}
+
+// ---- centred second moment ---------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_mc_accum(const float* __restrict__ em, const float* __restrict__ e,
+                                                  float* __restrict__ acc, size_t n, int first, int last, float Mf) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float d = em[i] - e[i];
+        float v = d * d;
+        if (!first) v = acc[i] + v;
+        if (last) v = v / Mf;
+        acc[i] = v;
+    }
+}
+extern "C" int dua_mc_centered_accum(const float* eps_m, const float* eps, float* acc, size_t n, int m, int M, void* stream) {
+    DUA_REQUIRE(eps_m && eps && acc && M >= 1 && m >= 0 && m < M, "dua_mc_centered_accum: bad arguments");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_mc_accum, stream_grid(n, BLK), BLK, 0, as_stream(stream), eps_m, eps, acc, n, m == 0, m == M - 1, (float)M);
+    return dua_check_launch("dua_mc_centered_accum");
+}
+
+__global__ __launch_bounds__(BLK) void k_mc_centered(const float* __restrict__ st, const float* __restrict__ e,
+                                                     float* __restrict__ u, size_t n, int M) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float c = e[i], s = 0.f;
+        for (int m = 0; m < M; ++m) {
+            float d = st[(size_t)m * n + i] - c;
+            s = s + d * d;
+        }
+        u[i] = s / (float)M;
+    }
+}
+extern "C" int dua_mc_reduce_centered(const float* stack, const float* eps, float* u, size_t n, int M, void* stream) {
+    DUA_REQUIRE(stack && eps && u && M >= 1, "dua_mc_reduce_centered: bad arguments");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_mc_centered, stream_grid(n, BLK), BLK, 0, as_stream(stream), stack, eps, u, n, M);
+    return dua_check_launch("dua_mc_reduce_centered");
+}
+
+__global__ __launch_bounds__(BLK) void k_mc_var(const float* __restrict__ st, float* __restrict__ u, size_t n, int M) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s = s + st[(size_t)m * n + i];
+        float mean = s / (float)M, q = 0.f;
+        for (int m = 0; m < M; ++m) {
+            float d = st[(size_t)m * n + i] - mean;
+            q = q + d * d;
+        }
+        u[i] = q / (float)(M - 1);
+    }
+}
+extern "C" int dua_mc_reduce_var(const float* stack, float* u, size_t n, int M, void* stream) {
+    DUA_REQUIRE(stack && u && M >= 2, "dua_mc_reduce_var: need M >= 2");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_mc_var, stream_grid(n, BLK), BLK, 0, as_stream(stream), stack, u, n, M);
+    return dua_check_launch("dua_mc_reduce_var");
+}
+
+// ---- exact per-sample quantile + strict mask ---------------------------------------------------
+// One 1024-thread workgroup per sample.  Four 8-bit radix-select passes over the order-preserving
+// integer image of the fp32 values find s[lo] exactly; one more pass finds s[lo+1]; the threshold is
+// interpolated with torch's lerp formula (no FMA) and the mask written in a last pass.
+#define QT 1024
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+__global__ __launch_bounds__(QT) void k_quantile_mask(const float* __restrict__ u, int n, int lo, int hi, float w,
+                                                      uint8_t* __restrict__ mask, float* __restrict__ q) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_rank, s_next, s_cnt_eq;
+    __shared__ float s_q;
+    const float* ub = u + (size_t)blockIdx.x * n;
+    uint8_t* mb = mask + (size_t)blockIdx.x * n;
+    int tid = threadIdx.x;
+    if (tid == 0) { s_prefix = 0; s_rank = (uint32_t)lo; }
+    for (int pass = 0; pass < 4; ++pass) {
+        int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        uint32_t prefix = s_prefix;
+        uint32_t pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < n; i += QT) {
+            uint32_t k = f2key(ub[i]);
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t r = s_rank, c = 0;
+            int d = 0;
+            for (; d < 256; ++d) {
+                if (c + hist[d] > r) break;
+                c += hist[d];
+            }
+            s_prefix = prefix | ((uint32_t)d << shift);
+            s_rank = r - c;
+            s_cnt_eq = hist[d];
+        }
+        __syncthreads();
+    }
+    uint32_t klo = s_prefix;
+    // s[lo+1]: equal to s[lo] if the run of equal keys extends past lo, else the smallest larger key.
+    if (tid == 0) s_next = 0xFFFFFFFFu;
+    __syncthreads();
+    if (hi != lo && s_rank + 1 >= s_cnt_eq) {
+        uint32_t best = 0xFFFFFFFFu;
+        for (int i = tid; i < n; i += QT) {
+            uint32_t k = f2key(ub[i]);
+            if (k > klo && k < best) best = k;
+        }
+        atomicMin(&s_next, best);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float a = key2f(klo);
+        float b = (hi == lo || s_rank + 1 < s_cnt_eq) ? a : key2f(s_next);
+        float d = __fsub_rn(b, a);
+        float r = (w < 0.5f) ? __fadd_rn(a, __fmul_rn(w, d)) : __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.0f, w)));
+        s_q = r;
+        q[blockIdx.x] = r;
+    }
+    __syncthreads();
+    float thr = s_q;
+    for (int i = tid; i < n; i += QT) mb[i] = ub[i] > thr ? 1 : 0;
+}
+
+extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uint8_t* mask, float* q, void* stream) {
+    DUA_REQUIRE(u && mask && q, "dua_quantile_mask: null pointer");
+    DUA_REQUIRE(B >= 0 && n >= 1 && lo >= 0 && hi >= lo && hi <= lo + 1 && hi < n, "dua_quantile_mask: bad rank split (n=%d lo=%d hi=%d)", n, lo, hi);
+    if (B == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_quantile_mask, B, QT, 0, as_stream(stream), u, n, lo, hi, w, mask, q);
+    return dua_check_launch("dua_quantile_mask");
+}
+
+// ---- posterior blend: uncertainty_guidance.py:115-120 ------------------------------------------
+__global__ __launch_bounds__(BLK) void k_posterior(const float* __restrict__ eps, const float* __restrict__ u,
+                                                   const uint8_t* __restrict__ mask, float* __restrict__ out, int B,
+                                                   int n, float Mf, float inv_alpha) {
+    size_t total = (size_t)B * n, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int j = (int)(i % n);
+        float es = 0.f;
+        for (int b = 0; b < B; ++b) es = es + eps[(size_t)b * n + j];      // pred_epsilon.sum(dim=0)
+        float inv = 1.0f / u[i];
+        float prec = 1.0f / (Mf * inv + inv_alpha);
+        float post = prec * (inv * es);
+        float m = (float)mask[i];
+        out[i] = eps[i] * (1.0f - m) + m * post;
+    }
+}
+extern "C" int dua_posterior_blend(const float* eps, const float* u, const uint8_t* mask, float* out, int B, int n, int M,
+                                   float alpha_hat_t, void* stream) {
+    DUA_REQUIRE(eps && u && mask && out && B >= 0 && n >= 0, "dua_posterior_blend: bad arguments");
+    if ((size_t)B * n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_posterior, stream_grid((size_t)B * n, BLK), BLK, 0, as_stream(stream), eps, u, mask, out, B, n, (float)M, 1.0f / alpha_hat_t);
+    return dua_check_launch("dua_posterior_blend");
+}
+
+// ---- uint8 conversion: generate_samples.py:203-215 ---------------------------------------------
+__global__ __launch_bounds__(BLK) void k_to_uint8(const float* __restrict__ x, uint8_t* __restrict__ o, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = x[i] / 2.0f + 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+        o[i] = (uint8_t)rintf(v);
+    }
+}
+extern "C" int dua_to_uint8(const float* x, uint8_t* out, size_t n, void* stream) {
+    DUA_REQUIRE(x && out, "dua_to_uint8: null pointer");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_to_uint8, stream_grid(n, BLK), BLK, 0, as_stream(stream), x, out, n);
+    return dua_check_launch("dua_to_uint8");
+}
+
+// ---- Philox4x32-10 normals ---------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(M0, c.x), l0 = M0 * c.x, h1 = __umulhi(M1, c.z), l1 = M1 * c.z;
+        c = make_uint4(h1 ^ c.y ^ k.x, l1, h0 ^ c.w ^ k.y, l0);
+        k.x += W0;
+        k.y += W1;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(BLK) void k_randn(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset) {
+    size_t stride = (size_t)gridDim.x * blockDim.x, n4 = (n + 3) / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        uint64_t ctr = offset + i;
+        uint4 r = philox4x32_10(make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        float r0 = sqrtf(-2.0f * __logf(u01(r.x))), r1 = sqrtf(-2.0f * __logf(u01(r.z)));
+        float s0, c0, s1, c1;
+        __sincosf(6.283185307179586f * u01(r.y), &s0, &c0);
+        __sincosf(6.283185307179586f * u01(r.w), &s1, &c1);
+        float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+        size_t b = i * 4;
+        if (b + 3 < n && (((uintptr_t)(out + b)) & 15) == 0) {
+            *(float4*)(out + b) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int j = 0; j < 4 && b + j < n; ++j) out[b + j] = v[j];
+        }
+    }
+}
+extern "C" int dua_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    DUA_REQUIRE(out, "dua_randn: null pointer");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_randn, stream_grid((n + 3) / 4, BLK), BLK, 0, as_stream(stream), out, n, seed, offset);
+    return dua_check_launch("dua_randn");
+}
+
+__global__ __launch_bounds__(BLK) void k_dropout_mask(float* __restrict__ out, size_t n, float keep, float scale, uint64_t seed, uint64_t offset) {
+    size_t stride = (size_t)gridDim.x * blockDim.x, n4 = (n + 3) / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        uint64_t ctr = offset + i;
+        uint4 r = philox4x32_10(make_uint4((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+        for (int j = 0; j < 4 && i * 4 + j < n; ++j) out[i * 4 + j] = u01(rr[j]) < keep ? scale : 0.f;
+    }
+}
+extern "C" int dua_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    DUA_REQUIRE(out && p >= 0.f && p < 1.f, "dua_dropout_mask: bad arguments");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_dropout_mask, stream_grid((n + 3) / 4, BLK), BLK, 0, as_stream(stream), out, n, 1.0f - p, 1.0f / (1.0f - p), seed, offset);
+    return dua_check_launch("dua_dropout_mask");
+}
+
+// ---- layout ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_nchw_to_nhwc(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW, int Cp) {
+    size_t total = (size_t)N * HW * Cp, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % Cp);
+        size_t p = i / Cp;
+        int hw = (int)(p % HW);
+        size_t nn = p / HW;
+        y[i] = c < C ? x[(nn * C + c) * HW + hw] : 0.f;
+    }
+}
+extern "C" int dua_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream) {
+    DUA_REQUIRE(x && y && Cpad >= C && C > 0, "dua_nchw_to_nhwc: bad arguments");
+    size_t total = (size_t)N * H * W * Cpad;
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, stream_grid(total, BLK), BLK, 0, as_stream(stream), x, y, N, C, H * W, Cpad);
+    return dua_check_launch("dua_nchw_to_nhwc");
+}
+__global__ __launch_bounds__(BLK) void k_nhwc_to_nchw(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW, int Ck) {
+    size_t total = (size_t)N * Ck * HW, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int hw = (int)(i % HW);
+        size_t p = i / HW;
+        int c = (int)(p % Ck);
+        size_t nn = p / Ck;
+        y[i] = x[(nn * HW + hw) * C + c];
+    }
+}
+extern "C" int dua_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Ckeep, void* stream) {
+    DUA_REQUIRE(x && y && Ckeep <= C && Ckeep > 0, "dua_nhwc_to_nchw: bad arguments");
+    size_t total = (size_t)N * H * W * Ckeep;
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_nhwc_to_nchw, stream_grid(total, BLK), BLK, 0, as_stream(stream), x, y, N, C, H * W, Ckeep);
+    return dua_check_launch("dua_nhwc_to_nchw");
+}

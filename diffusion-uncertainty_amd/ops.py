@@ -1,0 +1,286 @@
+"""Tensor-level wrappers over the C ABI (include/dua_hip.h).
+
+torch is used for device memory and the current HIP stream only; every arithmetic step runs in
+libdua_hip.so.  All tensors must be contiguous fp32 (or the stated integer type) on a HIP device.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _req(t, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a GPU tensor (got {getattr(t, 'device', type(t))}); "
+                           "there is no CPU fallback in this package")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _f32c(t):
+    """reference semantics: fp16/bf16 model outputs are promoted by the fp32 sample."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------ sampler kernels
+def ddim_step(eps, x, sqrt_beta_prod_t, sqrt_alpha_prod_t, sqrt_alpha_prod_prev, dir_coef, sigma=0.0, noise=None,
+              clip=True, clip_range=1.0):
+    eps, x = _req(_f32c(eps), name="eps"), _req(_f32c(x), name="x")
+    assert eps.shape == x.shape
+    prev, x0 = torch.empty_like(x), torch.empty_like(x)
+    if noise is not None:
+        _req(noise, name="noise")
+    check(_lib.lib().dua_ddim_step(_p(eps), _p(x), _p(noise), _p(prev), _p(x0), x.numel(), float(sqrt_beta_prod_t),
+                                   float(sqrt_alpha_prod_t), float(sqrt_alpha_prod_prev), float(dir_coef), float(sigma),
+                                   int(bool(clip)), float(clip_range), _stream()), "dua_ddim_step")
+    return prev, x0
+
+
+def axpby(src, noise, a, b, out=None):
+    _req(src, name="src"), _req(noise, name="noise")
+    assert src.shape == noise.shape
+    out = torch.empty_like(src) if out is None else out
+    check(_lib.lib().dua_axpby(_p(src), _p(noise), _p(out), src.numel(), float(a), float(b), _stream()), "dua_axpby")
+    return out
+
+
+def mc_centered_accum(eps_m, eps, acc, m, M):
+    _req(eps_m, name="eps_m"), _req(eps, name="eps"), _req(acc, name="acc")
+    check(_lib.lib().dua_mc_centered_accum(_p(eps_m), _p(eps), _p(acc), eps.numel(), int(m), int(M), _stream()),
+          "dua_mc_centered_accum")
+    return acc
+
+
+def mc_reduce_centered(stack, eps):
+    _req(stack, name="stack"), _req(eps, name="eps")
+    u = torch.empty_like(eps)
+    check(_lib.lib().dua_mc_reduce_centered(_p(stack), _p(eps), _p(u), eps.numel(), stack.shape[0], _stream()),
+          "dua_mc_reduce_centered")
+    return u
+
+
+def mc_reduce_var(stack):
+    _req(stack, name="stack")
+    u = torch.empty(stack.shape[1:], device=stack.device, dtype=torch.float32)
+    check(_lib.lib().dua_mc_reduce_var(_p(stack), _p(u), u.numel(), stack.shape[0], _stream()), "dua_mc_reduce_var")
+    return u
+
+
+def quantile_rank_split(p, n):
+    """fp32 rank arithmetic of torch.quantile."""
+    rank = np.float32(p) * np.float32(n - 1)
+    lo, hi = int(np.floor(rank)), int(np.ceil(rank))
+    return lo, hi, float(np.float32(rank - np.float32(lo)))
+
+
+def quantile_mask(u, p):
+    """mask = u > torch.quantile(u.flatten(1), p, dim=1) per sample -> (mask uint8 like u, q [B])."""
+    _req(u, name="u")
+    B = u.shape[0]
+    n = u.numel() // max(B, 1)
+    lo, hi, w = quantile_rank_split(p, n)
+    mask = torch.empty(u.shape, device=u.device, dtype=torch.uint8)
+    q = torch.empty(B, device=u.device, dtype=torch.float32)
+    check(_lib.lib().dua_quantile_mask(_p(u), B, n, lo, hi, w, _p(mask), _p(q), _stream()), "dua_quantile_mask")
+    return mask, q
+
+
+def posterior_blend(eps, u, mask, M, alpha_hat_t):
+    _req(eps, name="eps"), _req(u, name="u"), _req(mask, torch.uint8, "mask")
+    B = eps.shape[0]
+    out = torch.empty_like(eps)
+    check(_lib.lib().dua_posterior_blend(_p(eps), _p(u), _p(mask), _p(out), B, eps.numel() // max(B, 1), int(M),
+                                         float(alpha_hat_t), _stream()), "dua_posterior_blend")
+    return out
+
+
+def to_uint8(x):
+    _req(x, name="x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().dua_to_uint8(_p(x), _p(out), x.numel(), _stream()), "dua_to_uint8")
+    return out
+
+
+def randn(shape, device, seed, offset):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(_lib.lib().dua_randn(_p(out), out.numel(), int(seed), int(offset), _stream()), "dua_randn")
+    return out
+
+
+def dropout_mask(shape, device, p, seed, offset):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(_lib.lib().dua_dropout_mask(_p(out), out.numel(), float(p), int(seed), int(offset), _stream()), "dua_dropout_mask")
+    return out
+
+
+# ------------------------------------------------------------------ layout
+def nchw_to_nhwc(x, cpad=None):
+    _req(x, name="x")
+    N, C, H, W = x.shape
+    cpad = C if cpad is None else cpad
+    y = torch.empty((N, H, W, cpad), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_nchw_to_nhwc(_p(x), _p(y), N, C, H, W, cpad, _stream()), "dua_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, ckeep=None):
+    _req(x, name="x")
+    N, H, W, C = x.shape
+    ckeep = C if ckeep is None else ckeep
+    y = torch.empty((N, ckeep, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_nhwc_to_nchw(_p(x), _p(y), N, C, H, W, ckeep, _stream()), "dua_nhwc_to_nchw")
+    return y
+
+
+# ------------------------------------------------------------------ denoiser kernels
+def groupnorm_stats(x1, x2=None, groups=32, eps=1e-5):
+    _req(x1, name="x1")
+    N, H, W, C1 = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _req(x2, name="x2")
+        assert x2.shape[:3] == x1.shape[:3]
+        C2 = x2.shape[3]
+    L = _lib.lib()
+    ws = torch.empty(L.dua_groupnorm_ws_floats(N, H * W, C1 + C2, groups), device=x1.device, dtype=torch.float32)
+    stats = torch.empty((N, groups, 2), device=x1.device, dtype=torch.float32)
+    check(L.dua_groupnorm_stats(_p(x1), C1, _p(x2), C2, N, H * W, groups, float(eps), _p(ws), _p(stats), _stream()),
+          "dua_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32):
+    N, H, W, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
+    y = torch.empty((N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.float32)
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
+        _req(t, name=nm)
+    if film is not None:
+        _req(film, name="film")
+        assert film.shape == (N, 2 * (C1 + C2))
+    check(_lib.lib().dua_groupnorm_apply(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                                         int(act), int(resample), _p(dropmask), _p(y), _stream()), "dua_groupnorm_apply")
+    return y
+
+
+def resample2x(x, mode):
+    _req(x, name="x")
+    N, H, W, C = x.shape
+    Ho, Wo = (H // 2, W // 2) if mode < 0 else (2 * H, 2 * W)
+    y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_resample2x(_p(x), _p(y), N, H, W, C, int(mode), _stream()), "dua_resample2x")
+    return y
+
+
+def pack_conv3x3_weight(w):
+    """OIHW -> packed device layout consumed by conv3x3."""
+    _req(w, name="w")
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    wp = torch.empty(L.dua_conv3x3_packed_floats(Cout, Cin), device=w.device, dtype=torch.float32)
+    check(L.dua_pack_conv3x3_weight(_p(w), _p(wp), Cout, Cin, _stream()), "dua_pack_conv3x3_weight")
+    return wp
+
+
+def conv3x3(x, wp, bias, cout, residual=None, nchw_out=False):
+    _req(x, name="x"), _req(wp, name="wp")
+    N, H, W, Cin = x.shape
+    y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _req(residual, name="residual")
+        assert residual.shape == (N, H, W, cout)
+    check(_lib.lib().dua_conv3x3(_p(x), _p(wp), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _stream()),
+          "dua_conv3x3")
+    return y
+
+
+def gemm(a1, w, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0, out=None):
+    """C[M,N] = alpha * [a1 | a2] @ w.T (+bias) (+residual); a*: [M,K*] row-major, w: [N, K1+K2]."""
+    _req(a1, name="a1"), _req(w, name="w")
+    M, K1 = a1.shape
+    K2 = 0 if a2 is None else a2.shape[1]
+    N = w.shape[0]
+    assert w.shape[1] == K1 + K2
+    c = torch.empty((M, N), device=a1.device, dtype=torch.float32) if out is None else out
+    g = GemmArgs(A1=a1.data_ptr(), A2=(a2.data_ptr() if a2 is not None else None), B=w.data_ptr(),
+                 bias=(bias.data_ptr() if bias is not None else None),
+                 residual=(residual.data_ptr() if residual is not None else None), C=c.data_ptr(),
+                 M=M, N=N, K1=K1, K2=K2, lda1=K1, lda2=max(K2, 4), ldb=K1 + K2, ldc=N, ldr=N,
+                 batch=1, batch_inner=1, transB=1, act_in=act_in, act_out=act_out, alpha=alpha)
+    check(_lib.lib().dua_gemm(ctypes.byref(g), _stream()), "dua_gemm")
+    return c
+
+
+def gemm_raw(**kw):
+    g = GemmArgs(**kw)
+    check(_lib.lib().dua_gemm(ctypes.byref(g), _stream()), "dua_gemm")
+
+
+def softmax_rows_(S, rows, cols):
+    check(_lib.lib().dua_softmax_rows(_p(S), int(rows), int(cols), _stream()), "dua_softmax_rows")
+    return S
+
+
+def qkv_attention(qkv, B, T, heads, ch):
+    """qkv: [B*T, 3*heads*ch] laid out (q | k | v), head-major inside each third -> [B*T, heads*ch].
+
+    Reference: QKVAttentionLegacy / QKVAttention (unet_openai.py:338-355 / :371-390); the q/k scale
+    ch^-1/4 on both operands is applied as alpha = ch^-1/2 on the logits.  Materialises the logits in HBM
+    (round 1); S = QK^T and O = PV run on the fp32 MFMA tile engine, the softmax in dua_softmax_rows.
+    """
+    _req(qkv, name="qkv")
+    C = heads * ch
+    assert qkv.shape == (B * T, 3 * C)
+    S = torch.empty((B * heads, T, T), device=qkv.device, dtype=torch.float32)
+    out = torch.empty((B * T, C), device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    s = 1.0 / math.sqrt(math.sqrt(ch))
+    gemm_raw(A1=base, B=base + 4 * C, C=S.data_ptr(), M=T, N=T, K1=ch, K2=0, lda1=3 * C, lda2=4, ldb=3 * C, ldc=T, ldr=T,
+             sA1=T * 3 * C, sB=T * 3 * C, sC=heads * T * T, batch=B * heads, batch_inner=heads, sA1i=ch, sBi=ch,
+             sCi=T * T, transB=1, alpha=s * s)
+    softmax_rows_(S, B * heads * T, T)
+    gemm_raw(A1=S.data_ptr(), B=base + 8 * C, C=out.data_ptr(), M=T, N=ch, K1=T, K2=0, lda1=T, lda2=4, ldb=3 * C, ldc=C,
+             ldr=C, sA1=heads * T * T, sB=T * 3 * C, sC=T * C, batch=B * heads, batch_inner=heads, sA1i=T * T, sBi=ch,
+             sCi=ch, transB=0, alpha=1.0)
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _req(x, name="x")
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.lib().dua_layernorm(_p(x), _p(gamma), _p(beta), _p(y), x.numel() // D, D, float(eps), _stream()), "dua_layernorm")
+    return y
+
+
+def timestep_embedding(t, dim):
+    _req(t, torch.int64, "timesteps")
+    emb = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    check(_lib.lib().dua_timestep_embedding(_p(t), _p(emb), t.shape[0], dim, _stream()), "dua_timestep_embedding")
+    return emb
+
+
+def embedding_add(a, table, idx):
+    _req(table, name="table"), _req(idx, torch.int64, "idx")
+    N, D = idx.shape[0], table.shape[1]
+    out = torch.empty((N, D), device=table.device, dtype=torch.float32)
+    check(_lib.lib().dua_embedding_add(_p(a), _p(table), _p(idx), _p(out), N, D, _stream()), "dua_embedding_add")
+    return out

@@ -1,0 +1,152 @@
+/*
+ * dua_hip.h - C ABI of the MI355X (gfx950) hot-path library libdua_hip.so.
+ *
+ * The reference (Michedev/diffusion-uncertainty) is 100% Python: it has no FFI
+ * layer, its "kernels" are stock ATen ops.  This header is therefore the
+ * boundary a maintainer would bind with ctypes: one entry
+ * point per fused operation of the uncertainty-guided sampling hot path, each
+ * citing the reference lines it replaces (paths relative to
+ * diffusion_uncertainty/ in the reference tree).
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (HBM) unless the name ends in _host.
+ *  - fp32 everywhere; activations inside the denoiser are NHWC
+ *    ([N][H][W][C], C fastest), NCHW at the sampler edge.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *    Calls are asynchronous; nothing allocates, frees or synchronises.
+ *  - Return value: 0 on success, a negative DUA_E* code otherwise
+ *    (dua_last_error() returns a static description).  Caller owns all memory.
+ */
+#ifndef DUA_HIP_H
+#define DUA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUA_OK 0
+#define DUA_EINVAL (-1) /* bad shape / argument */
+#define DUA_EHIP (-2)   /* HIP runtime error at launch */
+
+int dua_version(void);
+const char* dua_last_error(void);
+
+/* ---------------- sampler (scheduler) kernels: HBM-bound ---------------- */
+
+/* DDIM update. schedulers_uncertainty/scheduling_ddim_uncertainty_zigzag_centered.py:473
+ * (x0), :490-493 (clip), :507-510 (prev), :523-525 (eta>0: + sigma*noise).
+ * noise may be NULL when sigma == 0. */
+int dua_ddim_step(const float* eps, const float* x, const float* noise, float* prev, float* x0, size_t n,
+                  float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float sqrt_alpha_prod_prev, float dir_coef,
+                  float sigma, int clip, float clip_range, void* stream);
+
+/* out = a*src + b*noise.  Re-noising of x_{t-1} (zigzag_centered.py:538, a=sqrt(1-beta_t), b=sqrt(beta_t)),
+ * DDPM add_noise (:575-604) and the SD guidance re-noise (uncertainty_guidance.py:88). */
+int dua_axpby(const float* src, const float* noise, float* out, size_t n, float a, float b, void* stream);
+
+/* Streaming centred second moment, zigzag_centered.py:549 / uncertainty_centered.py:540:
+ * acc = (m==0 ? 0 : acc) + (eps_m - eps)^2 ; when m == M-1 the sum is divided by M. */
+int dua_mc_centered_accum(const float* eps_m, const float* eps, float* acc, size_t n, int m, int M, void* stream);
+
+/* Same estimator from a materialised stack [M][n]. */
+int dua_mc_reduce_centered(const float* stack, const float* eps, float* u, size_t n, int M, void* stream);
+
+/* Unbiased variance over the leading axis of stack [M][n] (torch.var, scheduling_ddim_mc_dropout.py:506,
+ * uncertainty_guidance.py:106). */
+int dua_mc_reduce_var(const float* stack, float* u, size_t n, int M, void* stream);
+
+/* Per-sample quantile threshold, uncertainty_guidance.py:112: q[b] = torch.quantile(u[b].flatten(), p)
+ * ('linear', fp32 rank arithmetic) and mask = u > q (strict), bit-exact.  The caller passes the rank
+ * split computed in fp32 on the host: lo = floor(p32*(n-1)), hi = ceil(..), w = rank - lo.
+ * u: [B][n]; mask: [B][n] uint8 (0/1); q: [B]. */
+int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uint8_t* mask, float* q, void* stream);
+
+/* Posterior blend, uncertainty_guidance.py:115-120.  eps,u: [B][n]; mask: [B][n] uint8. */
+int dua_posterior_blend(const float* eps, const float* u, const uint8_t* mask, float* out, int B, int n, int M,
+                        float alpha_hat_t, void* stream);
+
+/* ((x/2+.5).clamp(0,1)*255).round() -> uint8, generate_samples.py:203-215. */
+int dua_to_uint8(const float* x, uint8_t* out, size_t n, void* stream);
+
+/* Device normal generator (Philox4x32-10 + Box-Muller); replaces torch.randn_like
+ * (zigzag_centered.py:500,532) when the caller does not need the CPU generator's stream. */
+int dua_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+
+/* Bernoulli keep-mask scaled by 1/(1-p) in place of nn.Dropout's mask (unet_openai.py:210). out: float [n]. */
+int dua_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---------------- layout ---------------- */
+/* NCHW [N][C][H][W] -> NHWC [N][H][W][Cpad] (channels >= C zero-filled). */
+int dua_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, void* stream);
+/* NHWC [N][H][W][C] -> NCHW [N][Ckeep][H][W] keeping the first Ckeep channels (traits.py:18 `[:, :3]`). */
+int dua_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int Ckeep, void* stream);
+
+/* ---------------- denoiser kernels (ADM UNet / U-ViT) ---------------- */
+
+/* GroupNorm statistics over the virtual channel-concat [x1 | x2] (x2 may be NULL, C2 = 0):
+ * guided_diffusion/nn.py:17-19 (GroupNorm32, 32 groups, eps 1e-5) on the concatenated skip input of
+ * unet_openai.py:662.  stats: [N][G][2] = (mean, rstd).  ws: >= dua_groupnorm_ws_floats(N, HW, C1+C2, G) floats. */
+size_t dua_groupnorm_ws_floats(int N, int HW, int C, int G);
+int dua_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N, int HW, int G, float eps,
+                        float* ws, float* stats, void* stream);
+
+/* y = act(GN(x)*gamma+beta [*(1+scale)+shift]) [*dropmask], optionally followed by 2x2 average pooling
+ * (resample=-1) or nearest x2 upsampling (resample=+1): unet_openai.py:183-187 (in_layers), :207-214 and
+ * :249-253 (FiLM out_layers), :191-196 (h_upd).  film: [N][2*C] (scale | shift) or NULL. act: 1 = SiLU.
+ * dropmask: [N][H][W][C] float keep/(1-p) or NULL.  y: NHWC at the resampled size. */
+int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                        const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                        int resample, const float* dropmask, float* y, void* stream);
+
+/* x_upd of an up/down ResBlock (unet_openai.py:191-196,243): resample=-1 avg-pool 2x2, +1 nearest x2. */
+int dua_resample2x(const float* x, float* y, int N, int H, int W, int C, int resample, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on fp32 MFMA (unet_openai.py:186,212,483,616).
+ * x: NHWC [N][H][W][Cin]; wp: weights packed by dua_pack_conv3x3_weight ([CoutPad][9][Cin], Cin%32==0, or the
+ * small-Cin form [CoutPad][16][4] when Cin == 4); bias [Cout]; residual NHWC [N][H][W][Cout] or NULL (the
+ * `skip_connection(x) + h` of :257).  nchw_out != 0 writes y as NCHW [N][Cout][H][W]. */
+int dua_conv3x3(const float* x, const float* wp, const float* bias, const float* residual, float* y, int N, int H,
+                int W, int Cin, int Cout, int nchw_out, void* stream);
+/* OIHW [Cout][CinReal][3][3] -> packed form above (CinPad is 4 for CinReal<=4, else CinReal). */
+size_t dua_conv3x3_packed_floats(int Cout, int Cin);
+int dua_pack_conv3x3_weight(const float* w_oihw, float* wp, int Cout, int CinReal, void* stream);
+
+/* Batched GEMM  C[b] = alpha * A[b] * op(B[b]) (+ bias) (+ residual), fp32 MFMA.
+ * A is the virtual K-concat [A1 | A2] (row-major, leading dims lda1/lda2; A2 may be NULL with K2 = 0):
+ * the 1x1 skip conv on the concatenated input (unet_openai.py:223,662), qkv / proj_out (:287,295),
+ * the time / label MLPs (:472-476, :200-206) and the attention products (:350-354).
+ * transB = 1: B is [N][K] (weights, K^T);  transB = 0: B is [K][N].
+ * act: 0 none, 1 SiLU on the INPUT A (emb_layers' leading SiLU), 2 GELU on the output (timm.py:105).
+ * Strides are in floats; batch strides may be 0 (shared operand). */
+typedef struct {
+    const float* A1; const float* A2; const float* B; const float* bias; const float* residual; float* C;
+    int M, N, K1, K2;
+    long lda1, lda2, ldb, ldc, ldr;
+    long sA1, sA2, sB, sC, sR;          /* batch strides */
+    int batch, batch_inner;              /* batch index b -> (b / batch_inner, b % batch_inner); see below */
+    long sA1i, sBi, sCi;                 /* inner batch strides (heads inside one image) */
+    int transB, act_in, act_out;
+    float alpha;
+} dua_gemm_args;
+int dua_gemm(const dua_gemm_args* args_host, void* stream);
+
+/* Row softmax in place over the last axis of S [rows][cols] fp32 (unet_openai.py:353 / :388). */
+int dua_softmax_rows(float* S, long rows, int cols, void* stream);
+
+/* LayerNorm over the last axis (U-ViT, uvit/uvit.py:108-110,225): y = (x-mean)*rstd*gamma+beta, eps 1e-5. */
+int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps,
+                  void* stream);
+
+/* emb[n][:] = sinusoidal timestep embedding (guided_diffusion/nn.py:103-121), t int64 [N]. */
+int dua_timestep_embedding(const int64_t* t, float* emb, int N, int dim, void* stream);
+
+/* out[n][:] = a[n][:] + table[idx[n]][:]  (label embedding add, unet_openai.py:654). a may be NULL. */
+int dua_embedding_add(const float* a, const float* table, const int64_t* idx, float* out, int N, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUA_HIP_H */

@@ -1,0 +1,235 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle / torch fp32 references."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import T
+
+pytestmark = pytest.mark.gpu
+
+dev = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diffusion_uncertainty_amd import ops as o
+    return o
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def test_ddim_step_bit_exact_vs_golden(ops, golden):
+    from oracle import ddim, schedule
+    g = golden("g2_ddim_step")
+    eps, x = T(g["eps"]), T(g["x"])
+    tabs = {0: schedule.Tables(), 1: schedule.Tables(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")}
+    for c in range(int(g["n_cases"])):
+        which, t, eta = g[f"c{c}_meta"]
+        tab = tabs[int(which)]
+        co = ddim.step_coefficients(tab, int(t), 50, float(eta))
+        noise = None
+        if eta > 0:
+            torch.manual_seed(100 + c)
+            noise = torch.randn_like(eps).to(dev)
+        prev, x0 = ops.ddim_step(eps.to(dev), x.to(dev), co["sqrt_b_t"], co["sqrt_a_t"], co["sqrt_a_prev"], co["dir_coef"],
+                                 sigma=float(co["sigma"]), noise=noise, clip=(int(which) == 0))
+        np.testing.assert_array_equal(x0.cpu().numpy(), g[f"c{c}_x0"])
+        np.testing.assert_allclose(prev.cpu().numpy(), g[f"c{c}_prev"], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 1024, 3 * 128 * 128 * 2 + 3])
+def test_elementwise_sizes(ops, n):
+    a, b = rnd(1, n), rnd(2, n)
+    out = ops.axpby(a.to(dev), b.to(dev), 0.75, -1.25)
+    np.testing.assert_array_equal(out.cpu().numpy(), (0.75 * a + (-1.25) * b).numpy())
+    if n:
+        u8 = ops.to_uint8((a * 1.2).to(dev))
+        ref = (((a * 1.2) / 2 + 0.5).clamp(0, 1) * 255.0).round().to(torch.uint8)
+        np.testing.assert_array_equal(u8.cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("M", [2, 5, 10])
+def test_mc_reductions(ops, M):
+    st, e = rnd(3, M, 2, 3, 16, 16), rnd(4, 2, 3, 16, 16)
+    u = ops.mc_reduce_centered(st.to(dev), e.to(dev))
+    ref = (st - e[None]).pow(2).mean(0)
+    np.testing.assert_allclose(u.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+    acc = torch.empty_like(e, device=dev)
+    for m in range(M):
+        ops.mc_centered_accum(st[m].to(dev), e.to(dev), acc, m, M)
+    np.testing.assert_array_equal(acc.cpu().numpy(), u.cpu().numpy())
+    v = ops.mc_reduce_var(st.to(dev))
+    np.testing.assert_allclose(v.cpu().numpy(), torch.var(st, dim=0).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_quantile_mask_bit_exact_golden(ops, golden):
+    g = golden("g7_guidance")
+    for name in ("rand", "ties", "const", "adm128_like", "odd_n"):
+        u = T(g[f"u_{name}"]).to(dev)
+        for p in g["ps"]:
+            mask, q = ops.quantile_mask(u, float(p))
+            np.testing.assert_array_equal(q.cpu().numpy(), g[f"q_{name}_{p}"])
+            np.testing.assert_array_equal(mask.cpu().numpy(), g[f"mask_{name}_{p}"])
+
+
+def test_quantile_mask_full_size_properties(ops):
+    """BASELINE size: [128, 3, 128, 128]; properties: exactly n - (hi+1) .. n - lo - 1 elements above q,
+    agreement with the oracle's sort-based quantile."""
+    from oracle import guidance
+    u = (rnd(5, 128, 3, 128, 128) ** 2)
+    mask, q = ops.quantile_mask(u.to(dev), 0.9)
+    mref, qref = guidance.quantile_mask(u.numpy(), 0.9)
+    np.testing.assert_array_equal(q.cpu().numpy(), qref)
+    np.testing.assert_array_equal(mask.cpu().numpy(), mref)
+    # negative values and -0.0 / +0.0 order correctly
+    v = rnd(6, 4, 1000)
+    v[:, :10] = 0.0
+    v[:, 10:20] = -0.0
+    for p in (0.0, 0.3, 0.5, 1.0):
+        mask, q = ops.quantile_mask(v.to(dev), p)
+        mref, qref = guidance.quantile_mask(v.numpy(), p)
+        np.testing.assert_array_equal(q.cpu().numpy(), qref)
+        np.testing.assert_array_equal(mask.cpu().numpy(), mref)
+
+
+def test_posterior_blend(ops):
+    from oracle import guidance
+    eps, u = rnd(7, 1, 4, 64, 64), rnd(8, 1, 4, 64, 64) ** 2 + 1e-3
+    mask, _ = guidance.quantile_mask(u.numpy(), 0.9)
+    out = ops.posterior_blend(eps.to(dev), u.to(dev), T(mask).to(dev), 5, 0.3)
+    ref = guidance.posterior_blend(eps.numpy(), u.numpy(), mask, 5, 0.3)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_randn_statistics(ops):
+    z = ops.randn((4, 3, 128, 128), dev, seed=1, offset=0).cpu()
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    assert torch.isfinite(z).all()
+    z2 = ops.randn((4, 3, 128, 128), dev, seed=1, offset=0).cpu()
+    assert torch.equal(z, z2)
+    z3 = ops.randn((4, 3, 128, 128), dev, seed=1, offset=z.numel() // 4).cpu()
+    assert not torch.equal(z, z3)
+    k = float(((z ** 4).mean() / (z ** 2).mean() ** 2))
+    assert abs(k - 3.0) < 0.1
+    m = ops.dropout_mask((1 << 20,), dev, 0.1, seed=3, offset=0).cpu()
+    assert set(np.unique(m.numpy()).tolist()) <= {0.0, np.float32(1 / 0.9).item()}
+    assert abs((m > 0).float().mean().item() - 0.9) < 3e-3
+
+
+def test_layout_roundtrip(ops):
+    x = rnd(9, 3, 5, 6, 7)
+    y = ops.nchw_to_nhwc(x.to(dev), 8)
+    assert torch.equal(y[..., :5].cpu(), nhwc(x)) and (y[..., 5:] == 0).all()
+    z = ops.nhwc_to_nchw(y, 3)
+    assert torch.equal(z.cpu(), x[:, :3])
+
+
+@pytest.mark.parametrize("C1,C2,H", [(32, 0, 8), (64, 32, 8), (192, 0, 16), (256, 0, 32), (576, 384, 4), (1024, 1024, 8), (1280, 0, 4)])
+def test_groupnorm(ops, C1, C2, H):
+    N = 2
+    x1 = rnd(10, N, C1, H, H) * 2 + 0.5
+    x2 = rnd(11, N, C2, H, H) - 1 if C2 else None
+    xc = torch.cat([x1, x2], 1) if C2 else x1
+    C = C1 + C2
+    ga, be = 1 + 0.1 * rnd(12, C), 0.1 * rnd(13, C)
+    film = rnd(14, N, 2 * C) * 0.5
+    d1, d2 = nhwc(x1).to(dev), (nhwc(x2).to(dev) if C2 else None)
+    stats = ops.groupnorm_stats(d1, d2)
+    xr = xc.reshape(N, 32, -1).double()
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), xr.mean(-1).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(stats[..., 1].cpu().numpy(), (xr.var(-1, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-5)
+    gn = F.group_norm(xc, 32, ga, be)
+    # plain GN+SiLU
+    y = ops.groupnorm_apply(d1, stats, ga.to(dev), be.to(dev), x2=d2, act=1)
+    np.testing.assert_allclose(nchw(y.cpu()).numpy(), F.silu(gn).numpy(), rtol=1e-4, atol=1e-5)
+    # FiLM + SiLU
+    sc, sh = film[:, :C, None, None], film[:, C:, None, None]
+    y = ops.groupnorm_apply(d1, stats, ga.to(dev), be.to(dev), x2=d2, film=film.to(dev), act=1)
+    np.testing.assert_allclose(nchw(y.cpu()).numpy(), F.silu(gn * (1 + sc) + sh).numpy(), rtol=1e-4, atol=1e-5)
+    # no activation (attention norm)
+    y = ops.groupnorm_apply(d1, stats, ga.to(dev), be.to(dev), x2=d2, act=0)
+    np.testing.assert_allclose(nchw(y.cpu()).numpy(), gn.numpy(), rtol=1e-4, atol=1e-5)
+    if C2 == 0:
+        y = ops.groupnorm_apply(d1, stats, ga.to(dev), be.to(dev), act=1, resample=-1)
+        np.testing.assert_allclose(nchw(y.cpu()).numpy(), F.avg_pool2d(F.silu(gn), 2, 2).numpy(), rtol=1e-4, atol=1e-5)
+        y = ops.groupnorm_apply(d1, stats, ga.to(dev), be.to(dev), act=1, resample=1)
+        np.testing.assert_allclose(nchw(y.cpu()).numpy(), F.interpolate(F.silu(gn), scale_factor=2, mode="nearest").numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(nchw(ops.resample2x(d1, -1).cpu()).numpy(), F.avg_pool2d(x1, 2, 2).numpy())
+        np.testing.assert_array_equal(nchw(ops.resample2x(d1, 1).cpu()).numpy(), F.interpolate(x1, scale_factor=2, mode="nearest").numpy())
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 8, 3, 32),
+                                             (2, 16, 16, 32, 6), (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192)])
+def test_conv3x3(ops, N, H, W, Cin, Cout):
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    wp = ops.pack_conv3x3_weight(w.to(dev))
+    xd = ops.nchw_to_nhwc(x.to(dev), 4) if Cin <= 4 else nhwc(x).to(dev)
+    y = ops.conv3x3(xd, wp, b.to(dev), Cout)
+    np.testing.assert_allclose(nchw(y.cpu()).numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
+    y = ops.conv3x3(xd, wp, b.to(dev), Cout, residual=nhwc(res).to(dev))
+    np.testing.assert_allclose(nchw(y.cpu()).numpy(), (ref + res).float().numpy(), rtol=1e-4, atol=2e-5)
+    y = ops.conv3x3(xd, wp, b.to(dev), Cout, nchw_out=True)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0),
+                                       (258, 1152, 16, 0), (130, 260, 100, 0)])
+def test_gemm(ops, M, N, K1, K2):
+    a1, a2 = rnd(30, M, K1), (rnd(31, M, K2) if K2 else None)
+    w, b, r = rnd(32, N, K1 + K2) / math.sqrt(K1 + K2), rnd(33, N), rnd(34, M, N)
+    a = torch.cat([a1, a2], 1) if K2 else a1
+    ref = a.double() @ w.double().T
+    c = ops.gemm(a1.to(dev), w.to(dev), a2=(a2.to(dev) if K2 else None))
+    np.testing.assert_allclose(c.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
+    c = ops.gemm(a1.to(dev), w.to(dev), bias=b.to(dev), a2=(a2.to(dev) if K2 else None), residual=r.to(dev), alpha=0.5)
+    np.testing.assert_allclose(c.cpu().numpy(), (0.5 * ref + b + r).float().numpy(), rtol=1e-4, atol=2e-5)
+    c = ops.gemm(a1.to(dev), w.to(dev), bias=b.to(dev), a2=(a2.to(dev) if K2 else None), act_in=1)
+    np.testing.assert_allclose(c.cpu().numpy(), (F.silu(a.double()) @ w.double().T + b).float().numpy(), rtol=1e-4, atol=2e-5)
+    c = ops.gemm(a1.to(dev), w.to(dev), bias=b.to(dev), a2=(a2.to(dev) if K2 else None), act_out=2)
+    np.testing.assert_allclose(c.cpu().numpy(), F.gelu(ref + b).float().numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,T_,heads,ch", [(2, 64, 4, 32), (1, 16, 2, 64), (2, 256, 4, 96), (1, 1024, 4, 128), (3, 64, 4, 256), (2, 258, 16, 72)])
+def test_qkv_attention(ops, B, T_, heads, ch):
+    from oracle import adm
+    C = heads * ch
+    qkv = rnd(40, B, 3 * C, T_)                       # reference layout [B, 3C, T], NEW order (q|k|v thirds)
+    ref = adm.qkv_attention(qkv, heads, True)         # [B, C, T]
+    d = qkv.permute(0, 2, 1).reshape(B * T_, 3 * C).contiguous().to(dev)
+    out = ops.qkv_attention(d, B, T_, heads, ch)
+    np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_softmax_layernorm_embeddings(ops):
+    from oracle import adm
+    for cols in (1, 64, 100, 258, 1024, 2048):
+        s = rnd(50, 37, cols) * 3
+        d = s.to(dev).clone()
+        ops.softmax_rows_(d, 37, cols)
+        np.testing.assert_allclose(d.cpu().numpy(), torch.softmax(s, -1).numpy(), rtol=1e-5, atol=1e-7)
+    for D in (64, 1152):
+        x, ga, be = rnd(51, 2, 18, D) * 2 + 1, rnd(52, D), rnd(53, D)
+        y = ops.layernorm(x.to(dev), ga.to(dev), be.to(dev))
+        np.testing.assert_allclose(y.cpu().numpy(), F.layer_norm(x, (D,), ga, be).numpy(), rtol=1e-4, atol=1e-5)
+    t = torch.tensor([0, 1, 500, 999])
+    for dim in (256, 192, 193):
+        e = ops.timestep_embedding(t.to(dev), dim)
+        np.testing.assert_allclose(e.cpu().numpy(), adm.timestep_embedding(t, dim).numpy(), rtol=0, atol=2e-4)
+    tab, idx, a = rnd(54, 10, 32), torch.tensor([3, 0, 9]), rnd(55, 3, 32)
+    o = ops.embedding_add(a.to(dev), tab.to(dev), idx.to(dev))
+    np.testing.assert_array_equal(o.cpu().numpy(), (a + tab[idx]).numpy())
