@@ -269,11 +269,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 template <int PER>
-__global__ __launch_bounds__(BLK) void k_softmax_rows(float* __restrict__ S, long rows, int cols) {
+__global__ __launch_bounds__(BLK) void k_softmax_rows(float* __restrict__ S, long rows, int cols, long ld) {
     long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
-    float* r = S + row * (long)cols;
+    float* r = S + row * ld;
     float v[PER];
     float m = -INFINITY;
 #pragma unroll
@@ -297,15 +297,15 @@ __global__ __launch_bounds__(BLK) void k_softmax_rows(float* __restrict__ S, lon
         if (c < cols) r[c] = v[j] * inv;
     }
 }
-extern "C" int dua_softmax_rows(float* S, long rows, int cols, void* stream) {
-    DUA_REQUIRE(S && rows >= 0 && cols >= 1 && cols <= 2048, "dua_softmax_rows: cols must be in [1, 2048]");
+extern "C" int dua_softmax_rows(float* S, long rows, int cols, long ld, void* stream) {
+    DUA_REQUIRE(S && rows >= 0 && cols >= 1 && cols <= 2048 && ld >= cols, "dua_softmax_rows: cols must be in [1, 2048], ld >= cols");
     if (rows == 0) return DUA_OK;
     unsigned grid = (unsigned)((rows + 3) / 4);
-    if (cols <= 64) hipLaunchKernelGGL(k_softmax_rows<1>, grid, BLK, 0, as_stream(stream), S, rows, cols);
-    else if (cols <= 256) hipLaunchKernelGGL(k_softmax_rows<4>, grid, BLK, 0, as_stream(stream), S, rows, cols);
-    else if (cols <= 512) hipLaunchKernelGGL(k_softmax_rows<8>, grid, BLK, 0, as_stream(stream), S, rows, cols);
-    else if (cols <= 1024) hipLaunchKernelGGL(k_softmax_rows<16>, grid, BLK, 0, as_stream(stream), S, rows, cols);
-    else hipLaunchKernelGGL(k_softmax_rows<32>, grid, BLK, 0, as_stream(stream), S, rows, cols);
+    if (cols <= 64) hipLaunchKernelGGL(k_softmax_rows<1>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
+    else if (cols <= 256) hipLaunchKernelGGL(k_softmax_rows<4>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
+    else if (cols <= 512) hipLaunchKernelGGL(k_softmax_rows<8>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
+    else if (cols <= 1024) hipLaunchKernelGGL(k_softmax_rows<16>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
+    else hipLaunchKernelGGL(k_softmax_rows<32>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
     return dua_check_launch("dua_softmax_rows");
 }
 
@@ -383,4 +383,67 @@ extern "C" int dua_embedding_add(const float* a, const float* table, const int64
     if (N == 0) return DUA_OK;
     hipLaunchKernelGGL(k_embedding_add, (N * D + 255) / 256, 256, 0, as_stream(stream), a, table, idx, out, N, D);
     return dua_check_launch("dua_embedding_add");
+}
+
+// =================================== U-ViT token plumbing ======================================
+__global__ void k_patchify(const float* __restrict__ x, float* __restrict__ rows, int B, int C, int H, int W, int P) {
+    int gw = W / P, gh = H / P, K = C * P * P;
+    size_t total = (size_t)B * gh * gw * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(i % K);
+        size_t r = i / K;
+        int pw = (int)(r % gw), ph = (int)((r / gw) % gh), b = (int)(r / ((size_t)gw * gh));
+        int c = k / (P * P), p1 = (k / P) % P, p2 = k % P;
+        rows[i] = x[(((size_t)b * C + c) * H + ph * P + p1) * W + pw * P + p2];
+    }
+}
+extern "C" int dua_patchify(const float* x, float* rows, int B, int C, int H, int W, int P, void* stream) {
+    DUA_REQUIRE(x && rows && P > 0 && H % P == 0 && W % P == 0, "dua_patchify: bad arguments");
+    size_t total = (size_t)B * C * H * W;
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_patchify, stream_grid(total, 256), 256, 0, as_stream(stream), x, rows, B, C, H, W, P);
+    return dua_check_launch("dua_patchify");
+}
+
+__global__ void k_uvit_assemble(const float* __restrict__ patches, const float* __restrict__ tt, const float* __restrict__ table,
+                                const int64_t* __restrict__ y, const float* __restrict__ pos, float* __restrict__ out, int B, int L, int D) {
+    int extras = y ? 2 : 1, T = L + extras;
+    size_t total = (size_t)B * T * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int d = (int)(i % D);
+        size_t r = i / D;
+        int tok = (int)(r % T), b = (int)(r / T);
+        float v;
+        if (y && tok == 0) v = table[(size_t)y[b] * D + d];
+        else if (tok == extras - 1) v = tt[(size_t)b * D + d];
+        else v = patches[((size_t)b * L + (tok - extras)) * D + d];
+        out[i] = v + pos[(size_t)tok * D + d];
+    }
+}
+extern "C" int dua_uvit_assemble(const float* patches, const float* time_tok, const float* label_table, const int64_t* y,
+                                 const float* pos_embed, float* out, int B, int L, int D, void* stream) {
+    DUA_REQUIRE(patches && time_tok && pos_embed && out && (!y || label_table), "dua_uvit_assemble: bad arguments");
+    size_t total = (size_t)B * (L + 2) * D;
+    if (B == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_uvit_assemble, stream_grid(total, 256), 256, 0, as_stream(stream), patches, time_tok, label_table, y, pos_embed, out, B, L, D);
+    return dua_check_launch("dua_uvit_assemble");
+}
+
+__global__ void k_unpatchify(const float* __restrict__ tok, float* __restrict__ img, int B, int L, int extras, int C, int P, int g) {
+    int H = g * P;
+    size_t total = (size_t)B * C * H * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int xw = (int)(i % H), yh = (int)((i / H) % H), c = (int)((i / ((size_t)H * H)) % C), b = (int)(i / ((size_t)H * H * C));
+        int ph = yh / P, p1 = yh % P, pw = xw / P, p2 = xw % P;
+        img[i] = tok[((size_t)b * (L + extras) + extras + ph * g + pw) * (P * P * C) + (p1 * P + p2) * C + c];
+    }
+}
+extern "C" int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C, int P, void* stream) {
+    int g = 1;
+    while (g * g < L) ++g;
+    DUA_REQUIRE(tok && img && g * g == L && extras >= 0, "dua_unpatchify: L must be a square");
+    size_t total = (size_t)B * C * g * P * g * P;
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_unpatchify, stream_grid(total, 256), 256, 0, as_stream(stream), tok, img, B, L, extras, C, P, g);
+    return dua_check_launch("dua_unpatchify");
 }

@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
             for (int i = 0; i < 4; ++i) {
                 int m = m0 + r0 + 32 * i;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < p.M && k < K) v = *(const float4*)(src + (long)m * ld + kk);
+                if (m < p.M) {
+                    const float* q = src + (long)m * ld + kk;
+                    if (k + 3 < K) v = *(const float4*)q;
+                    else if (k < K) { v.x = q[0]; if (k + 1 < K) v.y = q[1]; if (k + 2 < K) v.z = q[2]; }
+                }
                 if (p.act_in == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
                 ra[i] = v;
             }
@@ -143,7 +147,11 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
                 int n = n0 + r0 + 32 * i;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (MODE != MODE_GEMM) v = *(const float4*)(Bp + (long)n * K + k);          // packed + padded weights
-                else if (n < p.N && k < K) v = *(const float4*)(Bp + (long)n * p.ldb + k);
+                else if (n < p.N) {
+                    const float* q = Bp + (long)n * p.ldb + k;
+                    if (k + 3 < K) v = *(const float4*)q;
+                    else if (k < K) { v.x = q[0]; if (k + 1 < K) v.y = q[1]; if (k + 2 < K) v.z = q[2]; }
+                }
                 rb[i] = v;
             }
         } else {        // B is [K][N]: thread -> (k row kr + 8 i, float4 column n4)
@@ -253,7 +261,7 @@ static int launch_tile(TileP& p, int batch, hipStream_t s) {
 extern "C" int dua_gemm(const dua_gemm_args* a, void* stream) {
     DUA_REQUIRE(a && a->A1 && a->B && a->C, "dua_gemm: null pointer");
     DUA_REQUIRE(a->M > 0 && a->N > 0 && a->K1 > 0 && a->K2 >= 0 && a->batch >= 1 && a->batch_inner >= 1, "dua_gemm: bad sizes");
-    DUA_REQUIRE((a->K1 + a->K2) % 4 == 0 && a->lda1 % 4 == 0 && a->ldb % 4 == 0, "dua_gemm: K and leading dims must be multiples of 4 floats");
+    DUA_REQUIRE(a->lda1 % 4 == 0 && a->ldb % 4 == 0, "dua_gemm: leading dims must be multiples of 4 floats (K itself may be ragged)");
     DUA_REQUIRE((a->K2 == 0) == (a->A2 == nullptr), "dua_gemm: A2/K2 mismatch");
     DUA_REQUIRE(a->K2 == 0 || (a->K1 % 4 == 0 && a->lda2 % 4 == 0), "dua_gemm: K1 must be a multiple of 4 for a two-source A");
     DUA_REQUIRE(a->transB || a->N % 4 == 0, "dua_gemm: N must be a multiple of 4 when B is [K][N]");

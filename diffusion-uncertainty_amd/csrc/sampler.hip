@@ -53,8 +53,8 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int dua_ddim_step(const float* eps, const float* x, const float* noise, float* prev, float* x0, size_t n,
                              float sb, float sa, float sap, float dc, float sigma, int clip, float cr, void* stream) {
-    DUA_REQUIRE(eps && x && prev && x0, "dua_ddim_step: null pointer");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(eps && x && prev && x0, "dua_ddim_step: null pointer");
     if (sigma == 0.f) noise = nullptr;
     bool vec = (n % 4 == 0) && aligned16(eps) && aligned16(x) && aligned16(prev) && aligned16(x0) && (!noise || aligned16(noise));
     if (vec)
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(BLK) void k_axpby(const float* __restrict__ s, cons
     }
 }
 extern "C" int dua_axpby(const float* src, const float* noise, float* out, size_t n, float a, float b, void* stream) {
-    DUA_REQUIRE(src && noise && out, "dua_axpby: null pointer");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(src && noise && out, "dua_axpby: null pointer");
     int vec = (n % 4 == 0) && aligned16(src) && aligned16(noise) && aligned16(out);
     hipLaunchKernelGGL(k_axpby, stream_grid(vec ? n / 4 : n, BLK), BLK, 0, as_stream(stream), src, noise, out, n, a, b, vec);
     return dua_check_launch("dua_axpby");
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(BLK) void k_mc_accum(const float* __restrict__ em, 
     }
 }
 extern "C" int dua_mc_centered_accum(const float* eps_m, const float* eps, float* acc, size_t n, int m, int M, void* stream) {
-    DUA_REQUIRE(eps_m && eps && acc && M >= 1 && m >= 0 && m < M, "dua_mc_centered_accum: bad arguments");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(eps_m && eps && acc && M >= 1 && m >= 0 && m < M, "dua_mc_centered_accum: bad arguments");
     hipLaunchKernelGGL(k_mc_accum, stream_grid(n, BLK), BLK, 0, as_stream(stream), eps_m, eps, acc, n, m == 0, m == M - 1, (float)M);
     return dua_check_launch("dua_mc_centered_accum");
 }
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(BLK) void k_mc_centered(const float* __restrict__ s
     }
 }
 extern "C" int dua_mc_reduce_centered(const float* stack, const float* eps, float* u, size_t n, int M, void* stream) {
-    DUA_REQUIRE(stack && eps && u && M >= 1, "dua_mc_reduce_centered: bad arguments");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(stack && eps && u && M >= 1, "dua_mc_reduce_centered: bad arguments");
     hipLaunchKernelGGL(k_mc_centered, stream_grid(n, BLK), BLK, 0, as_stream(stream), stack, eps, u, n, M);
     return dua_check_launch("dua_mc_reduce_centered");
 }
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(BLK) void k_mc_var(const float* __restrict__ st, fl
     }
 }
 extern "C" int dua_mc_reduce_var(const float* stack, float* u, size_t n, int M, void* stream) {
-    DUA_REQUIRE(stack && u && M >= 2, "dua_mc_reduce_var: need M >= 2");
+    DUA_REQUIRE(M >= 2, "dua_mc_reduce_var: need M >= 2");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(stack && u, "dua_mc_reduce_var: null pointer");
     hipLaunchKernelGGL(k_mc_var, stream_grid(n, BLK), BLK, 0, as_stream(stream), stack, u, n, M);
     return dua_check_launch("dua_mc_reduce_var");
 }
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(BLK) void k_to_uint8(const float* __restrict__ x, u
     }
 }
 extern "C" int dua_to_uint8(const float* x, uint8_t* out, size_t n, void* stream) {
-    DUA_REQUIRE(x && out, "dua_to_uint8: null pointer");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(x && out, "dua_to_uint8: null pointer");
     hipLaunchKernelGGL(k_to_uint8, stream_grid(n, BLK), BLK, 0, as_stream(stream), x, out, n);
     return dua_check_launch("dua_to_uint8");
 }
@@ -298,8 +299,8 @@ __global__ __launch_bounds__(BLK) void k_randn(float* __restrict__ out, size_t n
     }
 }
 extern "C" int dua_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
-    DUA_REQUIRE(out, "dua_randn: null pointer");
     if (n == 0) return DUA_OK;
+    DUA_REQUIRE(out, "dua_randn: null pointer");
     hipLaunchKernelGGL(k_randn, stream_grid((n + 3) / 4, BLK), BLK, 0, as_stream(stream), out, n, seed, offset);
     return dua_check_launch("dua_randn");
 }

@@ -1,0 +1,299 @@
+"""ADM (guided-diffusion) UNet on the gfx950 HIP library.
+
+Host-side mirror of reference ``guided_diffusion/unet_openai.py``: same constructor arguments
+(``UNetModel.__init__`` :425-617), same module nesting and therefore the same state-dict keys as the
+OpenAI checkpoints (``input_blocks.N.0.in_layers.2.weight``, ``...1.qkv.weight`` ...), same call
+convention ``model(x[B,C,H,W], t[B] int64, y=labels) -> [B,out_channels,H,W]`` and the same assertion on a
+missing/extra ``y`` (:644-646).  The nn modules below only HOLD parameters; ``forward`` drives the
+C ABI (include/dua_hip.h): activations are NHWC fp32 in HBM, every conv / linear / attention product
+runs on the fp32 MFMA tile engine, GroupNorm+SiLU(+FiLM, +dropout mask, +2x resampling) is one fused
+kernel, the skip concat of :662 is never materialised (two-source GroupNorm / GEMM operands).
+
+Only the configuration family the reference instantiates (init_model.py:21,45-47) is supported:
+dims=2, use_scale_shift_norm=True, resblock_updown=True.  There is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .nn import normalization
+
+
+def zero_module(module):
+    """guided_diffusion/nn.py:68-74 - kept so a fresh model matches the reference's init."""
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class TimestepBlock(nn.Module):
+    pass
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    def run(self, ctx, h, skip=None):
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                h = layer.run(ctx, h, skip)
+                skip = None
+            elif isinstance(layer, AttentionBlock):
+                h = layer.run(ctx, h)
+            else:                                   # input conv
+                h = ops.conv3x3(h, ctx.packed(layer, "w3"), layer.bias, layer.out_channels)
+        return h
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None):
+        super().__init__()
+        assert not use_conv and dims == 2, "only the conv-free resampler of resblock_updown=True is built"
+        self.channels = channels
+
+
+class Downsample(Upsample):
+    pass
+
+
+class ResBlock(TimestepBlock):
+    """unet_openai.py:144-257."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        assert dims == 2 and use_scale_shift_norm and not use_conv, "unsupported ResBlock variant"
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(),
+                                       nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.updown = up or down
+        self.resample = 1 if up else (-1 if down else 0)
+        if up:
+            self.h_upd, self.x_upd = Upsample(channels, False), Upsample(channels, False)
+        elif down:
+            self.h_upd, self.x_upd = Downsample(channels, False), Downsample(channels, False)
+        else:
+            self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+
+    def run(self, ctx, x, skip=None):
+        """x (and optional skip = second half of the channel concat): NHWC."""
+        gn1, conv1 = self.in_layers[0], self.in_layers[2]
+        gn2, drop, conv2 = self.out_layers[0], self.out_layers[2], self.out_layers[3]
+        N, H, W, _ = x.shape
+        st = ops.groupnorm_stats(x, skip)
+        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample)
+        if self.updown:
+            x = ops.resample2x(x, self.resample)                                   # x_upd :243
+        h = ops.conv3x3(h, ctx.packed(conv1, "w3"), conv1.bias, self.out_channels)
+        film = ops.gemm(ctx.emb, self.emb_layers[1].weight, bias=self.emb_layers[1].bias, act_in=1)   # :245
+        st2 = ops.groupnorm_stats(h)
+        mask = None
+        if drop.training and drop.p > 0:
+            mask = ctx.dropout_mask(h.shape, drop.p)
+        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask)      # :249-253
+        if isinstance(self.skip_connection, nn.Identity):
+            assert skip is None
+            res = x
+        else:
+            sc = self.skip_connection
+            Hx, Wx = x.shape[1], x.shape[2]
+            res = ops.gemm(x.view(N * Hx * Wx, -1), ctx.packed(sc, "w1"), bias=sc.bias,
+                           a2=(skip.view(N * Hx * Wx, -1) if skip is not None else None)).view(N, Hx, Wx, self.out_channels)
+        return ops.conv3x3(h, ctx.packed(conv2, "w3"), conv2.bias, self.out_channels, residual=res)   # :257
+
+
+class QKVAttentionLegacy(nn.Module):
+    """Marker for the head-first qkv split (unet_openai.py:329-355)."""
+
+    def __init__(self, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+
+
+class QKVAttention(nn.Module):
+    """Marker for the chunk-first qkv split (unet_openai.py:362-390)."""
+
+    def __init__(self, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+
+
+class AttentionBlock(nn.Module):
+    """unet_openai.py:260-306."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False, use_new_attention_order=False):
+        super().__init__()
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0, \
+                f"q,k,v channels {channels} is not divisible by num_head_channels {num_head_channels}"
+            self.num_heads = channels // num_head_channels
+        self.norm = normalization(channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.attention = QKVAttention(self.num_heads) if use_new_attention_order else QKVAttentionLegacy(self.num_heads)
+        self.proj_out = zero_module(nn.Conv1d(channels, channels, 1))
+
+    def run(self, ctx, x):
+        N, H, W, C = x.shape
+        T = H * W
+        st = ops.groupnorm_stats(x)
+        xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0)
+        wq, bq = ctx.packed(self, "qkv")
+        qkv = ops.gemm(xn.view(N * T, C), wq, bias=bq)
+        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads)
+        out = ops.gemm(a, ctx.packed(self.proj_out, "w1"), bias=self.proj_out.bias, residual=x.view(N * T, C))
+        return out.view(N, H, W, C)
+
+
+class _Ctx:
+    """Per-forward state: timestep embedding, packed-weight cache, dropout-mask source."""
+
+    def __init__(self, model):
+        self.model = model
+        self.emb = None
+
+    def packed(self, mod, kind):
+        cache = self.model._packed
+        key = (id(mod), kind)
+        if key not in cache:
+            if kind == "w3":
+                cache[key] = ops.pack_conv3x3_weight(mod.weight.detach().contiguous())
+            elif kind == "w1":
+                w = mod.weight.detach()
+                cache[key] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            elif kind == "qkv":
+                w = mod.qkv.weight.detach().reshape(3 * mod.channels, mod.channels)
+                b = mod.qkv.bias.detach()
+                if isinstance(mod.attention, QKVAttentionLegacy):
+                    # rows (head, part, c) -> (part, head, c): one attention layout for both split orders
+                    Hh, ch = mod.num_heads, mod.channels // mod.num_heads
+                    w = w.reshape(Hh, 3, ch, mod.channels).permute(1, 0, 2, 3).reshape(3 * mod.channels, mod.channels)
+                    b = b.reshape(Hh, 3, ch).permute(1, 0, 2).reshape(-1)
+                cache[key] = (w.contiguous(), b.contiguous())
+        return cache[key]
+
+    def dropout_mask(self, shape_nhwc, p):
+        return self.model.dropout_mask_source(shape_nhwc, p)
+
+
+class UNetModel(nn.Module):
+    """unet_openai.py:397-665."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False):
+        super().__init__()
+        assert dims == 2 and resblock_updown and use_scale_shift_norm and not use_fp16, \
+            "the HIP path covers the configuration family of init_model.py (resblock_updown + scale-shift norm, fp32)"
+        assert in_channels <= 4
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_res_blocks = out_channels, num_res_blocks
+        self.attention_resolutions, self.dropout, self.channel_mult = attention_resolutions, dropout, channel_mult
+        self.conv_resample, self.num_classes, self.use_checkpoint = conv_resample, num_classes, use_checkpoint
+        self.dtype = torch.float32
+        self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        if num_classes is not None:
+            self.label_emb = nn.Embedding(num_classes, ted)
+        ch = input_ch = int(channel_mult[0] * model_channels)
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, ch, 3, padding=1))])
+        chans, ds = [ch], 1
+        rb = dict(use_scale_shift_norm=use_scale_shift_norm)
+        ab = dict(num_head_channels=num_head_channels, use_new_attention_order=use_new_attention_order)
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, ted, dropout, out_channels=int(mult * model_channels), **rb)]
+                ch = int(mult * model_channels)
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads=num_heads, **ab))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(ResBlock(ch, ted, dropout, out_channels=ch, down=True, **rb)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(ResBlock(ch, ted, dropout, **rb), AttentionBlock(ch, num_heads=num_heads, **ab),
+                                                    ResBlock(ch, ted, dropout, **rb))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [ResBlock(ch + ich, ted, dropout, out_channels=int(model_channels * mult), **rb)]
+                ch = int(model_channels * mult)
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads=num_heads_upsample, **ab))
+                if level and i == num_res_blocks:
+                    layers.append(ResBlock(ch, ted, dropout, out_channels=ch, up=True, **rb))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(nn.Conv2d(input_ch, out_channels, 3, padding=1)))
+        self._packed = {}
+        # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
+        # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
+        self.dropout_mask_source = host_dropout_mask
+
+    # ---- weight cache hygiene
+    def invalidate_packed_weights(self):
+        self._packed = {}
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = {}
+        return super().load_state_dict(*a, **k)
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, y=None, out_channels_keep=None):
+        """out_channels_keep: write only the first k output channels (the `[:, :3]` of traits.py:18)."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        if not x.is_cuda:
+            raise RuntimeError("UNetModel.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        ctx = _Ctx(self)
+        B = x.shape[0]
+        te, te2 = self.time_embed[0], self.time_embed[2]
+        emb = ops.timestep_embedding(timesteps.to(torch.int64).contiguous(), self.model_channels)
+        emb = ops.gemm(emb, te.weight, bias=te.bias)
+        emb = ops.gemm(emb, te2.weight, bias=te2.bias, act_in=1)
+        if self.num_classes is not None:
+            assert y.shape == (B,), f"{y.shape=} != {x.shape[0]=}"
+            emb = ops.embedding_add(emb, self.label_emb.weight, y.to(torch.int64).contiguous())
+        ctx.emb = emb
+        h = ops.nchw_to_nhwc(x.float().contiguous(), 4)
+        hs = []
+        for module in self.input_blocks:
+            h = module.run(ctx, h)
+            hs.append(h)
+        h = self.middle_block.run(ctx, h)
+        for module in self.output_blocks:
+            h = module.run(ctx, h, hs.pop())
+        gn, conv = self.out[0], self.out[2]
+        st = ops.groupnorm_stats(h)
+        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1)
+        keep = self.out_channels if out_channels_keep is None else out_channels_keep
+        wp = ctx.packed(conv, "w3")
+        return ops.conv3x3(h, wp, conv.bias, keep, nchw_out=True)
+
+
+def host_dropout_mask(shape_nhwc, p):
+    """Bernoulli keep-mask / (1-p) drawn from the global CPU generator in NCHW order, exactly the draw
+    nn.Dropout makes on the reference CPU path, uploaded as NHWC."""
+    N, H, W, C = shape_nhwc
+    m = torch.empty((N, C, H, W), dtype=torch.float32).bernoulli_(1 - p).div_(1 - p)
+    return m.permute(0, 2, 3, 1).contiguous().to("cuda", non_blocking=True)

@@ -234,8 +234,8 @@ def gemm_raw(**kw):
     check(_lib.lib().dua_gemm(ctypes.byref(g), _stream()), "dua_gemm")
 
 
-def softmax_rows_(S, rows, cols):
-    check(_lib.lib().dua_softmax_rows(_p(S), int(rows), int(cols), _stream()), "dua_softmax_rows")
+def softmax_rows_(S, rows, cols, ld=None):
+    check(_lib.lib().dua_softmax_rows(_p(S), int(rows), int(cols), int(cols if ld is None else ld), _stream()), "dua_softmax_rows")
     return S
 
 
@@ -249,16 +249,17 @@ def qkv_attention(qkv, B, T, heads, ch):
     _req(qkv, name="qkv")
     C = heads * ch
     assert qkv.shape == (B * T, 3 * C)
-    S = torch.empty((B * heads, T, T), device=qkv.device, dtype=torch.float32)
+    Tp = (T + 3) // 4 * 4            # row stride of the logits (16-byte aligned rows for the PV operand loads)
+    S = torch.empty((B * heads, T, Tp), device=qkv.device, dtype=torch.float32)
     out = torch.empty((B * T, C), device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
     s = 1.0 / math.sqrt(math.sqrt(ch))
-    gemm_raw(A1=base, B=base + 4 * C, C=S.data_ptr(), M=T, N=T, K1=ch, K2=0, lda1=3 * C, lda2=4, ldb=3 * C, ldc=T, ldr=T,
-             sA1=T * 3 * C, sB=T * 3 * C, sC=heads * T * T, batch=B * heads, batch_inner=heads, sA1i=ch, sBi=ch,
-             sCi=T * T, transB=1, alpha=s * s)
-    softmax_rows_(S, B * heads * T, T)
-    gemm_raw(A1=S.data_ptr(), B=base + 8 * C, C=out.data_ptr(), M=T, N=ch, K1=T, K2=0, lda1=T, lda2=4, ldb=3 * C, ldc=C,
-             ldr=C, sA1=heads * T * T, sB=T * 3 * C, sC=T * C, batch=B * heads, batch_inner=heads, sA1i=T * T, sBi=ch,
+    gemm_raw(A1=base, B=base + 4 * C, C=S.data_ptr(), M=T, N=T, K1=ch, K2=0, lda1=3 * C, lda2=4, ldb=3 * C, ldc=Tp, ldr=Tp,
+             sA1=T * 3 * C, sB=T * 3 * C, sC=heads * T * Tp, batch=B * heads, batch_inner=heads, sA1i=ch, sBi=ch,
+             sCi=T * Tp, transB=1, alpha=s * s)
+    softmax_rows_(S, B * heads * T, T, Tp)
+    gemm_raw(A1=S.data_ptr(), B=base + 8 * C, C=out.data_ptr(), M=T, N=ch, K1=T, K2=0, lda1=Tp, lda2=4, ldb=3 * C, ldc=C,
+             ldr=C, sA1=heads * T * Tp, sB=T * 3 * C, sC=T * C, batch=B * heads, batch_inner=heads, sA1i=T * Tp, sBi=ch,
              sCi=ch, transB=0, alpha=1.0)
     return out
 
@@ -284,3 +285,27 @@ def embedding_add(a, table, idx):
     out = torch.empty((N, D), device=table.device, dtype=torch.float32)
     check(_lib.lib().dua_embedding_add(_p(a), _p(table), _p(idx), _p(out), N, D, _stream()), "dua_embedding_add")
     return out
+
+
+# ------------------------------------------------------------------ U-ViT token plumbing
+def patchify(x, P):
+    _req(x, name="x")
+    B, C, H, W = x.shape
+    rows = torch.empty((B * (H // P) * (W // P), C * P * P), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_patchify(_p(x), _p(rows), B, C, H, W, P, _stream()), "dua_patchify")
+    return rows
+
+
+def uvit_assemble(patches, time_tok, label_table, y, pos_embed, B, L, D):
+    extras = 2 if y is not None else 1
+    out = torch.empty((B, L + extras, D), device=patches.device, dtype=torch.float32)
+    check(_lib.lib().dua_uvit_assemble(_p(patches), _p(time_tok), _p(label_table), _p(y), _p(pos_embed), _p(out), B, L, D,
+                                       _stream()), "dua_uvit_assemble")
+    return out
+
+
+def unpatchify(tok, B, L, extras, C, P):
+    g = int(round(math.sqrt(L)))
+    img = torch.empty((B, C, g * P, g * P), device=tok.device, dtype=torch.float32)
+    check(_lib.lib().dua_unpatchify(_p(tok), _p(img), B, L, extras, C, P, _stream()), "dua_unpatchify")
+    return img

@@ -1,0 +1,141 @@
+"""U-ViT on the gfx950 HIP library.
+
+Host-side mirror of reference ``uvit/uvit.py`` (``UViT.__init__`` :138-201, ``forward`` :203-231, ``Block``
+:95-120, ``Attention`` :54-92, ``PatchEmbed`` :123-135) and ``uvit/timm.py`` ``Mlp`` :96-111: same
+constructor, same module nesting / state-dict keys as the released checkpoints
+(``in_blocks.N.attn.qkv.weight`` ...), same call ``model(x[B,C,h,w], t[B], y[B]) -> [B,C,h,w]``.
+nn modules hold parameters only; the arithmetic runs in libdua_hip.so: LayerNorm kernel, fp32-MFMA GEMMs
+with fused bias / GELU / residual epilogues, two-source GEMM for ``skip_linear(cat([x, skip]))`` (:116-117),
+fp32 attention (the reference upcasts qkv to fp32 and calls SDPA, :71-73).  No CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        assert qk_scale is None, "custom qk_scale is not on the accelerated path"
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, act_layer=nn.GELU,
+                 norm_layer=nn.LayerNorm, skip=False, use_checkpoint=False):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
+        self.skip_linear = nn.Linear(2 * dim, dim) if skip else None
+
+    def run(self, x, B, L, skip=None):
+        """x, skip: [B*L, D]."""
+        D = x.shape[1]
+        if self.skip_linear is not None:
+            x = ops.gemm(x, self.skip_linear.weight, bias=self.skip_linear.bias, a2=skip)          # :116-117
+        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = ops.gemm(h, self.attn.qkv.weight, bias=self.attn.qkv.bias)
+        a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads)            # :69-73
+        x = ops.gemm(a, self.attn.proj.weight, bias=self.attn.proj.bias, residual=x)               # :118
+        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.gemm(h, self.mlp.fc1.weight, bias=self.mlp.fc1.bias, act_out=2)                    # fc1 + GELU
+        return ops.gemm(h, self.mlp.fc2.weight, bias=self.mlp.fc2.bias, residual=x)                # :119
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, patch_size, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.patch_size = patch_size
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class UViT(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.,
+                 qkv_bias=False, qk_scale=None, norm_layer=nn.LayerNorm, mlp_time_embed=False, num_classes=-1,
+                 use_checkpoint=False, conv=True, skip=True):
+        super().__init__()
+        assert not conv, "final 3x3 conv (conv=True) is not used by the released ImageNet models (load_pretrained_models.py:36)"
+        self.num_features = self.embed_dim = embed_dim
+        self.num_classes = num_classes
+        self.in_chans = in_chans
+        self.patch_embed = PatchEmbed(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = (img_size // patch_size) ** 2
+        self.time_embed = nn.Sequential(nn.Linear(embed_dim, 4 * embed_dim), nn.SiLU(),
+                                        nn.Linear(4 * embed_dim, embed_dim)) if mlp_time_embed else nn.Identity()
+        if self.num_classes > 0:
+            self.label_emb = nn.Embedding(self.num_classes, embed_dim)
+            self.extras = 2
+        else:
+            self.extras = 1
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.extras + num_patches, embed_dim))
+        kw = dict(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, norm_layer=norm_layer)
+        self.in_blocks = nn.ModuleList([Block(**kw) for _ in range(depth // 2)])
+        self.mid_block = Block(**kw)
+        self.out_blocks = nn.ModuleList([Block(skip=skip, **kw) for _ in range(depth // 2)])
+        self.norm = norm_layer(embed_dim)
+        self.patch_dim = patch_size ** 2 * in_chans
+        self.decoder_pred = nn.Linear(embed_dim, self.patch_dim, bias=True)
+        self.final_layer = nn.Identity()
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        self.apply(self._init_weights)
+        self.img_size = img_size
+        self.patch_size = patch_size
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.no_grad()
+    def forward(self, x, timesteps, y=None):
+        if not x.is_cuda:
+            raise RuntimeError("UViT.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        B, C, H, W = x.shape
+        P, D = self.patch_size, self.embed_dim
+        rows = ops.patchify(x.float().contiguous(), P)                                     # [B*L, C*P*P]
+        L = rows.shape[0] // B
+        w = self.patch_embed.proj.weight
+        tok = ops.gemm(rows, w.reshape(D, -1), bias=self.patch_embed.proj.bias)            # :205
+        tt = ops.timestep_embedding(timesteps.to(torch.int64).contiguous(), D)
+        if not isinstance(self.time_embed, nn.Identity):
+            tt = ops.gemm(tt, self.time_embed[0].weight, bias=self.time_embed[0].bias)
+            tt = ops.gemm(tt, self.time_embed[2].weight, bias=self.time_embed[2].bias, act_in=1)
+        yy = y.to(torch.int64).contiguous() if y is not None else None
+        assert (yy is not None) == (self.extras == 2), "label token count does not match the positional table"
+        h = ops.uvit_assemble(tok, tt, self.label_emb.weight if yy is not None else None, yy,
+                              self.pos_embed.reshape(-1, D), B, L, D)                      # :207-216
+        T = L + self.extras
+        h = h.view(B * T, D)
+        skips = []
+        for blk in self.in_blocks:
+            h = blk.run(h, B, T)
+            skips.append(h)
+        h = self.mid_block.run(h, B, T)
+        for blk in self.out_blocks:
+            h = blk.run(h, B, T, skips.pop())
+        h = ops.layernorm(h, self.norm.weight, self.norm.bias, self.norm.eps)
+        h = ops.gemm(h, self.decoder_pred.weight, bias=self.decoder_pred.bias)             # [B*T, P*P*C]
+        return ops.unpatchify(h, B, L, self.extras, C, P)                                  # :228-229

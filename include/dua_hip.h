@@ -133,8 +133,9 @@ typedef struct {
 } dua_gemm_args;
 int dua_gemm(const dua_gemm_args* args_host, void* stream);
 
-/* Row softmax in place over the last axis of S [rows][cols] fp32 (unet_openai.py:353 / :388). */
-int dua_softmax_rows(float* S, long rows, int cols, void* stream);
+/* Row softmax in place over the first `cols` entries of each row of S (row stride ld floats), fp32
+ * (unet_openai.py:353 / :388; uvit/uvit.py:73). */
+int dua_softmax_rows(float* S, long rows, int cols, long ld, void* stream);
 
 /* LayerNorm over the last axis (U-ViT, uvit/uvit.py:108-110,225): y = (x-mean)*rstd*gamma+beta, eps 1e-5. */
 int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps,
@@ -145,6 +146,18 @@ int dua_timestep_embedding(const int64_t* t, float* emb, int N, int dim, void* s
 
 /* out[n][:] = a[n][:] + table[idx[n]][:]  (label embedding add, unet_openai.py:654). a may be NULL. */
 int dua_embedding_add(const float* a, const float* table, const int64_t* idx, float* out, int N, int D, void* stream);
+
+/* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */
+/* PatchEmbed's strided conv as im2row: x NCHW [B][C][H][W] -> rows [B*(H/P)*(W/P)][C*P*P] in the
+ * (c, p1, p2) order of the flattened conv weight (uvit.py:123-135); the projection itself is dua_gemm. */
+int dua_patchify(const float* x, float* rows, int B, int C, int H, int W, int P, void* stream);
+/* tokens[b] = [label_emb[y[b]] ; time_tok[b] ; patches[b]] + pos_embed  (uvit.py:207-216).
+ * y may be NULL (no label token, extras = 1). patches [B][L][D], pos_embed [extras+L][D], out [B][extras+L][D]. */
+int dua_uvit_assemble(const float* patches, const float* time_tok, const float* label_table, const int64_t* y,
+                      const float* pos_embed, float* out, int B, int L, int D, void* stream);
+/* tok [B][extras+L][P*P*C] -> NCHW image, dropping the extras tokens:
+ * 'B (h w) (p1 p2 C) -> B C (h p1) (w p2)' (uvit.py:46-51,228-229). */
+int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C, int P, void* stream);
 
 #ifdef __cplusplus
 }
