@@ -200,8 +200,24 @@ def pack_conv3x3_weight(w):
     return wp
 
 
+# Optional per-launch timing hook used by bench.py: an object with .record(kind, flops, start_evt, end_evt).
+PROFILE = None
+
+
 def conv3x3(x, wp, bias, cout, residual=None, nchw_out=False):
     _req(x, name="x"), _req(wp, name="wp")
+    N, H, W, Cin = x.shape
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = _conv3x3(x, wp, bias, cout, residual, nchw_out)
+        e1.record()
+        PROFILE.record("conv3x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
+        return y
+    return _conv3x3(x, wp, bias, cout, residual, nchw_out)
+
+
+def _conv3x3(x, wp, bias, cout, residual=None, nchw_out=False):
     N, H, W, Cin = x.shape
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
     if residual is not None:
