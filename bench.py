@@ -126,6 +126,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from diffusion_uncertainty_amd import ops
+    from diffusion_uncertainty_amd.distributed import gather_images, max_over_ranks, shard_range
     from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
 
     model, base, sd = build_model(dev)
@@ -133,17 +134,14 @@ def main():
     g = torch.Generator().manual_seed(49394)
     X_all = torch.randn(a.batch * world, 3, 128, 128, generator=g)
     y_all = torch.randint(0, 1000, (a.batch * world,), generator=g)
-    X_T = X_all[rank * a.batch:(rank + 1) * a.batch].to(dev)
-    y = y_all[rank * a.batch:(rank + 1) * a.batch].to(dev)
+    lo, hi = shard_range(a.batch * world, rank, world)
+    X_T, y = X_all[lo:hi].to(dev), y_all[lo:hi].to(dev)
 
     def job(n_steps, start, num, seed):
         s = make_scheduler(model, base, a.M, start, num, a.num_zigzag, seed, a.faithful_zigzag)
         s.set_timesteps(n_steps)
         r = gen(X_T, y, a.batch, dev, model, s)
-        imgs = r["gen_images"].to(dev)
-        if world > 1:
-            out = torch.empty((world,) + tuple(imgs.shape), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(out, imgs)           # RCCL over xGMI: the only collective of the path
+        gather_images(r["gen_images"].to(dev))             # RCCL over xGMI: the only collective of the path
         return s.denoiser_calls
 
     def sync():
@@ -163,10 +161,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILE = None
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(dt, dev)
 
     if rank == 0:
         images = a.batch * world * a.steps

@@ -1,0 +1,31 @@
+"""Multi-GPU plumbing: the path shards by independent batches, one process per GPU.
+
+Reference: scripts/generate_dataset_score_uncertainty_imagenet.py:51,137-144 - `mp.spawn`, rank r takes
+`X_T[start + r*n : start + (r+1)*n]` with n = N // world (remainder dropped), no collective on the path.
+Here the launcher is torch.distributed.run; the only collective is an end-of-job all-gather of the uint8
+images (RCCL over xGMI with backend "nccl"; "gloo" in the CPU tests), plus a MAX all-reduce of the wall time.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total, rank, world, start=0):
+    n = n_total // world
+    return start + rank * n, start + (rank + 1) * n
+
+
+def gather_images(imgs):
+    """imgs: uint8 [n, C, H, W] on every rank -> [world, n, C, H, W] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return imgs.unsqueeze(0)
+    out = torch.empty((dist.get_world_size(),) + tuple(imgs.shape), dtype=imgs.dtype, device=imgs.device)
+    dist.all_gather_into_tensor(out, imgs.contiguous())
+    return out
+
+
+def max_over_ranks(seconds, device):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

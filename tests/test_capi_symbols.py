@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports every symbol include/dua_hip.h declares (no compute calls)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dua_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dua_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from diffusion_uncertainty_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"libdua_hip.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
+    assert sorted(_lib.SIGNATURES) == names
+    assert L.dua_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    """Host-side checks run before any launch: bad arguments return DUA_EINVAL with a message."""
+    import ctypes
+    from diffusion_uncertainty_amd import _lib
+    L = _lib.lib()
+    assert L.dua_quantile_mask(None, 1, 10, 0, 1, 0.5, None, None, None) == -1
+    assert b"null" in L.dua_last_error()
+    assert L.dua_mc_reduce_var(None, None, 0, 1, None) == -1                 # M >= 2 required (torch.var, unbiased)
+    assert L.dua_axpby(None, None, None, 0, 1.0, 1.0, None) == 0            # empty input is a no-op
+    assert L.dua_conv3x3(ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, ctypes.c_void_p(16), 1, 8, 8, 48, 32, 0, None) == -1
+    assert b"multiple of 32" in L.dua_last_error()
+
+
+def test_no_cpu_fallback():
+    import torch
+    from diffusion_uncertainty_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.axpby(torch.zeros(4), torch.zeros(4), 1.0, 1.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "diffusion-uncertainty_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f

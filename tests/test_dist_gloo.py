@@ -1,0 +1,62 @@
+"""world_size-2 coverage of the N>1 path on CPU (gloo): rank sharding as the reference script does it,
+end-of-job image collation and the max-over-ranks timing reduction."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffusion_uncertainty_amd.distributed import gather_images, max_over_ranks, shard_range
+    from diffusion_uncertainty_amd.utils import starting_points
+    X, y = starting_points(7, (3, 4, 4))                     # 7 samples over 2 ranks: n = 3, remainder dropped
+    lo, hi = shard_range(7, rank, world)
+    imgs = (X[lo:hi].clamp(-1, 1) * 127 + 128).to(torch.uint8)
+    allimgs = gather_images(imgs)
+    t = max_over_ranks(1.0 + rank, "cpu")
+    dist.barrier()
+    q.put((rank, lo, hi, allimgs, t))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_collation():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from diffusion_uncertainty_amd.utils import starting_points
+    X, _ = starting_points(7, (3, 4, 4))
+    ref = (X[:6].clamp(-1, 1) * 127 + 128).to(torch.uint8).reshape(2, 3, 3, 4, 4)
+    assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 6)]
+    for r in res:
+        assert torch.equal(r[3], ref)                        # every rank holds the full collation, in rank order
+        assert r[4] == 2.0                                   # max over ranks
+
+
+def test_single_process_fallbacks():
+    from diffusion_uncertainty_amd.distributed import gather_images, max_over_ranks, shard_range
+    x = torch.zeros(2, 3, 4, 4, dtype=torch.uint8)
+    assert gather_images(x).shape == (1, 2, 3, 4, 4)
+    assert max_over_ranks(1.5, "cpu") == 1.5
+    assert shard_range(1024, 3, 8) == (384, 512)
