@@ -18,9 +18,10 @@ def gather_images(imgs):
     """imgs: uint8 [n, C, H, W] on every rank -> [world, n, C, H, W] on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return imgs.unsqueeze(0)
-    out = torch.empty((dist.get_world_size(),) + tuple(imgs.shape), dtype=imgs.dtype, device=imgs.device)
-    dist.all_gather_into_tensor(out, imgs.contiguous())
-    return out
+    w = dist.get_world_size()
+    out = torch.empty((w * imgs.shape[0],) + tuple(imgs.shape[1:]), dtype=imgs.dtype, device=imgs.device)
+    dist.all_gather_into_tensor(out, imgs.contiguous())          # concatenated along dim 0, rank order
+    return out.view((w,) + tuple(imgs.shape))
 
 
 def max_over_ranks(seconds, device):
