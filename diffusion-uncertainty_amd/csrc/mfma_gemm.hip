@@ -40,7 +40,7 @@ struct TileP {
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
-template <int MODE, bool TRANSB>
+template <int MODE, bool TRANSB, bool SILU_IN, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,106 +79,105 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
     if (MODE != MODE_GEMM) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int m = m0 + r0 + 32 * i;
-            if (m < p.M) {
-                int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
-                py[i] = rem / p.W;
-                px[i] = rem - py[i] * p.W;
-                pbase[i] = (long)m * p.Cin;
-            } else {
-                py[i] = -100000;
-                px[i] = 0;
-                pbase[i] = 0;
-            }
+            const int m = min(m0 + r0 + 32 * i, p.M - 1);          // rows past M: clamped, never stored
+            const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
+            py[i] = rem / p.W;
+            px[i] = rem - py[i] * p.W;
+            pbase[i] = (long)m * p.Cin;
         }
     }
 
-    float4 ra[4], rb[4];
-    auto load_tiles = [&](int kt) {
+    // All loads are unconditional (clamped addresses + select) so the compiler never branches around a load:
+    // rows past M / N are clamped to the last valid row (their results are never stored), conv padding taps
+    // read the centre pixel and are zeroed by a select.  Only a ragged K tail takes the predicated slow path.
+    // The loaders return values (named registers in the caller): arrays captured by reference end up in scratch.
+    auto ragged4 = [&](const float* q, int k) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 3 < K) v = *(const float4*)q;
+        else if (k < K) { v.x = q[0]; if (k + 1 < K) v.y = q[1]; if (k + 2 < K) v.z = q[2]; }
+        return v;
+    };
+    unsigned amask = 0;       // conv: bit i = tap of staged row i is inside the image (applied at ds_write time)
+    auto load_a = [&](int kt, int i, bool ktail) -> float4 {
         const int k0 = kt * BK;
-        // ---------------- A ----------------
         if (MODE == MODE_GEMM) {
             const int k = k0 + 4 * c4;
             const float* src;
             long ld;
             int kk;
-            if (k < p.K1) { src = A1; ld = p.lda1; kk = k; } else { src = A2; ld = p.lda2; kk = k - p.K1; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int m = m0 + r0 + 32 * i;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < p.M) {
-                    const float* q = src + (long)m * ld + kk;
-                    if (k + 3 < K) v = *(const float4*)q;
-                    else if (k < K) { v.x = q[0]; if (k + 1 < K) v.y = q[1]; if (k + 2 < K) v.z = q[2]; }
-                }
-                if (p.act_in == 1) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                ra[i] = v;
+            if (k < p.K1 || p.K2 == 0) { src = A1; ld = p.lda1; kk = k; } else { src = A2; ld = p.lda2; kk = k - p.K1; }
+            const int m = min(m0 + r0 + 32 * i, p.M - 1);
+            const float* q = src + (long)m * ld + kk;
+            return ktail ? ragged4(q, k) : *(const float4*)q;
+        } else {
+            int dy, dx;
+            long off, coff;
+            bool tap_ok = true;
+            if (MODE == MODE_CONV) {
+                const int cpb = p.Cin / BK;
+                const int tap = kt / cpb, cb = kt - tap * cpb;
+                dy = tap / 3 - 1;
+                dx = tap - (tap / 3) * 3 - 1;
+                off = ((long)dy * p.W + dx) * p.Cin;
+                coff = cb * BK + 4 * c4;
+            } else {   // small-Cin: float4 column = one tap, 4 channels
+                const int tap = kt * 8 + c4;
+                dy = tap / 3 - 1;
+                dx = tap - (tap / 3) * 3 - 1;
+                off = ((long)dy * p.W + dx) * 4;
+                coff = 0;
+                tap_ok = tap < 9;
             }
-        } else if (MODE == MODE_CONV) {
-            const int cpb = p.Cin / BK;
-            const int tap = kt / cpb, cb = kt - tap * cpb;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const long off = ((long)dy * p.W + dx) * p.Cin + cb * BK + 4 * c4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int yy = py[i] + dy, xx = px[i] + dx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = *(const float4*)(A1 + pbase[i] + off);
-                ra[i] = v;
-            }
-        } else {   // small-Cin: float4 column = one tap, 4 channels
-            const int tap = kt * 8 + c4;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const long off = ((long)dy * p.W + dx) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int yy = py[i] + dy, xx = px[i] + dx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (tap < 9 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = *(const float4*)(A1 + pbase[i] + off);
-                ra[i] = v;
-            }
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            const bool ok = tap_ok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            amask = (amask & ~(1u << i)) | ((unsigned)ok << i);
+            return *(const float4*)(A1 + pbase[i] + (ok ? off : 0L) + coff);
         }
-        // ---------------- B ----------------
+    };
+    auto load_b = [&](int kt, int i, bool ktail) -> float4 {
+        const int k0 = kt * BK;
         if (TRANSB) {   // B is [N][K]: same geometry as A
             const int k = k0 + 4 * c4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int n = n0 + r0 + 32 * i;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (MODE != MODE_GEMM) v = *(const float4*)(Bp + (long)n * K + k);          // packed + padded weights
-                else if (n < p.N) {
-                    const float* q = Bp + (long)n * p.ldb + k;
-                    if (k + 3 < K) v = *(const float4*)q;
-                    else if (k < K) { v.x = q[0]; if (k + 1 < K) v.y = q[1]; if (k + 2 < K) v.z = q[2]; }
-                }
-                rb[i] = v;
-            }
-        } else {        // B is [K][N]: thread -> (k row kr + 8 i, float4 column n4)
+            if (MODE != MODE_GEMM) return *(const float4*)(Bp + (long)(n0 + r0 + 32 * i) * K + k);   // packed + padded weights
+            const int n = min(n0 + r0 + 32 * i, p.N - 1);
+            const float* q = Bp + (long)n * p.ldb + k;
+            return ktail ? ragged4(q, k) : *(const float4*)q;
+        } else {        // B is [K][N]: thread -> (k row kr + 8 i, float4 column n4); N % 4 == 0 checked on host
             const int n4 = tid & 31, kr = tid >> 5;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int k = k0 + kr + 8 * i, n = n0 + 4 * n4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && n < p.N) v = *(const float4*)(Bp + (long)k * p.ldb + n);       // N % 4 == 0 checked on host
-                rb[i] = v;
-            }
+            const int n = min(n0 + 4 * n4, p.N - 4), k = k0 + kr + 8 * i;
+            return *(const float4*)(Bp + (long)min(k, K - 1) * p.ldb + n);    // rows past K are zeroed at ds_write time
         }
     };
-    auto store_tiles = [&](int buf) {
-        float* la = lds + buf * 2 * TILE_F;
-        float* lb = la + TILE_F;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(float4*)(la + (r0 + 32 * i) * LDT + 4 * c4) = ra[i];
-        if (TRANSB) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *(float4*)(lb + (r0 + 32 * i) * LDT + 4 * c4) = rb[i];
-        } else {
-            const int n4 = tid & 31, kr = tid >> 5;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *(float4*)(lb + (kr + 8 * i) * LDN + 4 * n4) = rb[i];
+    // Fix-ups (zero padding, SiLU on the embedding input, K-tail rows) are applied here, at ds_write time, so that
+    // no instruction depends on a global load until its data has had most of a K step to land.
+    auto store_a = [&](int buf, int i, float4 v) {
+        if (MODE != MODE_GEMM) {
+            const bool ok = (amask >> i) & 1u;
+            v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        } else if (SILU_IN) {
+            v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+        }
+        *(float4*)(lds + buf * 2 * TILE_F + (r0 + 32 * i) * LDT + 4 * c4) = v;
+    };
+    auto store_b = [&](int buf, int i, float4 v, int kt) {
+        float* lb = lds + buf * 2 * TILE_F + TILE_F;
+        if (TRANSB) *(float4*)(lb + (r0 + 32 * i) * LDT + 4 * c4) = v;
+        else {
+            const bool ok = kt * BK + (tid >> 5) + 8 * i < K;
+            v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            *(float4*)(lb + ((tid >> 5) + 8 * i) * LDN + 4 * (tid & 31)) = v;
         }
     };
+#define LOAD_TILES_(kt, T)                                                                                  \
+    ra0 = load_a(kt, 0, T); ra1 = load_a(kt, 1, T); ra2 = load_a(kt, 2, T); ra3 = load_a(kt, 3, T);         \
+    rb0 = load_b(kt, 0, T); rb1 = load_b(kt, 1, T); rb2 = load_b(kt, 2, T); rb3 = load_b(kt, 3, T);
+    // RAGGED (K % 32 != 0, U-ViT attention / patch embedding only) is a separate kernel variant whose loads are all
+    // predicated; the common variant has straight-line unconditional loads and no branch in the K loop.
+#define LOAD_TILES(kt) LOAD_TILES_(kt, RAGGED)
+#define STORE_TILES(buf, kt)                                                                        \
+    store_a(buf, 0, ra0); store_a(buf, 1, ra1); store_a(buf, 2, ra2); store_a(buf, 3, ra3);         \
+    store_b(buf, 0, rb0, kt); store_b(buf, 1, rb1, kt); store_b(buf, 2, rb2, kt); store_b(buf, 3, rb3, kt);
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -189,39 +188,60 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
-    load_tiles(0);
-    store_tiles(0);
+
+    // Fragment reads for k-group g of the tile in LDS buffer `buf` (see header comment for the k permutation).
+    struct Frag { float4 a0, a1, b0, b1; };
+    auto read_frag = [&](int buf, int g) -> Frag {
+        Frag f;
+        const float* la = lds + buf * 2 * TILE_F + (wm * 64 + lr) * LDT + 4 * kh + 8 * g;
+        const float* lb = lds + buf * 2 * TILE_F + TILE_F;
+        f.a0 = *(const float4*)la;
+        f.a1 = *(const float4*)(la + 32 * LDT);
+        if (TRANSB) {
+            const float* q = lb + (wn * 64 + lr) * LDT + 4 * kh + 8 * g;
+            f.b0 = *(const float4*)q;
+            f.b1 = *(const float4*)(q + 32 * LDT);
+        } else {
+            const float* q = lb + (8 * g + 4 * kh) * LDN + wn * 64 + lr;
+            f.b0 = make_float4(q[0], q[LDN], q[2 * LDN], q[3 * LDN]);
+            f.b1 = make_float4(q[32], q[LDN + 32], q[2 * LDN + 32], q[3 * LDN + 32]);
+        }
+        return f;
+    };
+#define MFMA4(AV0, AV1, BV0, BV1)                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV0, BV0, acc[0][0], 0, 0, 0);        \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV0, BV1, acc[0][1], 0, 0, 0);        \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV1, BV0, acc[1][0], 0, 0, 0);        \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV1, BV1, acc[1][1], 0, 0, 0);
+#define MFMA16(F)                                   \
+    MFMA4(F.a0.x, F.a1.x, F.b0.x, F.b1.x)           \
+    MFMA4(F.a0.y, F.a1.y, F.b0.y, F.b1.y)           \
+    MFMA4(F.a0.z, F.a1.z, F.b0.z, F.b1.z)           \
+    MFMA4(F.a0.w, F.a1.w, F.b0.w, F.b1.w)
+
+    // Software pipeline, one barrier per 32-deep K step, everything else interleaved with the MFMA stream:
+    //   [MFMA g0 | read g1] [MFMA g1 | read g2] [write tile kt+1 -> other buffer]
+    //   [MFMA g2 | read g3] lgkmcnt(0) + barrier [MFMA g3 | read g0 of tile kt+1 | issue global loads of tile kt+2]
+    // The barrier orders (a) every wave's reads of this tile's buffer before the next step's writes into it and
+    // (b) every wave's writes of tile kt+1 before anyone reads it.
+    LOAD_TILES(0)
+    STORE_TILES(0, 0)
+    if (nk > 1) { LOAD_TILES(1) }
     __syncthreads();
+    Frag f0 = read_frag(0, 0), f1;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        const float* la = lds + buf * 2 * TILE_F + (wm * 64 + lr) * LDT + 4 * kh;
-        const float* lb = lds + buf * 2 * TILE_F + TILE_F;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 a0 = *(const float4*)(la + 8 * g), a1 = *(const float4*)(la + 32 * LDT + 8 * g);
-            float4 b0, b1;
-            if (TRANSB) {
-                const float* q = lb + (wn * 64 + lr) * LDT + 4 * kh + 8 * g;
-                b0 = *(const float4*)q;
-                b1 = *(const float4*)(q + 32 * LDT);
-            } else {
-                const float* q = lb + (8 * g + 4 * kh) * LDN + wn * 64 + lr;
-                b0 = make_float4(q[0], q[LDN], q[2 * LDN], q[3 * LDN]);
-                b1 = make_float4(q[32], q[LDN + 32], q[2 * LDN + 32], q[3 * LDN + 32]);
-            }
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        f1 = read_frag(buf, 1);
+        MFMA16(f0)
+        f0 = read_frag(buf, 2);
+        MFMA16(f1)
+        if (kt + 1 < nk) { STORE_TILES(buf ^ 1, kt + 1) }
+        f1 = read_frag(buf, 3);
+        MFMA16(f0)
         __syncthreads();
+        if (kt + 1 < nk) f0 = read_frag(buf ^ 1, 0);
+        if (kt + 2 < nk) { LOAD_TILES(kt + 2) }      // staging registers are free again: the writes above have retired
+        MFMA16(f1)
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -249,12 +269,12 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
         }
 }
 
-template <int MODE, bool TRANSB>
+template <int MODE, bool TRANSB, bool SILU_IN = false, bool RAGGED = false>
 static int launch_tile(TileP& p, int batch, hipStream_t s) {
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
     dim3 grid(p.ntm * p.ntn, batch);
-    hipLaunchKernelGGL((k_tile<MODE, TRANSB>), grid, 256, 0, s, p);
+    hipLaunchKernelGGL((k_tile<MODE, TRANSB, SILU_IN, RAGGED>), grid, 256, 0, s, p);
     return dua_check_launch("dua tile kernel");
 }
 
@@ -274,8 +294,12 @@ extern "C" int dua_gemm(const dua_gemm_args* a, void* stream) {
     p.sA1 = a->sA1; p.sA2 = a->sA2; p.sB = a->sB; p.sC = a->sC; p.sR = a->sR;
     p.sA1i = a->sA1i; p.sBi = a->sBi; p.sCi = a->sCi;
     p.batch_inner = a->batch_inner; p.act_in = a->act_in; p.act_out = a->act_out; p.alpha = a->alpha;
-    return a->transB ? launch_tile<MODE_GEMM, true>(p, a->batch, as_stream(stream))
-                     : launch_tile<MODE_GEMM, false>(p, a->batch, as_stream(stream));
+    DUA_REQUIRE(a->act_in == 0 || (a->act_in == 1 && a->transB), "dua_gemm: act_in must be 0, or 1 (SiLU) with transB=1");
+    const bool ragged = (a->K1 + a->K2) % BK != 0;
+    hipStream_t st = as_stream(stream);
+    if (a->act_in == 1) return ragged ? launch_tile<MODE_GEMM, true, true, true>(p, a->batch, st) : launch_tile<MODE_GEMM, true, true, false>(p, a->batch, st);
+    if (a->transB) return ragged ? launch_tile<MODE_GEMM, true, false, true>(p, a->batch, st) : launch_tile<MODE_GEMM, true, false, false>(p, a->batch, st);
+    return ragged ? launch_tile<MODE_GEMM, false, false, true>(p, a->batch, st) : launch_tile<MODE_GEMM, false, false, false>(p, a->batch, st);
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
