@@ -97,55 +97,80 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
         else if (k < K) { v.x = q[0]; if (k + 1 < K) v.y = q[1]; if (k + 2 < K) v.z = q[2]; }
         return v;
     };
+    // Staging pointers are carried across K steps and advanced by 32 floats per step; they are recomputed only at a
+    // wave-uniform boundary (new 3x3 tap / switch to the second K-concat source), which keeps the per-step address
+    // VALU work to a handful of 64-bit adds.  LOAD_TILES must be called with kt = 0, 1, 2, ... in order.
     unsigned amask = 0;       // conv: bit i = tap of staged row i is inside the image (applied at ds_write time)
-    auto load_a = [&](int kt, int i, bool ktail) -> float4 {
-        const int k0 = kt * BK;
+    const float* pa[4];
+    const float* pb[4];
+    int a_left = 0;           // K steps left before the A pointers must be recomputed
+    int tap_next = 0;         // conv: next tap to set up
+    auto setup_a = [&](int kt) {
         if (MODE == MODE_GEMM) {
-            const int k = k0 + 4 * c4;
-            const float* src;
-            long ld;
-            int kk;
-            if (k < p.K1 || p.K2 == 0) { src = A1; ld = p.lda1; kk = k; } else { src = A2; ld = p.lda2; kk = k - p.K1; }
-            const int m = min(m0 + r0 + 32 * i, p.M - 1);
-            const float* q = src + (long)m * ld + kk;
-            return ktail ? ragged4(q, k) : *(const float4*)q;
-        } else {
-            int dy, dx;
-            long off, coff;
-            bool tap_ok = true;
-            if (MODE == MODE_CONV) {
-                const int cpb = p.Cin / BK;
-                const int tap = kt / cpb, cb = kt - tap * cpb;
-                dy = tap / 3 - 1;
-                dx = tap - (tap / 3) * 3 - 1;
-                off = ((long)dy * p.W + dx) * p.Cin;
-                coff = cb * BK + 4 * c4;
-            } else {   // small-Cin: float4 column = one tap, 4 channels
-                const int tap = kt * 8 + c4;
-                dy = tap / 3 - 1;
-                dx = tap - (tap / 3) * 3 - 1;
-                off = ((long)dy * p.W + dx) * 4;
-                coff = 0;
-                tap_ok = tap < 9;
+            const int k = kt * BK + 4 * c4;
+            const bool second = p.K2 != 0 && kt * BK >= p.K1;          // host guarantees K1 % 32 == 0 when K2 != 0
+            const float* src = second ? A2 : A1;
+            const long ld = second ? p.lda2 : p.lda1;
+            const int kk = second ? k - p.K1 : k;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pa[i] = src + (long)min(m0 + r0 + 32 * i, p.M - 1) * ld + kk;
+            a_left = (p.K2 != 0 && !second) ? p.K1 / BK - kt : 0x7fffffff;
+        } else if (MODE == MODE_CONV) {
+            const int tap = tap_next++;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long off = ((long)dy * p.W + dx) * p.Cin;
+            amask = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(py[i] + dy) < (unsigned)p.H && (unsigned)(px[i] + dx) < (unsigned)p.W;
+                amask |= (unsigned)ok << i;
+                pa[i] = A1 + pbase[i] + (ok ? off : 0L) + 4 * c4;
             }
-            const int yy = py[i] + dy, xx = px[i] + dx;
-            const bool ok = tap_ok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            amask = (amask & ~(1u << i)) | ((unsigned)ok << i);
-            return *(const float4*)(A1 + pbase[i] + (ok ? off : 0L) + coff);
+            a_left = p.Cin / BK;
+        } else {   // small-Cin: float4 column = one tap, 4 channels; two K steps, both set up from scratch
+            const int tap = kt * 8 + c4;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long off = ((long)dy * p.W + dx) * 4;
+            amask = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = tap < 9 && (unsigned)(py[i] + dy) < (unsigned)p.H && (unsigned)(px[i] + dx) < (unsigned)p.W;
+                amask |= (unsigned)ok << i;
+                pa[i] = A1 + pbase[i] + (ok ? off : 0L);
+            }
+            a_left = 1;
         }
     };
-    auto load_b = [&](int kt, int i, bool ktail) -> float4 {
-        const int k0 = kt * BK;
-        if (TRANSB) {   // B is [N][K]: same geometry as A
-            const int k = k0 + 4 * c4;
-            if (MODE != MODE_GEMM) return *(const float4*)(Bp + (long)(n0 + r0 + 32 * i) * K + k);   // packed + padded weights
-            const int n = min(n0 + r0 + 32 * i, p.N - 1);
-            const float* q = Bp + (long)n * p.ldb + k;
-            return ktail ? ragged4(q, k) : *(const float4*)q;
-        } else {        // B is [K][N]: thread -> (k row kr + 8 i, float4 column n4); N % 4 == 0 checked on host
-            const int n4 = tid & 31, kr = tid >> 5;
-            const int n = min(n0 + 4 * n4, p.N - 4), k = k0 + kr + 8 * i;
-            return *(const float4*)(Bp + (long)min(k, K - 1) * p.ldb + n);    // rows past K are zeroed at ds_write time
+    {   // B pointers never need a re-setup
+        if (TRANSB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (MODE != MODE_GEMM) pb[i] = Bp + (long)(n0 + r0 + 32 * i) * K + 4 * c4;          // packed + padded weights
+                else pb[i] = Bp + (long)min(n0 + r0 + 32 * i, p.N - 1) * p.ldb + 4 * c4;
+            }
+        } else {   // B is [K][N]: thread -> (k row kr + 8 i, float4 column n4); N % 4 == 0 checked on host
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                pb[i] = Bp + (long)min((tid >> 5) + 8 * i, K - 1) * p.ldb + min(n0 + 4 * (tid & 31), p.N - 4);
+        }
+    }
+    auto load_a = [&](int kt, int i, bool ragged) -> float4 {
+        const float* q = pa[i];
+        pa[i] = q + BK;
+        if (MODE == MODE_GEMM && ragged) return ragged4(q, kt * BK + 4 * c4);
+        return *(const float4*)q;
+    };
+    auto load_b = [&](int kt, int i, bool ragged) -> float4 {
+        const float* q = pb[i];
+        if (TRANSB) {
+            pb[i] = q + BK;
+            if (MODE == MODE_GEMM && ragged) return ragged4(q, kt * BK + 4 * c4);
+            return *(const float4*)q;
+        } else {
+            // rows past K (ragged last step) re-read row K-1 and are zeroed at ds_write time
+            const int knext = (kt + 1) * BK + (tid >> 5) + 8 * i;
+            pb[i] = (!ragged || knext < K) ? q + (long)BK * p.ldb : q;
+            return *(const float4*)q;
         }
     };
     // Fix-ups (zero padding, SiLU on the embedding input, K-tail rows) are applied here, at ds_write time, so that
@@ -169,6 +194,8 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
         }
     };
 #define LOAD_TILES_(kt, T)                                                                                  \
+    if (a_left == 0) setup_a(kt);                                                                           \
+    --a_left;                                                                                               \
     ra0 = load_a(kt, 0, T); ra1 = load_a(kt, 1, T); ra2 = load_a(kt, 2, T); ra3 = load_a(kt, 3, T);         \
     rb0 = load_b(kt, 0, T); rb1 = load_b(kt, 1, T); rb2 = load_b(kt, 2, T); rb3 = load_b(kt, 3, T);
     // RAGGED (K % 32 != 0, U-ViT attention / patch embedding only) is a separate kernel variant whose loads are all
@@ -283,7 +310,7 @@ extern "C" int dua_gemm(const dua_gemm_args* a, void* stream) {
     DUA_REQUIRE(a->M > 0 && a->N > 0 && a->K1 > 0 && a->K2 >= 0 && a->batch >= 1 && a->batch_inner >= 1, "dua_gemm: bad sizes");
     DUA_REQUIRE(a->lda1 % 4 == 0 && a->ldb % 4 == 0, "dua_gemm: leading dims must be multiples of 4 floats (K itself may be ragged)");
     DUA_REQUIRE((a->K2 == 0) == (a->A2 == nullptr), "dua_gemm: A2/K2 mismatch");
-    DUA_REQUIRE(a->K2 == 0 || (a->K1 % 4 == 0 && a->lda2 % 4 == 0), "dua_gemm: K1 must be a multiple of 4 for a two-source A");
+    DUA_REQUIRE(a->K2 == 0 || (a->K1 % BK == 0 && a->lda2 % 4 == 0), "dua_gemm: K1 must be a multiple of 32 for a two-source A");
     DUA_REQUIRE(a->transB || a->N % 4 == 0, "dua_gemm: N must be a multiple of 4 when B is [K][N]");
     DUA_REQUIRE(a->batch % a->batch_inner == 0, "dua_gemm: batch must be a multiple of batch_inner");
     DUA_REQUIRE((((uintptr_t)a->A1 | (uintptr_t)a->B | (uintptr_t)a->A2) & 15) == 0, "dua_gemm: operands must be 16-byte aligned");
