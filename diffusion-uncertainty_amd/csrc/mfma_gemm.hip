@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
     // A rows / halo rows and the weight panel they share stay in that XCD's L2.
     const int nwg = gridDim.x;
     int lid = blockIdx.x;
+    // Stagger: two workgroups share a CU and would otherwise run their barrier / staging sections in lockstep, leaving
+    // the matrix pipe idle during both.  The second resident generation of the launch starts half a K step late, which
+    // the slots then keep (speed only; any placement gives the same result).
+    if (blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(64);
     {
         int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, idx = lid >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
