@@ -51,6 +51,10 @@ SIGNATURES = {
     "dua_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "dua_embedding_add": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "dua_bf16x3_plane_elems": (_Z, [_I, _I]),
+    "dua_pack_weight_bf16x3": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dua_conv3x3_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dua_gemm_bf16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P]),
     "dua_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dua_uvit_assemble": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dua_unpatchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,0 +1,294 @@
+// Split-bf16 ("bf16x3") tile engine: fp32 GEMM / 3x3 convolution evaluated on the bf16 matrix cores.
+//
+// Every fp32 operand is split a = hi + lo with hi = bf16(a) (RNE) and lo = bf16(a - hi); the product is
+// accumulated in fp32 as  hi*hi + hi*lo + lo*hi  with three v_mfma_f32_32x32x16_bf16 per tile and 16-deep K step
+// (the dropped lo*lo term is 2^-18 relative).  Per-product relative error is about 2^-17 (1e-5), i.e. between
+// fp16 autocast (what the reference's GPU scripts run) and exact fp32; tests hold the model output
+// to the north star's 1e-3 per pixel against the fp32 CPU oracle.
+//
+// Same structure as mfma_gemm.hip: 128x128 block tile, 4 waves x (2x2) 32x32 MFMA tiles, 32-deep K step, staging
+// global -> registers -> LDS with the im2col gather / zero padding / SiLU / split applied at ds_write time, one
+// barrier per K step, software-pipelined.  Activations (A) are fp32 in HBM and split on the fly; weights (B) are
+// pre-split once into two bf16 planes [Npad128][K] by dua_pack_*_bf16x3.  LDS rows are 32 bf16 + 8 pad (80 B): the
+// 16-lane groups of ds_read_b128 land on 16 distinct 16-byte slots.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDH 40                       // LDS row stride in bf16 elements (80 bytes)
+#define PLANE (BM * LDH)             // bf16 elements per plane tile (5120 -> 10 KB)
+#define BUF (4 * PLANE)              // A_hi, A_lo, B_hi, B_lo
+
+enum { XMODE_GEMM = 0, XMODE_CONV = 1 };
+
+struct XTileP {
+    const float *A1, *A2;
+    const __bf16 *Bhi, *Blo;         // pre-split weights [Npad][K]
+    const float *bias, *res;
+    float* C;
+    int M, N, K1, K2;
+    long lda1, lda2, ldc, ldr;
+    int act_out;
+    float alpha;
+    int H, W, Cin, nchw_out;
+    int ntm, ntn;
+};
+
+__device__ __forceinline__ float gelu_x(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+__device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
+    float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 h = (__bf16)f[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(f[j] - (float)h);
+    }
+}
+
+template <int MODE, bool SILU_IN>
+__global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];      // 80 KB: two workgroups fill a CU's 160 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    int lid = blockIdx.x;
+    if (blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(16);
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, idx = lid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tn = lid % p.ntn, tm = lid / p.ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const float *A1 = p.A1, *A2 = p.A2;
+
+    const int c4 = tid & 7, r0 = tid >> 3;
+    const int K = (MODE == XMODE_GEMM) ? p.K1 + p.K2 : 9 * p.Cin;
+    const int nk = K / BK;
+
+    int py[4], px[4];
+    long pbase[4];
+    if (MODE == XMODE_CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(m0 + r0 + 32 * i, p.M - 1);
+            const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
+            py[i] = rem / p.W;
+            px[i] = rem - py[i] * p.W;
+            pbase[i] = (long)m * p.Cin;
+        }
+    }
+
+    unsigned amask = 0xf;
+    const float* pa[4];
+    int a_left = 0, tap_next = 0;
+    auto setup_a = [&](int kt) {
+        if (MODE == XMODE_GEMM) {
+            const int k = kt * BK + 4 * c4;
+            const bool second = p.K2 != 0 && kt * BK >= p.K1;
+            const float* src = second ? A2 : A1;
+            const long ld = second ? p.lda2 : p.lda1;
+            const int kk = second ? k - p.K1 : k;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pa[i] = src + (long)min(m0 + r0 + 32 * i, p.M - 1) * ld + kk;
+            a_left = (p.K2 != 0 && !second) ? p.K1 / BK - kt : 0x7fffffff;
+        } else {
+            const int tap = tap_next++;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long off = ((long)dy * p.W + dx) * p.Cin;
+            amask = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(py[i] + dy) < (unsigned)p.H && (unsigned)(px[i] + dx) < (unsigned)p.W;
+                amask |= (unsigned)ok << i;
+                pa[i] = A1 + pbase[i] + (ok ? off : 0L) + 4 * c4;
+            }
+            a_left = p.Cin / BK;
+        }
+    };
+    // B: each plane tile is 128 rows x 32 bf16 = 512 chunks of 16 B; thread -> chunks tid and tid + 256
+    const int brow = tid >> 2, bch = tid & 3;
+    const __bf16* pbh[2];
+    const __bf16* pbl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long o = (long)(n0 + brow + 64 * j) * K + 8 * bch;                  // planes are padded to 128 rows
+        pbh[j] = p.Bhi + o;
+        pbl[j] = p.Blo + o;
+    }
+
+    float4 ra0, ra1, ra2, ra3;
+    uint4 rh0, rh1, rl0, rl1;
+#define XLOAD(kt)                                                                                   \
+    if (a_left == 0) setup_a(kt);                                                                   \
+    --a_left;                                                                                       \
+    ra0 = *(const float4*)pa[0]; ra1 = *(const float4*)pa[1]; ra2 = *(const float4*)pa[2]; ra3 = *(const float4*)pa[3]; \
+    pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;                                             \
+    rh0 = *(const uint4*)pbh[0]; rh1 = *(const uint4*)pbh[1]; rl0 = *(const uint4*)pbl[0]; rl1 = *(const uint4*)pbl[1]; \
+    pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
+    auto store_a = [&](int buf, int i, float4 v) {
+        if (MODE == XMODE_CONV) {
+            const bool ok = (amask >> i) & 1u;
+            v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        } else if (SILU_IN) {
+            v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        __bf16* base = lds + buf * BUF + (r0 + 32 * i) * LDH + 4 * c4;
+        *(bf16x4*)base = hi;
+        *(bf16x4*)(base + PLANE) = lo;
+    };
+#define XSTORE(buf)                                                                                 \
+    store_a(buf, 0, ra0); store_a(buf, 1, ra1); store_a(buf, 2, ra2); store_a(buf, 3, ra3);         \
+    *(uint4*)(lds + (buf) * BUF + 2 * PLANE + brow * LDH + 8 * bch) = rh0;                          \
+    *(uint4*)(lds + (buf) * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bch) = rh1;                   \
+    *(uint4*)(lds + (buf) * BUF + 3 * PLANE + brow * LDH + 8 * bch) = rl0;                          \
+    *(uint4*)(lds + (buf) * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bch) = rl1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lr = lane & 31, kh = lane >> 5;
+    struct XFrag { bf16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1; };
+    auto read_frag = [&](int buf, int s) -> XFrag {       // s = 16-deep sub-step 0 / 1 of the 32-deep tile
+        XFrag f;
+        const __bf16* a = lds + buf * BUF + (wm * 64 + lr) * LDH + 16 * s + 8 * kh;
+        const __bf16* b = lds + buf * BUF + 2 * PLANE + (wn * 64 + lr) * LDH + 16 * s + 8 * kh;
+        f.ah0 = *(const bf16x8*)a;
+        f.ah1 = *(const bf16x8*)(a + 32 * LDH);
+        f.al0 = *(const bf16x8*)(a + PLANE);
+        f.al1 = *(const bf16x8*)(a + PLANE + 32 * LDH);
+        f.bh0 = *(const bf16x8*)b;
+        f.bh1 = *(const bf16x8*)(b + 32 * LDH);
+        f.bl0 = *(const bf16x8*)(b + PLANE);
+        f.bl1 = *(const bf16x8*)(b + PLANE + 32 * LDH);
+        return f;
+    };
+#define XM(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
+#define XMFMA12(F)                                                                        \
+    XM(F.al0, F.bh0, acc[0][0]) XM(F.al0, F.bh1, acc[0][1]) XM(F.al1, F.bh0, acc[1][0]) XM(F.al1, F.bh1, acc[1][1]) \
+    XM(F.ah0, F.bl0, acc[0][0]) XM(F.ah0, F.bl1, acc[0][1]) XM(F.ah1, F.bl0, acc[1][0]) XM(F.ah1, F.bl1, acc[1][1]) \
+    XM(F.ah0, F.bh0, acc[0][0]) XM(F.ah0, F.bh1, acc[0][1]) XM(F.ah1, F.bh0, acc[1][0]) XM(F.ah1, F.bh1, acc[1][1])
+
+    // pipeline: [MFMA s0 | read s1] [write tile kt+1] barrier [MFMA s1 | read s0 of tile kt+1 | global loads kt+2]
+    XLOAD(0)
+    XSTORE(0)
+    if (nk > 1) { XLOAD(1) }
+    __syncthreads();
+    XFrag f0 = read_frag(0, 0), f1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        f1 = read_frag(buf, 1);
+        XMFMA12(f0)
+        if (kt + 1 < nk) { XSTORE(buf ^ 1) }
+        __syncthreads();
+        if (kt + 1 < nk) f0 = read_frag(buf ^ 1, 0);
+        if (kt + 2 < nk) { XLOAD(kt + 2) }
+        XMFMA12(f1)
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + lr;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row >= p.M) continue;
+                float v = acc[mi][ni][r] * p.alpha + bv;
+                if (p.act_out == 2) v = gelu_x(v);
+                if (p.res) v += p.res[(long)row * p.ldr + col];
+                if (MODE == XMODE_CONV && p.nchw_out) {
+                    int hw = p.H * p.W, n = row / hw, rem = row - n * hw;
+                    p.C[((long)n * p.N + col) * hw + rem] = v;
+                } else {
+                    p.C[(long)row * p.ldc + col] = v;
+                }
+            }
+        }
+}
+
+template <int MODE, bool SILU_IN = false>
+static int launch_x(XTileP& p, hipStream_t s) {
+    p.ntm = (p.M + BM - 1) / BM;
+    p.ntn = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN>), dim3(p.ntm * p.ntn), 256, 0, s, p);
+    return dua_check_launch("dua bf16x3 tile kernel");
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- weight splitting: fp32 [N][K] (or OIHW conv weights) -> two bf16 planes [Npad128][K] -------------------
+__global__ void k_split_weight(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int N, int K,
+                               int Npad, int conv_cin) {
+    size_t total = (size_t)Npad * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int n = (int)(i / K), k = (int)(i % K);
+        float v = 0.f;
+        if (n < N) {
+            if (conv_cin) {                       // OIHW -> [n][tap][ci]
+                int tap = k / conv_cin, ci = k % conv_cin;
+                v = w[((size_t)n * conv_cin + ci) * 9 + tap];
+            } else {
+                v = w[(size_t)n * K + k];
+            }
+        }
+        __bf16 h = (__bf16)v;
+        hi[i] = h;
+        lo[i] = (__bf16)(v - (float)h);
+    }
+}
+
+extern "C" size_t dua_bf16x3_plane_elems(int N, int K) { return (size_t)round_up(N, BN) * K; }
+
+extern "C" int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K, int conv_cin, void* stream) {
+    DUA_REQUIRE(w && planes && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_bf16x3: K must be a positive multiple of 32 (got %d)", K);
+    DUA_REQUIRE(conv_cin == 0 || K == 9 * conv_cin, "dua_pack_weight_bf16x3: conv K must be 9*Cin");
+    int Npad = round_up(N, BN);
+    size_t plane = (size_t)Npad * K;
+    __bf16* hi = (__bf16*)planes;
+    hipLaunchKernelGGL(k_split_weight, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, hi + plane, N, K, Npad, conv_cin);
+    return dua_check_launch("dua_pack_weight_bf16x3");
+}
+
+extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
+                                  int H, int W, int Cin, int Cout, int nchw_out, void* stream) {
+    DUA_REQUIRE(x && planes && y, "dua_conv3x3_bf16x3: null pointer");
+    DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3_bf16x3: Cin must be a multiple of 32 (got %d)", Cin);
+    DUA_REQUIRE((long)N * H * W < (1L << 31), "dua_conv3x3_bf16x3: too many pixels");
+    XTileP p{};
+    size_t plane = dua_bf16x3_plane_elems(Cout, 9 * Cin);
+    p.A1 = x; p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = y;
+    p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
+    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
+    return launch_x<XMODE_CONV>(p, as_stream(stream));
+}
+
+extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
+                               const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
+                               int act_out, float alpha, void* stream) {
+    DUA_REQUIRE(A1 && planes && C && M > 0 && N > 0 && K1 > 0 && K2 >= 0, "dua_gemm_bf16x3: bad arguments");
+    DUA_REQUIRE((K1 + K2) % BK == 0 && (K2 == 0 || K1 % BK == 0), "dua_gemm_bf16x3: K (and K1 for a two-source A) must be multiples of 32");
+    DUA_REQUIRE(lda1 % 4 == 0 && (K2 == 0 || lda2 % 4 == 0) && (K2 == 0) == (A2 == nullptr), "dua_gemm_bf16x3: bad A operands");
+    DUA_REQUIRE(act_in == 0 || act_in == 1, "dua_gemm_bf16x3: act_in must be 0 or 1");
+    XTileP p{};
+    size_t plane = dua_bf16x3_plane_elems(N, K1 + K2);
+    p.A1 = A1; p.A2 = A2; p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = C;
+    p.M = M; p.N = N; p.K1 = K1; p.K2 = K2; p.lda1 = lda1; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
+    p.act_out = act_out; p.alpha = alpha;
+    return act_in ? launch_x<XMODE_GEMM, true>(p, as_stream(stream)) : launch_x<XMODE_GEMM, false>(p, as_stream(stream));
+}

@@ -38,7 +38,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 skip = None
             elif isinstance(layer, AttentionBlock):
                 h = layer.run(ctx, h)
-            else:                                   # input conv
+            else:                                   # input conv (Cin padded to 4: always the fp32 small-Cin kernel)
                 h = ops.conv3x3(h, ctx.packed(layer, "w3"), layer.bias, layer.out_channels)
         return h
 
@@ -91,7 +91,7 @@ class ResBlock(TimestepBlock):
         h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample)
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
-        h = ops.conv3x3(h, ctx.packed(conv1, "w3"), conv1.bias, self.out_channels)
+        h = ctx.conv3x3(h, conv1, self.out_channels)
         film = ops.gemm(ctx.emb, self.emb_layers[1].weight, bias=self.emb_layers[1].bias, act_in=1)   # :245
         st2 = ops.groupnorm_stats(h)
         mask = None
@@ -104,9 +104,9 @@ class ResBlock(TimestepBlock):
         else:
             sc = self.skip_connection
             Hx, Wx = x.shape[1], x.shape[2]
-            res = ops.gemm(x.view(N * Hx * Wx, -1), ctx.packed(sc, "w1"), bias=sc.bias,
-                           a2=(skip.view(N * Hx * Wx, -1) if skip is not None else None)).view(N, Hx, Wx, self.out_channels)
-        return ops.conv3x3(h, ctx.packed(conv2, "w3"), conv2.bias, self.out_channels, residual=res)   # :257
+            res = ctx.linear(x.view(N * Hx * Wx, -1), sc, a2=(skip.view(N * Hx * Wx, -1) if skip is not None else None))
+            res = res.view(N, Hx, Wx, self.out_channels)
+        return ctx.conv3x3(h, conv2, self.out_channels, residual=res)                                   # :257
 
 
 class QKVAttentionLegacy(nn.Module):
@@ -147,10 +147,9 @@ class AttentionBlock(nn.Module):
         T = H * W
         st = ops.groupnorm_stats(x)
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0)
-        wq, bq = ctx.packed(self, "qkv")
-        qkv = ops.gemm(xn.view(N * T, C), wq, bias=bq)
+        qkv = ctx.qkv(xn.view(N * T, C), self)
         a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads)
-        out = ops.gemm(a, ctx.packed(self.proj_out, "w1"), bias=self.proj_out.bias, residual=x.view(N * T, C))
+        out = ctx.linear(a, self.proj_out, residual=x.view(N * T, C))
         return out.view(N, H, W, C)
 
 
@@ -170,6 +169,14 @@ class _Ctx:
             elif kind == "w1":
                 w = mod.weight.detach()
                 cache[key] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            elif kind == "w3x":
+                cache[key] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
+            elif kind == "w1x":
+                w = mod.weight.detach()
+                cache[key] = ops.pack_weight_bf16x3(w.reshape(w.shape[0], w.shape[1]).contiguous())
+            elif kind == "qkvx":
+                wq, bq = self.packed(mod, "qkv")
+                cache[key] = (ops.pack_weight_bf16x3(wq), bq)
             elif kind == "qkv":
                 w = mod.qkv.weight.detach().reshape(3 * mod.channels, mod.channels)
                 b = mod.qkv.bias.detach()
@@ -183,6 +190,27 @@ class _Ctx:
 
     def dropout_mask(self, shape_nhwc, p):
         return self.model.dropout_mask_source(shape_nhwc, p)
+
+    # ---- the FLOP carriers, in the model's precision mode
+    def conv3x3(self, h, conv, cout, residual=None, nchw_out=False):
+        if self.model.precision == "bf16x3" and h.shape[3] % 32 == 0:
+            return ops.conv3x3_bf16x3(h, self.packed(conv, "w3x"), conv.bias, cout, residual=residual, nchw_out=nchw_out)
+        return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out)
+
+    def linear(self, a, mod, a2=None, residual=None):
+        """1x1 conv / conv1d(k=1) as a GEMM over rows."""
+        n_out = mod.weight.shape[0]
+        K = a.shape[1] + (0 if a2 is None else a2.shape[1])
+        if self.model.precision == "bf16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:
+            return ops.gemm_bf16x3(a, self.packed(mod, "w1x"), n_out, bias=mod.bias, a2=a2, residual=residual)
+        return ops.gemm(a, self.packed(mod, "w1"), bias=mod.bias, a2=a2, residual=residual)
+
+    def qkv(self, xn, blk):
+        if self.model.precision == "bf16x3" and xn.shape[1] % 32 == 0:
+            planes, bq = self.packed(blk, "qkvx")
+            return ops.gemm_bf16x3(xn, planes, 3 * blk.channels, bias=bq)
+        wq, bq = self.packed(blk, "qkv")
+        return ops.gemm(xn, wq, bias=bq)
 
 
 class UNetModel(nn.Module):
@@ -242,6 +270,9 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(nn.Conv2d(input_ch, out_channels, 3, padding=1)))
         self._packed = {}
+        # "fp32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x3": convs and weight GEMMs on the bf16 matrix cores
+        # with split fp32 operands (csrc/mfma_bf16x3.hip); attention products, embeddings, norms stay fp32.
+        self.precision = "fp32"
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask
@@ -287,8 +318,7 @@ class UNetModel(nn.Module):
         st = ops.groupnorm_stats(h)
         h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1)
         keep = self.out_channels if out_channels_keep is None else out_channels_keep
-        wp = ctx.packed(conv, "w3")
-        return ops.conv3x3(h, wp, conv.bias, keep, nchw_out=True)
+        return ctx.conv3x3(h, conv, keep, nchw_out=True)
 
 
 def host_dropout_mask(shape_nhwc, p):

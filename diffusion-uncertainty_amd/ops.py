@@ -245,6 +245,48 @@ def gemm(a1, w, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.
     return c
 
 
+# ------------------------------------------------------------------ split-bf16 (bf16x3) variants
+def pack_weight_bf16x3(w):
+    """fp32 [N][K] linear / 1x1 weight, or OIHW 3x3 conv weight -> two bf16 planes (hi | lo) in one int16 buffer."""
+    _req(w, name="w")
+    L = _lib.lib()
+    if w.ndim == 4 and w.shape[2] == 3:
+        N, cin = w.shape[0], w.shape[1]
+        K = 9 * cin
+    else:
+        N, cin = w.shape[0], 0
+        K = w.numel() // N
+    planes = torch.empty(2 * L.dua_bf16x3_plane_elems(N, K), device=w.device, dtype=torch.int16)
+    check(L.dua_pack_weight_bf16x3(_p(w), _p(planes), N, K, cin, _stream()), "dua_pack_weight_bf16x3")
+    return planes
+
+
+def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False):
+    _req(x, name="x")
+    N, H, W, Cin = x.shape
+    y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
+    e0 = e1 = None
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_lib.lib().dua_conv3x3_bf16x3(_p(x), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
+                                        _stream()), "dua_conv3x3_bf16x3")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.record("conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
+    return y
+
+
+def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0):
+    _req(a1, name="a1")
+    M, K1 = a1.shape
+    K2 = 0 if a2 is None else a2.shape[1]
+    c = torch.empty((M, n_out), device=a1.device, dtype=torch.float32)
+    check(_lib.lib().dua_gemm_bf16x3(_p(a1), K1, K1, _p(a2), K2, max(K2, 4), _p(planes), _p(bias), _p(residual), n_out, _p(c), n_out,
+                                     M, n_out, int(act_in), int(act_out), float(alpha), _stream()), "dua_gemm_bf16x3")
+    return c
+
+
 def gemm_raw(**kw):
     g = GemmArgs(**kw)
     check(_lib.lib().dua_gemm(ctypes.byref(g), _stream()), "dua_gemm")

@@ -47,18 +47,18 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.skip_linear = nn.Linear(2 * dim, dim) if skip else None
 
-    def run(self, x, B, L, skip=None):
-        """x, skip: [B*L, D]."""
+    def run(self, lin, x, B, L, skip=None):
+        """x, skip: [B*L, D]; lin(a, linear_module, **kw) is the model's precision-aware GEMM."""
         D = x.shape[1]
         if self.skip_linear is not None:
-            x = ops.gemm(x, self.skip_linear.weight, bias=self.skip_linear.bias, a2=skip)          # :116-117
+            x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv = ops.gemm(h, self.attn.qkv.weight, bias=self.attn.qkv.bias)
+        qkv = lin(h, self.attn.qkv)
         a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads)            # :69-73
-        x = ops.gemm(a, self.attn.proj.weight, bias=self.attn.proj.bias, residual=x)               # :118
+        x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        h = ops.gemm(h, self.mlp.fc1.weight, bias=self.mlp.fc1.bias, act_out=2)                    # fc1 + GELU
-        return ops.gemm(h, self.mlp.fc2.weight, bias=self.mlp.fc2.bias, residual=x)                # :119
+        h = lin(h, self.mlp.fc1, act_out=2)                                                        # fc1 + GELU
+        return lin(h, self.mlp.fc2, residual=x)                                                    # :119
 
 
 class PatchEmbed(nn.Module):
@@ -99,6 +99,24 @@ class UViT(nn.Module):
         self.apply(self._init_weights)
         self.img_size = img_size
         self.patch_size = patch_size
+        self.precision = "fp32"          # or "bf16x3" (see guided_diffusion/unet_openai.py)
+        self._planes = {}
+
+    def _apply(self, fn, *a, **k):
+        self._planes = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._planes = {}
+        return super().load_state_dict(*a, **k)
+
+    def _lin(self, a, mod, a2=None, residual=None, act_out=0):
+        K = a.shape[1] + (0 if a2 is None else a2.shape[1])
+        if self.precision == "bf16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:
+            if id(mod) not in self._planes:
+                self._planes[id(mod)] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
+            return ops.gemm_bf16x3(a, self._planes[id(mod)], mod.weight.shape[0], bias=mod.bias, a2=a2, residual=residual, act_out=act_out)
+        return ops.gemm(a, mod.weight, bias=mod.bias, a2=a2, residual=residual, act_out=act_out)
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -131,11 +149,11 @@ class UViT(nn.Module):
         h = h.view(B * T, D)
         skips = []
         for blk in self.in_blocks:
-            h = blk.run(h, B, T)
+            h = blk.run(self._lin, h, B, T)
             skips.append(h)
-        h = self.mid_block.run(h, B, T)
+        h = self.mid_block.run(self._lin, h, B, T)
         for blk in self.out_blocks:
-            h = blk.run(h, B, T, skips.pop())
+            h = blk.run(self._lin, h, B, T, skips.pop())
         h = ops.layernorm(h, self.norm.weight, self.norm.bias, self.norm.eps)
-        h = ops.gemm(h, self.decoder_pred.weight, bias=self.decoder_pred.bias)             # [B*T, P*P*C]
+        h = self._lin(h, self.decoder_pred)                                                # [B*T, P*P*C]
         return ops.unpatchify(h, B, L, self.extras, C, P)                                  # :228-229

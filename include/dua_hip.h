@@ -147,6 +147,20 @@ int dua_timestep_embedding(const int64_t* t, float* emb, int N, int dim, void* s
 /* out[n][:] = a[n][:] + table[idx[n]][:]  (label embedding add, unet_openai.py:654). a may be NULL. */
 int dua_embedding_add(const float* a, const float* table, const int64_t* idx, float* out, int N, int D, void* stream);
 
+/* ---------------- split-bf16 ("bf16x3") variants of the two FLOP carriers ----------------
+ * Same contracts as dua_conv3x3 / dua_gemm (transB = 1 form), evaluated on the bf16 matrix cores with every fp32
+ * operand split a = hi + lo (bf16 each) and hi*hi + hi*lo + lo*hi accumulated in fp32 (per-product relative error
+ * about 2^-17; csrc/mfma_bf16x3.hip).  Weights are split once: `planes` holds two bf16 planes [Npad128][K]
+ * (hi, then lo), dua_bf16x3_plane_elems(N, K) elements each.  K must be a multiple of 32. */
+size_t dua_bf16x3_plane_elems(int N, int K);
+/* w: [N][K] fp32, or OIHW [N][conv_cin][3][3] when conv_cin != 0 (then K = 9*conv_cin, packed tap-major). */
+int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K, int conv_cin, void* stream);
+int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
+                       int H, int W, int Cin, int Cout, int nchw_out, void* stream);
+int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
+                    const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
+                    int act_out, float alpha, void* stream);
+
 /* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */
 /* PatchEmbed's strided conv as im2row: x NCHW [B][C][H][W] -> rows [B*(H/P)*(W/P)][C*P*P] in the
  * (c, p1, p2) order of the flattened conv weight (uvit.py:123-135); the projection itself is dua_gemm. */

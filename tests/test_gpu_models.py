@@ -82,9 +82,9 @@ def test_uvit_vs_golden(golden):
     o = m(T(g["tiny_x"]).to(dev), T(g["tiny_t"]).to(dev), T(g["tiny_y"]).to(dev))
     np.testing.assert_allclose(o.cpu().numpy(), g["tiny_out"], rtol=0, atol=1e-4)
     tok = T(g["block_in"]).to(dev).reshape(-1, 64).contiguous()
-    o = m.in_blocks[0].run(tok, 2, 18)
+    o = m.in_blocks[0].run(m._lin, tok, 2, 18)
     np.testing.assert_allclose(o.cpu().reshape(2, 18, 64).numpy(), g["block_noskip"], rtol=0, atol=1e-4)
-    o = m.out_blocks[0].run(tok, 2, 18, T(g["block_skip_in"]).to(dev).reshape(-1, 64).contiguous())
+    o = m.out_blocks[0].run(m._lin, tok, 2, 18, T(g["block_skip_in"]).to(dev).reshape(-1, 64).contiguous())
     np.testing.assert_allclose(o.cpu().reshape(2, 18, 64).numpy(), g["block_skip"], rtol=0, atol=1e-4)
 
 
@@ -237,3 +237,37 @@ def test_device_noise_mode():
         eps = m(x, torch.full((2,), 500, dtype=torch.long, device=dev), y=y, out_channels_keep=3)
         outs.append(s.step(eps, 500, x).uncertainty.cpu())
     assert torch.equal(outs[0], outs[1]) and (outs[0] >= 0).all() and outs[0].mean() > 0
+
+
+# ---------------------------------------------------------------- split-bf16 (bf16x3) precision mode
+@pytest.mark.parametrize("name", ["tiny", "adm64", "adm128"])
+def test_bf16x3_mode_adm(golden, name):
+    """Convs / weight GEMMs on the bf16 matrix cores with split fp32 operands: still within the 1e-3 bar."""
+    from oracle import adm
+    if name == "tiny":
+        g = golden("g5_adm_blocks")
+        m, _ = build_adm(TINY_ADM, 5)
+        x, t, y, ref = g["tiny_x"], g["tiny_t"], g["tiny_y"], g["tiny_out"]
+    else:
+        g = golden(f"g5_{name}_full")
+        m, _ = build_adm(dict(adm.ADM64 if name == "adm64" else adm.ADM128), int(g["seed"]))
+        x, t, y, ref = g["x"], g["t"], g["y"], g["out"]
+    m.precision = "bf16x3"
+    o = m(T(x).to(dev), T(t).to(dev), y=T(y).to(dev))
+    err = np.abs(o.cpu().numpy() - ref).max()
+    print(f"bf16x3 {name}: max|hip - reference| = {err:.3e} (|ref|max {np.abs(ref).max():.2f})")
+    assert err < TOL
+
+
+def test_bf16x3_mode_uvit(golden):
+    from diffusion_uncertainty_amd.init_model import load_uvit
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    g = golden("g6_uvit_h2_full")
+    m = load_uvit(256, device="cpu", load_checkpoint=False)
+    m.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(g["seed"])))
+    m.to(dev)
+    m.precision = "bf16x3"
+    o = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev))
+    err = np.abs(o.cpu().numpy() - g["out"]).max()
+    print(f"bf16x3 uvit-h/2: max|hip - reference| = {err:.3e}")
+    assert err < TOL

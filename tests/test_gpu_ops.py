@@ -236,3 +236,32 @@ def test_softmax_layernorm_embeddings(ops):
     tab, idx, a = rnd(54, 10, 32), torch.tensor([3, 0, 9]), rnd(55, 3, 32)
     o = ops.embedding_add(a.to(dev), tab.to(dev), idx.to(dev))
     np.testing.assert_array_equal(o.cpu().numpy(), (a + tab[idx]).numpy())
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 16, 32, 6),
+                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192)])
+def test_conv3x3_bf16x3(ops, N, H, W, Cin, Cout):
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    planes = ops.pack_weight_bf16x3(w.to(dev))
+    y = ops.conv3x3_bf16x3(nhwc(x).to(dev), planes, b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err = (nchw(y.cpu()).double() - (ref + res)).abs().max().item()
+    assert err < 1e-4, err                                   # split-bf16: ~1e-5 on O(1) outputs
+    y = ops.conv3x3_bf16x3(nhwc(x).to(dev), planes, b.to(dev), Cout, nchw_out=True)
+    assert (y.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0)])
+def test_gemm_bf16x3(ops, M, N, K1, K2):
+    a1, a2 = rnd(30, M, K1), (rnd(31, M, K2) if K2 else None)
+    w, b, r = rnd(32, N, K1 + K2) / math.sqrt(K1 + K2), rnd(33, N), rnd(34, M, N)
+    a = torch.cat([a1, a2], 1) if K2 else a1
+    ref = a.double() @ w.double().T
+    planes = ops.pack_weight_bf16x3(w.to(dev))
+    c = ops.gemm_bf16x3(a1.to(dev), planes, N, bias=b.to(dev), a2=(a2.to(dev) if K2 else None), residual=r.to(dev), alpha=0.5)
+    assert (c.cpu().double() - (0.5 * ref + b + r)).abs().max().item() < 1e-4
+    c = ops.gemm_bf16x3(a1.to(dev), planes, N, bias=b.to(dev), a2=(a2.to(dev) if K2 else None), act_in=1)
+    assert (c.cpu().double() - (F.silu(a.double()) @ w.double().T + b)).abs().max().item() < 1e-4
+    c = ops.gemm_bf16x3(a1.to(dev), planes, N, bias=b.to(dev), a2=(a2.to(dev) if K2 else None), act_out=2)
+    assert (c.cpu().double() - F.gelu(ref + b)).abs().max().item() < 1e-4
