@@ -143,7 +143,28 @@ struct GnApplyP {
     const float *x1, *x2, *stats, *gamma, *beta, *film, *drop;
     float* y;
     int C1, C2, N, H, W, G, act, resample;
+    int split;               // 1: y is two bf16 planes (hi | lo) of the output shape, for the bf16x3 conv
+    long plane;              // elements per plane
 };
+
+typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gn_store(const GnApplyP& p, size_t off, float4 v) {
+    if (!p.split) {
+        *(float4*)(p.y + off) = v;
+    } else {
+        __bf16* hi = (__bf16*)p.y + off;
+        float f[4] = {v.x, v.y, v.z, v.w};
+        gn_bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 t = (__bf16)f[j];
+            h[j] = t;
+            l[j] = (__bf16)(f[j] - (float)t);
+        }
+        *(gn_bf16x4*)hi = h;
+        *(gn_bf16x4*)(hi + p.plane) = l;
+    }
+}
 
 __device__ __forceinline__ float4 gn_xform(const GnApplyP& p, int n, size_t pix, int c) {
     const int C = p.C1 + p.C2, cpg = C / p.G;
@@ -179,37 +200,57 @@ __global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p) {
         int yo = (int)(t2 % Ho), n = (int)(t2 / Ho);
         if (p.resample == 0) {
             size_t pix = ((size_t)n * p.H + yo) * p.W + xo;
-            *(float4*)(p.y + pix * C + c) = gn_xform(p, n, pix, c);
+            gn_store(p, pix * C + c, gn_xform(p, n, pix, c));
         } else if (p.resample > 0) {
             size_t pix = ((size_t)n * p.H + yo) * p.W + xo;
             float4 v = gn_xform(p, n, pix, c);
             int W2 = 2 * p.W;
             size_t o = (((size_t)n * 2 * p.H + 2 * yo) * W2 + 2 * xo) * C + c;
-            *(float4*)(p.y + o) = v;
-            *(float4*)(p.y + o + C) = v;
-            *(float4*)(p.y + o + (size_t)W2 * C) = v;
-            *(float4*)(p.y + o + (size_t)W2 * C + C) = v;
+            gn_store(p, o, v);
+            gn_store(p, o + C, v);
+            gn_store(p, o + (size_t)W2 * C, v);
+            gn_store(p, o + (size_t)W2 * C + C, v);
         } else {
             size_t pix = ((size_t)n * p.H + 2 * yo) * p.W + 2 * xo;
             float4 a = gn_xform(p, n, pix, c), b = gn_xform(p, n, pix + 1, c);
             float4 d = gn_xform(p, n, pix + p.W, c), e = gn_xform(p, n, pix + p.W + 1, c);
             float4 o = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f,
                                    (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f);
-            *(float4*)(p.y + (((size_t)n * Ho + yo) * Wo + xo) * C + c) = o;
+            gn_store(p, (((size_t)n * Ho + yo) * Wo + xo) * C + c, o);
         }
     }
 }
 
+static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                         const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                         int resample, const float* dropmask, float* y, int split, void* stream);
+
 extern "C" int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                                    const float* stats, const float* gamma, const float* beta, const float* film, int act,
                                    int resample, const float* dropmask, float* y, void* stream) {
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, y, 0, stream);
+}
+
+extern "C" int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                         const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                         int resample, const float* dropmask, void* yplanes, void* stream) {
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, (float*)yplanes, 1, stream);
+}
+
+static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                         const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                         int resample, const float* dropmask, float* y, int split, void* stream) {
     int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && y, "dua_groupnorm_apply: null pointer");
     DUA_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0, "dua_groupnorm_apply: unsupported channels");
     DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply: x2/C2 mismatch");
     DUA_REQUIRE(resample >= 0 || (H % 2 == 0 && W % 2 == 0), "dua_groupnorm_apply: pooling needs even H, W");
     DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply: dropout mask with resampling unsupported");
-    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample};
+    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0};
+    {
+        long Hy = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wy = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
+        p.plane = (long)N * Hy * Wy * C;
+    }
     int Ho = resample < 0 ? H / 2 : H, Wo = resample < 0 ? W / 2 : W;
     size_t total = (size_t)N * Ho * Wo * (C / 4);
     if (total == 0) return DUA_OK;

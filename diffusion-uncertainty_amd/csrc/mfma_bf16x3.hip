@@ -28,6 +28,7 @@ enum { XMODE_GEMM = 0, XMODE_CONV = 1 };
 
 struct XTileP {
     const float *A1, *A2;
+    const __bf16 *Ahi, *Alo;         // PRESPLIT conv input: two bf16 NHWC planes written by dua_groupnorm_apply_split
     const __bf16 *Bhi, *Blo;         // pre-split weights [Npad][K]
     const float *bias, *res;
     float* C;
@@ -51,7 +52,7 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-template <int MODE, bool SILU_IN>
+template <int MODE, bool SILU_IN, bool PRESPLIT>
 __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];      // 80 KB: two workgroups fill a CU's 160 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,6 +85,21 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         }
     }
 
+    // ---- PRESPLIT: A tile per plane = 128 rows x 32 bf16 = 512 chunks of 16 B; thread -> rows brow, brow + 64
+    int qy[2], qx[2];
+    long qbase[2];
+    if (PRESPLIT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = min(m0 + (tid >> 2) + 64 * j, p.M - 1);
+            const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
+            qy[j] = rem / p.W;
+            qx[j] = rem - qy[j] * p.W;
+            qbase[j] = (long)m * p.Cin + 8 * (tid & 3);
+        }
+    }
+    const __bf16* qh[2];
+    const __bf16* ql[2];
     unsigned amask = 0xf;
     const float* pa[4];
     int a_left = 0, tap_next = 0;
@@ -97,6 +113,20 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pa[i] = src + (long)min(m0 + r0 + 32 * i, p.M - 1) * ld + kk;
             a_left = (p.K2 != 0 && !second) ? p.K1 / BK - kt : 0x7fffffff;
+        } else if (PRESPLIT) {
+            const int tap = tap_next++;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long off = ((long)dy * p.W + dx) * p.Cin;
+            amask = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = (unsigned)(qy[j] + dy) < (unsigned)p.H && (unsigned)(qx[j] + dx) < (unsigned)p.W;
+                amask |= (unsigned)ok << j;
+                const long o = qbase[j] + (ok ? off : 0L);
+                qh[j] = p.Ahi + o;
+                ql[j] = p.Alo + o;
+            }
+            a_left = p.Cin / BK;
         } else {
             const int tap = tap_next++;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -124,11 +154,17 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
 
     float4 ra0, ra1, ra2, ra3;
     uint4 rh0, rh1, rl0, rl1;
+    uint4 sh0, sh1, sl0, sl1;        // PRESPLIT A chunks
 #define XLOAD(kt)                                                                                   \
     if (a_left == 0) setup_a(kt);                                                                   \
     --a_left;                                                                                       \
-    ra0 = *(const float4*)pa[0]; ra1 = *(const float4*)pa[1]; ra2 = *(const float4*)pa[2]; ra3 = *(const float4*)pa[3]; \
-    pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;                                             \
+    if (PRESPLIT) {                                                                                 \
+        sh0 = *(const uint4*)qh[0]; sh1 = *(const uint4*)qh[1]; sl0 = *(const uint4*)ql[0]; sl1 = *(const uint4*)ql[1]; \
+        qh[0] += BK; qh[1] += BK; ql[0] += BK; ql[1] += BK;                                         \
+    } else {                                                                                        \
+        ra0 = *(const float4*)pa[0]; ra1 = *(const float4*)pa[1]; ra2 = *(const float4*)pa[2]; ra3 = *(const float4*)pa[3]; \
+        pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;                                         \
+    }                                                                                               \
     rh0 = *(const uint4*)pbh[0]; rh1 = *(const uint4*)pbh[1]; rl0 = *(const uint4*)pbl[0]; rl1 = *(const uint4*)pbl[1]; \
     pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
     auto store_a = [&](int buf, int i, float4 v) {
@@ -144,8 +180,17 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         *(bf16x4*)base = hi;
         *(bf16x4*)(base + PLANE) = lo;
     };
+    auto store_pre = [&](int buf, int j, uint4 h, uint4 l) {
+        const bool ok = (amask >> j) & 1u;
+        h = make_uint4(ok ? h.x : 0u, ok ? h.y : 0u, ok ? h.z : 0u, ok ? h.w : 0u);
+        l = make_uint4(ok ? l.x : 0u, ok ? l.y : 0u, ok ? l.z : 0u, ok ? l.w : 0u);
+        __bf16* base = lds + buf * BUF + (brow + 64 * j) * LDH + 8 * bch;
+        *(uint4*)base = h;
+        *(uint4*)(base + PLANE) = l;
+    };
 #define XSTORE(buf)                                                                                 \
-    store_a(buf, 0, ra0); store_a(buf, 1, ra1); store_a(buf, 2, ra2); store_a(buf, 3, ra3);         \
+    if (PRESPLIT) { store_pre(buf, 0, sh0, sl0); store_pre(buf, 1, sh1, sl1); }                     \
+    else { store_a(buf, 0, ra0); store_a(buf, 1, ra1); store_a(buf, 2, ra2); store_a(buf, 3, ra3); } \
     *(uint4*)(lds + (buf) * BUF + 2 * PLANE + brow * LDH + 8 * bch) = rh0;                          \
     *(uint4*)(lds + (buf) * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bch) = rh1;                   \
     *(uint4*)(lds + (buf) * BUF + 3 * PLANE + brow * LDH + 8 * bch) = rl0;                          \
@@ -222,11 +267,11 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         }
 }
 
-template <int MODE, bool SILU_IN = false>
+template <int MODE, bool SILU_IN = false, bool PRESPLIT = false>
 static int launch_x(XTileP& p, hipStream_t s) {
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN>), dim3(p.ntm * p.ntn), 256, 0, s, p);
+    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN, PRESPLIT>), dim3(p.ntm * p.ntn), 256, 0, s, p);
     return dua_check_launch("dua bf16x3 tile kernel");
 }
 
@@ -276,6 +321,20 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
     p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
     return launch_x<XMODE_CONV>(p, as_stream(stream));
+}
+
+extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
+                                           float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, void* stream) {
+    DUA_REQUIRE(xplanes && planes && y, "dua_conv3x3_bf16x3_presplit: null pointer");
+    DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3_bf16x3_presplit: Cin must be a multiple of 32 (got %d)", Cin);
+    DUA_REQUIRE((long)N * H * W < (1L << 31), "dua_conv3x3_bf16x3_presplit: too many pixels");
+    XTileP p{};
+    size_t plane = dua_bf16x3_plane_elems(Cout, 9 * Cin);
+    p.Ahi = (const __bf16*)xplanes; p.Alo = p.Ahi + (size_t)N * H * W * Cin;
+    p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = y;
+    p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
+    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
+    return launch_x<XMODE_CONV, false, true>(p, as_stream(stream));
 }
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,

@@ -88,7 +88,7 @@ class ResBlock(TimestepBlock):
         gn2, drop, conv2 = self.out_layers[0], self.out_layers[2], self.out_layers[3]
         N, H, W, _ = x.shape
         st = ops.groupnorm_stats(x, skip)
-        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample)
+        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample, split=ctx.split_acts)
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
         h = ctx.conv3x3(h, conv1, self.out_channels)
@@ -97,7 +97,7 @@ class ResBlock(TimestepBlock):
         mask = None
         if drop.training and drop.p > 0:
             mask = ctx.dropout_mask(h.shape, drop.p)
-        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask)      # :249-253
+        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask, split=ctx.split_acts)  # :249-253
         if isinstance(self.skip_connection, nn.Identity):
             assert skip is None
             res = x
@@ -159,6 +159,8 @@ class _Ctx:
     def __init__(self, model):
         self.model = model
         self.emb = None
+        # bf16x3 mode: GroupNorm+SiLU writes the conv input directly as split bf16 planes
+        self.split_acts = model.precision == "bf16x3"
 
     def packed(self, mod, kind):
         cache = self.model._packed
@@ -193,7 +195,7 @@ class _Ctx:
 
     # ---- the FLOP carriers, in the model's precision mode
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False):
-        if self.model.precision == "bf16x3" and h.shape[3] % 32 == 0:
+        if isinstance(h, ops.SplitPlanes) or (self.model.precision == "bf16x3" and h.shape[3] % 32 == 0):
             return ops.conv3x3_bf16x3(h, self.packed(conv, "w3x"), conv.bias, cout, residual=residual, nchw_out=nchw_out)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out)
 
@@ -316,7 +318,7 @@ class UNetModel(nn.Module):
             h = module.run(ctx, h, hs.pop())
         gn, conv = self.out[0], self.out[2]
         st = ops.groupnorm_stats(h)
-        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1)
+        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split=ctx.split_acts)
         keep = self.out_channels if out_channels_keep is None else out_channels_keep
         return ctx.conv3x3(h, conv, keep, nchw_out=True)
 

@@ -166,10 +166,25 @@ def groupnorm_stats(x1, x2=None, groups=32, eps=1e-5):
     return stats
 
 
-def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32):
+class SplitPlanes:
+    """Activation tensor stored as two bf16 NHWC planes (hi | lo) - the operand format of the bf16x3 conv."""
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape, self.device = buf, tuple(shape), buf.device
+
+
+def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32, split=False):
     N, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
+    if split:
+        buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
+        for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
+            _req(t, name=nm)
+        check(_lib.lib().dua_groupnorm_apply_split(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                                                   int(act), int(resample), _p(dropmask), _p(buf), _stream()),
+              "dua_groupnorm_apply_split")
+        return SplitPlanes(buf, (N, Ho, Wo, C1 + C2))
     y = torch.empty((N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.float32)
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
         _req(t, name=nm)
@@ -262,15 +277,21 @@ def pack_weight_bf16x3(w):
 
 
 def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False):
-    _req(x, name="x")
+    pre = isinstance(x, SplitPlanes)
+    if not pre:
+        _req(x, name="x")
     N, H, W, Cin = x.shape
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
     e0 = e1 = None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(_lib.lib().dua_conv3x3_bf16x3(_p(x), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
-                                        _stream()), "dua_conv3x3_bf16x3")
+    if pre:
+        check(_lib.lib().dua_conv3x3_bf16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout,
+                                                     int(nchw_out), _stream()), "dua_conv3x3_bf16x3_presplit")
+    else:
+        check(_lib.lib().dua_conv3x3_bf16x3(_p(x), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
+                                            _stream()), "dua_conv3x3_bf16x3")
     if PROFILE is not None:
         e1.record()
         PROFILE.record("conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)

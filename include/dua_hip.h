@@ -157,6 +157,14 @@ size_t dua_bf16x3_plane_elems(int N, int K);
 int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K, int conv_cin, void* stream);
 int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
                        int H, int W, int Cin, int Cout, int nchw_out, void* stream);
+/* Variant whose input was already split by dua_groupnorm_apply_split: xplanes = two bf16 NHWC planes (hi | lo). */
+int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
+                                float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, void* stream);
+/* dua_groupnorm_apply writing its result as two bf16 planes (hi = bf16(v), lo = bf16(v - hi)), N*Hy*Wy*C elements
+ * each (Hy, Wy = resampled size): the same bytes as the fp32 tensor, already in the bf16x3 conv's operand format. */
+int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                              const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                              int resample, const float* dropmask, void* yplanes, void* stream);
 int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
                     const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                     int act_out, float alpha, void* stream);
