@@ -152,24 +152,32 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         pbl[j] = p.Blo + o;
     }
 
-    float4 ra0, ra1, ra2, ra3;
-    uint4 rh0, rh1, rl0, rl1;
-    uint4 sh0, sh1, sl0, sl1;        // PRESPLIT A chunks
-#define XLOAD(kt)                                                                                   \
-    if (a_left == 0) setup_a(kt);                                                                   \
-    --a_left;                                                                                       \
-    if (PRESPLIT) {                                                                                 \
-        sh0 = *(const uint4*)qh[0]; sh1 = *(const uint4*)qh[1]; sl0 = *(const uint4*)ql[0]; sl1 = *(const uint4*)ql[1]; \
-        qh[0] += BK; qh[1] += BK; ql[0] += BK; ql[1] += BK;                                         \
-    } else {                                                                                        \
-        ra0 = *(const float4*)pa[0]; ra1 = *(const float4*)pa[1]; ra2 = *(const float4*)pa[2]; ra3 = *(const float4*)pa[3]; \
-        pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;                                         \
-    }                                                                                               \
-    rh0 = *(const uint4*)pbh[0]; rh1 = *(const uint4*)pbh[1]; rl0 = *(const uint4*)pbl[0]; rl1 = *(const uint4*)pbl[1]; \
-    pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
-    auto store_a = [&](int buf, int i, float4 v) {
+    // Two register stages: with ~2k-cycle K steps a global load needs more than one step to land, so tile kt+3 is
+    // requested while tile kt+1 is written to LDS (stage (kt+1)&1 is free again right after that write).
+    // A registers: 4 x float4 (fp32 rows, split at ds_write time) or, PRESPLIT, 4 x uint4 (hi, hi, lo, lo chunks)
+    struct Stage {
+        uint4 a0, a1, a2, a3;
+        uint4 bh0, bh1, bl0, bl1;        // pre-split weight chunks
+        unsigned mask;                   // conv: in-image bits of the staged rows, captured at load time
+    };
+    auto xload = [&](Stage& S, int kt) {
+        if (a_left == 0) setup_a(kt);
+        --a_left;
+        S.mask = amask;
+        if (PRESPLIT) {
+            S.a0 = *(const uint4*)qh[0]; S.a1 = *(const uint4*)qh[1]; S.a2 = *(const uint4*)ql[0]; S.a3 = *(const uint4*)ql[1];
+            qh[0] += BK; qh[1] += BK; ql[0] += BK; ql[1] += BK;
+        } else {
+            S.a0 = *(const uint4*)pa[0]; S.a1 = *(const uint4*)pa[1]; S.a2 = *(const uint4*)pa[2]; S.a3 = *(const uint4*)pa[3];
+            pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;
+        }
+        S.bh0 = *(const uint4*)pbh[0]; S.bh1 = *(const uint4*)pbh[1]; S.bl0 = *(const uint4*)pbl[0]; S.bl1 = *(const uint4*)pbl[1];
+        pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
+    };
+    auto store_a = [&](int buf, int i, uint4 u, unsigned mask) {
+        float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         if (MODE == XMODE_CONV) {
-            const bool ok = (amask >> i) & 1u;
+            const bool ok = (mask >> i) & 1u;
             v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         } else if (SILU_IN) {
             v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
@@ -180,21 +188,22 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         *(bf16x4*)base = hi;
         *(bf16x4*)(base + PLANE) = lo;
     };
-    auto store_pre = [&](int buf, int j, uint4 h, uint4 l) {
-        const bool ok = (amask >> j) & 1u;
+    auto store_pre = [&](int buf, int j, uint4 h, uint4 l, unsigned mask) {
+        const bool ok = (mask >> j) & 1u;
         h = make_uint4(ok ? h.x : 0u, ok ? h.y : 0u, ok ? h.z : 0u, ok ? h.w : 0u);
         l = make_uint4(ok ? l.x : 0u, ok ? l.y : 0u, ok ? l.z : 0u, ok ? l.w : 0u);
         __bf16* base = lds + buf * BUF + (brow + 64 * j) * LDH + 8 * bch;
         *(uint4*)base = h;
         *(uint4*)(base + PLANE) = l;
     };
-#define XSTORE(buf)                                                                                 \
-    if (PRESPLIT) { store_pre(buf, 0, sh0, sl0); store_pre(buf, 1, sh1, sl1); }                     \
-    else { store_a(buf, 0, ra0); store_a(buf, 1, ra1); store_a(buf, 2, ra2); store_a(buf, 3, ra3); } \
-    *(uint4*)(lds + (buf) * BUF + 2 * PLANE + brow * LDH + 8 * bch) = rh0;                          \
-    *(uint4*)(lds + (buf) * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bch) = rh1;                   \
-    *(uint4*)(lds + (buf) * BUF + 3 * PLANE + brow * LDH + 8 * bch) = rl0;                          \
-    *(uint4*)(lds + (buf) * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bch) = rl1;
+    auto xstore = [&](const Stage& S, int buf) {
+        if (PRESPLIT) { store_pre(buf, 0, S.a0, S.a2, S.mask); store_pre(buf, 1, S.a1, S.a3, S.mask); }
+        else { store_a(buf, 0, S.a0, S.mask); store_a(buf, 1, S.a1, S.mask); store_a(buf, 2, S.a2, S.mask); store_a(buf, 3, S.a3, S.mask); }
+        *(uint4*)(lds + buf * BUF + 2 * PLANE + brow * LDH + 8 * bch) = S.bh0;
+        *(uint4*)(lds + buf * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bch) = S.bh1;
+        *(uint4*)(lds + buf * BUF + 3 * PLANE + brow * LDH + 8 * bch) = S.bl0;
+        *(uint4*)(lds + buf * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bch) = S.bl1;
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -226,21 +235,29 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     XM(F.ah0, F.bl0, acc[0][0]) XM(F.ah0, F.bl1, acc[0][1]) XM(F.ah1, F.bl0, acc[1][0]) XM(F.ah1, F.bl1, acc[1][1]) \
     XM(F.ah0, F.bh0, acc[0][0]) XM(F.ah0, F.bh1, acc[0][1]) XM(F.ah1, F.bh0, acc[1][0]) XM(F.ah1, F.bh1, acc[1][1])
 
-    // pipeline: [MFMA s0 | read s1] [write tile kt+1] barrier [MFMA s1 | read s0 of tile kt+1 | global loads kt+2]
-    XLOAD(0)
-    XSTORE(0)
-    if (nk > 1) { XLOAD(1) }
+    // pipeline per K step: [MFMA s0 | read s1] [write tile kt+1 from its stage] barrier
+    //                      [MFMA s1 | read s0 of tile kt+1 | request tile kt+3 into the stage just written]
+    Stage st0, st1;
+    xload(st0, 0);
+    xstore(st0, 0);
+    if (nk > 1) xload(st1, 1);
+    if (nk > 2) xload(st0, 2);
     __syncthreads();
     XFrag f0 = read_frag(0, 0), f1;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        f1 = read_frag(buf, 1);
-        XMFMA12(f0)
-        if (kt + 1 < nk) { XSTORE(buf ^ 1) }
-        __syncthreads();
-        if (kt + 1 < nk) f0 = read_frag(buf ^ 1, 0);
-        if (kt + 2 < nk) { XLOAD(kt + 2) }
-        XMFMA12(f1)
+#define XSTEP(kt, S)                                                     \
+    {                                                                    \
+        const int buf = (kt) & 1;                                        \
+        f1 = read_frag(buf, 1);                                          \
+        XMFMA12(f0)                                                      \
+        if ((kt) + 1 < nk) xstore(S, buf ^ 1);                           \
+        __syncthreads();                                                 \
+        if ((kt) + 1 < nk) f0 = read_frag(buf ^ 1, 0);                   \
+        if ((kt) + 3 < nk) xload(S, (kt) + 3);                           \
+        XMFMA12(f1)                                                      \
+    }
+    for (int kt = 0; kt < nk; kt += 2) {
+        XSTEP(kt, st1)                       // tile kt+1 lives in st1 (odd tiles), kt+2 in st0
+        if (kt + 1 < nk) XSTEP(kt + 1, st0)
     }
 
 #pragma unroll
