@@ -9,8 +9,9 @@
 // Same structure as mfma_gemm.hip: 128x128 block tile, 4 waves x (2x2) 32x32 MFMA tiles, 32-deep K step, staging
 // global -> registers -> LDS with the im2col gather / zero padding / SiLU / split applied at ds_write time, one
 // barrier per K step, software-pipelined.  Activations (A) are fp32 in HBM and split on the fly; weights (B) are
-// pre-split once into two bf16 planes [Npad128][K] by dua_pack_*_bf16x3.  LDS rows are 32 bf16 + 8 pad (80 B): the
-// 16-lane groups of ds_read_b128 land on 16 distinct 16-byte slots.
+// pre-split once into two bf16 planes [Npad128][K] by dua_pack_*_bf16x3.  LDS rows are 32 bf16 = four 16-byte chunks;
+// chunk c of row r is stored at chunk position c ^ ((r >> 2) & 3): the 16-lane groups of ds_read_b128 (16 rows, one
+// chunk column) then land on 16 distinct 16-byte slots and the 8-lane groups of ds_write_b128 (2 rows x 4 chunks) on 8.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -20,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BM 128
 #define BN 128
 #define BK 32
-#define LDH 40                       // LDS row stride in bf16 elements (80 bytes)
+#define LDH 32                       // LDS row pitch in bf16 elements (64 bytes, no padding; XOR-swizzled chunks)
 #define PLANE (BM * LDH)             // bf16 elements per plane tile (5120 -> 10 KB)
 #define BUF (4 * PLANE)              // A_hi, A_lo, B_hi, B_lo
 
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     };
     // B: each plane tile is 128 rows x 32 bf16 = 512 chunks of 16 B; thread -> chunks tid and tid + 256
     const int brow = tid >> 2, bch = tid & 3;
+    const int bsw = bch ^ ((brow >> 2) & 3);          // swizzled chunk position (rows brow and brow + 64 share it)
     const __bf16* pbh[2];
     const __bf16* pbl[2];
 #pragma unroll
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         }
         bf16x4 hi, lo;
         split4(v, hi, lo);
-        __bf16* base = lds + buf * BUF + (r0 + 32 * i) * LDH + 4 * c4;
+        const int row = r0 + 32 * i;
+        __bf16* base = lds + buf * BUF + row * LDH + 8 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 4 * (c4 & 1);
         *(bf16x4*)base = hi;
         *(bf16x4*)(base + PLANE) = lo;
     };
@@ -192,17 +195,17 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         const bool ok = (mask >> j) & 1u;
         h = make_uint4(ok ? h.x : 0u, ok ? h.y : 0u, ok ? h.z : 0u, ok ? h.w : 0u);
         l = make_uint4(ok ? l.x : 0u, ok ? l.y : 0u, ok ? l.z : 0u, ok ? l.w : 0u);
-        __bf16* base = lds + buf * BUF + (brow + 64 * j) * LDH + 8 * bch;
+        __bf16* base = lds + buf * BUF + (brow + 64 * j) * LDH + 8 * bsw;
         *(uint4*)base = h;
         *(uint4*)(base + PLANE) = l;
     };
     auto xstore = [&](const Stage& S, int buf) {
         if (PRESPLIT) { store_pre(buf, 0, S.a0, S.a2, S.mask); store_pre(buf, 1, S.a1, S.a3, S.mask); }
         else { store_a(buf, 0, S.a0, S.mask); store_a(buf, 1, S.a1, S.mask); store_a(buf, 2, S.a2, S.mask); store_a(buf, 3, S.a3, S.mask); }
-        *(uint4*)(lds + buf * BUF + 2 * PLANE + brow * LDH + 8 * bch) = S.bh0;
-        *(uint4*)(lds + buf * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bch) = S.bh1;
-        *(uint4*)(lds + buf * BUF + 3 * PLANE + brow * LDH + 8 * bch) = S.bl0;
-        *(uint4*)(lds + buf * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bch) = S.bl1;
+        *(uint4*)(lds + buf * BUF + 2 * PLANE + brow * LDH + 8 * bsw) = S.bh0;
+        *(uint4*)(lds + buf * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bsw) = S.bh1;
+        *(uint4*)(lds + buf * BUF + 3 * PLANE + brow * LDH + 8 * bsw) = S.bl0;
+        *(uint4*)(lds + buf * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bsw) = S.bl1;
     };
 
     f32x16 acc[2][2];
@@ -217,8 +220,9 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     struct XFrag { bf16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1; };
     auto read_frag = [&](int buf, int s) -> XFrag {       // s = 16-deep sub-step 0 / 1 of the 32-deep tile
         XFrag f;
-        const __bf16* a = lds + buf * BUF + (wm * 64 + lr) * LDH + 16 * s + 8 * kh;
-        const __bf16* b = lds + buf * BUF + 2 * PLANE + (wn * 64 + lr) * LDH + 16 * s + 8 * kh;
+        const int cs = 8 * ((2 * s + kh) ^ ((lr >> 2) & 3));     // rows lr, lr + 32 (+64) share the swizzle
+        const __bf16* a = lds + buf * BUF + (wm * 64 + lr) * LDH + cs;
+        const __bf16* b = lds + buf * BUF + 2 * PLANE + (wn * 64 + lr) * LDH + cs;
         f.ah0 = *(const bf16x8*)a;
         f.ah1 = *(const bf16x8*)(a + 32 * LDH);
         f.al0 = *(const bf16x8*)(a + PLANE);
