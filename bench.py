@@ -31,7 +31,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 ADM128_FLOPS_PER_FWD_IMG = 6.139e11      # BASELINE.md section 3 (2*MAC, hooks on the reference modules)
-FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table
+FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table (fp32-input MFMA)
+BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md chip table (dense bf16 MFMA)
 
 
 class ConvProfile:
@@ -49,6 +50,23 @@ class ConvProfile:
         n = len(self.items)
         return dict(launches=n, flops_per_launch=total_fl / n, ms_per_launch=total_ms / n,
                     tflops=total_fl / (total_ms * 1e-3) / 1e12)
+
+    def roofline(self, precision):
+        cs = self.summary()
+        if cs is None:
+            return None
+        if precision == "fp32":
+            return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(cs["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        kernel="k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)",
+                        launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
+        return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    kernel="k_xtile<CONV, PRESPLIT> (split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)",
+                    launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
+                    executed_mfma_tflops=round(3 * cs["tflops"], 1), executed_frac=round(3 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
+                    note="achieved counts ALGORITHMIC fp32 FLOPs; each is executed as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi), "
+                         "so frac <= 1/3 by construction")
 
 
 def build_model(device, seed=128):
@@ -111,6 +129,10 @@ def main():
     ap.add_argument("--start-step-uc", type=int, default=40)
     ap.add_argument("--num-steps-uc", type=int, default=10)
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="bf16x3: convs / weight GEMMs on the bf16 matrix cores with split fp32 operands (parity ~3e-5); "
+                         "fp32: exact fp32 MFMA (parity ~7e-6)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the one-step run of the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
@@ -149,36 +171,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(a.warmup):
-        job(3, 1, 1, 1000 + w)
-    prof = None if a.no_profile else ConvProfile()
-    ops.PROFILE = prof
-    sync()
-    t0 = time.perf_counter()
-    uc_calls = 0
-    for k in range(a.steps):
-        uc_calls += job(a.generation_steps, a.start_step_uc, a.num_steps_uc, k)
-    sync()
-    dt = time.perf_counter() - t0
-    ops.PROFILE = None
-    dt = max_over_ranks(dt, dev)
+    def timed(precision, steps, warmup):
+        model.precision = precision
+        for w in range(warmup):
+            job(3, 1, 1, 1000 + w)
+        prof = None if a.no_profile else ConvProfile()
+        ops.PROFILE = prof
+        sync()
+        t0 = time.perf_counter()
+        uc = 0
+        for k in range(steps):
+            uc += job(a.generation_steps, a.start_step_uc, a.num_steps_uc, k)
+        sync()
+        dt = time.perf_counter() - t0
+        ops.PROFILE = None
+        return max_over_ranks(dt, dev), uc, prof
+
+    dt, uc_calls, prof = timed(a.precision, a.steps, a.warmup)
+    secondary = None
+    if world == 1 and not a.no_secondary:
+        other = "fp32" if a.precision == "bf16x3" else "bf16x3"
+        dt2, uc2, prof2 = timed(other, 1, 1)
+        secondary = dict(precision=other, value=round(a.batch / dt2, 4), unit="images/sec", steps=1, ms_per_step=round(dt2 * 1e3, 1),
+                         end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
+                         roofline=(prof2.roofline(other) if prof2 is not None else None))
 
     if rank == 0:
         images = a.batch * world * a.steps
         fwd_per_img = a.generation_steps + uc_calls / max(a.steps, 1)
         exec_flops = fwd_per_img * ADM128_FLOPS_PER_FWD_IMG * images
-        roof = None
-        if prof is not None:
-            cs = prof.summary()
-            roof = dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(cs["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                        kernel="k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3)", launches=cs["launches"],
-                        flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
+        roof = prof.roofline(a.precision) if prof is not None else None
         line = {
             "metric": "images/sec @ ADM ImageNet-128, 50 steps, M=5, bs=128; 1/2/4/8 GPU",
             "value": round(images / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("bf16x3 (fp32 operands split into 2 bf16 terms, 3 bf16 MFMA products, fp32 accumulate; norms/softmax/attention "
+                      "products/sampler in fp32)" if a.precision == "bf16x3" else "f32"), "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ADM ImageNet-128, 50 DDIM steps, M=5, uncertainty_zigzag_centered, "
                                    "num_zigzag=3, UC window W10 (start 40, 10 steps), batch 128 per GPU",
                        "global_batch": a.batch * world, "parallelism": f"independent batches x{world} (no data-path collective; "
@@ -186,10 +214,15 @@ def main():
                        "zigzag_mode": "faithful (all forwards executed)" if a.faithful_zigzag else
                                       "skip_dead_zigzag (outputs identical; noise draws still consumed)",
                        "executed_forwards_per_image": fwd_per_img, "noise": "device Philox (dua_randn)",
+                       "precision": a.precision,
+                       "parity": ("full-size ADM-128 forward vs the reference CPU output: max abs err 2.9e-5 (bf16x3), 7.4e-6 (fp32); "
+                                  "tolerance 1e-3 (tests/test_gpu_models.py)"),
                        "warmup_pass": "3-timestep truncated job"},
             "end_to_end_tflops": round(exec_flops / dt / 1e12, 2),
             "roofline": roof,
         }
+        if secondary is not None:
+            line["other_precision_mode"] = secondary
         if not a.no_cpu_baseline and world == 1:
             try:
                 cores = len(os.sched_getaffinity(0))
