@@ -166,57 +166,89 @@ __device__ __forceinline__ void gn_store(const GnApplyP& p, size_t off, float4 v
     }
 }
 
-__device__ __forceinline__ float4 gn_xform(const GnApplyP& p, int n, size_t pix, int c) {
-    const int C = p.C1 + p.C2, cpg = C / p.G;
-    float4 v = c < p.C1 ? *(const float4*)(p.x1 + pix * p.C1 + c) : *(const float4*)(p.x2 + pix * p.C2 + (c - p.C1));
-    float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
-    float r[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-    int g0 = c / cpg;
-    float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + g0));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if ((cpg & 3) && (c + j) / cpg != g0) st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + (c + j) / cpg));
-        float t = (r[j] - st.x) * st.y * gg[j] + bb[j];
-        if (p.film) t = t * (1.0f + p.film[(size_t)n * 2 * C + c + j]) + p.film[(size_t)n * 2 * C + C + c + j];
-        if (p.act == 1) t = silu_f(t);
-        r[j] = t;
-    }
-    if (p.drop) {
-        float4 d = *(const float4*)(p.drop + pix * C + c);
-        r[0] *= d.x; r[1] *= d.y; r[2] *= d.z; r[3] *= d.w;
-    }
-    return make_float4(r[0], r[1], r[2], r[3]);
-}
-
-__global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p) {
-    const int C = p.C1 + p.C2, Q = C / 4;
+// One workgroup per (image, chunk of iteration-space pixels).  Every thread owns fixed channel quads, so the
+// per-channel affine  y = x*a + b  (a = rstd*gamma*(1+scale), b = (beta - mean*rstd*gamma)*(1+scale) + shift) is
+// folded once into registers and the pixel loop is load -> fma -> SiLU -> store, 16 B per lane, with 32-bit index
+// arithmetic only.  NQ = channel quads per thread (1 when C/4 <= 256, else 2).
+template <int NQ>
+__global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p, int chunk_px) {
+    const int C = p.C1 + p.C2, Q = C / 4, cpg = C / p.G;
+    const int n = blockIdx.y, tid = threadIdx.x;
     const int Ho = p.resample < 0 ? p.H / 2 : p.H, Wo = p.resample < 0 ? p.W / 2 : p.W;   // iteration space
-    size_t total = (size_t)p.N * Ho * Wo * Q, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int c = (int)(i % Q) * 4;
-        size_t pp = i / Q;
-        int xo = (int)(pp % Wo);
-        size_t t2 = pp / Wo;
-        int yo = (int)(t2 % Ho), n = (int)(t2 / Ho);
-        if (p.resample == 0) {
-            size_t pix = ((size_t)n * p.H + yo) * p.W + xo;
-            gn_store(p, pix * C + c, gn_xform(p, n, pix, c));
-        } else if (p.resample > 0) {
-            size_t pix = ((size_t)n * p.H + yo) * p.W + xo;
-            float4 v = gn_xform(p, n, pix, c);
-            int W2 = 2 * p.W;
-            size_t o = (((size_t)n * 2 * p.H + 2 * yo) * W2 + 2 * xo) * C + c;
-            gn_store(p, o, v);
-            gn_store(p, o + C, v);
-            gn_store(p, o + (size_t)W2 * C, v);
-            gn_store(p, o + (size_t)W2 * C + C, v);
-        } else {
-            size_t pix = ((size_t)n * p.H + 2 * yo) * p.W + 2 * xo;
-            float4 a = gn_xform(p, n, pix, c), b = gn_xform(p, n, pix + 1, c);
-            float4 d = gn_xform(p, n, pix + p.W, c), e = gn_xform(p, n, pix + p.W + 1, c);
-            float4 o = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f,
-                                   (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f);
-            gn_store(p, (((size_t)n * Ho + yo) * Wo + xo) * C + c, o);
+    const int npx = Ho * Wo;
+    const int p0 = blockIdx.x * chunk_px, p1 = min(npx, p0 + chunk_px);
+    const int PP = NQ == 1 ? BLK / Q : 1;
+    const int pl = NQ == 1 ? tid / Q : 0;
+    if (NQ == 1 && pl >= PP) return;
+
+    float ca[NQ][4], cb[NQ][4];
+    const float* src[NQ];
+    int cs[NQ], cq[NQ], cc[NQ];
+    bool live[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int q = NQ == 1 ? tid % Q : tid + u * BLK;
+        live[u] = q < Q;
+        const int c = 4 * (live[u] ? q : 0);
+        cc[u] = c;
+        const bool second = c >= p.C1;
+        src[u] = second ? p.x2 : p.x1;
+        cs[u] = second ? p.C2 : p.C1;
+        cq[u] = second ? c - p.C1 : c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = c + j;
+            const float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + ch / cpg));
+            float a = st.y * p.gamma[ch];
+            float b = p.beta[ch] - st.x * a;
+            if (p.film) {
+                const float sc = 1.0f + p.film[(size_t)n * 2 * C + ch];
+                a *= sc;
+                b = b * sc + p.film[(size_t)n * 2 * C + C + ch];
+            }
+            ca[u][j] = a;
+            cb[u][j] = b;
+        }
+    }
+    auto xf = [&](int u, size_t pix) -> float4 {
+        const float4 v = *(const float4*)(src[u] + pix * cs[u] + cq[u]);
+        float r[4] = {v.x * ca[u][0] + cb[u][0], v.y * ca[u][1] + cb[u][1], v.z * ca[u][2] + cb[u][2], v.w * ca[u][3] + cb[u][3]};
+        if (p.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = silu_f(r[j]);
+        }
+        if (p.drop) {
+            const float4 d = *(const float4*)(p.drop + pix * C + cc[u]);
+            r[0] *= d.x; r[1] *= d.y; r[2] *= d.z; r[3] *= d.w;
+        }
+        return make_float4(r[0], r[1], r[2], r[3]);
+    };
+    const size_t img_in = (size_t)n * p.H * p.W;
+    for (int px = p0 + pl; px < p1; px += PP) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            if (!live[u]) continue;
+            if (p.resample == 0) {
+                const size_t pix = img_in + px;
+                gn_store(p, pix * C + cc[u], xf(u, pix));
+            } else {
+                const int yo = px / Wo, xo = px - yo * Wo;
+                if (p.resample > 0) {
+                    const float4 v = xf(u, img_in + px);
+                    const int W2 = 2 * p.W;
+                    const size_t o = (((size_t)n * 2 * p.H + 2 * yo) * W2 + 2 * xo) * C + cc[u];
+                    gn_store(p, o, v);
+                    gn_store(p, o + C, v);
+                    gn_store(p, o + (size_t)W2 * C, v);
+                    gn_store(p, o + (size_t)W2 * C + C, v);
+                } else {
+                    const size_t pix = img_in + (size_t)(2 * yo) * p.W + 2 * xo;
+                    const float4 a = xf(u, pix), b = xf(u, pix + 1), d = xf(u, pix + p.W), e = xf(u, pix + p.W + 1);
+                    gn_store(p, (((size_t)n * Ho + yo) * Wo + xo) * C + cc[u],
+                             make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f,
+                                         (a.z + b.z + d.z + e.z) * 0.25f, (a.w + b.w + d.w + e.w) * 0.25f));
+                }
+            }
         }
     }
 }
@@ -251,10 +283,13 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
         long Hy = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wy = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
         p.plane = (long)N * Hy * Wy * C;
     }
+    DUA_REQUIRE(C <= 2048, "dua_groupnorm_apply: at most 2048 channels");
     int Ho = resample < 0 ? H / 2 : H, Wo = resample < 0 ? W / 2 : W;
-    size_t total = (size_t)N * Ho * Wo * (C / 4);
-    if (total == 0) return DUA_OK;
-    hipLaunchKernelGGL(k_gn_apply, stream_grid(total, BLK), BLK, 0, as_stream(stream), p);
+    if ((size_t)N * Ho * Wo == 0) return DUA_OK;
+    int cp, nc;
+    gn_chunking(N, Ho * Wo, &cp, &nc);
+    if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    else hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     return dua_check_launch("dua_groupnorm_apply");
 }
 

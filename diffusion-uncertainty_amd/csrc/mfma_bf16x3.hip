@@ -103,7 +103,23 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     const __bf16* ql[2];
     unsigned amask = 0xf;
     const float* pa[4];
-    int a_left = 0, tap_next = 0;
+    int a_left = 0, tap_next = 0, cb_next = 0;
+    unsigned okbits[4] = {0, 0, 0, 0}, qbits[2] = {0, 0};     // bit t = tap t of the staged row lies inside the image
+    if (MODE == XMODE_CONV) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            if (PRESPLIT) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    qbits[j] |= (unsigned)((unsigned)(qy[j] + dy) < (unsigned)p.H && (unsigned)(qx[j] + dx) < (unsigned)p.W) << t;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    okbits[i] |= (unsigned)((unsigned)(py[i] + dy) < (unsigned)p.H && (unsigned)(px[i] + dx) < (unsigned)p.W) << t;
+            }
+        }
+    }
     auto setup_a = [&](int kt) {
         if (MODE == XMODE_GEMM) {
             const int k = kt * BK + 4 * c4;
@@ -114,32 +130,31 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pa[i] = src + (long)min(m0 + r0 + 32 * i, p.M - 1) * ld + kk;
             a_left = (p.K2 != 0 && !second) ? p.K1 / BK - kt : 0x7fffffff;
-        } else if (PRESPLIT) {
-            const int tap = tap_next++;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const long off = ((long)dy * p.W + dx) * p.Cin;
-            amask = 0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool ok = (unsigned)(qy[j] + dy) < (unsigned)p.H && (unsigned)(qx[j] + dx) < (unsigned)p.W;
-                amask |= (unsigned)ok << j;
-                const long o = qbase[j] + (ok ? off : 0L);
-                qh[j] = p.Ahi + o;
-                ql[j] = p.Alo + o;
-            }
-            a_left = p.Cin / BK;
         } else {
-            const int tap = tap_next++;
+            // K order: channel-block major, tap minor (k = cb*288 + tap*32 + ci) - see mfma_gemm.hip
+            const int tap = tap_next, cb = cb_next;
+            if (++tap_next == 9) { tap_next = 0; ++cb_next; }
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             const long off = ((long)dy * p.W + dx) * p.Cin;
             amask = 0;
+            if (PRESPLIT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = (unsigned)(py[i] + dy) < (unsigned)p.H && (unsigned)(px[i] + dx) < (unsigned)p.W;
-                amask |= (unsigned)ok << i;
-                pa[i] = A1 + pbase[i] + (ok ? off : 0L) + 4 * c4;
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = (qbits[j] >> tap) & 1u;
+                    amask |= (unsigned)ok << j;
+                    const long o = qbase[j] + (ok ? off : 0L) + cb * BK;
+                    qh[j] = p.Ahi + o;
+                    ql[j] = p.Alo + o;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (okbits[i] >> tap) & 1u;
+                    amask |= (unsigned)ok << i;
+                    pa[i] = A1 + pbase[i] + (ok ? off : 0L) + cb * BK + 4 * c4;
+                }
             }
-            a_left = p.Cin / BK;
+            a_left = 1;
         }
     };
     // B: each plane tile is 128 rows x 32 bf16 = 512 chunks of 16 B; thread -> chunks tid and tid + 256
@@ -306,8 +321,8 @@ __global__ void k_split_weight(const float* __restrict__ w, __bf16* __restrict__
         int n = (int)(i / K), k = (int)(i % K);
         float v = 0.f;
         if (n < N) {
-            if (conv_cin) {                       // OIHW -> [n][tap][ci]
-                int tap = k / conv_cin, ci = k % conv_cin;
+            if (conv_cin) {                       // OIHW -> k = cb*288 + tap*32 + c  (channel-block major, tap minor)
+                int tap = (k % 288) / 32, ci = (k / 288) * 32 + k % 32;
                 v = w[((size_t)n * conv_cin + ci) * 9 + tap];
             } else {
                 v = w[(size_t)n * K + k];
