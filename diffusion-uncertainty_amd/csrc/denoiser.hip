@@ -523,3 +523,34 @@ extern "C" int dua_unpatchify(const float* tok, float* img, int B, int L, int ex
     hipLaunchKernelGGL(k_unpatchify, stream_grid(total, 256), 256, 0, as_stream(stream), tok, img, B, L, extras, C, P, g);
     return dua_check_launch("dua_unpatchify");
 }
+
+// =================================== batched strided transpose =================================
+// out[b][c][r] = in[b][r][c] for r < R, c < Cc (32x32 LDS tiles; batch -> (outer, inner) strides).  Used to lay V out
+// K-major ([head channel][token]) so that P.V runs through the fast K-major ("NT") GEMM path.
+__global__ __launch_bounds__(BLK) void k_transpose(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, long ld_in,
+                                                   long ld_out, long sIn, long sIni, long sOut, long sOuti, int batch_inner) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, zo = z / batch_inner, zi = z % batch_inner;
+    in += zo * sIn + zi * sIni;
+    out += zo * sOut + zi * sOuti;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + 8 * j, c = c0 + tx;
+        tile[ty + 8 * j][tx] = (r < R && c < Cc) ? in[(long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, r = r0 + tx;
+        if (c < Cc && r < R) out[(long)c * ld_out + r] = tile[tx][ty + 8 * j];
+    }
+}
+extern "C" int dua_transpose_batched(const float* in, float* out, int R, int Cc, long ld_in, long ld_out, long sIn, long sIni,
+                                     long sOut, long sOuti, int batch, int batch_inner, void* stream) {
+    DUA_REQUIRE(in && out && R > 0 && Cc > 0 && batch >= 1 && batch_inner >= 1 && batch % batch_inner == 0 && batch <= 65535, "dua_transpose_batched: bad arguments");
+    hipLaunchKernelGGL(k_transpose, dim3((Cc + 31) / 32, (R + 31) / 32, batch), BLK, 0, as_stream(stream), in, out, R, Cc, ld_in, ld_out,
+                       sIn, sIni, sOut, sOuti, batch_inner);
+    return dua_check_launch("dua_transpose_batched");
+}

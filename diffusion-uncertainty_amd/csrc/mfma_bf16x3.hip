@@ -31,6 +31,10 @@ struct XTileP {
     const float *A1, *A2;
     const __bf16 *Ahi, *Alo;         // PRESPLIT conv input: two bf16 NHWC planes written by dua_groupnorm_apply_split
     const __bf16 *Bhi, *Blo;         // pre-split weights [Npad][K]
+    const float* Bf;                 // BSPLIT: fp32 B [N][K] (row-major, ldb), split on the fly like A
+    long ldb;
+    long sA, sAi, sB, sBi, sC, sCi;  // batch strides (outer / inner), floats
+    int batch_inner;
     const float *bias, *res;
     float* C;
     int M, N, K1, K2;
@@ -53,7 +57,7 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-template <int MODE, bool SILU_IN, bool PRESPLIT>
+template <int MODE, bool SILU_IN, bool PRESPLIT, bool BSPLIT>
 __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];      // 80 KB: two workgroups fill a CU's 160 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,7 +71,14 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     }
     const int tn = lid % p.ntn, tm = lid / p.ntn;
     const int m0 = tm * BM, n0 = tn * BN;
-    const float *A1 = p.A1, *A2 = p.A2;
+    const float *A1 = p.A1, *A2 = p.A2, *Bf = p.Bf;
+    float* Cp = p.C;
+    if (BSPLIT) {   // batched activation x activation products (attention): blockIdx.y = outer*batch_inner + inner
+        const int z = blockIdx.y, zo = z / p.batch_inner, zi = z % p.batch_inner;
+        A1 += zo * p.sA + zi * p.sAi;
+        Bf += zo * p.sB + zi * p.sBi;
+        Cp += zo * p.sC + zi * p.sCi;
+    }
 
     const int c4 = tid & 7, r0 = tid >> 3;
     const int K = (MODE == XMODE_GEMM) ? p.K1 + p.K2 : 9 * p.Cin;
@@ -162,11 +173,17 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     const int bsw = bch ^ ((brow >> 2) & 3);          // swizzled chunk position (rows brow and brow + 64 share it)
     const __bf16* pbh[2];
     const __bf16* pbl[2];
+    const float* pbf[4];
+    if (!BSPLIT) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long o = (long)(n0 + brow + 64 * j) * K + 8 * bch;                  // planes are padded to 128 rows
-        pbh[j] = p.Bhi + o;
-        pbl[j] = p.Blo + o;
+        for (int j = 0; j < 2; ++j) {
+            const long o = (long)(n0 + brow + 64 * j) * K + 8 * bch;              // planes are padded to 128 rows
+            pbh[j] = p.Bhi + o;
+            pbl[j] = p.Blo + o;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pbf[i] = Bf + (long)min(n0 + r0 + 32 * i, p.N - 1) * p.ldb + 4 * c4;
     }
 
     // Two register stages: with ~2k-cycle K steps a global load needs more than one step to land, so tile kt+3 is
@@ -188,8 +205,13 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
             S.a0 = *(const uint4*)pa[0]; S.a1 = *(const uint4*)pa[1]; S.a2 = *(const uint4*)pa[2]; S.a3 = *(const uint4*)pa[3];
             pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;
         }
-        S.bh0 = *(const uint4*)pbh[0]; S.bh1 = *(const uint4*)pbh[1]; S.bl0 = *(const uint4*)pbl[0]; S.bl1 = *(const uint4*)pbl[1];
-        pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
+        if (!BSPLIT) {
+            S.bh0 = *(const uint4*)pbh[0]; S.bh1 = *(const uint4*)pbh[1]; S.bl0 = *(const uint4*)pbl[0]; S.bl1 = *(const uint4*)pbl[1];
+            pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
+        } else {
+            S.bh0 = *(const uint4*)pbf[0]; S.bh1 = *(const uint4*)pbf[1]; S.bl0 = *(const uint4*)pbf[2]; S.bl1 = *(const uint4*)pbf[3];
+            pbf[0] += BK; pbf[1] += BK; pbf[2] += BK; pbf[3] += BK;
+        }
     };
     auto store_a = [&](int buf, int i, uint4 u, unsigned mask) {
         float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
@@ -206,6 +228,14 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         *(bf16x4*)base = hi;
         *(bf16x4*)(base + PLANE) = lo;
     };
+    auto store_b = [&](int buf, int i, uint4 u) {       // BSPLIT: fp32 row chunk -> hi / lo planes of the B tile
+        bf16x4 hi, lo;
+        split4(make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)), hi, lo);
+        const int row = r0 + 32 * i;
+        __bf16* base = lds + buf * BUF + 2 * PLANE + row * LDH + 8 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 4 * (c4 & 1);
+        *(bf16x4*)base = hi;
+        *(bf16x4*)(base + PLANE) = lo;
+    };
     auto store_pre = [&](int buf, int j, uint4 h, uint4 l, unsigned mask) {
         const bool ok = (mask >> j) & 1u;
         h = make_uint4(ok ? h.x : 0u, ok ? h.y : 0u, ok ? h.z : 0u, ok ? h.w : 0u);
@@ -217,10 +247,14 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     auto xstore = [&](const Stage& S, int buf) {
         if (PRESPLIT) { store_pre(buf, 0, S.a0, S.a2, S.mask); store_pre(buf, 1, S.a1, S.a3, S.mask); }
         else { store_a(buf, 0, S.a0, S.mask); store_a(buf, 1, S.a1, S.mask); store_a(buf, 2, S.a2, S.mask); store_a(buf, 3, S.a3, S.mask); }
-        *(uint4*)(lds + buf * BUF + 2 * PLANE + brow * LDH + 8 * bsw) = S.bh0;
-        *(uint4*)(lds + buf * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bsw) = S.bh1;
-        *(uint4*)(lds + buf * BUF + 3 * PLANE + brow * LDH + 8 * bsw) = S.bl0;
-        *(uint4*)(lds + buf * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bsw) = S.bl1;
+        if (!BSPLIT) {
+            *(uint4*)(lds + buf * BUF + 2 * PLANE + brow * LDH + 8 * bsw) = S.bh0;
+            *(uint4*)(lds + buf * BUF + 2 * PLANE + (brow + 64) * LDH + 8 * bsw) = S.bh1;
+            *(uint4*)(lds + buf * BUF + 3 * PLANE + brow * LDH + 8 * bsw) = S.bl0;
+            *(uint4*)(lds + buf * BUF + 3 * PLANE + (brow + 64) * LDH + 8 * bsw) = S.bl1;
+        } else {
+            store_b(buf, 0, S.bh0); store_b(buf, 1, S.bh1); store_b(buf, 2, S.bl0); store_b(buf, 3, S.bl1);
+        }
     };
 
     f32x16 acc[2][2];
@@ -295,19 +329,20 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
                 if (p.res) v += p.res[(long)row * p.ldr + col];
                 if (MODE == XMODE_CONV && p.nchw_out) {
                     int hw = p.H * p.W, n = row / hw, rem = row - n * hw;
-                    p.C[((long)n * p.N + col) * hw + rem] = v;
+                    Cp[((long)n * p.N + col) * hw + rem] = v;
                 } else {
-                    p.C[(long)row * p.ldc + col] = v;
+                    Cp[(long)row * p.ldc + col] = v;
                 }
             }
         }
 }
 
-template <int MODE, bool SILU_IN = false, bool PRESPLIT = false>
-static int launch_x(XTileP& p, hipStream_t s) {
+template <int MODE, bool SILU_IN = false, bool PRESPLIT = false, bool BSPLIT = false>
+static int launch_x(XTileP& p, hipStream_t s, int batch = 1) {
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN, PRESPLIT>), dim3(p.ntm * p.ntn), 256, 0, s, p);
+    if (p.batch_inner < 1) p.batch_inner = 1;
+    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN, PRESPLIT, BSPLIT>), dim3(p.ntm * p.ntn, batch), 256, 0, s, p);
     return dua_check_launch("dua bf16x3 tile kernel");
 }
 
@@ -386,4 +421,19 @@ extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* 
     p.M = M; p.N = N; p.K1 = K1; p.K2 = K2; p.lda1 = lda1; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
     p.act_out = act_out; p.alpha = alpha;
     return act_in ? launch_x<XMODE_GEMM, true>(p, as_stream(stream)) : launch_x<XMODE_GEMM, false>(p, as_stream(stream));
+}
+
+// Batched  C[b] = alpha * A[b] * B[b]^T  with BOTH operands fp32 activations split on the fly (attention products
+// q.k^T and P.v^T, unet_openai.py:350-354).  A: [M][K] lda, B: [N][K] ldb, K % 32 == 0; batch index
+// b -> (b / batch_inner, b % batch_inner) with outer / inner strides as in dua_gemm_args.
+extern "C" int dua_gemm_nt_bf16x3_batched(const float* A, long lda, long sA, long sAi, const float* B, long ldb, long sB, long sBi,
+                                          float* C, long ldc, long sC, long sCi, int M, int N, int K, int batch, int batch_inner,
+                                          float alpha, void* stream) {
+    DUA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && K % BK == 0, "dua_gemm_nt_bf16x3_batched: K must be a positive multiple of 32 (got %d)", K);
+    DUA_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && batch >= 1 && batch_inner >= 1 && batch % batch_inner == 0, "dua_gemm_nt_bf16x3_batched: bad strides / batch");
+    DUA_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0, "dua_gemm_nt_bf16x3_batched: operands must be 16-byte aligned");
+    XTileP p{};
+    p.A1 = A; p.Bf = B; p.C = C; p.M = M; p.N = N; p.K1 = K; p.lda1 = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldc;
+    p.sA = sA; p.sAi = sAi; p.sB = sB; p.sBi = sBi; p.sC = sC; p.sCi = sCi; p.batch_inner = batch_inner; p.alpha = alpha;
+    return launch_x<XMODE_GEMM, false, false, true>(p, as_stream(stream), batch);
 }

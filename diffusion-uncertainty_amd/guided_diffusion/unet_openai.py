@@ -148,7 +148,7 @@ class AttentionBlock(nn.Module):
         st = ops.groupnorm_stats(x)
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0)
         qkv = ctx.qkv(xn.view(N * T, C), self)
-        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads)
+        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision=ctx.model.precision)
         out = ctx.linear(a, self.proj_out, residual=x.view(N * T, C))
         return out.view(N, H, W, C)
 

@@ -318,28 +318,44 @@ def softmax_rows_(S, rows, cols, ld=None):
     return S
 
 
-def qkv_attention(qkv, B, T, heads, ch):
+def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     """qkv: [B*T, 3*heads*ch] laid out (q | k | v), head-major inside each third -> [B*T, heads*ch].
 
     Reference: QKVAttentionLegacy / QKVAttention (unet_openai.py:338-355 / :371-390); the q/k scale
-    ch^-1/4 on both operands is applied as alpha = ch^-1/2 on the logits.  Materialises the logits in HBM
-    (round 1); S = QK^T and O = PV run on the fp32 MFMA tile engine, the softmax in dua_softmax_rows.
+    ch^-1/4 on both operands is applied as alpha = ch^-1/2 on the logits.  The logits are materialised in HBM
+    (round 1): S = q.k^T (MFMA tile engine), softmax in dua_softmax_rows, V is transposed to [head channel][token]
+    so that O = P.(V^T)^T also runs through the K-major GEMM path.  precision="bf16x3" evaluates both products on
+    the bf16 matrix cores with both operands split on the fly (needs ch % 32 == 0 and T % 32 == 0); softmax is fp32.
     """
     _req(qkv, name="qkv")
     C = heads * ch
     assert qkv.shape == (B * T, 3 * C)
-    Tp = (T + 3) // 4 * 4            # row stride of the logits (16-byte aligned rows for the PV operand loads)
+    assert B * heads <= 65535
+    Tp = (T + 3) // 4 * 4            # row stride of the logits / of V^T (16-byte aligned rows)
     S = torch.empty((B * heads, T, Tp), device=qkv.device, dtype=torch.float32)
+    Vt = torch.empty((B * heads, ch, Tp), device=qkv.device, dtype=torch.float32)
     out = torch.empty((B * T, C), device=qkv.device, dtype=torch.float32)
     base = qkv.data_ptr()
+    L = _lib.lib()
     s = 1.0 / math.sqrt(math.sqrt(ch))
-    gemm_raw(A1=base, B=base + 4 * C, C=S.data_ptr(), M=T, N=T, K1=ch, K2=0, lda1=3 * C, lda2=4, ldb=3 * C, ldc=Tp, ldr=Tp,
-             sA1=T * 3 * C, sB=T * 3 * C, sC=heads * T * Tp, batch=B * heads, batch_inner=heads, sA1i=ch, sBi=ch,
-             sCi=T * Tp, transB=1, alpha=s * s)
+    check(L.dua_transpose_batched(base + 8 * C, _p(Vt), T, ch, 3 * C, Tp, T * 3 * C, ch, heads * ch * Tp, ch * Tp, B * heads, heads,
+                                  _stream()), "dua_transpose_batched")
+    fast = precision == "bf16x3" and ch % 32 == 0 and T % 32 == 0
+    if fast:
+        check(L.dua_gemm_nt_bf16x3_batched(base, 3 * C, T * 3 * C, ch, base + 4 * C, 3 * C, T * 3 * C, ch, _p(S), Tp, heads * T * Tp, T * Tp,
+                                           T, T, ch, B * heads, heads, s * s, _stream()), "dua_gemm_nt_bf16x3_batched")
+    else:
+        gemm_raw(A1=base, B=base + 4 * C, C=S.data_ptr(), M=T, N=T, K1=ch, K2=0, lda1=3 * C, lda2=4, ldb=3 * C, ldc=Tp, ldr=Tp,
+                 sA1=T * 3 * C, sB=T * 3 * C, sC=heads * T * Tp, batch=B * heads, batch_inner=heads, sA1i=ch, sBi=ch,
+                 sCi=T * Tp, transB=1, alpha=s * s)
     softmax_rows_(S, B * heads * T, T, Tp)
-    gemm_raw(A1=S.data_ptr(), B=base + 8 * C, C=out.data_ptr(), M=T, N=ch, K1=T, K2=0, lda1=Tp, lda2=4, ldb=3 * C, ldc=C,
-             ldr=C, sA1=heads * T * Tp, sB=T * 3 * C, sC=T * C, batch=B * heads, batch_inner=heads, sA1i=T * Tp, sBi=ch,
-             sCi=ch, transB=0, alpha=1.0)
+    if fast:
+        check(L.dua_gemm_nt_bf16x3_batched(_p(S), Tp, heads * T * Tp, T * Tp, _p(Vt), Tp, heads * ch * Tp, ch * Tp, _p(out), C, T * C, ch,
+                                           T, ch, T, B * heads, heads, 1.0, _stream()), "dua_gemm_nt_bf16x3_batched")
+    else:
+        gemm_raw(A1=S.data_ptr(), B=Vt.data_ptr(), C=out.data_ptr(), M=T, N=ch, K1=T, K2=0, lda1=Tp, lda2=4, ldb=Tp, ldc=C, ldr=C,
+                 sA1=heads * T * Tp, sB=heads * ch * Tp, sC=T * C, batch=B * heads, batch_inner=heads, sA1i=T * Tp, sBi=ch * Tp,
+                 sCi=ch, transB=1, alpha=1.0)
     return out
 
 

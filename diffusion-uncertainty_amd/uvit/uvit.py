@@ -47,14 +47,14 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.skip_linear = nn.Linear(2 * dim, dim) if skip else None
 
-    def run(self, lin, x, B, L, skip=None):
+    def run(self, lin, x, B, L, skip=None, precision="fp32"):
         """x, skip: [B*L, D]; lin(a, linear_module, **kw) is the model's precision-aware GEMM."""
         D = x.shape[1]
         if self.skip_linear is not None:
             x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         qkv = lin(h, self.attn.qkv)
-        a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads)            # :69-73
+        a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads, precision=precision)   # :69-73
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = lin(h, self.mlp.fc1, act_out=2)                                                        # fc1 + GELU
@@ -149,11 +149,11 @@ class UViT(nn.Module):
         h = h.view(B * T, D)
         skips = []
         for blk in self.in_blocks:
-            h = blk.run(self._lin, h, B, T)
+            h = blk.run(self._lin, h, B, T, precision=self.precision)
             skips.append(h)
-        h = self.mid_block.run(self._lin, h, B, T)
+        h = self.mid_block.run(self._lin, h, B, T, precision=self.precision)
         for blk in self.out_blocks:
-            h = blk.run(self._lin, h, B, T, skips.pop())
+            h = blk.run(self._lin, h, B, T, skips.pop(), precision=self.precision)
         h = ops.layernorm(h, self.norm.weight, self.norm.bias, self.norm.eps)
         h = self._lin(h, self.decoder_pred)                                                # [B*T, P*P*C]
         return ops.unpatchify(h, B, L, self.extras, C, P)                                  # :228-229

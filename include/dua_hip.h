@@ -169,6 +169,16 @@ int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2,
                     const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                     int act_out, float alpha, void* stream);
 
+/* Batched C[b] = alpha * A[b] * B[b]^T with BOTH operands fp32 activations split on the fly (the attention products
+ * q.k^T and P.v^T of unet_openai.py:350-354 in bf16x3 mode).  A: [M][K] (lda), B: [N][K] (ldb), K % 32 == 0; batch
+ * index b -> (b / batch_inner, b % batch_inner) with outer (s*) / inner (s*i) strides in floats. */
+int dua_gemm_nt_bf16x3_batched(const float* A, long lda, long sA, long sAi, const float* B, long ldb, long sB, long sBi,
+                               float* C, long ldc, long sC, long sCi, int M, int N, int K, int batch, int batch_inner,
+                               float alpha, void* stream);
+/* out[b][c][r] = in[b][r][c], r < R, c < Cc: lays V out K-major so P.V uses the K-major GEMM path. batch <= 65535. */
+int dua_transpose_batched(const float* in, float* out, int R, int Cc, long ld_in, long ld_out, long sIn, long sIni,
+                          long sOut, long sOuti, int batch, int batch_inner, void* stream);
+
 /* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */
 /* PatchEmbed's strided conv as im2row: x NCHW [B][C][H][W] -> rows [B*(H/P)*(W/P)][C*P*P] in the
  * (c, p1, p2) order of the flattened conv weight (uvit.py:123-135); the projection itself is dua_gemm. */

@@ -216,6 +216,8 @@ def test_qkv_attention(ops, B, T_, heads, ch):
     d = qkv.permute(0, 2, 1).reshape(B * T_, 3 * C).contiguous().to(dev)
     out = ops.qkv_attention(d, B, T_, heads, ch)
     np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    out = ops.qkv_attention(d, B, T_, heads, ch, precision="bf16x3")     # falls back to fp32 products unless ch, T % 32 == 0
+    np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
 
 
 def test_softmax_layernorm_embeddings(ops):
