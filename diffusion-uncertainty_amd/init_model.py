@@ -87,9 +87,12 @@ def load_uvit_scheduler():
     return DDPMScheduler.from_config(scheduler_config)
 
 
-def load_autoencoder_uvit(device="cuda"):
-    raise NotImplementedError("the KL-VAE decoder (uvit/autoencoder.py) is the next row of the hot-path scope table "
-                              "(SURVEY.md 8f rank 1); pass your own decoder module to UViTAE for now")
+def load_autoencoder_uvit(device="cuda", load_checkpoint=True):
+    """load_pretrained_models.py:66-... : the f8 KL-VAE (uvit/autoencoder.py get_model), decoder on the HIP library."""
+    from .uvit.autoencoder import get_model
+    ae = get_model(str(MODELS / "autoencoder_kl_ema.pth") if load_checkpoint else None)
+    ae.to(device)
+    return ae
 
 
 __all__ = ["UNetModel", "UViT", "UViTAE", "DDPMScheduler"]

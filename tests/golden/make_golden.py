@@ -336,7 +336,39 @@ def g8():
     save("g8_mc_dropout", **out)
 
 
+class _RefKL(torch.nn.Module):
+    """The reference FrozenAutoencoderKL without its checkpoint load (uvit/autoencoder.py:412-450)."""
+
+
+def g9():
+    with _quiet:
+        from diffusion_uncertainty.uvit import autoencoder as ref_ae
+
+    class RefKL(ref_ae.FrozenAutoencoderKL):
+        def __init__(self, ddconfig, embed_dim, scale_factor):
+            torch.nn.Module.__init__(self)
+            self.encoder = ref_ae.Encoder(**ddconfig)
+            self.decoder = ref_ae.Decoder(**ddconfig)
+            self.quant_conv = torch.nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+            self.post_quant_conv = torch.nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+            self.embed_dim, self.scale_factor = embed_dim, scale_factor
+
+    out = {}
+    base = dict(double_z=True, z_channels=4, in_channels=3, out_ch=3, attn_resolutions=[], dropout=0.0)
+    for name, dd, zshape in (("tiny", dict(base, resolution=32, ch=32, ch_mult=[1, 2], num_res_blocks=1), (2, 4, 8, 8)),
+                             ("full", dict(base, resolution=256, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2), (1, 4, 32, 32))):   # get_model :463-476
+        with _quiet:
+            m = RefKL(dd, 4, 0.18215)
+        m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 9))
+        m.eval()
+        z = randn(91, *zshape) * 0.18215 * 3
+        with torch.no_grad():
+            o = m.decode(z)
+        out[f"{name}_z"], out[f"{name}_out"], out[f"{name}_nkeys"] = z, o, len(m.state_dict())
+    save("g9_vae_decode", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -271,3 +271,65 @@ def test_bf16x3_mode_uvit(golden):
     err = np.abs(o.cpu().numpy() - g["out"]).max()
     print(f"bf16x3 uvit-h/2: max|hip - reference| = {err:.3e}")
     assert err < TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_vae_decode_vs_golden(golden, precision):
+    """KL-VAE decoder: full-size f8 decoder, 32x32 latents -> 256x256, vs the reference's output."""
+    from diffusion_uncertainty_amd.uvit.autoencoder import FrozenAutoencoderKL, get_model
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    g = golden("g9_vae_decode")
+    tiny = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2], num_res_blocks=1,
+                attn_resolutions=[], dropout=0.0)
+    for name, m in (("tiny", FrozenAutoencoderKL(tiny, 4)), ("full", get_model(None))):
+        sd = seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 9)
+        assert len(sd) == int(g[f"{name}_nkeys"])
+        m.load_state_dict(sd, strict=True)
+        m.to(dev)
+        m.precision = precision
+        o = m.decode(T(g[f"{name}_z"]).to(dev))
+        err = np.abs(o.cpu().numpy() - g[f"{name}_out"]).max()
+        print(f"vae {name} {precision}: max|hip - reference| = {err:.3e} (|ref|max {np.abs(g[name + '_out']).max():.2f})")
+        assert err < TOL
+    with pytest.raises(RuntimeError):
+        m.decode(T(g["tiny_z"]))
+
+
+def test_uvit_driver_with_vae():
+    """generate_samples_..._uvit_from_tensor end to end: tiny U-ViT + tiny VAE decode + uint8, vs the oracle."""
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_uvit_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import load_uvit_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.uvit.autoencoder import FrozenAutoencoderKL
+    from diffusion_uncertainty_amd.uvit.uvit import UViT
+    from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    from oracle import driver, schedule, uvit as ouvit, vae as ovae
+    ucfg = dict(TINY_UVIT)
+    nn_ = UViT(**ucfg)
+    usd = seeded_state_dict({k: tuple(v.shape) for k, v in nn_.state_dict().items()}, 6)
+    nn_.load_state_dict(usd)
+    tiny = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2], num_res_blocks=1,
+                attn_resolutions=[], dropout=0.0)
+    ae = FrozenAutoencoderKL(tiny, 4)
+    asd = seeded_state_dict({k: tuple(v.shape) for k, v in ae.state_dict().items()}, 9)
+    ae.load_state_dict(asd)
+    model = UViTAE(nn_, ae).to(dev)
+    args = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=2, start_step_uc=2, num_steps_uc=2, predict_next=True, eta=0.0,
+                              num_zigzag=2, uncertainty_distance=1)
+    s = get_uncertainty_scheduler(args, None, model, load_uvit_scheduler())
+    s.set_timesteps(5)
+    X_T = torch.randn(3, 4, 8, 8, generator=torch.Generator().manual_seed(2))
+    y = torch.tensor([1, 5, 10])
+    torch.manual_seed(0)
+    r = gen(X_T, y, 2, model, s, device=dev)
+    assert r["gen_images"].shape == (3, 3, 16, 16) and r["gen_images"].dtype == torch.uint8
+    tab = schedule.Tables(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    vcfg = dict(ovae.KL_F8, ch=32, ch_mult=(1, 2), num_res_blocks=1)
+    torch.manual_seed(0)
+    ref = driver.generate(X_T, y, 2, lambda x, t, yy, train=False: ouvit.forward(usd, ucfg, x, t, yy), tab, 5, "zigzag_centered", M=2,
+                          after_step=2, num_steps_uc=2, num_zigzag=2, clip_sample=False, steps_offset=1,
+                          decode=lambda z: ovae.decode(asd, vcfg, z), slice3=False)
+    np.testing.assert_allclose(r["score"].numpy(), ref["score"].numpy(), rtol=0, atol=TOL)
+    d = np.abs(r["gen_images"].numpy().astype(int) - ref["gen_images"].numpy().astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-2
