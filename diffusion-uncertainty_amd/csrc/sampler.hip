@@ -356,3 +356,57 @@ extern "C" int dua_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, i
     hipLaunchKernelGGL(k_nhwc_to_nchw, stream_grid(total, BLK), BLK, 0, as_stream(stream), x, y, N, C, H * W, Ckeep);
     return dua_check_launch("dua_nhwc_to_nchw");
 }
+
+// ---- dataset-level pixel-wise order statistic (scripts/compute_threshold_pixel_wise.py:143-165) ------------
+// thresholds[s][p] = k-th smallest over the N samples of half(u[n][s][p]) - what `argsort(dim=0)[k]` + `gather`
+// select in the reference (ties give the same value whichever index wins).  One thread per (s, p) column, adjacent
+// threads on adjacent pixels (coalesced); exact two-pass 8-bit radix select on the order-preserving image of the
+// fp16 bit pattern with a private 256-bin histogram column in LDS.
+#include <hip/hip_fp16.h>
+#define OS_T 64
+__device__ __forceinline__ uint32_t h2key(float f) {
+    uint32_t b = (uint32_t)__half_as_ushort(__float2half_rn(f));
+    return (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
+}
+__global__ __launch_bounds__(OS_T) void k_order_stat(const float* __restrict__ u, int N, long SP, int k, uint16_t* __restrict__ out) {
+    __shared__ uint32_t hist[256 * OS_T];
+    const int tid = threadIdx.x;
+    const long col = (long)blockIdx.x * OS_T + tid;
+    const bool live = col < SP;
+    const float* c = u + (live ? col : 0);
+    for (int b = 0; b < 256; ++b) hist[b * OS_T + tid] = 0;
+    if (live)
+        for (int n = 0; n < N; ++n) hist[(h2key(c[(long)n * SP]) >> 8) * OS_T + tid]++;
+    uint32_t r = (uint32_t)k, acc = 0;
+    int b1 = 0;
+    for (; b1 < 255; ++b1) {
+        uint32_t h = hist[b1 * OS_T + tid];
+        if (acc + h > r) break;
+        acc += h;
+    }
+    r -= acc;
+    for (int b = 0; b < 256; ++b) hist[b * OS_T + tid] = 0;
+    if (live)
+        for (int n = 0; n < N; ++n) {
+            uint32_t key = h2key(c[(long)n * SP]);
+            if ((int)(key >> 8) == b1) hist[(key & 255u) * OS_T + tid]++;
+        }
+    acc = 0;
+    int b2 = 0;
+    for (; b2 < 255; ++b2) {
+        uint32_t h = hist[b2 * OS_T + tid];
+        if (acc + h > r) break;
+        acc += h;
+    }
+    if (live) {
+        uint32_t key = ((uint32_t)b1 << 8) | (uint32_t)b2;
+        out[col] = (uint16_t)((key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu));
+    }
+}
+extern "C" int dua_pixelwise_order_statistic(const float* u, int N, long SP, int k, uint16_t* out, void* stream) {
+    DUA_REQUIRE(N >= 1 && k >= 0 && k < N, "dua_pixelwise_order_statistic: need 0 <= k < N (N=%d k=%d)", N, k);
+    if (SP == 0) return DUA_OK;
+    DUA_REQUIRE(u && out && SP > 0, "dua_pixelwise_order_statistic: null pointer");
+    hipLaunchKernelGGL(k_order_stat, dim3((unsigned)((SP + OS_T - 1) / OS_T)), OS_T, 0, as_stream(stream), u, N, SP, k, out);
+    return dua_check_launch("dua_pixelwise_order_statistic");
+}

@@ -111,6 +111,16 @@ def posterior_blend(eps, u, mask, M, alpha_hat_t):
     return out
 
 
+def pixelwise_order_statistic(u, k):
+    """u: [N, ...] fp32 -> [...] fp16: k-th smallest over dim 0 of u.half() (exact)."""
+    _req(u, name="u")
+    N = u.shape[0]
+    out = torch.empty(u.shape[1:], device=u.device, dtype=torch.float16)
+    check(_lib.lib().dua_pixelwise_order_statistic(_p(u), N, u.numel() // max(N, 1), int(k), _p(out), _stream()),
+          "dua_pixelwise_order_statistic")
+    return out
+
+
 def to_uint8(x):
     _req(x, name="x")
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)

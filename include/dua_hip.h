@@ -71,6 +71,11 @@ int dua_posterior_blend(const float* eps, const float* u, const uint8_t* mask, f
 /* ((x/2+.5).clamp(0,1)*255).round() -> uint8, generate_samples.py:203-215. */
 int dua_to_uint8(const float* x, uint8_t* out, size_t n, void* stream);
 
+/* Dataset-level pixel-wise threshold, scripts/compute_threshold_pixel_wise.py:143-165: for each of the SP = S*3*H*W
+ * (timestep, pixel) columns, the k-th smallest (0-based, k = int(N*perc)) over the N samples of half(u[n][...]), as
+ * selected there by argsort(dim=0)[k] + gather.  u: [N][SP] fp32; out: [SP] fp16 bit patterns. Exact. */
+int dua_pixelwise_order_statistic(const float* u, int N, long SP, int k, uint16_t* out, void* stream);
+
 /* Device normal generator (Philox4x32-10 + Box-Muller); replaces torch.randn_like
  * (zigzag_centered.py:500,532) when the caller does not need the CPU generator's stream. */
 int dua_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);

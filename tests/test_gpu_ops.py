@@ -267,3 +267,16 @@ def test_gemm_bf16x3(ops, M, N, K1, K2):
     assert (c.cpu().double() - (F.silu(a.double()) @ w.double().T + b)).abs().max().item() < 1e-4
     c = ops.gemm_bf16x3(a1.to(dev), planes, N, bias=b.to(dev), a2=(a2.to(dev) if K2 else None), act_out=2)
     assert (c.cpu().double() - F.gelu(ref + b)).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("N,S,H,perc", [(7, 2, 5, 0.15), (100, 3, 16, 0.15), (257, 2, 9, 0.5), (1000, 1, 32, 0.9), (3, 1, 4, 0.0)])
+def test_pixelwise_threshold_bit_exact(N, S, H, perc):
+    from diffusion_uncertainty_amd.thresholds import compute_threshold_pixel_wise
+    from oracle import thresholds as oth
+    u = rnd(60, N, S, 3, H, H) ** 2
+    u[: N // 2, :, :, 0, 0] = 0.25                       # ties
+    u[0, :, 1, 1, 1] = -1.0                              # a negative value orders below everything
+    got = compute_threshold_pixel_wise(u.to(dev), perc)
+    ref = oth.compute_threshold_pixel_wise(u, perc)
+    assert got.dtype == torch.float16 and got.shape == (S, 3, H, H)
+    assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
