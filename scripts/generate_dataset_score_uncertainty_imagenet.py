@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate a dataset of score / uncertainty maps (counterpart of the reference's
+scripts/generate_dataset_score_uncertainty_imagenet.py on the MI355X engine).
+
+Same flags and defaults as the reference's ``parse_args`` (:147-196) and the same flow as ``generate_and_save``
+(:33-93): one process per GPU (``torch.multiprocessing.spawn``), rank r samples
+``X_T[start + r*n : start + (r+1)*n]``, per-rank output files ``uncertainty_{scheduler}_{rank}.pth`` /
+``gen_images_{rank}.pth`` / ``timesteps.pth`` (+ ``args.yaml``).  Deviations: ``score_{rank}.pth`` carries the rank
+suffix (the reference's shared ``score.pth`` is a last-writer-wins race, :91); ``--synthetic`` / ``--random-weights``
+run without the starting-point files / checkpoints; ``--precision`` and ``--noise`` select the engine modes.
+"""
+import argparse
+import datetime
+import os
+import sys
+from pathlib import Path
+
+import torch
+import yaml
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from diffusion_uncertainty_amd.generate_samples import (  # noqa: E402
+    generate_samples_model_scheduler_class_conditioned_from_tensor,
+    generate_samples_model_scheduler_class_conditioned_uvit_from_tensor)
+from diffusion_uncertainty_amd.init_model import (  # noqa: E402
+    init_guided_diffusion_imagenet64_and_scheduler, init_guided_diffusion_imagenet128_and_scheduler, load_autoencoder_uvit,
+    load_uvit, load_uvit_scheduler)
+from diffusion_uncertainty_amd.paths import DIFFUSION_STARTING_POINTS, RESULTS  # noqa: E402
+from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler  # noqa: E402
+from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise  # noqa: E402
+from diffusion_uncertainty_amd.utils import randomize_parameters_, seed_everything, starting_points  # noqa: E402
+from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE  # noqa: E402
+
+CONFIG = ROOT / "config"
+
+
+@torch.no_grad()
+def generate_and_save(gpu_idx, args, num_samples, dest):
+    seed_everything(args.seed)
+    device = torch.device("cuda", gpu_idx)
+    torch.cuda.set_device(device)
+    suffix = "_uvit" if (args.image_size == 128 and args.model_type == "uvit") else ""
+    lo, hi = args.start_index + gpu_idx * num_samples, args.start_index + (gpu_idx + 1) * num_samples
+    folder = DIFFUSION_STARTING_POINTS / f"imagenet{args.image_size}{suffix}"
+    if args.synthetic or not (folder / "X_T.pth").exists():
+        shape = (4, args.image_size // 8, args.image_size // 8) if args.model_type == "uvit" else (3, args.image_size, args.image_size)
+        X_T, y = starting_points(hi, shape)
+        X_T, y = X_T[lo:hi], y[lo:hi]
+    else:
+        y = torch.load(folder / "y.pth", map_location="cpu")[lo:hi]
+        X_T = torch.load(folder / "X_T.pth", map_location="cpu")[lo:hi]
+    ckpt = not args.random_weights
+    if args.model_type == "unet":
+        if args.image_size == 64:
+            unet, scheduler = init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=ckpt, dropout=args.dropout)
+        elif args.image_size == 128:
+            unet, scheduler = init_guided_diffusion_imagenet128_and_scheduler(load_checkpoint=ckpt)
+        else:
+            raise ValueError(f"image_size {args.image_size} not supported for the ADM UNet")
+        if not ckpt:
+            randomize_parameters_(unet, seed=args.image_size)
+        unet.eval().to(device)
+        unet.precision = args.precision
+        model = unet
+    else:
+        uvit = load_uvit(args.image_size, device="cpu", load_checkpoint=ckpt)
+        if not ckpt:
+            randomize_parameters_(uvit, seed=7)
+        ae = load_autoencoder_uvit(device="cpu", load_checkpoint=ckpt)
+        if not ckpt:
+            randomize_parameters_(ae, seed=9)
+        uvit.precision = ae.precision = args.precision
+        model = UViTAE(uvit, ae).to(device)
+        scheduler = load_uvit_scheduler()
+    uc_scheduler = get_uncertainty_scheduler(args, y.to(device), model, scheduler)
+    if args.noise == "device":
+        uc_scheduler.noise_source = DeviceNoise(seed=args.seed + gpu_idx)
+    uc_scheduler.set_timesteps(args.generation_steps)
+    if args.model_type == "unet":
+        results = generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, args.batch_size, device, model, uc_scheduler)
+    else:
+        results = generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(X_T, y, args.batch_size, model, uc_scheduler, device)
+    torch.save(uc_scheduler.timesteps, dest / "timesteps.pth")
+    torch.save(results["score"], dest / f"score_{gpu_idx}.pth")
+    torch.save(results["uncertainty"], dest / f"uncertainty_{args.scheduler_type}_{gpu_idx}.pth")
+    torch.save(results["gen_images"], dest / f"gen_images_{gpu_idx}.pth")
+
+
+def load_config(folder, name):
+    with open(folder / f"{name}.yaml") as f:
+        return argparse.Namespace(**yaml.safe_load(f))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--num-samples", type=int, default=300, dest="num_samples")
+    p.add_argument("--batch-size", type=int, default=32)
+    p.add_argument("--generation-steps", type=int, default=20, dest="generation_steps")
+    p.add_argument("-M", type=int, default=30, dest="M")
+    p.add_argument("--start-step-uc", "--start-step", type=int, default=0, dest="start_step_uc")
+    p.add_argument("--num-steps-uc", type=int, default=20, dest="num_steps_uc")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--eta", type=float, default=0.00)
+    p.add_argument("--dropout", type=float, default=0.1)
+    p.add_argument("--class-condition")
+    p.add_argument("--image-size", type=int, choices=[64, 128, 256, 512], dest="image_size", default=None)
+    p.add_argument("--scheduler-type", "--scheduler", type=str, default=None, dest="scheduler_type",
+                   choices=["mc_dropout", "uncertainty_centered", "uncertainty_zigzag_centered"])
+    p.add_argument("--start-index", type=int, default=None, dest="start_index")
+    p.add_argument("--multi-gpu", action="store_true", default=False)
+    p.add_argument("--model-type", type=str, default=None, choices=["unet", "uvit"], dest="model_type")
+    p.add_argument("--predict-next", action="store_true", dest="predict_next")
+    p.add_argument("--uncertainty-distance", type=int, default=20, dest="uncertainty_distance")
+    p.add_argument("--num-zigzag", "--num-zigzags", "--num-zig-zag", "--num-zig-zags", type=int, default=3, dest="num_zigzag")
+    # engine options (not in the reference)
+    p.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3")
+    p.add_argument("--noise", choices=["host", "device"], default="host", help="host: CPU-generator noise tape in the reference's draw order")
+    p.add_argument("--synthetic", action="store_true", help="generate X_T / y like scripts/generate_diffusion_starting_data.py")
+    p.add_argument("--random-weights", action="store_true", help="seeded random weights instead of checkpoints")
+    p.add_argument("--dest", type=str, default=None)
+    options = sorted(x.stem for x in (CONFIG / "generation").glob("*.yaml"))
+    p.add_argument("--config", type=str, default=None, choices=options, help="name of a config/generation/*.yaml file")
+    args = p.parse_args(argv)
+    if args.config is not None:
+        p.set_defaults(**load_config(CONFIG / "generation", args.config).__dict__)
+        args = p.parse_args(argv)
+    else:
+        assert args.image_size is not None, "--image-size must be specified"
+        assert args.scheduler_type is not None, "--scheduler-type must be specified"
+        assert args.model_type is not None, "--model-type must be specified"
+        assert args.start_index is not None, "--start-index must be specified"
+    return args
+
+
+def main():
+    args = parse_args()
+    if args.scheduler_type == "mc_dropout":
+        assert args.image_size == 64, "mc_dropout only implemented for image_size=64"
+    seed_everything(args.seed)
+    dest = Path(args.dest) if args.dest else RESULTS / "score-uncertainty" / datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
+    dest.mkdir(parents=True, exist_ok=True)
+    args.__dict__["dataset"] = f"imagenet{args.image_size}"
+    with open(dest / "args.yaml", "w") as f:
+        yaml.dump(args.__dict__, f)
+    num_gpus = torch.cuda.device_count()
+    if num_gpus == 0:
+        raise SystemExit("no GPU visible: the engine has no CPU path")
+    if num_gpus == 1:
+        generate_and_save(0, args, args.num_samples, dest)
+    else:
+        torch.multiprocessing.spawn(fn=generate_and_save, args=(args, args.num_samples // num_gpus, dest), nprocs=num_gpus, join=True)
+    print("Done:", dest)
+
+
+if __name__ == "__main__":
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    main()

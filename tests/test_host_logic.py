@@ -83,3 +83,19 @@ def test_seeded_inputs_and_starting_points():
     a, b = starting_points(4, (3, 8, 8))
     g = torch.Generator().manual_seed(49394)
     assert torch.equal(a, torch.randn(4, 3, 8, 8, generator=g)) and torch.equal(b, torch.randint(0, 1000, (4,), generator=g))
+
+
+def test_cli_flags_mirror_reference_defaults():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_cli", os.path.join(root, "scripts", "generate_dataset_score_uncertainty_imagenet.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    a = cli.parse_args(["--image-size", "128", "--scheduler-type", "uncertainty_zigzag_centered", "--model-type", "unet", "--start-index", "0"])
+    assert (a.num_samples, a.batch_size, a.generation_steps, a.M, a.start_step_uc, a.num_steps_uc, a.seed, a.eta, a.dropout, a.num_zigzag) == \
+        (300, 32, 20, 30, 0, 20, 0, 0.0, 0.1, 3)                       # reference parse_args :150-174
+    b = cli.parse_args(["--config", "imagenet128_readme_example", "-M", "7"])
+    assert (b.M, b.generation_steps, b.start_step_uc, b.num_steps_uc, b.batch_size, b.image_size) == (7, 50, 40, 10, 128, 128)
+    with pytest.raises(AssertionError):
+        cli.parse_args(["--image-size", "128"])
