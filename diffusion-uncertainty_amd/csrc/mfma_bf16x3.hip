@@ -346,6 +346,154 @@ static int launch_x(XTileP& p, hipStream_t s, int batch = 1) {
     return dua_check_launch("dua bf16x3 tile kernel");
 }
 
+// ================================================================================================================
+// LDS-DMA variant of the pre-split 3x3 convolution: 256 x 128 block tile, 8 waves (4 x 2, each 64 x 64), 32-deep K
+// steps, THREE LDS stages of 48 KB filled by `buffer_load_dwordx4 ... lds` straight from HBM/L2 (no staging
+// registers, no ds_write, no padding selects: taps outside the image use an out-of-range buffer offset, which the
+// buffer unit returns as zeros).  The XOR swizzle of the LDS image is applied on the per-lane SOURCE chunk (the DMA
+// writes lane-linear 1 KB pieces = 16 rows x 64 B).  Tile kt+2 is requested while tile kt is multiplied; a counted
+// `s_waitcnt vmcnt(6)` + one raw s_barrier per step publishes tile kt+1.
+#define DBM 256
+#define DSTAGE_A (DBM * LDH)                 // bf16 elements per A plane of a stage (8192 -> 16 KB)
+#define DSTAGE_B (BN * LDH)                  // 4096 -> 8 KB
+#define DSTAGE (2 * DSTAGE_A + 2 * DSTAGE_B) // 24576 elements = 48 KB
+
+struct DConvP {
+    const __bf16* A;         // hi plane; lo plane follows at +a_plane elements
+    const __bf16* B;         // pre-split weights, hi plane then lo plane (+b_plane elements)
+    const float *bias, *res;
+    float* C;
+    long a_plane, b_plane;
+    int M, N, K, H, W, Cin, nchw_out, ntm, ntn;
+};
+
+__global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[3 * DSTAGE];       // 144 KB: one workgroup per CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    int lid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, idx = lid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tn = lid % p.ntn, tm = lid / p.ntn;
+    const int m0 = tm * DBM, n0 = tn * BN;
+    const int nk = p.K / BK;
+
+    // ---- DMA geometry.  One wave instruction = 16 rows x 4 chunks of 16 B.  Wave w stages A row groups 2w, 2w+1
+    // (both planes) and B row group w (both planes): 6 instructions per K step.
+    const int lrow = lane >> 2;
+    const int csrc = (lane & 3) ^ ((lane >> 4) & 3);                     // source chunk for this lane's LDS slot
+    const unsigned OOB = 0xFFFFFFF0u;
+    unsigned abase[2], abits[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = min(m0 + 16 * (2 * wave + j) + lrow, p.M - 1);
+        const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
+        const int y = rem / p.W, x = rem - y * p.W;
+        abase[j] = (unsigned)(((long)m * p.Cin + 8 * csrc) * 2);
+        unsigned bits = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            bits |= (unsigned)((unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) << t;
+        }
+        abits[j] = bits;
+    }
+    unsigned boff = (unsigned)(((long)(n0 + 16 * wave + lrow) * p.K + 8 * csrc) * 2);
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(2 * p.a_plane * 2), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
+    const int a_lo = (int)(p.a_plane * 2), b_lo = (int)(p.b_plane * 2);      // byte distance hi -> lo plane
+    int tap = 0, cb = 0;
+    auto issue = [&](int stage) {
+        __bf16* st = lds + stage * DSTAGE;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int toff = ((dy * p.W + dx) * p.Cin + cb * BK) * 2;           // byte offset of this (tap, channel block)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = ((abits[j] >> tap) & 1u) ? abase[j] + (unsigned)toff : OOB;
+            __bf16* dst = st + (16 * (2 * wave + j)) * LDH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst + DSTAGE_A, 16, vo, a_lo, 0, 0);
+        }
+        {
+            __bf16* dst = st + 2 * DSTAGE_A + (16 * wave) * LDH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + DSTAGE_B, 16, boff, b_lo, 0, 0);
+            boff += BK * 2;
+        }
+        if (++tap == 9) { tap = 0; ++cb; }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lr = lane & 31, kh = lane >> 5;
+    struct XFrag { bf16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1; };
+    auto read_frag = [&](int stage, int s) -> XFrag {
+        XFrag f;
+        const int cs = 8 * ((2 * s + kh) ^ ((lr >> 2) & 3));
+        const __bf16* a = lds + stage * DSTAGE + (wm * 64 + lr) * LDH + cs;
+        const __bf16* b = lds + stage * DSTAGE + 2 * DSTAGE_A + (wn * 64 + lr) * LDH + cs;
+        f.ah0 = *(const bf16x8*)a;
+        f.ah1 = *(const bf16x8*)(a + 32 * LDH);
+        f.al0 = *(const bf16x8*)(a + DSTAGE_A);
+        f.al1 = *(const bf16x8*)(a + DSTAGE_A + 32 * LDH);
+        f.bh0 = *(const bf16x8*)b;
+        f.bh1 = *(const bf16x8*)(b + 32 * LDH);
+        f.bl0 = *(const bf16x8*)(b + DSTAGE_B);
+        f.bl1 = *(const bf16x8*)(b + DSTAGE_B + 32 * LDH);
+        return f;
+    };
+
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        int s2 = stage + 2;
+        if (s2 >= 3) s2 -= 3;
+        if (kt + 2 < nk) issue(s2);
+        XFrag f0 = read_frag(stage, 0);
+        XFrag f1 = read_frag(stage, 1);
+        XMFMA12(f0)
+        XMFMA12(f1)
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++stage == 3) stage = 0;
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + lr;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row >= p.M) continue;
+                float v = acc[mi][ni][r] + bv;
+                if (p.res) v += p.res[(long)row * p.N + col];
+                if (p.nchw_out) {
+                    int hw = p.H * p.W, n = row / hw, rem = row - n * hw;
+                    p.C[((long)n * p.N + col) * hw + rem] = v;
+                } else {
+                    p.C[(long)row * p.N + col] = v;
+                }
+            }
+        }
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---- weight splitting: fp32 [N][K] (or OIHW conv weights) -> two bf16 planes [Npad128][K] -------------------
@@ -394,6 +542,10 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
     return launch_x<XMODE_CONV>(p, as_stream(stream));
 }
 
+// Engine selector for the pre-split conv: 1 = LDS-DMA kernel (default), 0 = register-staged kernel (debug / A-B).
+static int dua_dma_conv_enabled = 1;
+extern "C" int dua_set_dma_conv(int on) { int o = dua_dma_conv_enabled; dua_dma_conv_enabled = on; return o; }
+
 extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
                                            float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, void* stream) {
     DUA_REQUIRE(xplanes && planes && y, "dua_conv3x3_bf16x3_presplit: null pointer");
@@ -405,6 +557,15 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
     p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = y;
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
     p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
+    const size_t a_plane = (size_t)N * H * W * Cin;
+    if (dua_dma_conv_enabled && 4 * a_plane < 0xFFFFFFF0ull && 4 * plane < 0xFFFFFFF0ull) {
+        DConvP d{};
+        d.A = p.Ahi; d.B = p.Bhi; d.bias = bias; d.res = residual; d.C = y; d.a_plane = (long)a_plane; d.b_plane = (long)plane;
+        d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out;
+        d.ntm = (d.M + DBM - 1) / DBM; d.ntn = (Cout + BN - 1) / BN;
+        hipLaunchKernelGGL(k_xconv_dma, dim3(d.ntm * d.ntn), 512, 0, as_stream(stream), d);
+        return dua_check_launch("dua_conv3x3_bf16x3_presplit (dma)");
+    }
     return launch_x<XMODE_CONV, false, true>(p, as_stream(stream));
 }
 
