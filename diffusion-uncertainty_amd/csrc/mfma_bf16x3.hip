@@ -407,24 +407,33 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
     const int a_lo = (int)(p.a_plane * 2), b_lo = (int)(p.b_plane * 2);      // byte distance hi -> lo plane
     int tap = 0, cb = 0;
-    auto issue = [&](int stage) {
-        __bf16* st = lds + stage * DSTAGE;
+    // The six DMA pieces of a tile are issued one at a time (piece i = 0..5) so that the caller can spread them
+    // between MFMA groups: an LDS-DMA issue holds the wave for ~60-180 cycles, which the SIMD's other wave can only
+    // cover if the stalls are not clustered.
+    unsigned vo0 = 0, vo1 = 0;
+    auto dma_setup = [&]() {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int toff = ((dy * p.W + dx) * p.Cin + cb * BK) * 2;           // byte offset of this (tap, channel block)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned vo = ((abits[j] >> tap) & 1u) ? abase[j] + (unsigned)toff : OOB;
-            __bf16* dst = st + (16 * (2 * wave + j)) * LDH;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, vo, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst + DSTAGE_A, 16, vo, a_lo, 0, 0);
-        }
-        {
-            __bf16* dst = st + 2 * DSTAGE_A + (16 * wave) * LDH;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + DSTAGE_B, 16, boff, b_lo, 0, 0);
+        vo0 = ((abits[0] >> tap) & 1u) ? abase[0] + (unsigned)toff : OOB;
+        vo1 = ((abits[1] >> tap) & 1u) ? abase[1] + (unsigned)toff : OOB;
+        if (++tap == 9) { tap = 0; ++cb; }
+    };
+    auto dma_piece = [&](int stage, int i) {
+        __bf16* st = lds + stage * DSTAGE;
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH, 16, vo0, 0, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH + DSTAGE_A, 16, vo0, a_lo, 0, 0);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH, 16, vo1, 0, 0, 0);
+        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH + DSTAGE_A, 16, vo1, a_lo, 0, 0);
+        if (i == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + 2 * DSTAGE_A + (16 * wave) * LDH, 16, boff, 0, 0, 0);
+        if (i == 5) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + 2 * DSTAGE_A + (16 * wave) * LDH + DSTAGE_B, 16, boff, b_lo, 0, 0);
             boff += BK * 2;
         }
-        if (++tap == 9) { tap = 0; ++cb; }
+    };
+    auto issue = [&](int stage) {
+        dma_setup();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dma_piece(stage, i);
     };
 
     f32x16 acc[2][2];
@@ -461,11 +470,22 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     for (int kt = 0; kt < nk; ++kt) {
         int s2 = stage + 2;
         if (s2 >= 3) s2 -= 3;
-        if (kt + 2 < nk) issue(s2);
+        const bool pre = kt + 2 < nk;
+        if (pre) dma_setup();
         XFrag f0 = read_frag(stage, 0);
         XFrag f1 = read_frag(stage, 1);
-        XMFMA12(f0)
-        XMFMA12(f1)
+        __builtin_amdgcn_sched_barrier(0);       // keep all 16 fragment reads in flight ahead of the MFMA stream
+#define XG(F, A0, A1, B0, B1, I)                                                                         \
+        XM(F.A0, F.B0, acc[0][0]) XM(F.A0, F.B1, acc[0][1]) XM(F.A1, F.B0, acc[1][0]) XM(F.A1, F.B1, acc[1][1]) \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (pre) dma_piece(s2, I);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);
+        XG(f0, al0, al1, bh0, bh1, 0)
+        XG(f0, ah0, ah1, bl0, bl1, 1)
+        XG(f0, ah0, ah1, bh0, bh1, 2)
+        XG(f1, al0, al1, bh0, bh1, 3)
+        XG(f1, ah0, ah1, bl0, bl1, 4)
+        XG(f1, ah0, ah1, bh0, bh1, 5)
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (++stage == 3) stage = 0;
