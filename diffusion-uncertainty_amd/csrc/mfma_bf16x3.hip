@@ -354,9 +354,6 @@ static int launch_x(XTileP& p, hipStream_t s, int batch = 1) {
 // writes lane-linear 1 KB pieces = 16 rows x 64 B).  Tile kt+2 is requested while tile kt is multiplied; a counted
 // `s_waitcnt vmcnt(6)` + one raw s_barrier per step publishes tile kt+1.
 #define DBM 256
-#define DSTAGE_A (DBM * LDH)                 // bf16 elements per A plane of a stage (8192 -> 16 KB)
-#define DSTAGE_B (BN * LDH)                  // 4096 -> 8 KB
-#define DSTAGE (2 * DSTAGE_A + 2 * DSTAGE_B) // 24576 elements = 48 KB
 
 struct DConvP {
     const __bf16* A;         // hi plane; lo plane follows at +a_plane elements
@@ -367,8 +364,19 @@ struct DConvP {
     int M, N, K, H, W, Cin, nchw_out, ntm, ntn;
 };
 
+// NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
+//   NT = 2: 256 x 128, three 48 KB stages (tile kt+2 in flight while tile kt is multiplied);
+//   NT = 4: 256 x 256, two 64 KB stages (half the L2->LDS bytes per MFMA; one tile in flight).
+template <int NT>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[3 * DSTAGE];       // 144 KB: one workgroup per CU
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
+    constexpr int DBN = 64 * NT;
+    constexpr int NST = NT == 2 ? 3 : 2;
+    constexpr int SA = DBM * LDH;                    // bf16 elements per A plane of a stage
+    constexpr int SB = DBN * LDH;
+    constexpr int STG = 2 * SA + 2 * SB;
+    constexpr int NPIECE = 4 + NT;                   // DMA pieces per wave per tile: 4 (A) + NT (B)
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NST * STG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -379,21 +387,24 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tn = lid % p.ntn, tm = lid / p.ntn;
-    const int m0 = tm * DBM, n0 = tn * BN;
+    const int m0 = tm * DBM, n0 = tn * DBN;
     const int nk = p.K / BK;
 
     // ---- DMA geometry.  One wave instruction = 16 rows x 4 chunks of 16 B.  Wave w stages A row groups 2w, 2w+1
-    // (both planes) and B row group w (both planes): 6 instructions per K step.
+    // (both planes) and B row groups (NT/2)*w .. (both planes).
     const int lrow = lane >> 2;
     const int csrc = (lane & 3) ^ ((lane >> 4) & 3);                     // source chunk for this lane's LDS slot
     const unsigned OOB = 0xFFFFFFF0u;
+    // The buffer descriptors are rebased per workgroup at the first pixel its taps can touch (tile start minus one
+    // image row and one pixel), so the 32-bit buffer offsets stay tiny whatever the size of the activation planes.
+    const int mbase = max(0, m0 - (p.W + 1));
     unsigned abase[2], abits[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = min(m0 + 16 * (2 * wave + j) + lrow, p.M - 1);
         const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
         const int y = rem / p.W, x = rem - y * p.W;
-        abase[j] = (unsigned)(((long)m * p.Cin + 8 * csrc) * 2);
+        abase[j] = (unsigned)(((long)(m - mbase) * p.Cin + 8 * csrc) * 2);
         unsigned bits = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -402,14 +413,18 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         }
         abits[j] = bits;
     }
-    unsigned boff = (unsigned)(((long)(n0 + 16 * wave + lrow) * p.K + 8 * csrc) * 2);
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(2 * p.a_plane * 2), 0x00020000);
+    unsigned boff[NT / 2];
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) boff[j] = (unsigned)(((long)(n0 + 16 * ((NT / 2) * wave + j) + lrow) * p.K + 8 * csrc) * 2);
+    const long arem = ((long)p.M - mbase) * p.Cin * 2;                       // bytes from the rebased origin to the plane's end
+    const int arec = (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)mbase * p.Cin), 0, arec, 0x00020000);
+    const auto ral = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + p.a_plane + (long)mbase * p.Cin), 0, arec, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
-    const int a_lo = (int)(p.a_plane * 2), b_lo = (int)(p.b_plane * 2);      // byte distance hi -> lo plane
+    const int b_lo = (int)(p.b_plane * 2);                                   // byte distance hi -> lo weight plane
     int tap = 0, cb = 0;
-    // The six DMA pieces of a tile are issued one at a time (piece i = 0..5) so that the caller can spread them
-    // between MFMA groups: an LDS-DMA issue holds the wave for ~60-180 cycles, which the SIMD's other wave can only
-    // cover if the stalls are not clustered.
+    // The DMA pieces of a tile are issued one at a time so that the caller can spread them between MFMA groups
+    // (an LDS-DMA issue holds the wave for ~60-180 cycles).
     unsigned vo0 = 0, vo1 = 0;
     auto dma_setup = [&]() {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -419,83 +434,102 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         if (++tap == 9) { tap = 0; ++cb; }
     };
     auto dma_piece = [&](int stage, int i) {
-        __bf16* st = lds + stage * DSTAGE;
+        __bf16* st = lds + stage * STG;
         if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH, 16, vo0, 0, 0, 0);
-        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH + DSTAGE_A, 16, vo0, a_lo, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave)) * LDH + SA, 16, vo0, 0, 0, 0);
         if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH, 16, vo1, 0, 0, 0);
-        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH + DSTAGE_A, 16, vo1, a_lo, 0, 0);
-        if (i == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + 2 * DSTAGE_A + (16 * wave) * LDH, 16, boff, 0, 0, 0);
-        if (i == 5) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + 2 * DSTAGE_A + (16 * wave) * LDH + DSTAGE_B, 16, boff, b_lo, 0, 0);
-            boff += BK * 2;
+        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave + 1)) * LDH + SA, 16, vo1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT / 2; ++j) {
+            __bf16* dst = st + 2 * SA + (16 * ((NT / 2) * wave + j)) * LDH;
+            if (i == 4 + 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
+            if (i == 5 + 2 * j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);
+                boff[j] += BK * 2;
+            }
         }
     };
     auto issue = [&](int stage) {
         dma_setup();
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dma_piece(stage, i);
+        for (int i = 0; i < NPIECE; ++i) dma_piece(stage, i);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
-    struct XFrag { bf16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1; };
-    auto read_frag = [&](int stage, int s) -> XFrag {
-        XFrag f;
+    struct DFrag { bf16x8 ah[2], al[2], bh[NT], bl[NT]; };
+    auto read_frag = [&](int stage, int s) -> DFrag {
+        DFrag f;
         const int cs = 8 * ((2 * s + kh) ^ ((lr >> 2) & 3));
-        const __bf16* a = lds + stage * DSTAGE + (wm * 64 + lr) * LDH + cs;
-        const __bf16* b = lds + stage * DSTAGE + 2 * DSTAGE_A + (wn * 64 + lr) * LDH + cs;
-        f.ah0 = *(const bf16x8*)a;
-        f.ah1 = *(const bf16x8*)(a + 32 * LDH);
-        f.al0 = *(const bf16x8*)(a + DSTAGE_A);
-        f.al1 = *(const bf16x8*)(a + DSTAGE_A + 32 * LDH);
-        f.bh0 = *(const bf16x8*)b;
-        f.bh1 = *(const bf16x8*)(b + 32 * LDH);
-        f.bl0 = *(const bf16x8*)(b + DSTAGE_B);
-        f.bl1 = *(const bf16x8*)(b + DSTAGE_B + 32 * LDH);
+        const __bf16* a = lds + stage * STG + (wm * 64 + lr) * LDH + cs;
+        const __bf16* b = lds + stage * STG + 2 * SA + (wn * 32 * NT + lr) * LDH + cs;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *(const bf16x8*)(a + 32 * i * LDH);
+            f.al[i] = *(const bf16x8*)(a + SA + 32 * i * LDH);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f.bh[j] = *(const bf16x8*)(b + 32 * j * LDH);
+            f.bl[j] = *(const bf16x8*)(b + SB + 32 * j * LDH);
+        }
         return f;
     };
 
+#define DWAIT_TILE(more) \
+    if (NST == 3 && (more)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
     issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST == 3 && nk > 1) issue(1);
+    DWAIT_TILE(nk > 1)
     __builtin_amdgcn_s_barrier();
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        int s2 = stage + 2;
-        if (s2 >= 3) s2 -= 3;
-        const bool pre = kt + 2 < nk;
+        int s2 = stage + (NST - 1);
+        if (s2 >= NST) s2 -= NST;
+        const bool pre = kt + (NST - 1) < nk;        // the tile requested during this step: kt+2 (3 stages) / kt+1 (2 stages)
         if (pre) dma_setup();
-        XFrag f0 = read_frag(stage, 0);
-        XFrag f1 = read_frag(stage, 1);
-        __builtin_amdgcn_sched_barrier(0);       // keep all 16 fragment reads in flight ahead of the MFMA stream
-#define XG(F, A0, A1, B0, B1, I)                                                                         \
-        XM(F.A0, F.B0, acc[0][0]) XM(F.A0, F.B1, acc[0][1]) XM(F.A1, F.B0, acc[1][0]) XM(F.A1, F.B1, acc[1][1]) \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        if (pre) dma_piece(s2, I);                                                                       \
-        __builtin_amdgcn_sched_barrier(0);
-        XG(f0, al0, al1, bh0, bh1, 0)
-        XG(f0, ah0, ah1, bl0, bl1, 1)
-        XG(f0, ah0, ah1, bh0, bh1, 2)
-        XG(f1, al0, al1, bh0, bh1, 3)
-        XG(f1, ah0, ah1, bl0, bl1, 4)
-        XG(f1, ah0, ah1, bh0, bh1, 5)
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int piece = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            DFrag f = read_frag(stage, s);
+            __builtin_amdgcn_sched_barrier(0);       // keep the fragment reads in flight ahead of the MFMA stream
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {   // lo*hi, hi*lo, hi*hi
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const bf16x8 av = term == 0 ? f.al[i] : f.ah[i];
+                        const bf16x8 bv = term == 1 ? f.bl[j] : f.bh[j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pre) {
+                    if (piece < NPIECE) dma_piece(s2, piece);
+                    ++piece;
+                    if (NT == 4 && piece < NPIECE) { dma_piece(s2, piece); ++piece; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DWAIT_TILE(kt + 2 < nk)
         __builtin_amdgcn_s_barrier();
-        if (++stage == 3) stage = 0;
+        if (++stage == NST) stage = 0;
     }
 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + lr;
+        for (int ni = 0; ni < NT; ++ni) {
+            const int col = n0 + wn * 32 * NT + ni * 32 + lr;
             if (col >= p.N) continue;
             const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
@@ -512,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                 }
             }
         }
+#endif
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -562,7 +597,8 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
     return launch_x<XMODE_CONV>(p, as_stream(stream));
 }
 
-// Engine selector for the pre-split conv: 1 = LDS-DMA kernel (default), 0 = register-staged kernel (debug / A-B).
+// Engine selector for the pre-split conv: 1 = LDS-DMA kernels (default; 256x256 tile where Cout % 256 == 0),
+// 2 = LDS-DMA 256x128 only, 0 = register-staged kernel (debug / A-B).
 static int dua_dma_conv_enabled = 1;
 extern "C" int dua_set_dma_conv(int on) { int o = dua_dma_conv_enabled; dua_dma_conv_enabled = on; return o; }
 
@@ -578,12 +614,17 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
     p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
     const size_t a_plane = (size_t)N * H * W * Cin;
-    if (dua_dma_conv_enabled && 4 * a_plane < 0xFFFFFFF0ull && 4 * plane < 0xFFFFFFF0ull) {
+    if (dua_dma_conv_enabled != 0 && 4 * plane < 0x7FFFFFF0ull && (size_t)(2 * W + 260) * Cin * 2 < 0x7FFFFFF0ull) {
         DConvP d{};
         d.A = p.Ahi; d.B = p.Bhi; d.bias = bias; d.res = residual; d.C = y; d.a_plane = (long)a_plane; d.b_plane = (long)plane;
         d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out;
-        d.ntm = (d.M + DBM - 1) / DBM; d.ntn = (Cout + BN - 1) / BN;
-        hipLaunchKernelGGL(k_xconv_dma, dim3(d.ntm * d.ntn), 512, 0, as_stream(stream), d);
+        d.ntm = (d.M + DBM - 1) / DBM;
+        // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile Cout exactly and still give every CU
+        // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
+        const bool wide = dua_dma_conv_enabled == 1 && Cout % 256 == 0 && (long)d.ntm * (Cout / 256) >= 512;
+        d.ntn = wide ? Cout / 256 : (Cout + BN - 1) / BN;
+        if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(d.ntm * d.ntn), 512, 0, as_stream(stream), d);
+        else hipLaunchKernelGGL(k_xconv_dma<2>, dim3(d.ntm * d.ntn), 512, 0, as_stream(stream), d);
         return dua_check_launch("dua_conv3x3_bf16x3_presplit (dma)");
     }
     return launch_x<XMODE_CONV, false, true>(p, as_stream(stream));
