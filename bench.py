@@ -42,6 +42,10 @@ class ConvProfile:
     def record(self, kind, flops, e0, e1):
         self.items.append((flops, e0, e1))
 
+    # HBM-side bytes per conv launch from the PMC passes of profiles/r01d_pmc_traffic_conv.json (FETCH_SIZE doubled per the
+    # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
+    PMC_TRAFFIC_BF16X3 = 2.145e9
+
     def summary(self):
         if not self.items:
             return None
@@ -61,7 +65,8 @@ class ConvProfile:
                         kernel="k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)",
                         launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
         return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                    frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_BF16X3,
+                    traffic_source="profiles/r01d_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                     kernel="k_xtile<CONV, PRESPLIT> (split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)",
                     launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
                     executed_mfma_tflops=round(3 * cs["tflops"], 1), executed_frac=round(3 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
