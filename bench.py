@@ -149,7 +149,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ          # under torch.distributed.run
+    if world > 1 or launched:
         dist.init_process_group("nccl", device_id=dev)
 
     from diffusion_uncertainty_amd import ops
@@ -172,7 +173,7 @@ def main():
         return s.denoiser_calls
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -237,7 +238,7 @@ def main():
             # full at batch 2: use at most 32 threads and report that count.
             line["cpu_baseline"] = cpu_baseline(sd, min(cores, 32))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

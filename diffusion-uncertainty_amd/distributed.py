@@ -16,16 +16,16 @@ def shard_range(n_total, rank, world, start=0):
 
 def gather_images(imgs):
     """imgs: uint8 [n, C, H, W] on every rank -> [world, n, C, H, W] on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return imgs.unsqueeze(0)
-    w = dist.get_world_size()
+    w = dist.get_world_size()          # a 1-rank group still goes through the collective (exercises RCCL under torchrun)
     out = torch.empty((w * imgs.shape[0],) + tuple(imgs.shape[1:]), dtype=imgs.dtype, device=imgs.device)
     dist.all_gather_into_tensor(out, imgs.contiguous())          # concatenated along dim 0, rank order
     return out.view((w,) + tuple(imgs.shape))
 
 
 def max_over_ranks(seconds, device):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
