@@ -380,15 +380,19 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x;
-    int lid = blockIdx.x;
-    {
-        int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, idx = lid >> 3;
-        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    // Persistent workgroups: gridDim.x <= #CUs workgroups walk the tile list.  Workgroups that share an XCD (equal
+    // blockIdx % 8) own one contiguous chunk of tiles and sweep it side by side, so concurrently running workgroups
+    // of an XCD work on neighbouring tiles (shared halo rows / weight panel in that XCD's L2).  A workgroup moves to
+    // its next tile right after issuing its output stores: they drain while the next tile's first DMA is in flight.
+    const int ntiles = p.ntm * p.ntn;
+    const int nk = p.K / BK;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
+  for (int ti = slot; ti < chunk_n; ti += nslot) {
+    const int lid = chunk0 + ti;
     const int tn = lid % p.ntn, tm = lid / p.ntn;
     const int m0 = tm * DBM, n0 = tn * DBN;
-    const int nk = p.K / BK;
 
     // ---- DMA geometry.  One wave instruction = 16 rows x 4 chunks of 16 B.  Wave w stages A row groups 2w, 2w+1
     // (both planes) and B row groups (NT/2)*w .. (both planes).
@@ -525,27 +529,66 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         if (++stage == NST) stage = 0;
     }
 
+    if (!p.nchw_out && (p.N & 3) == 0) {
+        // ---- epilogue through LDS: each wave re-lays its 32 x (32*NT) half tile as rows in a private LDS patch
+        // (the K loop's last barrier has retired every read of the stages), then moves whole rows: 16 B per lane,
+        // 128*NT contiguous bytes per row for the residual read and the output store (the accumulator layout itself
+        // would give 4-byte accesses in 128 B runs, which made the residual read cost as much as a third of the kernel).
+        constexpr int WC = 32 * NT;                       // columns of a wave tile
+        float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WC);
+        const int c4 = lane % (WC / 4), rr = lane / (WC / 4);          // float4 column, row within a group
+        constexpr int RPI = 64 / (WC / 4);                // rows per wave instruction (4 for NT=2, 2 for NT=4)
+        const int colq = n0 + wn * WC + 4 * c4;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const int col = n0 + wn * 32 * NT + ni * 32 + lr;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row >= p.M) continue;
-                float v = acc[mi][ni][r] + bv;
-                if (p.res) v += p.res[(long)row * p.N + col];
-                if (p.nchw_out) {
-                    int hw = p.H * p.W, n = row / hw, rem = row - n * hw;
-                    p.C[((long)n * p.N + col) * hw + rem] = v;
-                } else {
-                    p.C[(long)row * p.N + col] = v;
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * kh) * WC + ni * 32 + lr] = acc[mi][ni][r];
+            // same-wave LDS write -> read: in-order LDS queue, no barrier needed
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int rl = it * RPI + rr;
+                const int row = m0 + wm * 64 + mi * 32 + rl;
+                float4 v = *(const float4*)(patch + rl * WC + 4 * c4);
+                if (row < p.M && colq < p.N) {
+                    v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                    if (p.res) {
+                        const float4 q = *(const float4*)(p.res + (long)row * p.N + colq);
+                        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                    }
+                    *(float4*)(p.C + (long)row * p.N + colq) = v;
                 }
             }
         }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+    #pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int col = n0 + wn * 32 * NT + ni * 32 + lr;
+                if (col >= p.N) continue;
+                const float bv = p.bias ? p.bias[col] : 0.f;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row >= p.M) continue;
+                    float v = acc[mi][ni][r] + bv;
+                    if (p.res) v += p.res[(long)row * p.N + col];
+                    if (p.nchw_out) {
+                        int hw = p.H * p.W, n = row / hw, rem = row - n * hw;
+                        p.C[((long)n * p.N + col) * hw + rem] = v;
+                    } else {
+                        p.C[(long)row * p.N + col] = v;
+                    }
+                }
+            }
+        }
+    __builtin_amdgcn_s_barrier();      // every wave is done with this tile's LDS stages before the next tile's DMA
+  }
 #endif
 }
 
@@ -623,8 +666,9 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
         // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
         const bool wide = dua_dma_conv_enabled == 1 && Cout % 256 == 0 && (long)d.ntm * (Cout / 256) >= 512;
         d.ntn = wide ? Cout / 256 : (Cout + BN - 1) / BN;
-        if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(d.ntm * d.ntn), 512, 0, as_stream(stream), d);
-        else hipLaunchKernelGGL(k_xconv_dma<2>, dim3(d.ntm * d.ntn), 512, 0, as_stream(stream), d);
+        const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
+        if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(grid), 512, 0, as_stream(stream), d);
+        else hipLaunchKernelGGL(k_xconv_dma<2>, dim3(grid), 512, 0, as_stream(stream), d);
         return dua_check_launch("dua_conv3x3_bf16x3_presplit (dma)");
     }
     return launch_x<XMODE_CONV, false, true>(p, as_stream(stream));
