@@ -275,6 +275,40 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
         MFMA16(f1)
     }
 
+    // ---- epilogue.  Fast path: each wave re-lays its 32 x 64 half tile as rows in a private LDS patch (the K loop's
+    // last barrier has retired every read of the staging buffers) and moves whole rows, 16 B per lane, 256 contiguous
+    // bytes per row, for the residual read and the output store.
+    if (!(MODE != MODE_GEMM && p.nchw_out) && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (!res || (p.ldr & 3) == 0)) {
+        float* patch = reinterpret_cast<float*>(lds) + wave * (32 * 64);
+        const int c4e = lane & 15, rre = lane >> 4;
+        const int colq = n0 + wn * 64 + 4 * c4e;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * kh) * 64 + ni * 32 + lr] = acc[mi][ni][r];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 4 + rre;
+                const int row = m0 + wm * 64 + mi * 32 + rl;
+                float4 v = *(const float4*)(patch + rl * 64 + 4 * c4e);
+                if (row < p.M && colq < p.N) {
+                    v.x = v.x * p.alpha + bq.x; v.y = v.y * p.alpha + bq.y; v.z = v.z * p.alpha + bq.z; v.w = v.w * p.alpha + bq.w;
+                    if (p.act_out == 2) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+                    if (res) {
+                        const float4 q = *(const float4*)(res + (long)row * p.ldr + colq);
+                        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                    }
+                    *(float4*)(Cp + (long)row * p.ldc + colq) = v;
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
