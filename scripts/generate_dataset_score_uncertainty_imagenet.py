@@ -77,11 +77,21 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
     uc_scheduler = get_uncertainty_scheduler(args, y.to(device), model, scheduler)
     if args.noise == "device":
         uc_scheduler.noise_source = DeviceNoise(seed=args.seed + gpu_idx)
+        if args.model_type == "unet":
+            model.dropout_mask_source = DeviceNoise(seed=args.seed + 1000 + gpu_idx).dropout_mask      # mc_dropout masks on the GPU
     uc_scheduler.set_timesteps(args.generation_steps)
+    import time
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
     if args.model_type == "unet":
         results = generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, args.batch_size, device, model, uc_scheduler)
     else:
         results = generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(X_T, y, args.batch_size, model, uc_scheduler, device)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if args.measure_time:
+        print(f"[rank {gpu_idx}] {X_T.shape[0]} images in {elapsed:.2f} s -> {X_T.shape[0] / elapsed:.3f} images/s "
+              f"({uc_scheduler.denoiser_calls} UC forwards + {args.generation_steps} main forwards per batch)")
     torch.save(uc_scheduler.timesteps, dest / "timesteps.pth")
     torch.save(results["score"], dest / f"score_{gpu_idx}.pth")
     torch.save(results["uncertainty"], dest / f"uncertainty_{args.scheduler_type}_{gpu_idx}.pth")
@@ -111,6 +121,7 @@ def parse_args(argv=None):
     p.add_argument("--start-index", type=int, default=None, dest="start_index")
     p.add_argument("--multi-gpu", action="store_true", default=False)
     p.add_argument("--model-type", type=str, default=None, choices=["unet", "uvit"], dest="model_type")
+    p.add_argument("--measure-time", action="store_true", dest="measure_time")
     p.add_argument("--predict-next", action="store_true", dest="predict_next")
     p.add_argument("--uncertainty-distance", type=int, default=20, dest="uncertainty_distance")
     p.add_argument("--num-zigzag", "--num-zigzags", "--num-zig-zag", "--num-zig-zags", type=int, default=3, dest="num_zigzag")
