@@ -20,7 +20,7 @@ class GemmArgs(_c.Structure):
                 ("sA1", _L), ("sA2", _L), ("sB", _L), ("sC", _L), ("sR", _L),
                 ("batch", _I), ("batch_inner", _I),
                 ("sA1i", _L), ("sBi", _L), ("sCi", _L),
-                ("transB", _I), ("act_in", _I), ("act_out", _I), ("alpha", _F)]
+                ("transB", _I), ("act_in", _I), ("act_out", _I), ("alpha", _F), ("colsum", _P)]
 
 
 # name -> (restype, argtypes); every symbol include/dua_hip.h declares
@@ -44,7 +44,8 @@ SIGNATURES = {
     "dua_groupnorm_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dua_groupnorm_apply": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "dua_resample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "dua_conv3x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dua_conv3x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dua_groupnorm_stats_from_colsums": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
     "dua_conv3x3_packed_floats": (_Z, [_I, _I]),
     "dua_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _P]),
     "dua_gemm": (_I, [_c.POINTER(GemmArgs), _P]),
@@ -54,10 +55,10 @@ SIGNATURES = {
     "dua_embedding_add": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dua_bf16x3_plane_elems": (_Z, [_I, _I]),
     "dua_pack_weight_bf16x3": (_I, [_P, _P, _I, _I, _I, _P]),
-    "dua_conv3x3_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dua_conv3x3_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dua_conv3x3_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dua_conv3x3_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_groupnorm_apply_split": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "dua_gemm_bf16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P]),
+    "dua_gemm_bf16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _P]),
     "dua_gemm_nt_bf16x3_batched": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _I, _I, _F, _P]),
     "dua_transpose_batched": (_I, [_P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _P]),
     "dua_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -136,6 +136,44 @@ extern "C" int dua_groupnorm_stats(const float* x1, int C1, const float* x2, int
     return dua_check_launch("dua_groupnorm_stats");
 }
 
+// GroupNorm statistics from the per-64-row column sums a producing conv / GEMM epilogue left behind (`colsum`,
+// [ceil(M/64)][2][C]): one workgroup per (group, image) folds HW/64 blocks x C/G channels in double.  The activation
+// itself is not read again.  ws2/C2: second half of a virtual channel concat (may be NULL / 0).
+__global__ __launch_bounds__(BLK) void k_gn_from_colsums(const float* __restrict__ ws1, int C1, const float* __restrict__ ws2, int C2,
+                                                         int HW, int G, float eps, float* __restrict__ stats) {
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int C = C1 + C2, cpg = C / G, nb = HW >> 6;
+    double a = 0, b = 0;
+    for (int i = tid; i < nb * cpg; i += BLK) {
+        const int blk = i / cpg, c = g * cpg + i % cpg;
+        const long row = (long)n * nb + blk;
+        if (c < C1) { a += ws1[row * 2 * C1 + c]; b += ws1[row * 2 * C1 + C1 + c]; }
+        else { a += ws2[row * 2 * C2 + (c - C1)]; b += ws2[row * 2 * C2 + C2 + (c - C1)]; }
+    }
+    __shared__ double sa[BLK], sb[BLK];
+    sa[tid] = a;
+    sb[tid] = b;
+    __syncthreads();
+    for (int o = BLK / 2; o > 0; o >>= 1) {
+        if (tid < o) { sa[tid] += sa[tid + o]; sb[tid] += sb[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)HW * cpg, mean = sa[0] / cnt;
+        double var = sb[0] / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * ((size_t)n * G + g)] = (float)mean;
+        stats[2 * ((size_t)n * G + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+extern "C" int dua_groupnorm_stats_from_colsums(const float* ws1, int C1, const float* ws2, int C2, int N, int HW, int G, float eps,
+                                                float* stats, void* stream) {
+    DUA_REQUIRE(ws1 && stats && N > 0 && G > 0 && HW > 0 && HW % 64 == 0, "dua_groupnorm_stats_from_colsums: HW must be a positive multiple of 64 (got %d)", HW);
+    DUA_REQUIRE((C1 + C2) % G == 0 && (C2 == 0) == (ws2 == nullptr), "dua_groupnorm_stats_from_colsums: bad channel split");
+    hipLaunchKernelGGL(k_gn_from_colsums, dim3(G, N), BLK, 0, as_stream(stream), ws1, C1, ws2, C2, HW, G, eps, stats);
+    return dua_check_launch("dua_groupnorm_stats_from_colsums");
+}
+
 // =================================== GroupNorm apply ===========================================
 // One float4 of the (virtually concatenated) input per lane-iteration.  resample: 0 none, +1 nearest x2
 // (each value written 4x), -1 2x2 average of the ACTIVATED values (unet_openai.py:238-243: h_upd after in_rest).

@@ -43,6 +43,7 @@ struct XTileP {
     float alpha;
     int H, W, Cin, nchw_out;
     int ntm, ntn;
+    float* colsum;                   // optional [ceil(M/64)][2][N] column sums / sums of squares of C per 64-row block
 };
 
 __device__ __forceinline__ float gelu_x(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         const int colq = n0 + wn * 64 + 4 * c4e;
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;      // this lane's column sums / sums of squares
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -342,7 +344,19 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
                         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                     }
                     *(float4*)(Cp + (long)row * p.ldc + colq) = v;
+                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                    cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
                 }
+            }
+        }
+        if (p.colsum) {
+            float t[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t[j] += __shfl_xor(t[j], 16); t[j] += __shfl_xor(t[j], 32); }
+            if (rre == 0 && colq < p.N && m0 + wm * 64 < p.M) {
+                float* o = p.colsum + (long)((m0 + wm * 64) >> 6) * 2 * p.N + colq;
+                *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
+                *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
             }
         }
         return;
@@ -396,6 +410,7 @@ struct DConvP {
     float* C;
     long a_plane, b_plane;
     int M, N, K, H, W, Cin, nchw_out, ntm, ntn;
+    float* colsum;           // optional [ceil(M/64)][2][N] column sums / sums of squares per 64-row block
 };
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
@@ -575,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         const int colq = n0 + wn * WC + 4 * c4;
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;      // this lane's column sums / sums of squares
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -595,7 +611,22 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                     }
                     *(float4*)(p.C + (long)row * p.N + colq) = v;
+                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                    cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
                 }
+            }
+        }
+        if (p.colsum) {   // GroupNorm statistics of the NEXT layer: fold the row lanes, one float4 store per column quad
+            float t[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (NT == 2) t[j] += __shfl_xor(t[j], 16);
+                t[j] += __shfl_xor(t[j], 32);
+            }
+            if (rr == 0 && colq < p.N && m0 + wm * 64 < p.M) {
+                float* o = p.colsum + (long)((m0 + wm * 64) >> 6) * 2 * p.N + colq;
+                *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
+                *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
             }
         }
     } else {
@@ -662,7 +693,8 @@ extern "C" int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K
 }
 
 extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
-                                  int H, int W, int Cin, int Cout, int nchw_out, void* stream) {
+                                  int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
+    DUA_REQUIRE(!colsum || (!nchw_out && Cout % 4 == 0), "dua_conv3x3_bf16x3: colsum needs an NHWC output with Cout %% 4 == 0");
     DUA_REQUIRE(x && planes && y, "dua_conv3x3_bf16x3: null pointer");
     DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3_bf16x3: Cin must be a multiple of 32 (got %d)", Cin);
     DUA_REQUIRE((long)N * H * W < (1L << 31), "dua_conv3x3_bf16x3: too many pixels");
@@ -670,7 +702,7 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
     size_t plane = dua_bf16x3_plane_elems(Cout, 9 * Cin);
     p.A1 = x; p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = y;
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
-    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
+    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out; p.colsum = colsum;
     return launch_x<XMODE_CONV>(p, as_stream(stream));
 }
 
@@ -680,7 +712,8 @@ static int dua_dma_conv_enabled = 1;
 extern "C" int dua_set_dma_conv(int on) { int o = dua_dma_conv_enabled; dua_dma_conv_enabled = on; return o; }
 
 extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
-                                           float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, void* stream) {
+                                           float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
+    DUA_REQUIRE(!colsum || (!nchw_out && Cout % 4 == 0), "dua_conv3x3_bf16x3_presplit: colsum needs an NHWC output with Cout %% 4 == 0");
     DUA_REQUIRE(xplanes && planes && y, "dua_conv3x3_bf16x3_presplit: null pointer");
     DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3_bf16x3_presplit: Cin must be a multiple of 32 (got %d)", Cin);
     DUA_REQUIRE((long)N * H * W < (1L << 31), "dua_conv3x3_bf16x3_presplit: too many pixels");
@@ -689,12 +722,12 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
     p.Ahi = (const __bf16*)xplanes; p.Alo = p.Ahi + (size_t)N * H * W * Cin;
     p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = y;
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
-    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out;
+    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out; p.colsum = colsum;
     const size_t a_plane = (size_t)N * H * W * Cin;
     if (dua_dma_conv_enabled != 0 && 4 * plane < 0x7FFFFFF0ull && (size_t)(2 * W + 260) * Cin * 2 < 0x7FFFFFF0ull) {
         DConvP d{};
         d.A = p.Ahi; d.B = p.Bhi; d.bias = bias; d.res = residual; d.C = y; d.a_plane = (long)a_plane; d.b_plane = (long)plane;
-        d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out;
+        d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
         d.ntm = (d.M + DBM - 1) / DBM;
         // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile Cout exactly and still give every CU
         // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
@@ -710,7 +743,8 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
                                const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
-                               int act_out, float alpha, void* stream) {
+                               int act_out, float alpha, float* colsum, void* stream) {
+    DUA_REQUIRE(!colsum || (N % 4 == 0 && ldc == N && (!residual || ldr % 4 == 0)), "dua_gemm_bf16x3: colsum needs N %% 4 == 0 and a dense row-major C");
     DUA_REQUIRE(A1 && planes && C && M > 0 && N > 0 && K1 > 0 && K2 >= 0, "dua_gemm_bf16x3: bad arguments");
     DUA_REQUIRE((K1 + K2) % BK == 0 && (K2 == 0 || K1 % BK == 0), "dua_gemm_bf16x3: K (and K1 for a two-source A) must be multiples of 32");
     DUA_REQUIRE(lda1 % 4 == 0 && (K2 == 0 || lda2 % 4 == 0) && (K2 == 0) == (A2 == nullptr), "dua_gemm_bf16x3: bad A operands");
@@ -719,7 +753,7 @@ extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* 
     size_t plane = dua_bf16x3_plane_elems(N, K1 + K2);
     p.A1 = A1; p.A2 = A2; p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = C;
     p.M = M; p.N = N; p.K1 = K1; p.K2 = K2; p.lda1 = lda1; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
-    p.act_out = act_out; p.alpha = alpha;
+    p.act_out = act_out; p.alpha = alpha; p.colsum = colsum;
     return act_in ? launch_x<XMODE_GEMM, true>(p, as_stream(stream)) : launch_x<XMODE_GEMM, false>(p, as_stream(stream));
 }
 

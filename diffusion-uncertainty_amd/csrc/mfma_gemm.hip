@@ -36,6 +36,7 @@ struct TileP {
     // conv
     int H, W, Cin, nchw_out;
     int ntm, ntn;                  // tile counts
+    float* colsum;                 // optional [ceil(M/64)][2][N]: per 64-row block column sums / sums of squares of C
 };
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
         const int colq = n0 + wn * 64 + 4 * c4e;
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;      // this lane's column sums / sums of squares
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -304,7 +306,19 @@ __global__ __launch_bounds__(256, 2) void k_tile(TileP p) {
                         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                     }
                     *(float4*)(Cp + (long)row * p.ldc + colq) = v;
+                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                    cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
                 }
+            }
+        }
+        if (p.colsum) {   // GroupNorm statistics of the NEXT layer: fold the 4 row lanes, one float4 store per column quad
+            float t[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t[j] += __shfl_xor(t[j], 16); t[j] += __shfl_xor(t[j], 32); }
+            if (rre == 0 && colq < p.N && m0 + wm * 64 < p.M) {
+                float* o = p.colsum + (long)((m0 + wm * 64) >> 6) * 2 * p.N + colq;
+                *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
+                *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
             }
         }
         return;
@@ -359,6 +373,9 @@ extern "C" int dua_gemm(const dua_gemm_args* a, void* stream) {
     p.sA1 = a->sA1; p.sA2 = a->sA2; p.sB = a->sB; p.sC = a->sC; p.sR = a->sR;
     p.sA1i = a->sA1i; p.sBi = a->sBi; p.sCi = a->sCi;
     p.batch_inner = a->batch_inner; p.act_in = a->act_in; p.act_out = a->act_out; p.alpha = a->alpha;
+    p.colsum = a->colsum;
+    DUA_REQUIRE(!a->colsum || (a->batch == 1 && a->N % 4 == 0 && a->ldc == a->N && (!a->residual || a->ldr % 4 == 0)),
+                "dua_gemm: colsum needs batch 1, N %% 4 == 0 and a dense row-major C");
     DUA_REQUIRE(a->act_in == 0 || (a->act_in == 1 && a->transB), "dua_gemm: act_in must be 0, or 1 (SiLU) with transB=1");
     const bool ragged = (a->K1 + a->K2) % BK != 0;
     hipStream_t st = as_stream(stream);
@@ -397,7 +414,8 @@ extern "C" int dua_pack_conv3x3_weight(const float* w, float* wp, int Cout, int 
 }
 
 extern "C" int dua_conv3x3(const float* x, const float* wp, const float* bias, const float* residual, float* y, int N, int H,
-                           int W, int Cin, int Cout, int nchw_out, void* stream) {
+                           int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
+    DUA_REQUIRE(!colsum || (!nchw_out && Cout % 4 == 0), "dua_conv3x3: colsum needs an NHWC output with Cout %% 4 == 0");
     DUA_REQUIRE(x && wp && y, "dua_conv3x3: null pointer");
     DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0, "dua_conv3x3: bad sizes");
     DUA_REQUIRE(Cin == 4 || (Cin > 4 && Cin % BK == 0), "dua_conv3x3: Cin must be 4 (padded small-C form) or a multiple of 32 (got %d)", Cin);
@@ -405,7 +423,7 @@ extern "C" int dua_conv3x3(const float* x, const float* wp, const float* bias, c
     TileP p{};
     p.A1 = x; p.B = wp; p.bias = bias; p.res = residual; p.C = y;
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
-    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out; p.batch_inner = 1;
+    p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out; p.batch_inner = 1; p.colsum = colsum;
     return Cin == 4 ? launch_tile<MODE_CONV_SMALLC, true>(p, 1, as_stream(stream))
                     : launch_tile<MODE_CONV, true>(p, 1, as_stream(stream));
 }

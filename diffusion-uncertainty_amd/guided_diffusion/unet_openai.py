@@ -39,7 +39,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
             elif isinstance(layer, AttentionBlock):
                 h = layer.run(ctx, h)
             else:                                   # input conv (Cin padded to 4: always the fp32 small-Cin kernel)
-                h = ops.conv3x3(h, ctx.packed(layer, "w3"), layer.bias, layer.out_channels)
+                h = ops.conv3x3(h, ctx.packed(layer, "w3"), layer.bias, layer.out_channels, colsum=ctx.model.fuse_gn_stats)
         return h
 
 
@@ -91,7 +91,7 @@ class ResBlock(TimestepBlock):
         h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample, split=ctx.split_acts)
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
-        h = ctx.conv3x3(h, conv1, self.out_channels)
+        h = ctx.conv3x3(h, conv1, self.out_channels, colsum=True)      # epilogue leaves GroupNorm statistics for out_layers[0]
         film = ops.gemm(ctx.emb, self.emb_layers[1].weight, bias=self.emb_layers[1].bias, act_in=1)   # :245
         st2 = ops.groupnorm_stats(h)
         mask = None
@@ -106,7 +106,7 @@ class ResBlock(TimestepBlock):
             Hx, Wx = x.shape[1], x.shape[2]
             res = ctx.linear(x.view(N * Hx * Wx, -1), sc, a2=(skip.view(N * Hx * Wx, -1) if skip is not None else None))
             res = res.view(N, Hx, Wx, self.out_channels)
-        return ctx.conv3x3(h, conv2, self.out_channels, residual=res)                                   # :257
+        return ctx.conv3x3(h, conv2, self.out_channels, residual=res, colsum=True)                      # :257
 
 
 class QKVAttentionLegacy(nn.Module):
@@ -149,8 +149,12 @@ class AttentionBlock(nn.Module):
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0)
         qkv = ctx.qkv(xn.view(N * T, C), self)
         a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision=ctx.model.precision)
-        out = ctx.linear(a, self.proj_out, residual=x.view(N * T, C))
-        return out.view(N, H, W, C)
+        out2d = ctx.linear(a, self.proj_out, residual=x.view(N * T, C), colsum=True)
+        out = out2d.view(N, H, W, C)
+        ws = getattr(out2d, "_dua_colsums_rows", None)
+        if ws is not None and T % 64 == 0:
+            out._dua_colsums = ws                     # statistics for the next block's GroupNorm
+        return out
 
 
 class _Ctx:
@@ -194,18 +198,20 @@ class _Ctx:
         return self.model.dropout_mask_source(shape_nhwc, p)
 
     # ---- the FLOP carriers, in the model's precision mode
-    def conv3x3(self, h, conv, cout, residual=None, nchw_out=False):
+    def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
+        colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.model.precision == "bf16x3" and h.shape[3] % 32 == 0):
-            return ops.conv3x3_bf16x3(h, self.packed(conv, "w3x"), conv.bias, cout, residual=residual, nchw_out=nchw_out)
-        return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out)
+            return ops.conv3x3_bf16x3(h, self.packed(conv, "w3x"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
+        return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
-    def linear(self, a, mod, a2=None, residual=None):
+    def linear(self, a, mod, a2=None, residual=None, colsum=False):
         """1x1 conv / conv1d(k=1) as a GEMM over rows."""
         n_out = mod.weight.shape[0]
         K = a.shape[1] + (0 if a2 is None else a2.shape[1])
+        colsum = colsum and self.model.fuse_gn_stats
         if self.model.precision == "bf16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:
-            return ops.gemm_bf16x3(a, self.packed(mod, "w1x"), n_out, bias=mod.bias, a2=a2, residual=residual)
-        return ops.gemm(a, self.packed(mod, "w1"), bias=mod.bias, a2=a2, residual=residual)
+            return ops.gemm_bf16x3(a, self.packed(mod, "w1x"), n_out, bias=mod.bias, a2=a2, residual=residual, colsum=colsum)
+        return ops.gemm(a, self.packed(mod, "w1"), bias=mod.bias, a2=a2, residual=residual, colsum=colsum)
 
     def qkv(self, xn, blk):
         if self.model.precision == "bf16x3" and xn.shape[1] % 32 == 0:
@@ -275,6 +281,9 @@ class UNetModel(nn.Module):
         # "fp32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x3": convs and weight GEMMs on the bf16 matrix cores
         # with split fp32 operands (csrc/mfma_bf16x3.hip); attention products, embeddings, norms stay fp32.
         self.precision = "fp32"
+        # GroupNorm statistics produced in the epilogue of the conv / GEMM that writes the tensor (no re-read); set False to
+        # use the stand-alone statistics kernel everywhere.
+        self.fuse_gn_stats = True
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask

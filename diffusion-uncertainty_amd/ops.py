@@ -160,9 +160,31 @@ def nhwc_to_nchw(x, ckeep=None):
 
 
 # ------------------------------------------------------------------ denoiser kernels
+def _colsum_ws(M, cout, device, want):
+    """Workspace for the epilogue column sums ([ceil(M/64)][2][cout]) or None."""
+    if not want or cout % 4:
+        return None
+    return torch.empty(((M + 63) // 64, 2, cout), device=device, dtype=torch.float32)
+
+
+def _attach_colsums(y, ws, hw):
+    """Remember the producer's column sums on the tensor (consumed by groupnorm_stats when H*W % 64 == 0)."""
+    if ws is not None and hw % 64 == 0:
+        y._dua_colsums = ws
+    return y
+
+
 def groupnorm_stats(x1, x2=None, groups=32, eps=1e-5):
     _req(x1, name="x1")
     N, H, W, C1 = x1.shape
+    cs1 = getattr(x1, "_dua_colsums", None)
+    cs2 = getattr(x2, "_dua_colsums", None) if x2 is not None else None
+    if cs1 is not None and (x2 is None or cs2 is not None) and (H * W) % 64 == 0:
+        # statistics from the column sums the producing conv / GEMM epilogue left behind: x is not read again
+        stats = torch.empty((N, groups, 2), device=x1.device, dtype=torch.float32)
+        check(_lib.lib().dua_groupnorm_stats_from_colsums(_p(cs1), C1, _p(cs2), 0 if x2 is None else x2.shape[3], N, H * W, groups,
+                                                          float(eps), _p(stats), _stream()), "dua_groupnorm_stats_from_colsums")
+        return stats
     C2 = 0
     if x2 is not None:
         _req(x2, name="x2")
@@ -229,31 +251,32 @@ def pack_conv3x3_weight(w):
 PROFILE = None
 
 
-def conv3x3(x, wp, bias, cout, residual=None, nchw_out=False):
+def conv3x3(x, wp, bias, cout, residual=None, nchw_out=False, colsum=False):
     _req(x, name="x"), _req(wp, name="wp")
     N, H, W, Cin = x.shape
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        y = _conv3x3(x, wp, bias, cout, residual, nchw_out)
+        y = _conv3x3(x, wp, bias, cout, residual, nchw_out, colsum)
         e1.record()
         PROFILE.record("conv3x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
         return y
-    return _conv3x3(x, wp, bias, cout, residual, nchw_out)
+    return _conv3x3(x, wp, bias, cout, residual, nchw_out, colsum)
 
 
-def _conv3x3(x, wp, bias, cout, residual=None, nchw_out=False):
+def _conv3x3(x, wp, bias, cout, residual=None, nchw_out=False, colsum=False):
     N, H, W, Cin = x.shape
+    ws = _colsum_ws(N * H * W, cout, x.device, colsum and not nchw_out)
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
     if residual is not None:
         _req(residual, name="residual")
         assert residual.shape == (N, H, W, cout)
-    check(_lib.lib().dua_conv3x3(_p(x), _p(wp), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _stream()),
+    check(_lib.lib().dua_conv3x3(_p(x), _p(wp), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _p(ws), _stream()),
           "dua_conv3x3")
-    return y
+    return _attach_colsums(y, ws, H * W)
 
 
-def gemm(a1, w, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0, out=None):
+def gemm(a1, w, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0, out=None, colsum=False):
     """C[M,N] = alpha * [a1 | a2] @ w.T (+bias) (+residual); a*: [M,K*] row-major, w: [N, K1+K2]."""
     _req(a1, name="a1"), _req(w, name="w")
     M, K1 = a1.shape
@@ -261,11 +284,15 @@ def gemm(a1, w, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.
     N = w.shape[0]
     assert w.shape[1] == K1 + K2
     c = torch.empty((M, N), device=a1.device, dtype=torch.float32) if out is None else out
+    ws = _colsum_ws(M, N, a1.device, colsum)
+    if ws is not None:
+        c._dua_colsums_rows = ws          # attached to the 2-D result; the caller re-attaches after reshaping to NHWC
     g = GemmArgs(A1=a1.data_ptr(), A2=(a2.data_ptr() if a2 is not None else None), B=w.data_ptr(),
                  bias=(bias.data_ptr() if bias is not None else None),
                  residual=(residual.data_ptr() if residual is not None else None), C=c.data_ptr(),
                  M=M, N=N, K1=K1, K2=K2, lda1=K1, lda2=max(K2, 4), ldb=K1 + K2, ldc=N, ldr=N,
-                 batch=1, batch_inner=1, transB=1, act_in=act_in, act_out=act_out, alpha=alpha)
+                 batch=1, batch_inner=1, transB=1, act_in=act_in, act_out=act_out, alpha=alpha,
+                 colsum=(ws.data_ptr() if ws is not None else None))
     check(_lib.lib().dua_gemm(ctypes.byref(g), _stream()), "dua_gemm")
     return c
 
@@ -286,35 +313,39 @@ def pack_weight_bf16x3(w):
     return planes
 
 
-def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False):
+def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=False):
     pre = isinstance(x, SplitPlanes)
     if not pre:
         _req(x, name="x")
     N, H, W, Cin = x.shape
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
+    ws = _colsum_ws(N * H * W, cout, x.device, colsum and not nchw_out)
     e0 = e1 = None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if pre:
         check(_lib.lib().dua_conv3x3_bf16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout,
-                                                     int(nchw_out), _stream()), "dua_conv3x3_bf16x3_presplit")
+                                                     int(nchw_out), _p(ws), _stream()), "dua_conv3x3_bf16x3_presplit")
     else:
         check(_lib.lib().dua_conv3x3_bf16x3(_p(x), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
-                                            _stream()), "dua_conv3x3_bf16x3")
+                                            _p(ws), _stream()), "dua_conv3x3_bf16x3")
     if PROFILE is not None:
         e1.record()
         PROFILE.record("conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
-    return y
+    return _attach_colsums(y, ws, H * W)
 
 
-def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0):
+def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0, colsum=False):
     _req(a1, name="a1")
     M, K1 = a1.shape
     K2 = 0 if a2 is None else a2.shape[1]
     c = torch.empty((M, n_out), device=a1.device, dtype=torch.float32)
+    ws = _colsum_ws(M, n_out, a1.device, colsum)
+    if ws is not None:
+        c._dua_colsums_rows = ws
     check(_lib.lib().dua_gemm_bf16x3(_p(a1), K1, K1, _p(a2), K2, max(K2, 4), _p(planes), _p(bias), _p(residual), n_out, _p(c), n_out,
-                                     M, n_out, int(act_in), int(act_out), float(alpha), _stream()), "dua_gemm_bf16x3")
+                                     M, n_out, int(act_in), int(act_out), float(alpha), _p(ws), _stream()), "dua_gemm_bf16x3")
     return c
 
 

@@ -114,7 +114,13 @@ int dua_resample2x(const float* x, float* y, int N, int H, int W, int C, int res
  * small-Cin form [CoutPad][16][4] when Cin == 4); bias [Cout]; residual NHWC [N][H][W][Cout] or NULL (the
  * `skip_connection(x) + h` of :257).  nchw_out != 0 writes y as NCHW [N][Cout][H][W]. */
 int dua_conv3x3(const float* x, const float* wp, const float* bias, const float* residual, float* y, int N, int H,
-                int W, int Cin, int Cout, int nchw_out, void* stream);
+                int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
+/* `colsum` (here and in the other conv / GEMM entry points; may be NULL): [ceil(M/64)][2][Cout] floats that receive, per
+ * block of 64 output rows (pixels), the column sums and sums of squares of the values written to y - the GroupNorm
+ * statistics of the NEXT layer, produced in the epilogue so that layer does not re-read y.  Needs an NHWC / row-major
+ * output with Cout % 4 == 0; consumed by dua_groupnorm_stats_from_colsums when H*W % 64 == 0. */
+int dua_groupnorm_stats_from_colsums(const float* ws1, int C1, const float* ws2, int C2, int N, int HW, int G, float eps,
+                                     float* stats, void* stream);
 /* OIHW [Cout][CinReal][3][3] -> packed form above (CinPad is 4 for CinReal<=4, else CinReal). */
 size_t dua_conv3x3_packed_floats(int Cout, int Cin);
 int dua_pack_conv3x3_weight(const float* w_oihw, float* wp, int Cout, int CinReal, void* stream);
@@ -135,6 +141,7 @@ typedef struct {
     long sA1i, sBi, sCi;                 /* inner batch strides (heads inside one image) */
     int transB, act_in, act_out;
     float alpha;
+    float* colsum;                       /* optional column sums of C (see dua_conv3x3); batch must be 1 */
 } dua_gemm_args;
 int dua_gemm(const dua_gemm_args* args_host, void* stream);
 
@@ -161,10 +168,10 @@ size_t dua_bf16x3_plane_elems(int N, int K);
 /* w: [N][K] fp32, or OIHW [N][conv_cin][3][3] when conv_cin != 0 (then K = 9*conv_cin, packed tap-major). */
 int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K, int conv_cin, void* stream);
 int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
-                       int H, int W, int Cin, int Cout, int nchw_out, void* stream);
+                       int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
 /* Variant whose input was already split by dua_groupnorm_apply_split: xplanes = two bf16 NHWC planes (hi | lo). */
 int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
-                                float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, void* stream);
+                                float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
 /* dua_groupnorm_apply writing its result as two bf16 planes (hi = bf16(v), lo = bf16(v - hi)), N*Hy*Wy*C elements
  * each (Hy, Wy = resampled size): the same bytes as the fp32 tensor, already in the bf16x3 conv's operand format. */
 int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
@@ -172,7 +179,7 @@ int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, 
                               int resample, const float* dropmask, void* yplanes, void* stream);
 int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
                     const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
-                    int act_out, float alpha, void* stream);
+                    int act_out, float alpha, float* colsum, void* stream);
 
 /* Batched C[b] = alpha * A[b] * B[b]^T with BOTH operands fp32 activations split on the fly (the attention products
  * q.k^T and P.v^T of unet_openai.py:350-354 in bf16x3 mode).  A: [M][K] (lda), B: [N][K] (ldb), K % 32 == 0; batch

@@ -37,7 +37,7 @@ def test_argument_validation_without_gpu():
     assert b"null" in L.dua_last_error()
     assert L.dua_mc_reduce_var(None, None, 0, 1, None) == -1                 # M >= 2 required (torch.var, unbiased)
     assert L.dua_axpby(None, None, None, 0, 1.0, 1.0, None) == 0            # empty input is a no-op
-    assert L.dua_conv3x3(ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, ctypes.c_void_p(16), 1, 8, 8, 48, 32, 0, None) == -1
+    assert L.dua_conv3x3(ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, ctypes.c_void_p(16), 1, 8, 8, 48, 32, 0, None, None) == -1
     assert b"multiple of 32" in L.dua_last_error()
 
 

@@ -333,3 +333,16 @@ def test_uvit_driver_with_vae():
     np.testing.assert_allclose(r["score"].numpy(), ref["score"].numpy(), rtol=0, atol=TOL)
     d = np.abs(r["gen_images"].numpy().astype(int) - ref["gen_images"].numpy().astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 2e-2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_fused_groupnorm_stats_equivalent(precision):
+    """fuse_gn_stats (statistics from producer epilogues) vs the stand-alone statistics kernel: same model output."""
+    m, _ = build_adm(TINY_ADM, 5)
+    m.precision = precision
+    x = torch.randn(3, 3, 16, 16, generator=torch.Generator().manual_seed(3)).to(dev)
+    t, y = torch.tensor([999, 10, 500]).to(dev), torch.tensor([0, 1, 2]).to(dev)
+    a = m(x, t, y=y)
+    m.fuse_gn_stats = False
+    b = m(x, t, y=y)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 if precision == "fp32" else 2e-4)

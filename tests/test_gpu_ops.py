@@ -280,3 +280,25 @@ def test_pixelwise_threshold_bit_exact(N, S, H, perc):
     ref = oth.compute_threshold_pixel_wise(u, perc)
     assert got.dtype == torch.float16 and got.shape == (S, 3, H, H)
     assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,x3", [(2, 8, 32, 64, False), (3, 16, 64, 96, True), (2, 16, 96, 256, True), (1, 32, 256, 256, True), (2, 8, 4, 32, False)])
+def test_epilogue_colsums_feed_groupnorm(ops, N, H, Cin, Cout, x3):
+    """Column sums left by the conv epilogue give the same GroupNorm statistics as the stand-alone kernel."""
+    x, w, b = rnd(70, N, Cin, H, H), rnd(71, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(72, Cout) * 0.5
+    res = nhwc(rnd(73, N, Cout, H, H)).to(dev)
+    if Cin <= 4:
+        y = ops.conv3x3(ops.nchw_to_nhwc(x.to(dev), 4), ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=res, colsum=True)
+    elif x3:
+        y = ops.conv3x3_bf16x3(nhwc(x).to(dev), ops.pack_weight_bf16x3(w.to(dev)), b.to(dev), Cout, residual=res, colsum=True)
+    else:
+        y = ops.conv3x3(nhwc(x).to(dev), ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=res, colsum=True)
+    assert hasattr(y, "_dua_colsums")
+    fused = ops.groupnorm_stats(y)
+    plain = ops.groupnorm_stats(y.clone())                       # clone drops the attribute -> stand-alone kernel
+    np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # two-source (virtual concat) statistics from two producers
+    y2 = ops.conv3x3(nhwc(x).to(dev) if Cin > 4 else ops.nchw_to_nhwc(x.to(dev), 4), ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, colsum=True)
+    fused = ops.groupnorm_stats(y, y2)
+    plain = ops.groupnorm_stats(y.clone(), y2.clone())
+    np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=2e-5, atol=2e-6)
