@@ -67,7 +67,7 @@ class ConvProfile:
         return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_BF16X3,
                     traffic_source="profiles/r01d_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                    kernel="k_xtile<CONV, PRESPLIT> (split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)",
+                    kernel="k_xconv_dma<NT> (LDS-DMA split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)",
                     launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
                     executed_mfma_tflops=round(3 * cs["tflops"], 1), executed_frac=round(3 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
                     note="achieved counts ALGORITHMIC fp32 FLOPs; each is executed as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi), "
