@@ -566,9 +566,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 if (pre) {
-                    if (piece < NPIECE) dma_piece(s2, piece);
-                    ++piece;
-                    if (NT == 4 && piece < NPIECE) { dma_piece(s2, piece); ++piece; }
+                    // two stages (NT = 4): the tile requested now is needed at the end of THIS step, so its pieces go out
+                    // in the first two MFMA groups; three stages (NT = 2): one piece per group is enough.
+                    constexpr int PER = NT == 4 ? 4 : 2;
+#pragma unroll
+                    for (int u = 0; u < PER; ++u)
+                        if (piece < NPIECE) { dma_piece(s2, piece); ++piece; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
