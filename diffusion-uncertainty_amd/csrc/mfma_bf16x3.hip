@@ -411,21 +411,23 @@ struct DConvP {
     long a_plane, b_plane;
     int M, N, K, H, W, Cin, nchw_out, ntm, ntn;
     float* colsum;           // optional [ceil(M/64)][2][N] column sums / sums of squares per 64-row block
+    int dbg_norec;           // diagnostic: zero-record descriptors (every DMA returns zeros at once) - prices the memory path
 };
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
-//   NT = 2: 256 x 128, three 48 KB stages (tile kt+2 in flight while tile kt is multiplied);
-//   NT = 4: 256 x 256, two 64 KB stages (half the L2->LDS bytes per MFMA; one tile in flight).
+//   NT = 2: 256 x 128; activation ring 3 x 32 KB + weight ring 3 x 16 KB (tile kt+2 of both in flight during step kt);
+//   NT = 4: 256 x 256 (half the L2->LDS bytes per MFMA); activation ring 3 x 32 KB + weight ring 2 x 32 KB = the whole
+//           160 KB of LDS: the activation operand (unique per workgroup, the one that misses L2) is requested two
+//           tiles ahead, the L2-resident weight panel one tile ahead.
 template <int NT>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
     constexpr int DBN = 64 * NT;
-    constexpr int NST = NT == 2 ? 3 : 2;
+    constexpr int RA = 3, RB = NT == 2 ? 3 : 2;      // ring depths (stages) of the activation / weight operand
     constexpr int SA = DBM * LDH;                    // bf16 elements per A plane of a stage
     constexpr int SB = DBN * LDH;
-    constexpr int STG = 2 * SA + 2 * SB;
-    constexpr int NPIECE = 4 + NT;                   // DMA pieces per wave per tile: 4 (A) + NT (B)
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NST * STG];
+    constexpr int BOFF = RA * 2 * SA;                // start of the weight ring
+    __shared__ __attribute__((aligned(16))) __bf16 lds[RA * 2 * SA + RB * 2 * SB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -470,10 +472,10 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
     for (int j = 0; j < NT / 2; ++j) boff[j] = (unsigned)(((long)(n0 + 16 * ((NT / 2) * wave + j) + lrow) * p.K + 8 * csrc) * 2);
     const long arem = ((long)p.M - mbase) * p.Cin * 2;                       // bytes from the rebased origin to the plane's end
-    const int arec = (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
+    const int arec = p.dbg_norec ? 0 : (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
     const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)mbase * p.Cin), 0, arec, 0x00020000);
     const auto ral = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + p.a_plane + (long)mbase * p.Cin), 0, arec, 0x00020000);
-    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.dbg_norec ? 0 : (int)(2 * p.b_plane * 2), 0x00020000);
     const int b_lo = (int)(p.b_plane * 2);                                   // byte distance hi -> lo weight plane
     int tap = 0, cb = 0;
     // The DMA pieces of a tile are issued one at a time so that the caller can spread them between MFMA groups
@@ -486,26 +488,33 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         vo1 = ((abits[1] >> tap) & 1u) ? abase[1] + (unsigned)toff : OOB;
         if (++tap == 9) { tap = 0; ++cb; }
     };
-    auto dma_piece = [&](int stage, int i) {
-        __bf16* st = lds + stage * STG;
+    auto dma_a = [&](int sa, int i) {          // piece i = 0..3 of the activation tile whose offsets dma_setup() prepared
+        __bf16* st = lds + sa * 2 * SA;
         if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH, 16, vo0, 0, 0, 0);
         if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave)) * LDH + SA, 16, vo0, 0, 0, 0);
         if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH, 16, vo1, 0, 0, 0);
         if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave + 1)) * LDH + SA, 16, vo1, 0, 0, 0);
+    };
+    auto dma_b = [&](int sb, int i) {          // piece i = 0..NT-1 of the next weight tile (sequential in K)
+        __bf16* st = lds + BOFF + sb * 2 * SB;
 #pragma unroll
         for (int j = 0; j < NT / 2; ++j) {
-            __bf16* dst = st + 2 * SA + (16 * ((NT / 2) * wave + j)) * LDH;
-            if (i == 4 + 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
-            if (i == 5 + 2 * j) {
+            __bf16* dst = st + (16 * ((NT / 2) * wave + j)) * LDH;
+            if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
+            if (i == 2 * j + 1) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);
                 boff[j] += BK * 2;
             }
         }
     };
-    auto issue = [&](int stage) {
+    auto issue_a = [&](int sa) {
         dma_setup();
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) dma_piece(stage, i);
+        for (int i = 0; i < 4; ++i) dma_a(sa, i);
+    };
+    auto issue_b = [&](int sb) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) dma_b(sb, i);
     };
 
     f32x16 acc[2][NT];
@@ -518,11 +527,11 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 
     const int lr = lane & 31, kh = lane >> 5;
     struct DFrag { bf16x8 ah[2], al[2], bh[NT], bl[NT]; };
-    auto read_frag = [&](int stage, int s) -> DFrag {
+    auto read_frag = [&](int sa, int sb, int s) -> DFrag {
         DFrag f;
         const int cs = 8 * ((2 * s + kh) ^ ((lr >> 2) & 3));
-        const __bf16* a = lds + stage * STG + (wm * 64 + lr) * LDH + cs;
-        const __bf16* b = lds + stage * STG + 2 * SA + (wn * 32 * NT + lr) * LDH + cs;
+        const __bf16* a = lds + sa * 2 * SA + (wm * 64 + lr) * LDH + cs;
+        const __bf16* b = lds + BOFF + sb * 2 * SB + (wn * 32 * NT + lr) * LDH + cs;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f.ah[i] = *(const bf16x8*)(a + 32 * i * LDH);
@@ -536,23 +545,34 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         return f;
     };
 
+    // In-order vmcnt: at the end of step kt everything older than the pieces that may stay in flight must have landed.
+    //   NT = 4: order per step  B(kt+1) x4, A(kt+2) x4  -> wait vmcnt(4) keeps only A(kt+2) outstanding;
+    //   NT = 2: order per step  A(kt+2) x4, B(kt+2) x2  -> wait vmcnt(6).
+    constexpr int KEEP = NT == 4 ? 4 : 6;
 #define DWAIT_TILE(more) \
-    if (NST == 3 && (more)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    issue(0);
-    if (NST == 3 && nk > 1) issue(1);
+    issue_a(0);
+    issue_b(0);
+    if (nk > 1) {
+        issue_a(1);
+        if (NT == 2) issue_b(1);
+    }
     DWAIT_TILE(nk > 1)
     __builtin_amdgcn_s_barrier();
-    int stage = 0;
+    int sa = 0, sb = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        int s2 = stage + (NST - 1);
-        if (s2 >= NST) s2 -= NST;
-        const bool pre = kt + (NST - 1) < nk;        // the tile requested during this step: kt+2 (3 stages) / kt+1 (2 stages)
-        if (pre) dma_setup();
+        int sa2 = sa + 2;                                // activation stage of tile kt+2
+        if (sa2 >= RA) sa2 -= RA;
+        int sbn = sb + (RB - 1);                         // weight stage of tile kt+2 (NT = 2) / kt+1 (NT = 4)
+        if (sbn >= RB) sbn -= RB;
+        const bool preA = kt + 2 < nk;
+        const bool preB = NT == 4 ? kt + 1 < nk : kt + 2 < nk;
+        if (preA) dma_setup();
         int piece = 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            DFrag f = read_frag(stage, s);
+            DFrag f = read_frag(sa, sb, s);
             __builtin_amdgcn_sched_barrier(0);       // keep the fragment reads in flight ahead of the MFMA stream
 #pragma unroll
             for (int term = 0; term < 3; ++term) {   // lo*hi, hi*lo, hi*hi
@@ -565,20 +585,27 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                if (pre) {
-                    // two stages (NT = 4): the tile requested now is needed at the end of THIS step, so its pieces go out
-                    // in the first two MFMA groups; three stages (NT = 2): one piece per group is enough.
-                    constexpr int PER = NT == 4 ? 4 : 2;
+                // DMA pieces of the step, a few per MFMA group (an LDS-DMA issue holds the wave ~60-180 cycles), front-loaded:
+                // NT = 4: [B0..B3 | A0..A3 | - ...]; NT = 2: [A0 A1 | A2 A3 | B0 B1 | - ...]
+                constexpr int PER = NT == 4 ? 4 : 2;
 #pragma unroll
-                    for (int u = 0; u < PER; ++u)
-                        if (piece < NPIECE) { dma_piece(s2, piece); ++piece; }
+                for (int u = 0; u < PER; ++u) {
+                    if (NT == 4) {
+                        if (piece < 4) { if (preB) dma_b(sbn, piece); }
+                        else if (piece < 8) { if (preA) dma_a(sa2, piece - 4); }
+                    } else {
+                        if (piece < 4) { if (preA) dma_a(sa2, piece); }
+                        else if (piece < 6) { if (preB) dma_b(sbn, piece - 4); }
+                    }
+                    ++piece;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        DWAIT_TILE(kt + 2 < nk)
+        DWAIT_TILE(preA)
         __builtin_amdgcn_s_barrier();
-        if (++stage == NST) stage = 0;
+        if (++sa == RA) sa = 0;
+        if (++sb == RB) sb = 0;
     }
 
     if (!p.nchw_out && (p.N & 3) == 0) {
@@ -731,10 +758,11 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
         DConvP d{};
         d.A = p.Ahi; d.B = p.Bhi; d.bias = bias; d.res = residual; d.C = y; d.a_plane = (long)a_plane; d.b_plane = (long)plane;
         d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
+        d.dbg_norec = dua_dma_conv_enabled == 3;
         d.ntm = (d.M + DBM - 1) / DBM;
         // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile Cout exactly and still give every CU
         // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
-        const bool wide = dua_dma_conv_enabled == 1 && Cout % 256 == 0 && (long)d.ntm * (Cout / 256) >= 512;
+        const bool wide = dua_dma_conv_enabled != 2 && Cout % 256 == 0 && (long)d.ntm * (Cout / 256) >= 512;
         d.ntn = wide ? Cout / 256 : (Cout + BN - 1) / BN;
         const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
         if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(grid), 512, 0, as_stream(stream), d);

@@ -177,6 +177,10 @@ int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const f
 int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                               const float* stats, const float* gamma, const float* beta, const float* film, int act,
                               int resample, const float* dropmask, void* yplanes, void* stream);
+/* Diagnostic engine selector for dua_conv3x3_bf16x3_presplit (returns the previous mode): 1 = LDS-DMA kernels, 256x256
+ * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
+ * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */
+int dua_set_dma_conv(int mode);
 int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
                     const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                     int act_out, float alpha, float* colsum, void* stream);
