@@ -412,6 +412,7 @@ struct DConvP {
     int M, N, K, H, W, Cin, nchw_out, ntm, ntn;
     float* colsum;           // optional [ceil(M/64)][2][N] column sums / sums of squares per 64-row block
     int dbg_norec;           // diagnostic: zero-record descriptors (every DMA returns zeros at once) - prices the memory path
+    int ntaps;               // 9 = 3x3 convolution, 1 = plain GEMM over rows (1x1 convolution / linear layer)
 };
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
@@ -452,19 +453,22 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const unsigned OOB = 0xFFFFFFF0u;
     // The buffer descriptors are rebased per workgroup at the first pixel its taps can touch (tile start minus one
     // image row and one pixel), so the 32-bit buffer offsets stay tiny whatever the size of the activation planes.
-    const int mbase = max(0, m0 - (p.W + 1));
+    const int mbase = p.ntaps == 9 ? max(0, m0 - (p.W + 1)) : m0;
     unsigned abase[2], abits[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = min(m0 + 16 * (2 * wave + j) + lrow, p.M - 1);
-        const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
-        const int y = rem / p.W, x = rem - y * p.W;
         abase[j] = (unsigned)(((long)(m - mbase) * p.Cin + 8 * csrc) * 2);
-        unsigned bits = 0;
+        unsigned bits = 1;
+        if (p.ntaps == 9) {
+            const int hw = p.H * p.W, n = m / hw, rem = m - n * hw;
+            const int y = rem / p.W, x = rem - y * p.W;
+            bits = 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            bits |= (unsigned)((unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) << t;
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                bits |= (unsigned)((unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W) << t;
+            }
         }
         abits[j] = bits;
     }
@@ -482,11 +486,11 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // (an LDS-DMA issue holds the wave for ~60-180 cycles).
     unsigned vo0 = 0, vo1 = 0;
     auto dma_setup = [&]() {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int dy = p.ntaps == 9 ? tap / 3 - 1 : 0, dx = p.ntaps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
         const int toff = ((dy * p.W + dx) * p.Cin + cb * BK) * 2;           // byte offset of this (tap, channel block)
         vo0 = ((abits[0] >> tap) & 1u) ? abase[0] + (unsigned)toff : OOB;
         vo1 = ((abits[1] >> tap) & 1u) ? abase[1] + (unsigned)toff : OOB;
-        if (++tap == 9) { tap = 0; ++cb; }
+        if (++tap == p.ntaps) { tap = 0; ++cb; }
     };
     auto dma_a = [&](int sa, int i) {          // piece i = 0..3 of the activation tile whose offsets dma_setup() prepared
         __bf16* st = lds + sa * 2 * SA;
@@ -759,6 +763,7 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
         d.A = p.Ahi; d.B = p.Bhi; d.bias = bias; d.res = residual; d.C = y; d.a_plane = (long)a_plane; d.b_plane = (long)plane;
         d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
         d.dbg_norec = dua_dma_conv_enabled == 3;
+        d.ntaps = 9;
         d.ntm = (d.M + DBM - 1) / DBM;
         // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile Cout exactly and still give every CU
         // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
@@ -770,6 +775,28 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
         return dua_check_launch("dua_conv3x3_bf16x3_presplit (dma)");
     }
     return launch_x<XMODE_CONV, false, true>(p, as_stream(stream));
+}
+
+// C[M][N] = A * W^T (+ bias) (+ residual) with A given as split bf16 planes (hi | lo, [M][K] each, written by
+// dua_groupnorm_apply_split) and W pre-split by dua_pack_weight_bf16x3: the LDS-DMA kernel with a single tap.
+extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
+                                        int M, int N, int K, float* colsum, void* stream) {
+    DUA_REQUIRE(aplanes && planes && C && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm_bf16x3_presplit: K must be a multiple of 32 (got %d)", K);
+    DUA_REQUIRE(N % 4 == 0, "dua_gemm_bf16x3_presplit: N must be a multiple of 4");
+    size_t plane = dua_bf16x3_plane_elems(N, K);
+    DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm_bf16x3_presplit: operand too large");
+    DConvP d{};
+    d.A = (const __bf16*)aplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = C;
+    d.a_plane = (long)M * K; d.b_plane = (long)plane;
+    d.M = M; d.N = N; d.K = K; d.H = 1; d.W = 1; d.Cin = K; d.nchw_out = 0; d.colsum = colsum; d.ntaps = 1;
+    d.dbg_norec = dua_dma_conv_enabled == 3;
+    d.ntm = (M + DBM - 1) / DBM;
+    const bool wide = dua_dma_conv_enabled != 2 && N % 256 == 0 && (long)d.ntm * (N / 256) >= 512;
+    d.ntn = wide ? N / 256 : (N + BN - 1) / BN;
+    const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;
+    if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(grid), 512, 0, as_stream(stream), d);
+    else hipLaunchKernelGGL(k_xconv_dma<2>, dim3(grid), 512, 0, as_stream(stream), d);
+    return dua_check_launch("dua_gemm_bf16x3_presplit");
 }
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,

@@ -146,8 +146,10 @@ class AttentionBlock(nn.Module):
         N, H, W, C = x.shape
         T = H * W
         st = ops.groupnorm_stats(x)
-        xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0)
-        qkv = ctx.qkv(xn.view(N * T, C), self)
+        # bf16x3 mode: the normalised tokens go straight out as split bf16 planes and the qkv projection runs on the
+        # LDS-DMA kernel (one tap)
+        xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0, split=ctx.split_acts and ctx.model.presplit_qkv and C % 32 == 0)
+        qkv = ctx.qkv(xn if isinstance(xn, ops.SplitPlanes) else xn.view(N * T, C), self)
         a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision=ctx.model.precision)
         out2d = ctx.linear(a, self.proj_out, residual=x.view(N * T, C), colsum=True)
         out = out2d.view(N, H, W, C)
@@ -214,6 +216,9 @@ class _Ctx:
         return ops.gemm(a, self.packed(mod, "w1"), bias=mod.bias, a2=a2, residual=residual, colsum=colsum)
 
     def qkv(self, xn, blk):
+        if isinstance(xn, ops.SplitPlanes):
+            planes, bq = self.packed(blk, "qkvx")
+            return ops.gemm_bf16x3_presplit(xn, planes, 3 * blk.channels, bias=bq)
         if self.model.precision == "bf16x3" and xn.shape[1] % 32 == 0:
             planes, bq = self.packed(blk, "qkvx")
             return ops.gemm_bf16x3(xn, planes, 3 * blk.channels, bias=bq)
@@ -284,6 +289,7 @@ class UNetModel(nn.Module):
         # GroupNorm statistics produced in the epilogue of the conv / GEMM that writes the tensor (no re-read); set False to
         # use the stand-alone statistics kernel everywhere.
         self.fuse_gn_stats = True
+        self.presplit_qkv = True         # bf16x3: attention GroupNorm writes split planes, qkv runs on the LDS-DMA kernel
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask

@@ -349,6 +349,18 @@ def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, 
     return c
 
 
+def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None):
+    """a: SplitPlanes whose trailing dim is K (rows = all leading dims) -> [rows, n_out] fp32."""
+    K = a.shape[-1]
+    M = 1
+    for d in a.shape[:-1]:
+        M *= d
+    c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
+    check(_lib.lib().dua_gemm_bf16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), M, n_out, K, None, _stream()),
+          "dua_gemm_bf16x3_presplit")
+    return c
+
+
 def gemm_raw(**kw):
     g = GemmArgs(**kw)
     check(_lib.lib().dua_gemm(ctypes.byref(g), _stream()), "dua_gemm")

@@ -177,6 +177,10 @@ int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const f
 int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                               const float* stats, const float* gamma, const float* beta, const float* film, int act,
                               int resample, const float* dropmask, void* yplanes, void* stream);
+/* C[M][N] = A W^T (+bias) (+residual) with A as split bf16 planes [M][K] (hi | lo) from dua_groupnorm_apply_split and W
+ * from dua_pack_weight_bf16x3: the LDS-DMA kernel with one tap (qkv projection after the attention GroupNorm). */
+int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
+                             int M, int N, int K, float* colsum, void* stream);
 /* Diagnostic engine selector for dua_conv3x3_bf16x3_presplit (returns the previous mode): 1 = LDS-DMA kernels, 256x256
  * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
  * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */
