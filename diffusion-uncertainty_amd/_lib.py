@@ -59,7 +59,8 @@ SIGNATURES = {
     "dua_conv3x3_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_groupnorm_apply_split": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "dua_set_dma_conv": (_I, [_I]),
-    "dua_gemm_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "dua_gemm_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dua_layernorm_split": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_gemm_bf16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _P]),
     "dua_gemm_nt_bf16x3_batched": (_I, [_P, _L, _L, _L, _P, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _I, _I, _F, _P]),
     "dua_transpose_batched": (_I, [_P, _P, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _P]),

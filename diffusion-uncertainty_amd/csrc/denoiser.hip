@@ -426,7 +426,8 @@ extern "C" int dua_softmax_rows(float* S, long rows, int cols, long ld, void* st
 // =================================== LayerNorm =================================================
 template <int PER>
 __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, const float* __restrict__ ga,
-                                                   const float* __restrict__ be, float* __restrict__ y, long rows, int D, float eps) {
+                                                   const float* __restrict__ be, float* __restrict__ y, long rows, int D, float eps,
+                                                   int split) {
     long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
@@ -449,17 +450,33 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         int c = lane + 64 * j;
-        if (c < D) y[row * (long)D + c] = (v[j] - mean) * rstd * ga[c] + be[c];
+        if (c < D) {
+            const float o = (v[j] - mean) * rstd * ga[c] + be[c];
+            if (!split) y[row * (long)D + c] = o;
+            else {
+                __bf16* hi = (__bf16*)y;
+                const __bf16 h = (__bf16)o;
+                hi[row * (long)D + c] = h;
+                hi[rows * (long)D + row * (long)D + c] = (__bf16)(o - (float)h);
+            }
+        }
     }
 }
-extern "C" int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, void* stream) {
+static int layernorm_impl(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, int split, void* stream) {
     DUA_REQUIRE(x && gamma && beta && y && D >= 1 && D <= 2048, "dua_layernorm: D must be in [1, 2048]");
     if (rows == 0) return DUA_OK;
     unsigned grid = (unsigned)((rows + 3) / 4);
-    if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps);
-    else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps);
-    else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps);
+    if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+    else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+    else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
     return dua_check_launch("dua_layernorm");
+}
+extern "C" int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, void* stream) {
+    return layernorm_impl(x, gamma, beta, y, rows, D, eps, 0, stream);
+}
+extern "C" int dua_layernorm_split(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
+                                   void* stream) {
+    return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 1, stream);
 }
 
 // =================================== embeddings ================================================

@@ -413,6 +413,8 @@ struct DConvP {
     float* colsum;           // optional [ceil(M/64)][2][N] column sums / sums of squares per 64-row block
     int dbg_norec;           // diagnostic: zero-record descriptors (every DMA returns zeros at once) - prices the memory path
     int ntaps;               // 9 = 3x3 convolution, 1 = plain GEMM over rows (1x1 convolution / linear layer)
+    int act_out;             // 2 = GELU on the output (U-ViT fc1)
+    __bf16* Csplit;          // optional: write the output as split bf16 planes (hi | lo, [M][N] each) instead of fp32 C
 };
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
@@ -640,11 +642,20 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                 float4 v = *(const float4*)(patch + rl * WC + 4 * c4);
                 if (row < p.M && colq < p.N) {
                     v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                    if (p.act_out == 2) { v.x = gelu_x(v.x); v.y = gelu_x(v.y); v.z = gelu_x(v.z); v.w = gelu_x(v.w); }
                     if (p.res) {
                         const float4 q = *(const float4*)(p.res + (long)row * p.N + colq);
                         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                     }
-                    *(float4*)(p.C + (long)row * p.N + colq) = v;
+                    if (p.Csplit) {        // the consumer is another bf16x3 GEMM: hand it the operand format directly
+                        bf16x4 hi, lo;
+                        split4(v, hi, lo);
+                        __bf16* o = p.Csplit + (long)row * p.N + colq;
+                        *(bf16x4*)o = hi;
+                        *(bf16x4*)(o + (long)p.M * p.N) = lo;
+                    } else {
+                        *(float4*)(p.C + (long)row * p.N + colq) = v;
+                    }
                     cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
                     cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
                 }
@@ -780,8 +791,8 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
 // C[M][N] = A * W^T (+ bias) (+ residual) with A given as split bf16 planes (hi | lo, [M][K] each, written by
 // dua_groupnorm_apply_split) and W pre-split by dua_pack_weight_bf16x3: the LDS-DMA kernel with a single tap.
 extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
-                                        int M, int N, int K, float* colsum, void* stream) {
-    DUA_REQUIRE(aplanes && planes && C && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm_bf16x3_presplit: K must be a multiple of 32 (got %d)", K);
+                                        void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
+    DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm_bf16x3_presplit: K must be a multiple of 32 (got %d)", K);
     DUA_REQUIRE(N % 4 == 0, "dua_gemm_bf16x3_presplit: N must be a multiple of 4");
     size_t plane = dua_bf16x3_plane_elems(N, K);
     DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm_bf16x3_presplit: operand too large");
@@ -789,6 +800,7 @@ extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes,
     d.A = (const __bf16*)aplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = C;
     d.a_plane = (long)M * K; d.b_plane = (long)plane;
     d.M = M; d.N = N; d.K = K; d.H = 1; d.W = 1; d.Cin = K; d.nchw_out = 0; d.colsum = colsum; d.ntaps = 1;
+    d.act_out = act_out; d.Csplit = (__bf16*)Csplit;
     d.dbg_norec = dua_dma_conv_enabled == 3;
     d.ntm = (M + DBM - 1) / DBM;
     const bool wide = dua_dma_conv_enabled != 2 && N % 256 == 0 && (long)d.ntm * (N / 256) >= 512;

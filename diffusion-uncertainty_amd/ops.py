@@ -349,15 +349,20 @@ def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, 
     return c
 
 
-def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None):
-    """a: SplitPlanes whose trailing dim is K (rows = all leading dims) -> [rows, n_out] fp32."""
+def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, split_out=False):
+    """a: SplitPlanes whose trailing dim is K (rows = all leading dims) -> [rows, n_out] fp32, or SplitPlanes if split_out."""
     K = a.shape[-1]
     M = 1
     for d in a.shape[:-1]:
         M *= d
+    if split_out:
+        buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
+        check(_lib.lib().dua_gemm_bf16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), None, _p(buf), M, n_out, K, int(act_out),
+                                                  None, _stream()), "dua_gemm_bf16x3_presplit")
+        return SplitPlanes(buf, (M, n_out))
     c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
-    check(_lib.lib().dua_gemm_bf16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), M, n_out, K, None, _stream()),
-          "dua_gemm_bf16x3_presplit")
+    check(_lib.lib().dua_gemm_bf16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), None, M, n_out, K, int(act_out), None,
+                                              _stream()), "dua_gemm_bf16x3_presplit")
     return c
 
 
@@ -412,9 +417,14 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
+def layernorm(x, gamma, beta, eps=1e-5, split=False):
     _req(x, name="x")
     D = x.shape[-1]
+    if split:
+        buf = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.int16)
+        check(_lib.lib().dua_layernorm_split(_p(x), _p(gamma), _p(beta), _p(buf), x.numel() // D, D, float(eps), _stream()),
+              "dua_layernorm_split")
+        return SplitPlanes(buf, tuple(x.shape))
     y = torch.empty_like(x)
     check(_lib.lib().dua_layernorm(_p(x), _p(gamma), _p(beta), _p(y), x.numel() // D, D, float(eps), _stream()), "dua_layernorm")
     return y

@@ -52,12 +52,13 @@ class Block(nn.Module):
         D = x.shape[1]
         if self.skip_linear is not None:
             x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
-        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        fast = precision == "bf16x3" and D % 32 == 0       # LayerNorm / GELU outputs go out as split bf16 planes (LDS-DMA GEMMs)
+        h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=fast)
         qkv = lin(h, self.attn.qkv)
         a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads, precision=precision)   # :69-73
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
-        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        h = lin(h, self.mlp.fc1, act_out=2)                                                        # fc1 + GELU
+        h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, split=fast)
+        h = lin(h, self.mlp.fc1, act_out=2, split_out=fast)                                        # fc1 + GELU
         return lin(h, self.mlp.fc2, residual=x)                                                    # :119
 
 
@@ -110,7 +111,12 @@ class UViT(nn.Module):
         self._planes = {}
         return super().load_state_dict(*a, **k)
 
-    def _lin(self, a, mod, a2=None, residual=None, act_out=0):
+    def _lin(self, a, mod, a2=None, residual=None, act_out=0, split_out=False):
+        if isinstance(a, ops.SplitPlanes):                # operand already in split-bf16 format: LDS-DMA GEMM
+            if id(mod) not in self._planes:
+                self._planes[id(mod)] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
+            return ops.gemm_bf16x3_presplit(a, self._planes[id(mod)], mod.weight.shape[0], bias=mod.bias, residual=residual,
+                                            act_out=act_out, split_out=split_out)
         K = a.shape[1] + (0 if a2 is None else a2.shape[1])
         if self.precision == "bf16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:
             if id(mod) not in self._planes:

@@ -180,7 +180,12 @@ int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, 
 /* C[M][N] = A W^T (+bias) (+residual) with A as split bf16 planes [M][K] (hi | lo) from dua_groupnorm_apply_split and W
  * from dua_pack_weight_bf16x3: the LDS-DMA kernel with one tap (qkv projection after the attention GroupNorm). */
 int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
-                             int M, int N, int K, float* colsum, void* stream);
+                             void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream);
+/* Csplit != NULL: the result is written as split bf16 planes ([M][N] hi | lo) instead of fp32 C - the operand format of
+ * the next presplit GEMM (U-ViT fc1 -> GELU -> fc2).  act_out: 0 none, 2 GELU. */
+/* LayerNorm writing split bf16 planes ([rows][D] hi | lo): operand of the presplit GEMM (uvit/uvit.py:108-110). */
+int dua_layernorm_split(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
+                        void* stream);
 /* Diagnostic engine selector for dua_conv3x3_bf16x3_presplit (returns the previous mode): 1 = LDS-DMA kernels, 256x256
  * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
  * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */
