@@ -376,19 +376,42 @@ def softmax_rows_(S, rows, cols, ld=None):
     return S
 
 
+# "auto": fused kernel wherever it applies except where the split-bf16 GEMM pair is faster (see qkv_attention);
+# "fused" / "gemm" force one path (A/B measurements, tests).
+ATTENTION_MODE = "auto"
+
+
+def fused_attention(qkv, B, T, heads, ch):
+    """Flash-style fp32 attention in one kernel (dua_attention): same contract as qkv_attention."""
+    _req(qkv, name="qkv")
+    C = heads * ch
+    assert qkv.shape == (B * T, 3 * C)
+    out = torch.empty((B * T, C), device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().dua_attention(_p(qkv), _p(out), B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()), "dua_attention")
+    return out
+
+
 def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     """qkv: [B*T, 3*heads*ch] laid out (q | k | v), head-major inside each third -> [B*T, heads*ch].
 
     Reference: QKVAttentionLegacy / QKVAttention (unet_openai.py:338-355 / :371-390); the q/k scale
-    ch^-1/4 on both operands is applied as alpha = ch^-1/2 on the logits.  The logits are materialised in HBM
-    (round 1): S = q.k^T (MFMA tile engine), softmax in dua_softmax_rows, V is transposed to [head channel][token]
-    so that O = P.(V^T)^T also runs through the K-major GEMM path.  precision="bf16x3" evaluates both products on
+    ch^-1/4 on both operands is applied as alpha = ch^-1/2 on the logits.  Default path: the fused flash-style fp32
+    kernel (dua_attention), logits never leave the CU.  GEMM path (head dims > 256, or wide heads in bf16x3 mode): the
+    logits are materialised in HBM, S = q.k^T (MFMA tile engine), softmax in dua_softmax_rows, V is transposed to
+    [head channel][token] so that O = P.(V^T)^T also runs through the K-major GEMM path.  precision="bf16x3" evaluates both products on
     the bf16 matrix cores with both operands split on the fly (needs ch % 32 == 0 and T % 32 == 0); softmax is fp32.
     """
     _req(qkv, name="qkv")
     C = heads * ch
     assert qkv.shape == (B * T, 3 * C)
     assert B * heads <= 65535
+    fast = precision == "bf16x3" and ch % 32 == 0 and T % 32 == 0
+    fusable = ch % 8 == 0 and ch <= 256
+    # measured (MI355X, B=128): fused fp32 117 TF vs 64 TF for the split-bf16 GEMM pair at ch=64, T=1024; at ch=128 the
+    # GEMM pair is ~5 % ahead (105 vs 100 TF), and heads wider than 128 leave the fused kernel no registers for its K/V
+    # prefetch (ch=192, T=256: 39 TF fused vs 65 / 89 TF for the fp32 / split-bf16 GEMM pair), so "auto" keeps those.
+    if fusable and (ATTENTION_MODE == "fused" or (ATTENTION_MODE == "auto" and ch <= 128 and not (fast and ch > 96))):
+        return fused_attention(qkv, B, T, heads, ch)
     Tp = (T + 3) // 4 * 4            # row stride of the logits / of V^T (16-byte aligned rows)
     S = torch.empty((B * heads, T, Tp), device=qkv.device, dtype=torch.float32)
     Vt = torch.empty((B * heads, ch, Tp), device=qkv.device, dtype=torch.float32)
@@ -398,7 +421,6 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     s = 1.0 / math.sqrt(math.sqrt(ch))
     check(L.dua_transpose_batched(base + 8 * C, _p(Vt), T, ch, 3 * C, Tp, T * 3 * C, ch, heads * ch * Tp, ch * Tp, B * heads, heads,
                                   _stream()), "dua_transpose_batched")
-    fast = precision == "bf16x3" and ch % 32 == 0 and T % 32 == 0
     if fast:
         check(L.dua_gemm_nt_bf16x3_batched(base, 3 * C, T * 3 * C, ch, base + 4 * C, 3 * C, T * 3 * C, ch, _p(S), Tp, heads * T * Tp, T * Tp,
                                            T, T, ch, B * heads, heads, s * s, _stream()), "dua_gemm_nt_bf16x3_batched")

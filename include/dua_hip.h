@@ -149,6 +149,14 @@ int dua_gemm(const dua_gemm_args* args_host, void* stream);
  * (unet_openai.py:353 / :388; uvit/uvit.py:73). */
 int dua_softmax_rows(float* S, long rows, int cols, long ld, void* stream);
 
+/* Fused multi-head attention, exact fp32 on the matrix cores, logits never materialised:
+ *   out[b][t][h*ch + c] = sum_s softmax_s(scale * q[b,t,h,:].k[b,s,h,:]) v[b,s,h,c]
+ * qkv rows [B*T][3*heads*ch] = (q | k | v), head-major inside each third; out [B*T][heads*ch].  Any T >= 1;
+ * ch a multiple of 8, <= 256; B*heads <= 65535.  Replaces the body of QKVAttentionLegacy.forward / QKVAttention.forward
+ * (guided_diffusion/unet_openai.py:338-355, :371-390; scale = ch^-1/2 = the two ch^-1/4 operand scales) and
+ * F.scaled_dot_product_attention in uvit/uvit.py:69-73. */
+int dua_attention(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream);
+
 /* LayerNorm over the last axis (U-ViT, uvit/uvit.py:108-110,225): y = (x-mean)*rstd*gamma+beta, eps 1e-5. */
 int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps,
                   void* stream);

@@ -207,17 +207,23 @@ def test_gemm(ops, M, N, K1, K2):
     np.testing.assert_allclose(c.cpu().numpy(), F.gelu(ref + b).float().numpy(), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("B,T_,heads,ch", [(2, 64, 4, 32), (1, 16, 2, 64), (2, 256, 4, 96), (1, 1024, 4, 128), (3, 64, 4, 256), (2, 258, 16, 72)])
+@pytest.mark.parametrize("B,T_,heads,ch", [(2, 64, 4, 32), (1, 16, 2, 64), (2, 256, 4, 96), (1, 1024, 4, 128), (3, 64, 4, 256), (2, 258, 16, 72), (1, 1, 2, 8), (2, 77, 3, 40), (1, 600, 2, 192)])
 def test_qkv_attention(ops, B, T_, heads, ch):
     from oracle import adm
     C = heads * ch
     qkv = rnd(40, B, 3 * C, T_)                       # reference layout [B, 3C, T], NEW order (q|k|v thirds)
     ref = adm.qkv_attention(qkv, heads, True)         # [B, C, T]
     d = qkv.permute(0, 2, 1).reshape(B * T_, 3 * C).contiguous().to(dev)
-    out = ops.qkv_attention(d, B, T_, heads, ch)
-    np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
-    out = ops.qkv_attention(d, B, T_, heads, ch, precision="bf16x3")     # falls back to fp32 products unless ch, T % 32 == 0
-    np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
+    import diffusion_uncertainty_amd.ops as O
+    try:
+        for mode in ("gemm", "fused", "auto"):        # materialised-logits GEMM pair, flash kernel, default dispatch
+            O.ATTENTION_MODE = mode
+            out = ops.qkv_attention(d, B, T_, heads, ch)
+            np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5, err_msg=mode)
+            out = ops.qkv_attention(d, B, T_, heads, ch, precision="bf16x3")     # split-bf16 products only when ch, T % 32 == 0
+            np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-3, atol=1e-4, err_msg=mode)
+    finally:
+        O.ATTENTION_MODE = "auto"
 
 
 def test_softmax_layernorm_embeddings(ops):
