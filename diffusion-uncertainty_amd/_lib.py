@@ -34,6 +34,10 @@ SIGNATURES = {
     "dua_mc_reduce_var": (_I, [_P, _P, _Z, _I, _P]),
     "dua_quantile_mask": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dua_posterior_blend": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "dua_threshold_map": (_I, [_P, _P, _P, _I, _Z, _I, _I, _P]),
+    "dua_batch_sum": (_I, [_P, _P, _I, _Z, _P]),
+    "dua_posterior_score": (_I, [_P, _P, _P, _I, _Z, _I, _F, _P]),
+    "dua_map_blend": (_I, [_P, _P, _P, _P, _Z, _P]),
     "dua_pixelwise_order_statistic": (_I, [_P, _I, _L, _I, _P, _P]),
     "dua_to_uint8": (_I, [_P, _P, _Z, _P]),
     "dua_randn": (_I, [_P, _Z, _U64, _U64, _P]),

@@ -250,6 +250,73 @@ extern "C" int dua_posterior_blend(const float* eps, const float* u, const uint8
     return dua_check_launch("dua_posterior_blend");
 }
 
+// ---- class-conditional posterior guidance (pipeline_uncertainty/pipeline_sampler_class_conditional_uncertainty_
+// guided_posterior_distribution.py): threshold map :10-30, posterior score :59-66, masked blend :150 -----------------
+__global__ __launch_bounds__(BLK) void k_threshold_map(const float* __restrict__ u, const float* __restrict__ thr,
+                                                       float* __restrict__ map, size_t n, size_t total, long sb, long sn, int lower) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / n, j = i - b * n;
+        const float t = thr[b * sb + j * sn], v = u[i];
+        map[i] = (lower ? v < t : v > t) ? 1.0f : 0.0f;
+    }
+}
+extern "C" int dua_threshold_map(const float* u, const float* thr, float* map, int B, size_t n, int per_sample, int lower, void* stream) {
+    DUA_REQUIRE(u && thr && map && B >= 0, "dua_threshold_map: bad arguments");
+    const size_t total = (size_t)B * n;
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_threshold_map, stream_grid(total, BLK), BLK, 0, as_stream(stream), u, thr, map, n, total,
+                       per_sample ? 1L : 0L, per_sample ? 0L : 1L, lower);
+    return dua_check_launch("dua_threshold_map");
+}
+
+__global__ __launch_bounds__(BLK) void k_batch_sum(const float* __restrict__ x, float* __restrict__ out, int B, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = s + x[(size_t)b * n + j];
+        out[j] = s;
+    }
+}
+extern "C" int dua_batch_sum(const float* x, float* out, int B, size_t n, void* stream) {
+    DUA_REQUIRE(x && out && B >= 0, "dua_batch_sum: bad arguments");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_batch_sum, stream_grid(n, BLK), BLK, 0, as_stream(stream), x, out, B, n);
+    return dua_check_launch("dua_batch_sum");
+}
+
+__global__ __launch_bounds__(BLK) void k_posterior_score(const float* __restrict__ u, const float* __restrict__ bsum,
+                                                         float* __restrict__ out, size_t n, size_t total, float Mf, float inv_alpha) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float inv = 1.0f / u[i];                         // inv_var :62
+        const float prec = 1.0f / (Mf * inv + inv_alpha);      // post_var_trace :63, post_precision :64
+        out[i] = prec * (inv * bsum[i % n]);                   // new_score :65
+    }
+}
+extern "C" int dua_posterior_score(const float* u, const float* bsum, float* out, int B, size_t n, int M, float inv_alpha, void* stream) {
+    DUA_REQUIRE(u && bsum && out && B >= 0, "dua_posterior_score: bad arguments");
+    const size_t total = (size_t)B * n;
+    if (total == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_posterior_score, stream_grid(total, BLK), BLK, 0, as_stream(stream), u, bsum, out, n, total, (float)M, inv_alpha);
+    return dua_check_launch("dua_posterior_score");
+}
+
+__global__ __launch_bounds__(BLK) void k_map_blend(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ map, float* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float m = map[i];
+        out[i] = a[i] * m + b[i] * (1.0f - m);
+    }
+}
+extern "C" int dua_map_blend(const float* a, const float* b, const float* map, float* out, size_t n, void* stream) {
+    DUA_REQUIRE(a && b && map && out, "dua_map_blend: bad arguments");
+    if (n == 0) return DUA_OK;
+    hipLaunchKernelGGL(k_map_blend, stream_grid(n, BLK), BLK, 0, as_stream(stream), a, b, map, out, n);
+    return dua_check_launch("dua_map_blend");
+}
+
 // ---- uint8 conversion: generate_samples.py:203-215 ---------------------------------------------
 __global__ __launch_bounds__(BLK) void k_to_uint8(const float* __restrict__ x, uint8_t* __restrict__ o, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -29,6 +29,15 @@ def _eps3(model, x, t_tensor, y):
     return model(x, t_tensor, y=y)[:, :3]
 
 
+def predict_model(model, sample, t_tensor, y):
+    """Model-agnostic denoiser call, reference generate_samples.py:670-676 (the diffusers UNet2DModel branch :671-672 is
+    the CIFAR-10 path, SURVEY 8f, not built)."""
+    from .uvit.uvit_ae import UViTAE
+    if isinstance(model, UViTAE):
+        return model(sample, t_tensor, y)
+    return _eps3(model, sample, t_tensor, y)
+
+
 def _loop(x, y_batch, model_call, scheduler, device, intermediates=None):
     is_uc = isinstance(scheduler, SchedulerUncertaintyMixin)
     uncertanties, scores = [], []

@@ -111,6 +111,45 @@ def posterior_blend(eps, u, mask, M, alpha_hat_t):
     return out
 
 
+def threshold_map(u, thr, per_sample, lower=False):
+    """0/1 float map of u > thr (or u < thr): thr is [B] per-sample scalars (per_sample) or one [n] map broadcast over B."""
+    _req(u, name="u"), _req(thr, name="thr")
+    B = u.shape[0]
+    n = u.numel() // max(B, 1)
+    assert thr.numel() == (B if per_sample else n), f"threshold has {thr.numel()} elements, expected {B if per_sample else n}"
+    out = torch.empty_like(u)
+    check(_lib.lib().dua_threshold_map(_p(u), _p(thr), _p(out), B, n, int(bool(per_sample)), int(bool(lower)), _stream()),
+          "dua_threshold_map")
+    return out
+
+
+def batch_sum(x):
+    _req(x, name="x")
+    B = x.shape[0]
+    out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_batch_sum(_p(x), _p(out), B, x.numel() // max(B, 1), _stream()), "dua_batch_sum")
+    return out
+
+
+def posterior_score(u, bsum, M, inv_alpha):
+    _req(u, name="u"), _req(bsum, name="bsum")
+    B = u.shape[0]
+    n = u.numel() // max(B, 1)
+    assert bsum.numel() == n
+    out = torch.empty_like(u)
+    check(_lib.lib().dua_posterior_score(_p(u), _p(bsum), _p(out), B, n, int(M), float(inv_alpha), _stream()), "dua_posterior_score")
+    return out
+
+
+def map_blend(a, b, m):
+    """a*m + b*(1-m)."""
+    _req(a, name="a"), _req(b, name="b"), _req(m, name="map")
+    assert a.shape == b.shape == m.shape
+    out = torch.empty_like(a)
+    check(_lib.lib().dua_map_blend(_p(a), _p(b), _p(m), _p(out), a.numel(), _stream()), "dua_map_blend")
+    return out
+
+
 def pixelwise_order_statistic(u, k):
     """u: [N, ...] fp32 -> [...] fp16: k-th smallest over dim 0 of u.half() (exact)."""
     _req(u, name="u")

@@ -85,6 +85,12 @@ class DDIMUncertaintyCore(SchedulerMixin, ConfigMixin):
         return ((1 - alpha_prod_t_prev) / (1 - alpha_prod_t)) * (1 - alpha_prod_t / alpha_prod_t_prev)
 
     def set_timesteps(self, num_inference_steps, device=None):
+        self._set_grid(num_inference_steps, device)
+        # IndexError when the window exceeds the grid, like the reference (:383-384)
+        self.timestep_after_step = self.timesteps[self.config.after_step].item()
+        self.timestep_end_step = self.timesteps[self.config.after_step + self.config.num_steps_uc - 1].item()
+
+    def _set_grid(self, num_inference_steps, device=None):
         if num_inference_steps > self.config.num_train_timesteps:
             raise ValueError(
                 f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`:"
@@ -106,9 +112,6 @@ class DDIMUncertaintyCore(SchedulerMixin, ConfigMixin):
             raise ValueError(f"{self.config.timestep_spacing} is not supported. Please make sure to choose one of "
                              "'leading' or 'trailing'.")
         self.timesteps = torch.from_numpy(timesteps).to(device)
-        # IndexError when the window exceeds the grid, like the reference (:383-384)
-        self.timestep_after_step = self.timesteps[self.config.after_step].item()
-        self.timestep_end_step = self.timesteps[self.config.after_step + self.config.num_steps_uc - 1].item()
 
     def in_uc_window(self, timestep):
         return self.timestep_end_step <= timestep <= self.timestep_after_step

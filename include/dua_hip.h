@@ -68,6 +68,19 @@ int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uin
 int dua_posterior_blend(const float* eps, const float* u, const uint8_t* mask, float* out, int B, int n, int M,
                         float alpha_hat_t, void* stream);
 
+/* Class-conditional posterior guidance
+ * (pipeline_uncertainty/pipeline_sampler_class_conditional_uncertainty_guided_posterior_distribution.py).
+ * dua_threshold_map (:10-30): map = (lower ? u < thr : u > thr) as 0.0/1.0 floats; u, map [B][n];
+ *   per_sample = 1: thr[B] (the per-sample quantile of the float-threshold branch), 0: thr[n] broadcast over the batch
+ *   (threshold[i] of the tensor branch, converted to fp32 by the caller).
+ * dua_batch_sum: out[n] = sum_b x[b][n] (pred_epsilon.sum(dim=0) at :65 reduces over the BATCH axis; reproduced as is).
+ * dua_posterior_score (:62-65): inv = 1/u; out = 1/(M*inv + inv_alpha) * (inv * bsum), bsum [n] broadcast over B.
+ * dua_map_blend (:150): out = a*map + b*(1 - map). */
+int dua_threshold_map(const float* u, const float* thr, float* map, int B, size_t n, int per_sample, int lower, void* stream);
+int dua_batch_sum(const float* x, float* out, int B, size_t n, void* stream);
+int dua_posterior_score(const float* u, const float* bsum, float* out, int B, size_t n, int M, float inv_alpha, void* stream);
+int dua_map_blend(const float* a, const float* b, const float* map, float* out, size_t n, void* stream);
+
 /* ((x/2+.5).clamp(0,1)*255).round() -> uint8, generate_samples.py:203-215. */
 int dua_to_uint8(const float* x, uint8_t* out, size_t n, void* stream);
 

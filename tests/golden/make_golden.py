@@ -368,7 +368,85 @@ def g9():
     save("g9_vae_decode", **out)
 
 
+def g10():
+    """Posterior-guided class-conditional pipeline (pipeline_uncertainty/).
+
+    The reference module imports ``beartype`` (not installed): a pass-through decorator stands in.  Its class
+    ``__call__`` calls the module-level ``calculate_threshold_map`` without the required ``threshold_type`` (:150), so it
+    cannot run as written; for the loop fixtures ONLY that name is rebound in the reference module's namespace to the
+    same function with ``threshold_type='higher'`` defaulted (what the class's own method :230-238 computes).  The
+    scheduler handed to the pipelines is the reference's own ``uncertainty_centered`` scheduler with M=1 (diffusers'
+    DDIMScheduler is not available): its step() is the DDIM update plus RNG draws (one ``best_noise`` per call, one more
+    and one extra denoiser call inside its window) that do not influence ``prev_sample``.
+    """
+    import types
+    bt = types.ModuleType("beartype")
+    bt.beartype = lambda f: f
+    sys.modules.setdefault("beartype", bt)
+    with _quiet:
+        import diffusion_uncertainty.pipeline_uncertainty.pipeline_sampler_class_conditional_uncertainty_guided_posterior_distribution as ref_pp
+        import diffusion_uncertainty.pipeline_uncertainty.pipeline_sampler_class_conditional as ref_pc
+    out = {}
+    # -- calculate_threshold_map
+    u4 = randn(101, 2, 3, 8, 8).abs() * 1e-2
+    thr = (randn(102, 5, 3, 8, 8).abs() * 1e-2).half()
+    out["tm_u"], out["tm_thr"] = u4, thr
+    case = 0
+    for tt in ("higher", "lower"):
+        for th in (0.9, 0.5, "tensor"):
+            r = ref_pp.calculate_threshold_map(thr if th == "tensor" else th, 2, u4, tt)
+            out[f"tm{case}_meta"] = np.array([tt, str(th)])
+            out[f"tm{case}_map"] = r
+            case += 1
+        out[f"tm3d_{tt}"] = ref_pp.calculate_threshold_map(thr, 4, u4[1], tt)
+    out["tm_n"] = case
+    # -- estimate_score_update_posterior
+    tiny = build_adm(TINY_ADM, seed=5)
+    x, y = randn(103, 2, 3, 16, 16), torch.tensor([3, 7])
+    out["x"], out["y"] = x, y
+    acp = torch.cumprod(1 - torch.linspace(1e-4, 0.02, 1000), 0)
+    case = 0
+    for model_name, model in (("stub", StubDenoiser()), ("tiny_adm", tiny)):
+        for M in (2, 5):
+            for t, ai in ((500, 3), (100, 700)):
+                tv = torch.full((2,), t, dtype=torch.long)
+                with torch.no_grad():
+                    eps = model(x, tv, y=y)[:, :3]
+                    torch.manual_seed(2000 + case)
+                    u, ns = ref_pp.estimate_score_update_posterior(M, model, None, x, y, tv, eps, x, acp[ai])
+                out[f"e{case}_meta"] = np.array([model_name, str(M), str(t), str(ai), str(2000 + case)])
+                out[f"e{case}_eps"], out[f"e{case}_u"], out[f"e{case}_score"] = eps, u, ns
+                case += 1
+    out["e_n"] = case
+    # -- plain pipeline
+    X_T, yy = randn(104, 4, 3, 16, 16), torch.tensor([1, 2, 3, 4])
+    out["X_T"], out["yy"] = X_T, yy
+    with _quiet:
+        s = RefCentered.from_config(CONFIGS["adm128"], M=1, after_step=0, num_steps_uc=1, unet=tiny, predict_next=False, y=None)
+        s.set_timesteps(10)
+        torch.manual_seed(0)
+        r = ref_pc.DiffusionClassConditional(tiny, s, 16, torch.device("cpu"), 3, 0)(X_T=X_T, y=yy)
+    out["plain_gen_images"], out["plain_score"] = r["gen_images"], r["score"]
+    # -- guided loop (see docstring for the one rebinding)
+    orig = ref_pp.calculate_threshold_map
+    ref_pp.calculate_threshold_map = lambda th, i, u, tt="higher": orig(th, i, u, tt)
+    thr10 = (randn(105, 10, 3, 16, 16).abs() * 2e-4).half()
+    out["thr10"] = thr10
+    try:
+        for name, th in (("p90", 0.9), ("tensor", thr10)):
+            with _quiet:
+                s = RefCentered.from_config(CONFIGS["adm128"], M=1, after_step=0, num_steps_uc=1, unet=tiny, predict_next=False, y=None)
+                s.set_timesteps(10)
+                torch.manual_seed(7)
+                pipe = ref_pp.DiffusionClassConditionalGuidedPosteriorDistribution(tiny, s, th, 16, torch.device("cpu"), 3, 0, M=2)
+                r = pipe(X_T=X_T, y=yy, start_step=6, num_steps=2)
+            out[f"guided_{name}_gen_images"] = r["gen_images"]
+    finally:
+        ref_pp.calculate_threshold_map = orig
+    save("g10_posterior_pipeline", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

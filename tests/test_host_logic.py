@@ -99,3 +99,29 @@ def test_cli_flags_mirror_reference_defaults():
     assert (b.M, b.generation_steps, b.start_step_uc, b.num_steps_uc, b.batch_size, b.image_size) == (7, 50, 40, 10, 128, 128)
     with pytest.raises(AssertionError):
         cli.parse_args(["--image-size", "128"])
+
+
+def test_plain_ddim_scheduler_and_pipeline_surface():
+    """Plain DDIM scheduler (what the guided-sampling script hands to the pipelines) and the pipelines' host-side checks."""
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128
+    from diffusion_uncertainty_amd.pipeline_uncertainty.pipeline_sampler_class_conditional import DiffusionClassConditional
+    from diffusion_uncertainty_amd.pipeline_uncertainty.pipeline_sampler_class_conditional_uncertainty_guided_posterior_distribution import \
+        DiffusionClassConditionalGuidedPosteriorDistribution as Guided
+    from diffusion_uncertainty_amd.schedulers_uncertainty.mixin import SchedulerUncertaintyMixin
+    from diffusion_uncertainty_amd.schedulers_uncertainty.scheduling_ddim import DDIMScheduler
+    s = DDIMScheduler.from_config(init_scheduler_imagenet128().config)
+    with pytest.raises(ValueError):
+        s._ddim(None, 0, None, 0.0, False, None)                       # set_timesteps not called
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == list(range(900, -1, -100))
+    assert not isinstance(s, SchedulerUncertaintyMixin)                # no uncertainty window on the plain scheduler
+    s.config.after_step, s.config.num_steps_uc = 6, 2                  # the guided pipeline assigns these (:117-118)
+    s.set_timesteps(len(s.timesteps))
+    assert s.timesteps.tolist() == list(range(900, -1, -100)) and s.config.after_step == 6
+    model = torch.nn.Identity()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DiffusionClassConditional(model, s, 16, torch.device("cpu"), 2, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Guided(model, s, 0.9, 16, torch.device("cpu"), 2, 0)
+    with pytest.raises(AssertionError):
+        Guided(model, s, 2, 16, torch.device("cuda"), 2, 0)            # threshold must be a float or a tensor

@@ -6,7 +6,7 @@ import torch
 
 from conftest import T
 from diffusion_uncertainty_amd.utils import seeded_state_dict
-from oracle import adm, ddim, driver, guidance, schedule, uvit
+from oracle import adm, ddim, driver, guidance, posterior_pipeline, schedule, uvit
 
 TINY_ADM = dict(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1,
                 attention_resolutions=(2,), dropout=0.0, channel_mult=(1, 2), num_classes=10,
@@ -264,3 +264,64 @@ def test_g9_vae_decode_full(golden):
     with torch.no_grad():
         o = vae.decode(sd, dict(vae.KL_F8), T(g["full_z"]))
     np.testing.assert_allclose(o.numpy(), g["full_out"], rtol=1e-4, atol=1e-4)
+
+
+def test_g10_threshold_map_bit_exact(golden):
+    g = golden("g10_posterior_pipeline")
+    u, thr = T(g["tm_u"]), T(g["tm_thr"])
+    for c in range(int(g["tm_n"])):
+        tt, th = g[f"tm{c}_meta"]
+        m = posterior_pipeline.threshold_map(thr if th == "tensor" else float(th), 2, u, str(tt))
+        np.testing.assert_array_equal(m.numpy(), g[f"tm{c}_map"])
+    for tt in ("higher", "lower"):
+        np.testing.assert_array_equal(posterior_pipeline.threshold_map(thr, 4, u[1], tt).numpy(), g[f"tm3d_{tt}"])
+
+
+def test_g10_score_update_posterior(golden):
+    g = golden("g10_posterior_pipeline")
+    x, y = T(g["x"]), T(g["y"])
+    sd = tiny_adm()
+    acp = TABLES["adm128"]().alphas_cumprod
+    for c in range(int(g["e_n"])):
+        model_name, M, t, ai, seed = g[f"e{c}_meta"]
+        if model_name == "stub":
+            den = lambda xh: stub_denoiser(y)(xh, int(t))
+        else:
+            den = lambda xh: adm.forward(sd, TINY_ADM, xh, torch.full((xh.shape[0],), int(t), dtype=torch.long), y)[:, :3]
+        torch.manual_seed(int(seed))
+        u, score = posterior_pipeline.score_update_posterior(int(M), den, x, T(g[f"e{c}_eps"]), acp[int(ai)])
+        np.testing.assert_allclose(u.numpy(), g[f"e{c}_u"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(score.numpy(), g[f"e{c}_score"], rtol=2e-4, atol=1e-6)
+
+
+def test_g10_pipelines(golden):
+    g = golden("g10_posterior_pipeline")
+    sd = tiny_adm()
+    tab = TABLES["adm128"]()
+    ts = schedule.leading_timesteps(1000, 10)
+    X_T, y = T(g["X_T"]), T(g["yy"])
+
+    def den(x, t, yb):
+        return adm.forward(sd, TINY_ADM, x, torch.full((x.shape[0],), int(t), dtype=torch.long), yb)[:, :3]
+
+    imgs, score = posterior_pipeline.sample_plain(tab, den, X_T, y, 3, 10, ts)
+    np.testing.assert_allclose(score.numpy(), g["plain_score"], rtol=1e-4, atol=1e-5)
+    diff = np.abs(imgs.numpy().astype(int) - g["plain_gen_images"].astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    # the fixtures were produced with the reference's uncertainty_centered scheduler (M=1) standing in for diffusers'
+    # DDIMScheduler: every step() draws best_noise, plus one re-noising draw inside its window (timesteps[6..7])
+    window = schedule.uc_window(ts, 6, 2)
+
+    def hook(x, t):
+        torch.randn_like(x)
+        if window[0] >= t >= window[1]:
+            torch.randn_like(x)
+
+    for name, th in (("p90", 0.9), ("tensor", T(g["thr10"]))):
+        torch.manual_seed(7)
+        out = posterior_pipeline.sample_posterior_guided(tab, den, X_T, y, 3, 10, ts, th, M=2, start_step=6, num_steps=2,
+                                                         step_hook=hook)
+        ref = g[f"guided_{name}_gen_images"]
+        diff = np.abs(out.numpy().astype(int) - ref.astype(int))
+        assert (diff > 1).mean() < 2e-3, (name, (diff > 1).mean(), diff.max())
+        assert np.abs(ref.astype(int) - g["plain_gen_images"].astype(int)).max() > 1      # guidance changed the images
