@@ -31,8 +31,9 @@ class TimestepBlock(nn.Module):
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def run(self, ctx, h, skip=None):
-        for layer in self:
+    def run(self, ctx, h, skip=None, name=None):
+        hooks = ctx.model.activation_noise
+        for j, layer in enumerate(self):
             if isinstance(layer, ResBlock):
                 h = layer.run(ctx, h, skip)
                 skip = None
@@ -40,6 +41,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 h = layer.run(ctx, h)
             else:                                   # input conv (Cin padded to 4: always the fp32 small-Cin kernel)
                 h = ops.conv3x3(h, ctx.packed(layer, "w3"), layer.bias, layer.out_channels, colsum=ctx.model.fuse_gn_stats)
+            if hooks and f"{name}.{j}" in hooks:
+                h = ctx.add_activation_noise(h, hooks[f"{name}.{j}"])
         return h
 
 
@@ -199,6 +202,16 @@ class _Ctx:
     def dropout_mask(self, shape_nhwc, p):
         return self.model.dropout_mask_source(shape_nhwc, p)
 
+    def add_activation_noise(self, h, std):
+        """h + std * randn_like(h): the forward hooks of schedulers_uncertainty/scheduling_ddim_uncertainty.py:36-40,
+        520-529.  The draw has the reference's NCHW shape (same tape order as torch.randn_like on the module output)."""
+        N, H, W, C = h.shape
+        src = self.model.activation_noise_source
+        if src is None:
+            raise RuntimeError("UNetModel.activation_noise is set but activation_noise_source is None")
+        noise = ops.nchw_to_nhwc(src.draw((N, C, H, W), h.device))
+        return ops.axpby(h, noise, 1.0, std)
+
     # ---- the FLOP carriers, in the model's precision mode
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
@@ -293,6 +306,10 @@ class UNetModel(nn.Module):
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask
+        # {module name: std}: Gaussian noise added to that module's output (scheduler_type 'uncertainty'); drawn from
+        # activation_noise_source.draw(shape, device)
+        self.activation_noise = None
+        self.activation_noise_source = None
 
     # ---- weight cache hygiene
     def invalidate_packed_weights(self):
@@ -325,12 +342,12 @@ class UNetModel(nn.Module):
         ctx.emb = emb
         h = ops.nchw_to_nhwc(x.float().contiguous(), 4)
         hs = []
-        for module in self.input_blocks:
-            h = module.run(ctx, h)
+        for i, module in enumerate(self.input_blocks):
+            h = module.run(ctx, h, name=f"input_blocks.{i}")
             hs.append(h)
-        h = self.middle_block.run(ctx, h)
-        for module in self.output_blocks:
-            h = module.run(ctx, h, hs.pop())
+        h = self.middle_block.run(ctx, h, name="middle_block")
+        for i, module in enumerate(self.output_blocks):
+            h = module.run(ctx, h, hs.pop(), name=f"output_blocks.{i}")
         gn, conv = self.out[0], self.out[2]
         st = ops.groupnorm_stats(h)
         h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split=ctx.split_acts)

@@ -139,6 +139,15 @@ class DDIMUncertaintyCore(SchedulerMixin, ConfigMixin):
                                  clip_range=self.config.clip_sample_range)
         return eps, prev, x0
 
+    def _coefficients(self, timestep, eta=0.0):
+        """(sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2)) of the DDIM update at ``timestep`` (:462-507)."""
+        prev_timestep = timestep - self.config.num_train_timesteps // self.num_inference_steps
+        alpha_prod_t = self.alphas_cumprod[timestep]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        std_dev_t = eta * self._get_variance(timestep, prev_timestep) ** 0.5
+        return ((1 - alpha_prod_t) ** 0.5, alpha_prod_t ** 0.5, alpha_prod_t_prev ** 0.5,
+                (1 - alpha_prod_t_prev - std_dev_t ** 2) ** 0.5)
+
     def _renoise_next(self, prev_sample, noise, timestep):
         """x_t_hat = sqrt(1-beta_t) x_{t-1} + sqrt(beta_t) noise  (:538)."""
         return ops.axpby(prev_sample, noise, torch.sqrt(1 - self.betas[timestep]), torch.sqrt(self.betas[timestep]))

@@ -133,8 +133,11 @@ def attnblock(sd, p, x, n_heads, new_order):
     return (xf + a).reshape(b, c, hh, ww)
 
 
-def forward(sd, cfg, x, t, y, train=False, drop_p=None):
-    """UNetModel.forward :635-665 -> [B, out_channels, H, W]."""
+def forward(sd, cfg, x, t, y, train=False, drop_p=None, output_hook=None):
+    """UNetModel.forward :635-665 -> [B, out_channels, H, W].
+
+    ``output_hook(name, h) -> h`` is applied to the output of every ResBlock / AttentionBlock / input conv, ``name`` being
+    the torch module name (``input_blocks.8.0`` ...): the forward hooks of scheduling_ddim_uncertainty.py:520-529."""
     assert (y is not None) == (cfg.get("num_classes") is not None), \
         "must specify y if and only if the model is class-conditional"
     drop_p = cfg.get("dropout", 0.0) if drop_p is None else drop_p
@@ -154,6 +157,8 @@ def forward(sd, cfg, x, t, y, train=False, drop_p=None):
                 h = resblock(sd, op[1], h, emb, op[4], drop_p, train)
             else:
                 h = attnblock(sd, op[1], h, op[3], new_order)
+            if output_hook is not None:
+                h = output_hook(op[1], h)
         return h
 
     h, hs = x.float(), []

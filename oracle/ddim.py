@@ -112,3 +112,78 @@ def step_mc_dropout(tab, denoise_train, eps, t, x, n_steps, window, M, eta=0.0, 
         prev = prev + c["sigma"] * draw(eps)
     out.update(prev_sample=prev, pred_original_sample=x0)
     return out
+
+
+def step_uncertainty_image(tab, denoise, eps, t, x, n_steps, window, M, predict_next=False, eta=0.0,
+                           clip_sample=True, draw=torch.randn_like):
+    """scheduling_ddim_uncertainty_image.py:388-543: like ``step_centered`` but every MC prediction is pushed through an
+    unclipped DDIM update (``predict_x_t1`` :545-554) and the map is the unbiased variance of those x_{t-1} (:533)."""
+    prev, x0, c = ddim_update(tab, eps, t, x, n_steps, eta, clip_sample)
+    best_noise = draw(x0)
+    if eta > 0:
+        prev = prev + c["sigma"] * best_noise
+    out = dict(prev_sample=prev, pred_original_sample=x0)
+    hi, lo = window
+    if lo <= t <= hi:
+        xs = []
+        for _ in range(M):
+            noise = draw(x0)
+            x_hat = renoise_next(tab, prev, noise, t) if predict_next else add_noise(tab, x0, noise, t)
+            e = denoise(x_hat, t)
+            x0_m = (x_hat - c["sqrt_b_t"] * e) / c["sqrt_a_t"]
+            xs.append(c["sqrt_a_prev"] * x0_m + c["dir_coef"] * e)
+        out["uncertainty"] = torch.var(torch.stack(xs, 0), dim=0)
+        out["pred_epsilon"] = eps
+    return out
+
+
+def step_uncertainty_hooks(tab, denoise_noisy, eps, t, x, n_steps, window, M, eta=0.0, clip_sample=True,
+                           draw=torch.randn_like):
+    """scheduling_ddim_uncertainty.py:393-552 (scheduler_type 'uncertainty' / 'uncertainty_original'): M forwards of the
+    SAME x_t with Gaussian noise (std 0.01, :37-40) added to the outputs of four named UNet modules (:520-529);
+    ``denoise_noisy(x, t)`` runs the denoiser with those hooks live.  uncertainty = mean_m (eps_m - eps)^2 (:540)."""
+    prev, x0, c = ddim_update(tab, eps, t, x, n_steps, eta, clip_sample)
+    best_noise = draw(x0)
+    if eta > 0:
+        prev = prev + c["sigma"] * best_noise
+    out = dict(prev_sample=prev, pred_original_sample=x0)
+    hi, lo = window
+    if lo <= t <= hi:
+        acc = torch.zeros_like(eps)
+        for _ in range(M):
+            acc += (denoise_noisy(x, t) - eps) ** 2
+        out["uncertainty"] = acc / M
+        out["pred_epsilon"] = eps
+    return out
+
+
+HOOKED_MODULES = ("input_blocks.8.0", "output_blocks.12.0", "output_blocks.1.0", "output_blocks.4.0")     # :522-528
+
+
+def step_centered_d(tab, denoise, eps, t, x, n_steps, window, M, timesteps, uncertainty_distance, eta=0.0,
+                    clip_sample=True, draw=torch.randn_like):
+    """scheduling_ddim_uncertainty_centered_d.py:396-551.  Kept as written: ``alphas_cumprod`` is indexed by the STEP
+    INDEX + distance (:532), not by a timestep, and the denoiser receives the step index ``ending_step`` as its timestep
+    (:528,537-539)."""
+    prev, x0, c = ddim_update(tab, eps, t, x, n_steps, eta, clip_sample)
+    best_noise = draw(x0)
+    if eta > 0:
+        prev = prev + c["sigma"] * best_noise
+    out = dict(prev_sample=prev, pred_original_sample=x0)
+    hi, lo = window
+    if lo <= t <= hi:
+        ts = sorted([int(v) for v in timesteps], reverse=True)
+        idx = ts.index(t)
+        acc = torch.zeros_like(eps)
+        for _ in range(M):
+            noise = draw(x0)
+            d = min(uncertainty_distance, len(ts) - idx - 1)
+            ending_step = idx + d - 1
+            end_alpha = 1 if ts[idx + d] == 0 else tab.alphas_cumprod[idx + d]
+            true_alpha = c["a_t"] / end_alpha
+            x_next = (x - (1 - true_alpha) ** 0.5 * eps) / true_alpha ** 0.5
+            x_hat = x_next * true_alpha ** 0.5 + (1 - true_alpha) ** 0.5 * noise
+            acc += (denoise(x_hat, ending_step) - eps) ** 2
+        out["uncertainty"] = acc / M
+        out["pred_epsilon"] = eps
+    return out

@@ -446,7 +446,61 @@ def g10():
     save("g10_posterior_pipeline", **out)
 
 
+DEEP_ADM = dict(TINY_ADM, channel_mult=(1, 1, 2, 2), num_res_blocks=3, attention_resolutions=(4,))   # has input_blocks.8, output_blocks.12
+
+
+def g11():
+    """Remaining forward-only estimators: uncertainty (activation-noise hooks), uncertainty_image,
+    uncertainty_centered_d - step() of the reference's own scheduler classes on a seeded noise tape."""
+    with _quiet:
+        from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_uncertainty import \
+            DDIMSchedulerUncertaintyImagenetClassConditioned as RefHooks
+        from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_uncertainty_image import \
+            DDIMSchedulerUncertaintyImagenetClassConditioned as RefImage
+        from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_uncertainty_centered_d import \
+            DDIMSchedulerUncertaintyImagenetClassConditioned as RefCenteredD
+    out = {}
+    x, y = randn(111, 2, 3, 16, 16), torch.tensor([3, 7])
+    out["x"], out["y"] = x, y
+    deep = build_adm(DEEP_ADM, seed=6)
+    names = [n for n, _ in deep.named_modules()]
+    assert all(n in names for n in ("input_blocks.8.0", "output_blocks.12.0", "output_blocks.1.0", "output_blocks.4.0"))
+    case = 0
+    for kind in ("hooks", "image_x0", "image_next", "centered_d1", "centered_d3"):
+        for M, t in ((2, 500), (3, 400), (2, 300)):
+            with _quiet:
+                kw = dict(M=M, after_step=4, num_steps_uc=3, unet=deep)
+                if kind == "hooks":
+                    s = RefHooks.from_config(CONFIGS["adm128"], predict_next=False, y=None, **kw)
+                elif kind.startswith("image"):
+                    s = RefImage.from_config(CONFIGS["adm128"], predict_next=(kind == "image_next"), y=None, **kw)
+                else:
+                    s = RefCenteredD.from_config(CONFIGS["adm128"], uncertainty_distance=int(kind[-1]), **kw)
+                s.set_timesteps(10)
+                s.prompt_embeds = y
+                with torch.no_grad():
+                    tv = torch.full((2,), t, dtype=torch.long)
+                    eps = deep(x, tv, y=y)[:, :3]
+                    torch.manual_seed(3000 + case)
+                    o = s.step(eps, t, x)
+            out[f"c{case}_meta"] = np.array([kind, str(M), str(t), str(3000 + case)])
+            out[f"c{case}_eps"], out[f"c{case}_prev"], out[f"c{case}_unc"] = eps, o.prev_sample, o.uncertainty
+            case += 1
+    out["n_cases"] = case
+    # driver run with the centered_d estimator close to the end of the grid (effective distance clamps, end alpha = 1)
+    X_T, yy = randn(112, 3, 3, 16, 16), torch.tensor([1, 2, 3])
+    out["X_T"], out["yy"] = X_T, yy
+    with _quiet:
+        s = RefCenteredD.from_config(CONFIGS["adm128"], M=2, after_step=7, num_steps_uc=3, unet=deep, uncertainty_distance=2)
+        s.set_timesteps(10)
+        torch.manual_seed(0)
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, yy, 2, torch.device("cpu"), deep, s)
+    for k in ("gen_images", "uncertainty", "score"):
+        out[f"drv_{k}"] = r[k]
+    save("g11_more_estimators", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -444,3 +444,50 @@ def test_posterior_pipelines_vs_golden(golden):
     assert (d > 1).mean() < 2e-2, ((d > 1).mean(), d.max())
     with pytest.raises(AssertionError):
         Guided(m, s, 1.5, 16, torch.device(dev), 3, 0)
+
+
+DEEP_ADM = dict(TINY_ADM, channel_mult=(1, 1, 2, 2), num_res_blocks=3, attention_resolutions=(4,))
+
+
+def test_more_estimators_vs_golden(golden):
+    """uncertainty (activation-noise hooks) / uncertainty_image / uncertainty_centered_d: step() vs the reference's step()."""
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    g = golden("g11_more_estimators")
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    m, _ = build_adm(DEEP_ADM, 6)
+
+    def sched(kind, M, **kw):
+        a = argparse.Namespace(scheduler_type=kind, M=M, start_step_uc=kw.get("start", 4), num_steps_uc=3,
+                               predict_next=kw.get("predict_next", False), eta=0.0, num_zigzag=3,
+                               uncertainty_distance=kw.get("d", 1))
+        s = get_uncertainty_scheduler(a, None, m, init_scheduler_imagenet128())
+        s.set_timesteps(10)
+        return s
+
+    for c in range(int(g["n_cases"])):
+        kind, M, t, seed = g[f"c{c}_meta"]
+        M, t = int(M), int(t)
+        if kind == "hooks":
+            s = sched("uncertainty", M)
+        elif kind.startswith("image"):
+            s = sched("uncertainty_image", M, predict_next=(kind == "image_next"))
+        else:
+            s = sched("uncertainty_centered_d", M, d=int(kind[-1]))
+        s.prompt_embeds = y
+        torch.manual_seed(int(seed))
+        o = s.step(T(g[f"c{c}_eps"]).to(dev), t, x)                   # teacher-forced eps
+        np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"c{c}_prev"], rtol=1e-6, atol=1e-6)
+        u, ref = o.uncertainty.cpu().numpy(), g[f"c{c}_unc"]
+        assert np.abs(u - ref).max() <= 5e-2 * ref.max(), (kind, np.abs(u - ref).max(), ref.max())
+        assert np.median(np.abs(u - ref) / (ref + 1e-12)) < 2e-2, kind
+        assert s.denoiser_calls == M and m.activation_noise is None      # hooks removed after the step
+    s = sched("uncertainty_centered_d", 2, start=7, d=2)
+    torch.manual_seed(0)
+    r = gen(T(g["X_T"]), T(g["yy"]), 2, torch.device(dev), m, s)
+    np.testing.assert_allclose(r["score"].numpy(), g["drv_score"], rtol=0, atol=5e-3)
+    ref = g["drv_uncertainty"]
+    assert np.abs(r["uncertainty"].numpy() - ref).max() <= 5e-2 * ref.max()
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["drv_gen_images"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-2

@@ -48,8 +48,17 @@ def test_factory_semantics():
         assert isinstance(s, SchedulerUncertaintyMixin) and isinstance(s, SchedulerUncertaintyClassConditionedMixin)
     u = load_uvit_scheduler()
     assert "set_alpha_to_one" not in u.config and u.config.steps_offset == 1 and u.config.clip_sample is False
-    with pytest.raises(NotImplementedError):
-        get_uncertainty_scheduler(args("uncertainty_centered_d"), y, None, base)
+    for kind in ("flip", "flip_grad", "dpm_2_uncertainty_centered"):
+        with pytest.raises(NotImplementedError):
+            get_uncertainty_scheduler(args(kind), y, None, base)
+    d = get_uncertainty_scheduler(args("uncertainty_centered_d", uncertainty_distance=3), y, None, base)
+    assert d.prompt_embeds is None and d.uncertainty_distance == 3       # y= is dropped: this __init__ takes prompt_embed
+    d.set_timesteps(10)
+    assert d.timestep_index[900] == 0 and d.index_timestep[9] == 0
+    im = get_uncertainty_scheduler(args("uncertainty_image", predict_next=True), y, None, base)
+    assert im.predict_next is True and im.prompt_embeds is y
+    assert get_uncertainty_scheduler(args("uncertainty_original", predict_next=True), y, None, base).predict_next is False
+    assert type(get_uncertainty_scheduler(args("uncertainty"), y, None, base)).__module__.endswith("scheduling_ddim_uncertainty")
 
 
 def test_mc_dropout_factory_overrides_dropout_p():

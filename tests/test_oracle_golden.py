@@ -325,3 +325,37 @@ def test_g10_pipelines(golden):
         diff = np.abs(out.numpy().astype(int) - ref.astype(int))
         assert (diff > 1).mean() < 2e-3, (name, (diff > 1).mean(), diff.max())
         assert np.abs(ref.astype(int) - g["plain_gen_images"].astype(int)).max() > 1      # guidance changed the images
+
+
+DEEP_ADM = dict(TINY_ADM, channel_mult=(1, 1, 2, 2), num_res_blocks=3, attention_resolutions=(4,))
+
+
+def test_g11_more_estimators(golden):
+    g = golden("g11_more_estimators")
+    x, y = T(g["x"]), T(g["y"])
+    sd = tiny_adm(DEEP_ADM, seed=6)
+    tab = TABLES["adm128"]()
+    ts = schedule.leading_timesteps(1000, 10)
+    window = schedule.uc_window(ts, 4, 3)
+
+    def den(xx, t, hook=None):
+        tv = torch.full((xx.shape[0],), int(t), dtype=torch.long)
+        return adm.forward(sd, DEEP_ADM, xx, tv, y, output_hook=hook)[:, :3]
+
+    def noisy(name, h):                                    # add_gaussian_noise, scheduling_ddim_uncertainty.py:36-40
+        return h + torch.randn_like(h) * 0.01 if name in ddim.HOOKED_MODULES else h
+
+    for c in range(int(g["n_cases"])):
+        kind, M, t, seed = g[f"c{c}_meta"]
+        M, t = int(M), int(t)
+        eps = T(g[f"c{c}_eps"])
+        np.testing.assert_allclose(den(x, t).numpy(), g[f"c{c}_eps"], rtol=1e-5, atol=2e-6)
+        torch.manual_seed(int(seed))
+        if kind == "hooks":
+            o = ddim.step_uncertainty_hooks(tab, lambda a, b: den(a, b, noisy), eps, t, x, 10, window, M)
+        elif kind.startswith("image"):
+            o = ddim.step_uncertainty_image(tab, den, eps, t, x, 10, window, M, predict_next=(kind == "image_next"))
+        else:
+            o = ddim.step_centered_d(tab, den, eps, t, x, 10, window, M, ts, int(kind[-1]))
+        np.testing.assert_array_equal(o["prev_sample"].numpy(), g[f"c{c}_prev"])
+        np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"c{c}_unc"], rtol=2e-3, atol=1e-8, err_msg=str(kind))
