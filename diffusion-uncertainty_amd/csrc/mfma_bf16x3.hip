@@ -422,6 +422,72 @@ struct DConvP {
 //   NT = 4: 256 x 256 (half the L2->LDS bytes per MFMA); activation ring 3 x 32 KB + weight ring 2 x 32 KB = the whole
 //           160 KB of LDS: the activation operand (unique per workgroup, the one that misses L2) is requested two
 //           tiles ahead, the L2-resident weight panel one tile ahead.
+// Row epilogue of a FULL 256 x (64*NT) tile, specialised at compile time (no per-row predicates, no run-time branches in
+// the row loop).  Each wave re-lays one 32 x (32*NT) half of its accumulators as rows in a private LDS patch (pitch +8
+// floats: the two half-waves write rows 4 apart and must land on different banks), then moves whole rows, 16 B per lane.
+// All residual rows of the half are requested BEFORE the transposition so that their latency runs under it (read one by
+// one they cost a full memory round trip per row group: 55k of the 87k epilogue cycles of a 256x256 tile).
+template <int ACT, bool RES, bool SPLIT>
+__device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const float4 q, const float4 bq, long o, float4& cs, float4& cq) {
+    w.x += bq.x; w.y += bq.y; w.z += bq.z; w.w += bq.w;
+    if (ACT == 2) { w.x = gelu_x(w.x); w.y = gelu_x(w.y); w.z = gelu_x(w.z); w.w = gelu_x(w.w); }
+    if (RES) { w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
+    if (SPLIT) {               // the consumer is another bf16x3 GEMM: hand it the operand format directly
+        bf16x4 hi, lo;
+        split4(w, hi, lo);
+        *(bf16x4*)(p.Csplit + o) = hi;
+        *(bf16x4*)(p.Csplit + o + (long)p.M * p.N) = lo;
+    } else {
+        *(float4*)(p.C + o) = w;
+    }
+    cs.x += w.x; cs.y += w.y; cs.z += w.z; cs.w += w.w;
+    cq.x += w.x * w.x; cq.y += w.y * w.y; cq.z += w.z * w.z; cq.w += w.w * w.w;
+}
+
+template <int NT, bool RES, int ACT, bool SPLIT>
+__device__ __forceinline__ void dconv_rows_full(const DConvP& p, f32x16 (&acc)[2][NT], float* patch, int lane, int row0, int colq,
+                                                float4 bq, float4& cs, float4& cq) {
+    constexpr int WC = 32 * NT, WCP = WC + 8, RPI = 64 / (WC / 4), NIT = 32 / RPI;
+    const int c4 = lane % (WC / 4), rr = lane / (WC / 4), lr = lane & 31, kh = lane >> 5;
+    const long rstep = (long)RPI * p.N;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* rd = patch + rr * WCP + 4 * c4;
+    float* wr = patch + (4 * kh) * WCP + lr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const long rb = (long)(row0 + mi * 32 + rr) * p.N + colq;
+        // the residual rows of this half are requested before the transposition: their latency runs under it
+        float4 q[RES ? NIT : 1];
+        if (RES) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) q[it] = *(const float4*)(p.res + rb + it * rstep);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * WCP + ni * 32] = acc[mi][ni][r];
+        // same-wave LDS write -> read: in-order LDS queue, no barrier needed
+#pragma unroll
+        for (int g = 0; g < NIT; g += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(rd + (g + u) * RPI * WCP);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dconv_row_out<ACT, RES, SPLIT>(p, v[u], RES ? q[g + u] : z4, bq, rb + (g + u) * rstep, cs, cq);
+        }
+    }
+}
+
+#ifdef DUA_CONV_TIMING   // diagnostic build only (scratch/): shader-clock stamps of the tile phases of every workgroup
+__device__ unsigned long long dua_tt[256 * 8 * 4];
+extern "C" int dua_debug_tile_times(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(dua_tt), sizeof(unsigned long long) * 256 * 8 * 4) == hipSuccess ? 0 : 1;
+}
+#define DUA_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 256 && (ti - slot) / nslot < 8) dua_tt[(blockIdx.x * 8 + (ti - slot) / nslot) * 4 + (k)] = clock64();
+#else
+#define DUA_STAMP(k)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
@@ -447,6 +513,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const int lid = chunk0 + ti;
     const int tn = lid % p.ntn, tm = lid / p.ntn;
     const int m0 = tm * DBM, n0 = tn * DBN;
+    DUA_STAMP(0)
 
     // ---- DMA geometry.  One wave instruction = 16 rows x 4 chunks of 16 B.  Wave w stages A row groups 2w, 2w+1
     // (both planes) and B row groups (NT/2)*w .. (both planes).
@@ -532,26 +599,43 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
-    struct DFrag { bf16x8 ah[2], al[2], bh[NT], bl[NT]; };
-    auto read_frag = [&](int sa, int sb, int s) -> DFrag {
-        DFrag f;
-        const int cs = 8 * ((2 * s + kh) ^ ((lr >> 2) & 3));
-        const __bf16* a = lds + sa * 2 * SA + (wm * 64 + lr) * LDH + cs;
-        const __bf16* b = lds + BOFF + sb * 2 * SB + (wn * 32 * NT + lr) * LDH + cs;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f.ah[i] = *(const bf16x8*)(a + 32 * i * LDH);
-            f.al[i] = *(const bf16x8*)(a + SA + 32 * i * LDH);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            f.bh[j] = *(const bf16x8*)(b + 32 * j * LDH);
-            f.bl[j] = *(const bf16x8*)(b + SB + 32 * j * LDH);
-        }
-        return f;
-    };
+    // Fragment registers of ONE half step (16 of the 32 K columns of a stage); they are refilled in place while the
+    // MFMA group that no longer needs them is executing, so the matrix pipe always has a full group queued when the
+    // next one's operands arrive (no extra registers: the accumulators already take 128 of the 256):
+    //   reload ah           | T1 lo*hi (al, bh)
+    //   reload bl           | T2 hi*hi (ah, bh)
+    //   reload al, bh (NEXT half step; free since T1 / T2 were issued) | T3 hi*lo (ah, bl)
+    // Each reload is issued just before the MFMA group that precedes its consumer, so its LDS latency runs under that
+    // group.  The barrier that publishes stage kt+1 therefore sits before T3 of the second half step of step kt.
+    bf16x8 ah[2], al[2], bh[NT], bl[NT];
+    const int csw0 = 8 * ((0 + kh) ^ ((lr >> 2) & 3)), csw1 = 8 * ((2 + kh) ^ ((lr >> 2) & 3));
+    const __bf16* abase_l = lds + (wm * 64 + lr) * LDH;
+    const __bf16* bbase_l = lds + BOFF + (wn * 32 * NT + lr) * LDH;
+#define FR_A(st, s) (abase_l + (st) * 2 * SA + ((s) ? csw1 : csw0))
+#define FR_B(st, s) (bbase_l + (st) * 2 * SB + ((s) ? csw1 : csw0))
+#define LD_AH(st, s) { const __bf16* a_ = FR_A(st, s); ah[0] = *(const bf16x8*)a_; ah[1] = *(const bf16x8*)(a_ + 32 * LDH); }
+#define LD_AL(st, s) { const __bf16* a_ = FR_A(st, s) + SA; al[0] = *(const bf16x8*)a_; al[1] = *(const bf16x8*)(a_ + 32 * LDH); }
+#define LD_BH(st, s) { const __bf16* b_ = FR_B(st, s); _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) bh[j_] = *(const bf16x8*)(b_ + 32 * j_ * LDH); }
+#define LD_BL(st, s) { const __bf16* b_ = FR_B(st, s) + SB; _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) bl[j_] = *(const bf16x8*)(b_ + 32 * j_ * LDH); }
+#define MM(AV, BV)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)          \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[i_], BV[j_], acc[i_][j_], 0, 0, 0);
+    // DMA pieces of the step, a few per MFMA group (an LDS-DMA issue holds the wave ~60-180 cycles), front-loaded:
+    // NT = 4: [B0..B3 | A0..A3 | - ...]; NT = 2: [A0 A1 | A2 A3 | B0 B1 | - ...]
+#define DMA_GROUP()                                                                   \
+    _Pragma("unroll") for (int u_ = 0; u_ < (NT == 4 ? 4 : 2); ++u_) {                \
+        if (NT == 4) {                                                                \
+            if (piece < 4) { if (preB) dma_b(sbn, piece); }                           \
+            else if (piece < 8) { if (preA) dma_a(sa2, piece - 4); }                  \
+        } else {                                                                      \
+            if (piece < 4) { if (preA) dma_a(sa2, piece); }                           \
+            else if (piece < 6) { if (preB) dma_b(sbn, piece - 4); }                  \
+        }                                                                             \
+        ++piece;                                                                      \
+    }
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
 
-    // In-order vmcnt: at the end of step kt everything older than the pieces that may stay in flight must have landed.
+    // In-order vmcnt: when stage kt+1 is published everything older than the pieces that may stay in flight must have landed.
     //   NT = 4: order per step  B(kt+1) x4, A(kt+2) x4  -> wait vmcnt(4) keeps only A(kt+2) outstanding;
     //   NT = 2: order per step  A(kt+2) x4, B(kt+2) x2  -> wait vmcnt(6).
     constexpr int KEEP = NT == 4 ? 4 : 6;
@@ -566,7 +650,10 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     }
     DWAIT_TILE(nk > 1)
     __builtin_amdgcn_s_barrier();
+    DUA_STAMP(1)
     int sa = 0, sb = 0;
+    LD_AL(0, 0)
+    LD_BH(0, 0)
     for (int kt = 0; kt < nk; ++kt) {
         int sa2 = sa + 2;                                // activation stage of tile kt+2
         if (sa2 >= RA) sa2 -= RA;
@@ -576,52 +663,80 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         const bool preB = NT == 4 ? kt + 1 < nk : kt + 2 < nk;
         if (preA) dma_setup();
         int piece = 0;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            DFrag f = read_frag(sa, sb, s);
-            __builtin_amdgcn_sched_barrier(0);       // keep the fragment reads in flight ahead of the MFMA stream
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {   // lo*hi, hi*lo, hi*hi
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const bf16x8 av = term == 0 ? f.al[i] : f.ah[i];
-                        const bf16x8 bv = term == 1 ? f.bl[j] : f.bh[j];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                // DMA pieces of the step, a few per MFMA group (an LDS-DMA issue holds the wave ~60-180 cycles), front-loaded:
-                // NT = 4: [B0..B3 | A0..A3 | - ...]; NT = 2: [A0 A1 | A2 A3 | B0 B1 | - ...]
-                constexpr int PER = NT == 4 ? 4 : 2;
-#pragma unroll
-                for (int u = 0; u < PER; ++u) {
-                    if (NT == 4) {
-                        if (piece < 4) { if (preB) dma_b(sbn, piece); }
-                        else if (piece < 8) { if (preA) dma_a(sa2, piece - 4); }
-                    } else {
-                        if (piece < 4) { if (preA) dma_a(sa2, piece); }
-                        else if (piece < 6) { if (preB) dma_b(sbn, piece - 4); }
-                    }
-                    ++piece;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        SBAR();
+        // ---- K columns 0..15 of the stage.  Every reload is issued one MFMA group AHEAD of its consumer.
+        LD_AH(sa, 0) SBAR(); MM(al, bh) SBAR(); DMA_GROUP() SBAR();
+        LD_BL(sb, 0) SBAR(); MM(ah, bh) SBAR(); DMA_GROUP() SBAR();
+        LD_AL(sa, 1) LD_BH(sb, 1) SBAR(); MM(ah, bl) SBAR(); DMA_GROUP() SBAR();
+        // ---- K columns 16..31
+        LD_AH(sa, 1) SBAR(); MM(al, bh) SBAR(); DMA_GROUP() SBAR();
+        LD_BL(sb, 1) SBAR(); MM(ah, bh) SBAR(); DMA_GROUP() SBAR();
+        // every LDS read of stage kt has been issued; let them land, then publish stage kt+1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         DWAIT_TILE(preA)
         __builtin_amdgcn_s_barrier();
         if (++sa == RA) sa = 0;
         if (++sb == RB) sb = 0;
+        SBAR();
+        LD_AL(sa, 0) LD_BH(sb, 0) SBAR(); MM(ah, bl) SBAR();   // (after the last step: a harmless read of a stale stage)
     }
+#undef FR_A
+#undef FR_B
+#undef LD_AH
+#undef LD_AL
+#undef LD_BH
+#undef LD_BL
+#undef MM
+#undef DMA_GROUP
+#undef SBAR
 
-    if (!p.nchw_out && (p.N & 3) == 0) {
-        // ---- epilogue through LDS: each wave re-lays its 32 x (32*NT) half tile as rows in a private LDS patch
+    DUA_STAMP(2)
+    // The epilogue's lane-derived addresses must not be hoisted above the K loop (the loop owns every VGPR: hoisted
+    // values end up in scratch, and their reload waits on vmcnt(0), i.e. on the whole DMA pipeline).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lr_e = lane_e & 31, kh_e = lane_e >> 5;
+    const bool full_tile = m0 + DBM <= p.M && n0 + DBN <= p.N && !p.nchw_out && !(p.res && (p.act_out == 2 || p.Csplit));
+    if (full_tile) {
+        constexpr int WC = 32 * NT, WCP = WC + 8;
+        float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WCP);
+        const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);
+        const int colq = n0 + wn * WC + 4 * c4;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bq = *(const float4*)(p.bias + colq);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
+        const int row0 = m0 + wm * 64;
+        if (p.Csplit) {
+            if (p.act_out == 2) dconv_rows_full<NT, false, 2, true>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            else dconv_rows_full<NT, false, 0, true>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+        } else if (p.res) {
+            dconv_rows_full<NT, true, 0, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+        } else if (p.act_out == 2) {
+            dconv_rows_full<NT, false, 2, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+        } else {
+            dconv_rows_full<NT, false, 0, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+        }
+        if (p.colsum) {   // GroupNorm statistics of the NEXT layer: fold the row lanes, one float4 store per column quad
+            float t[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (NT == 2) t[j] += __shfl_xor(t[j], 16);
+                t[j] += __shfl_xor(t[j], 32);
+            }
+            if (rr == 0) {
+                float* o = p.colsum + (long)(row0 >> 6) * 2 * p.N + colq;
+                *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
+                *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
+            }
+        }
+    } else if (!p.nchw_out && (p.N & 3) == 0) {
+        // ---- edge tiles: same scheme with per-row / per-column predicates.  Epilogue through LDS: each wave re-lays its 32 x (32*NT) half tile as rows in a private LDS patch
         // (the K loop's last barrier has retired every read of the stages), then moves whole rows: 16 B per lane,
         // 128*NT contiguous bytes per row for the residual read and the output store (the accumulator layout itself
         // would give 4-byte accesses in 128 B runs, which made the residual read cost as much as a third of the kernel).
         constexpr int WC = 32 * NT;                       // columns of a wave tile
         float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WC);
-        const int c4 = lane % (WC / 4), rr = lane / (WC / 4);          // float4 column, row within a group
+        const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);          // float4 column, row within a group
         constexpr int RPI = 64 / (WC / 4);                // rows per wave instruction (4 for NT=2, 2 for NT=4)
         const int colq = n0 + wn * WC + 4 * c4;
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -633,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    patch[((r & 3) + 8 * (r >> 2) + 4 * kh) * WC + ni * 32 + lr] = acc[mi][ni][r];
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * kh_e) * WC + ni * 32 + lr_e] = acc[mi][ni][r];
             // same-wave LDS write -> read: in-order LDS queue, no barrier needed
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
@@ -679,12 +794,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         for (int mi = 0; mi < 2; ++mi)
     #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
-                const int col = n0 + wn * 32 * NT + ni * 32 + lr;
+                const int col = n0 + wn * 32 * NT + ni * 32 + lr_e;
                 if (col >= p.N) continue;
                 const float bv = p.bias ? p.bias[col] : 0.f;
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_e;
                     if (row >= p.M) continue;
                     float v = acc[mi][ni][r] + bv;
                     if (p.res) v += p.res[(long)row * p.N + col];
@@ -698,6 +813,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             }
         }
     __builtin_amdgcn_s_barrier();      // every wave is done with this tile's LDS stages before the next tile's DMA
+    DUA_STAMP(3)
   }
 #endif
 }
