@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
     allimgs = gather_images(imgs)
     t = max_over_ranks(1.0 + rank, "cpu")
     dist.barrier()
-    q.put((rank, lo, hi, allimgs, t))
+    q.put((rank, lo, hi, allimgs.numpy(), t))        # numpy: pickled by value (a torch tensor travels as an fd the
+                                                     # worker may close on exit before the parent receives it)
     dist.destroy_process_group()
 
 
@@ -50,7 +51,7 @@ def test_two_rank_sharding_and_collation():
     ref = (X[:6].clamp(-1, 1) * 127 + 128).to(torch.uint8).reshape(2, 3, 3, 4, 4)
     assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 6)]
     for r in res:
-        assert torch.equal(r[3], ref)                        # every rank holds the full collation, in rank order
+        assert torch.equal(torch.from_numpy(r[3]), ref)                        # every rank holds the full collation, in rank order
         assert r[4] == 2.0                                   # max over ranks
 
 
