@@ -29,6 +29,8 @@ SIGNATURES = {
     "dua_last_error": (_c.c_char_p, []),
     "dua_ddim_step": (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P]),
     "dua_axpby": (_I, [_P, _P, _P, _Z, _F, _F, _P]),
+    "dua_x0_from_eps": (_I, [_P, _P, _P, _Z, _F, _F, _P]),
+    "dua_dpmpp_2m_update": (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P]),
     "dua_mc_centered_accum": (_I, [_P, _P, _P, _Z, _I, _I, _P]),
     "dua_mc_reduce_centered": (_I, [_P, _P, _P, _Z, _I, _P]),
     "dua_mc_reduce_var": (_I, [_P, _P, _Z, _I, _P]),

@@ -86,6 +86,58 @@ extern "C" int dua_axpby(const float* src, const float* noise, float* out, size_
     return dua_check_launch("dua_axpby");
 }
 
+// ---- DPM-Solver++ (multistep, order <= 2): scheduling_dpm_2_uncertainty_centered.py:523-528,624-632,716-727 ----
+// x0 = (x - sigma_t * eps) / alpha_t  (convert_model_output, epsilon prediction)
+__global__ __launch_bounds__(BLK) void k_x0_from_eps(const float* __restrict__ eps, const float* __restrict__ x,
+                                                     float* __restrict__ o, size_t n, float st, float at, int vec) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t n4 = n / 4; i < n4; i += stride) {
+            float4 e = ((const float4*)eps)[i], xv = ((const float4*)x)[i];
+            ((float4*)o)[i] = make_float4((xv.x - st * e.x) / at, (xv.y - st * e.y) / at, (xv.z - st * e.z) / at, (xv.w - st * e.w) / at);
+        }
+    } else {
+        for (; i < n; i += stride) o[i] = (x[i] - st * eps[i]) / at;
+    }
+}
+extern "C" int dua_x0_from_eps(const float* eps, const float* x, float* x0, size_t n, float sigma_t, float alpha_t, void* stream) {
+    if (n == 0) return DUA_OK;
+    DUA_REQUIRE(eps && x && x0, "dua_x0_from_eps: null pointer");
+    int vec = (n % 4 == 0) && aligned16(eps) && aligned16(x) && aligned16(x0);
+    hipLaunchKernelGGL(k_x0_from_eps, stream_grid(vec ? n / 4 : n, BLK), BLK, 0, as_stream(stream), eps, x, x0, n, sigma_t, alpha_t, vec);
+    return dua_check_launch("dua_x0_from_eps");
+}
+
+// second-order multistep update, midpoint form (:716-727), in the reference's operation order:
+//   D1 = rinv * (m0 - m1);  x_t = (c1 * sample - c2 * m0) - c3 * D1      (c3 = 0.5 * c2, evaluated on the host in fp32)
+__global__ __launch_bounds__(BLK) void k_dpmpp_2m(const float* __restrict__ s, const float* __restrict__ m0,
+                                                  const float* __restrict__ m1, float* __restrict__ o, size_t n, float c1,
+                                                  float c2, float c3, float rinv, int vec) {
+    auto one = [&](float sv, float a, float b) -> float {
+        float d1 = rinv * (a - b);
+        return (c1 * sv - c2 * a) - c3 * d1;
+    };
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        for (size_t n4 = n / 4; i < n4; i += stride) {
+            float4 sv = ((const float4*)s)[i], a = ((const float4*)m0)[i], b = ((const float4*)m1)[i];
+            ((float4*)o)[i] = make_float4(one(sv.x, a.x, b.x), one(sv.y, a.y, b.y), one(sv.z, a.z, b.z), one(sv.w, a.w, b.w));
+        }
+    } else {
+        for (; i < n; i += stride) o[i] = one(s[i], m0[i], m1[i]);
+    }
+}
+extern "C" int dua_dpmpp_2m_update(const float* sample, const float* m0, const float* m1, float* out, size_t n, float c1,
+                                   float c2, float c3, float rinv, void* stream) {
+    if (n == 0) return DUA_OK;
+    DUA_REQUIRE(sample && m0 && m1 && out, "dua_dpmpp_2m_update: null pointer");
+    int vec = (n % 4 == 0) && aligned16(sample) && aligned16(m0) && aligned16(m1) && aligned16(out);
+    hipLaunchKernelGGL(k_dpmpp_2m, stream_grid(vec ? n / 4 : n, BLK), BLK, 0, as_stream(stream), sample, m0, m1, out, n, c1, c2, c3, rinv, vec);
+    return dua_check_launch("dua_dpmpp_2m_update");
+}
+
 // ---- centred second moment ---------------------------------------------------------------------
 __global__ __launch_bounds__(BLK) void k_mc_accum(const float* __restrict__ em, const float* __restrict__ e,
                                                   float* __restrict__ acc, size_t n, int first, int last, float Mf) {

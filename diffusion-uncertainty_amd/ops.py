@@ -61,6 +61,25 @@ def axpby(src, noise, a, b, out=None):
     return out
 
 
+def x0_from_eps(eps, x, sigma_t, alpha_t):
+    """(x - sigma_t*eps) / alpha_t  (DPM-Solver++ data prediction)."""
+    _req(eps, name="eps"), _req(x, name="x")
+    assert eps.shape == x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().dua_x0_from_eps(_p(eps), _p(x), _p(out), x.numel(), float(sigma_t), float(alpha_t), _stream()), "dua_x0_from_eps")
+    return out
+
+
+def dpmpp_2m_update(sample, m0, m1, c1, c2, c3, rinv):
+    """(c1*sample - c2*m0) - c3*(rinv*(m0 - m1))  (second-order multistep DPM-Solver++, midpoint)."""
+    _req(sample, name="sample"), _req(m0, name="m0"), _req(m1, name="m1")
+    assert sample.shape == m0.shape == m1.shape
+    out = torch.empty_like(sample)
+    check(_lib.lib().dua_dpmpp_2m_update(_p(sample), _p(m0), _p(m1), _p(out), sample.numel(), float(c1), float(c2), float(c3),
+                                         float(rinv), _stream()), "dua_dpmpp_2m_update")
+    return out
+
+
 def mc_centered_accum(eps_m, eps, acc, m, M):
     _req(eps_m, name="eps_m"), _req(eps, name="eps"), _req(acc, name="acc")
     check(_lib.lib().dua_mc_centered_accum(_p(eps_m), _p(eps), _p(acc), eps.numel(), int(m), int(M), _stream()),

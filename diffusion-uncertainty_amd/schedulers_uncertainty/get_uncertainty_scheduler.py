@@ -1,18 +1,19 @@
 """Scheduler factory keyed on ``args.scheduler_type`` (reference
 schedulers_uncertainty/get_uncertainty_scheduler.py:13-40).  The forward-only estimators are built here
 (zigzag_centered, centered, mc_dropout: the hot path; uncertainty / uncertainty_original / uncertainty_image /
-uncertainty_centered_d: SURVEY 8f rank 4).  ``flip`` (its class-conditioned class keeps the diffusers-style
-``predict_model`` and cannot call an ADM / U-ViT denoiser upstream), ``flip_grad`` (needs denoiser backward) and
-``dpm_2_uncertainty_centered`` raise instead of silently falling back."""
+uncertainty_centered_d, dpm_2_uncertainty_centered: SURVEY 8f rank 4).  ``flip`` (its class-conditioned class keeps the
+diffusers-style ``predict_model`` and cannot call an ADM / U-ViT denoiser upstream) and ``flip_grad`` (needs denoiser
+backward) raise instead of silently falling back."""
 from .scheduling_ddim_mc_dropout import DDIMSchedulerUncertaintyImagenetClassConditioned as DDIMSchedulerUncertaintyImagenetClassConditionedMCDropout
 from .scheduling_ddim_uncertainty import DDIMSchedulerUncertaintyImagenetClassConditioned as DDIMSchedulerUncertaintyUncertainty
 from .scheduling_ddim_uncertainty_centered_d import DDIMSchedulerUncertaintyImagenetClassConditioned as DDIMSchedulerUncertaintyUncertaintyCenteredD
 from .scheduling_ddim_uncertainty_image import DDIMSchedulerUncertaintyImagenetClassConditioned as DDIMSchedulerUncertaintyUncertaintyImage
 from .scheduling_ddim_uncertainty_centered import DDIMSchedulerUncertaintyImagenetClassConditioned as DDIMSchedulerUncertaintyUncertaintyCentered
+from .scheduling_dpm_2_uncertainty_centered import KDPM2SchedulerUncertaintyImagenetClassConditioned as DPM2UncertaintyCentered
 from .scheduling_ddim_uncertainty_zigzag_centered import DDIMSchedulerUncertaintyImagenetClassConditioned as DDIMSchedulerUncertaintyUncertaintyZigZagCentered
 
 DDIMSchedulerUncertaintyUncertaintyOriginal = DDIMSchedulerUncertaintyUncertainty
-_UNSUPPORTED = ("flip", "flip_grad", "dpm_2_uncertainty_centered")
+_UNSUPPORTED = ("flip", "flip_grad")
 
 
 def get_uncertainty_scheduler(args, y, unet, scheduler):
@@ -40,10 +41,14 @@ def get_uncertainty_scheduler(args, y, unet, scheduler):
         return DDIMSchedulerUncertaintyUncertaintyCenteredD.from_config(
             scheduler.config, M=args.M, after_step=args.start_step_uc, num_steps_uc=args.num_steps_uc, unet=unet, y=y,
             eta=args.eta, uncertainty_distance=args.uncertainty_distance)
+    if args.scheduler_type == "dpm_2_uncertainty_centered":
+        return DPM2UncertaintyCentered.from_config(
+            scheduler.config, M=args.M, after_step=args.start_step_uc, num_steps_uc=args.num_steps_uc, unet=unet, y=y,
+            eta=args.eta)
     if args.scheduler_type in _UNSUPPORTED:
         raise NotImplementedError(f"scheduler_type={args.scheduler_type!r} is outside the accelerated hot path "
                                   "(built: uncertainty_zigzag_centered, uncertainty_centered, mc_dropout, uncertainty, "
-                                  "uncertainty_original, uncertainty_image, uncertainty_centered_d)")
+                                  "uncertainty_original, uncertainty_image, uncertainty_centered_d, dpm_2_uncertainty_centered)")
     # the reference's catch-all else-branch (:33-34) is MC dropout
     return DDIMSchedulerUncertaintyImagenetClassConditionedMCDropout.from_config(
         scheduler.config, prompt_embeds=y, unet=unet, M=args.M, after_step=args.start_step_uc,

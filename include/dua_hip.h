@@ -47,6 +47,18 @@ int dua_ddim_step(const float* eps, const float* x, const float* noise, float* p
  * DDPM add_noise (:575-604) and the SD guidance re-noise (uncertainty_guidance.py:88). */
 int dua_axpby(const float* src, const float* noise, float* out, size_t n, float a, float b, void* stream);
 
+/* DPM-Solver++ data prediction from an epsilon model output,
+ * schedulers_uncertainty/scheduling_dpm_2_uncertainty_centered.py:523-528 (convert_model_output):
+ * x0 = (x - sigma_t*eps) / alpha_t.  Also the (quirky) pred_original_sample of its UC window, :946. */
+int dua_x0_from_eps(const float* eps, const float* x, float* x0, size_t n, float sigma_t, float alpha_t, void* stream);
+
+/* Second-order multistep DPM-Solver++ update, midpoint form, scheduling_dpm_2_uncertainty_centered.py:709-727:
+ * D1 = rinv*(m0 - m1); out = (c1*sample - c2*m0) - c3*D1 with c1 = sigma_t/sigma_s0, c2 = alpha_t*(exp(-h)-1),
+ * c3 = 0.5*c2, rinv = 1/r0 (all evaluated by the caller as fp32 scalars, like the reference's 0-dim tensors).
+ * The first-order update (:624-632) is dua_axpby(sample, m0, c1, -c2). */
+int dua_dpmpp_2m_update(const float* sample, const float* m0, const float* m1, float* out, size_t n, float c1, float c2,
+                        float c3, float rinv, void* stream);
+
 /* Streaming centred second moment, zigzag_centered.py:549 / uncertainty_centered.py:540:
  * acc = (m==0 ? 0 : acc) + (eps_m - eps)^2 ; when m == M-1 the sum is divided by M. */
 int dua_mc_centered_accum(const float* eps_m, const float* eps, float* acc, size_t n, int m, int M, void* stream);

@@ -6,7 +6,7 @@ Follows reference ``generate_samples.py``
 """
 import torch
 
-from . import ddim
+from . import ddim, dpm
 
 
 def to_uint8(x):
@@ -18,10 +18,14 @@ def to_uint8(x):
 def generate(X_T, y, batch_size, model, tab, n_steps, kind, M, after_step, num_steps_uc,
              num_zigzag=3, predict_next=False, eta=0.0, clip_sample=True, steps_offset=0,
              decode=None, slice3=True):
-    """``model(x, t_vec, y, train=False) -> eps_full``; kind in {'zigzag_centered','centered','mc_dropout'}."""
+    """``model(x, t_vec, y, train=False) -> eps_full``; kind in {'zigzag_centered','centered','mc_dropout','dpm'}."""
     from .schedule import leading_timesteps, uc_window
-    ts = leading_timesteps(tab.num_train_timesteps, n_steps, steps_offset)
-    window = uc_window(ts, after_step, num_steps_uc)
+    if kind == "dpm":
+        st = dpm.DPMState(tab, n_steps, after_step, num_steps_uc, steps_offset=steps_offset)
+        ts, window = st.timesteps, st.window
+    else:
+        ts = leading_timesteps(tab.num_train_timesteps, n_steps, steps_offset)
+        window = uc_window(ts, after_step, num_steps_uc)
     imgs, ucs, scs = [], [], []
     for s in range(0, X_T.shape[0], batch_size):
         x, yb = X_T[s:s + batch_size].clone(), y[s:s + batch_size]
@@ -32,11 +36,15 @@ def generate(X_T, y, batch_size, model, tab, n_steps, kind, M, after_step, num_s
             return o[:, :3] if slice3 else o
 
         u_l, s_l = [], []
+        if kind == "dpm":                 # the reference driver re-calls set_timesteps per batch (generate_samples.py:177)
+            st = dpm.DPMState(tab, n_steps, after_step, num_steps_uc, steps_offset=steps_offset)
         for t in ts:
             t = int(t)
             eps = call(x, t)
             if kind == "zigzag_centered":
                 o = ddim.step_zigzag_centered(tab, call, eps, t, x, n_steps, window, M, num_zigzag, eta, clip_sample)
+            elif kind == "dpm":
+                o = dpm.step(st, call, eps, t, x, M)
             elif kind == "centered":
                 o = ddim.step_centered(tab, call, eps, t, x, n_steps, window, M, predict_next, eta, clip_sample)
             else:

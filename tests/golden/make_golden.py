@@ -500,7 +500,51 @@ def g11():
     save("g11_more_estimators", **out)
 
 
+def g12():
+    """`dpm_2_uncertainty_centered`: the reference's multistep DPM-Solver++ class.  (a) tables after
+    set_timesteps; (b) a teacher-forced trajectory (seeded eps tape, every step() output) that crosses the first-order
+    start, the second-order body, the UC window and the first-order final step; (c) a full driver run."""
+    with _quiet:
+        from diffusion_uncertainty.schedulers_uncertainty.scheduling_dpm_2_uncertainty_centered import \
+            KDPM2SchedulerUncertaintyImagenetClassConditioned as RefDPM
+    out = {}
+    tiny = build_adm(TINY_ADM, seed=5)
+    for name, n in (("adm128", 10), ("adm128", 20), ("uvit", 50)):
+        with _quiet:
+            s = RefDPM.from_config(CONFIGS[name], M=2, after_step=3, num_steps_uc=4, unet=tiny)
+            s.set_timesteps(n)
+        out[f"tab_{name}_{n}_timesteps"], out[f"tab_{name}_{n}_sigmas"] = s.timesteps, s.sigmas
+        out[f"tab_{name}_{n}_window"] = np.array([s.timestep_after_step, s.timestep_end_step])
+    x, y = randn(121, 2, 3, 16, 16), torch.tensor([3, 7])
+    out["x"], out["y"] = x, y
+    with _quiet:
+        s = RefDPM.from_config(CONFIGS["adm128"], M=3, after_step=5, num_steps_uc=3, unet=tiny)
+        s.set_timesteps(10)
+        s.prompt_embeds = y
+    out["traj_timesteps"] = s.timesteps
+    cur = x
+    for i, t in enumerate(s.timesteps.tolist()):
+        eps = randn(1210 + i, 2, 3, 16, 16)
+        torch.manual_seed(4000 + i)
+        with _quiet, torch.no_grad():
+            o = s.step(eps, t, cur)
+        out[f"traj{i}_eps"], out[f"traj{i}_prev"] = eps, o.prev_sample
+        if "uncertainty" in o:
+            out[f"traj{i}_unc"], out[f"traj{i}_x0"], out[f"traj{i}_score"] = o.uncertainty, o.pred_original_sample, o.pred_epsilon
+        cur = o.prev_sample
+    X_T, yy = randn(122, 3, 3, 16, 16), torch.tensor([1, 2, 3])
+    out["X_T"], out["yy"] = X_T, yy
+    with _quiet:
+        s = RefDPM.from_config(CONFIGS["adm128"], M=2, after_step=6, num_steps_uc=3, unet=tiny)
+        s.set_timesteps(10)
+        torch.manual_seed(0)
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, yy, 2, torch.device("cpu"), tiny, s)
+    for k in ("gen_images", "uncertainty", "score"):
+        out[f"drv_{k}"] = r[k]
+    save("g12_dpm_solver", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

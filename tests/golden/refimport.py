@@ -84,6 +84,14 @@ class SchedulerMixin:
     pass
 
 
+class SchedulerOutput(OrderedDict):
+    """diffusers.schedulers.scheduling_utils.SchedulerOutput: a record with ``prev_sample``."""
+
+    def __init__(self, prev_sample=None):
+        super().__init__(prev_sample=prev_sample)
+        self.prev_sample = prev_sample
+
+
 class KarrasDiffusionSchedulers(enum.Enum):
     DDIMScheduler = 1
     DDPMScheduler = 2
@@ -110,10 +118,11 @@ def install():
     _mod("diffusers")
     _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
     _mod("diffusers.utils", BaseOutput=BaseOutput)
+    _mod("diffusers.utils.outputs", BaseOutput=BaseOutput)
     _mod("diffusers.utils.torch_utils", randn_tensor=randn_tensor)
     _mod("diffusers.schedulers")
     _mod("diffusers.schedulers.scheduling_utils", SchedulerMixin=SchedulerMixin,
-         KarrasDiffusionSchedulers=KarrasDiffusionSchedulers)
+         KarrasDiffusionSchedulers=KarrasDiffusionSchedulers, SchedulerOutput=SchedulerOutput)
     _mod("diffusers.models")
     _mod("diffusers.models.unets", UNet2DModel=UNet2DModel)
     _mod("diffusers.models.resnet", ResnetBlock2D=ResnetBlock2D)

@@ -491,3 +491,65 @@ def test_more_estimators_vs_golden(golden):
     assert np.abs(r["uncertainty"].numpy() - ref).max() <= 5e-2 * ref.max()
     d = np.abs(r["gen_images"].numpy().astype(int) - g["drv_gen_images"].astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 2e-2
+
+
+def test_dpm_solver_vs_golden(golden):
+    """`dpm_2_uncertainty_centered` (multistep DPM-Solver++ + centred estimator): tables, a teacher-forced trajectory and a
+    driver run against the reference's own class."""
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128, load_uvit_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.mixin import SchedulerUncertaintyMixin
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    g = golden("g12_dpm_solver")
+    m, _ = build_adm(TINY_ADM, 5)
+
+    def sched(M, start, num, base=None):
+        a = argparse.Namespace(scheduler_type="dpm_2_uncertainty_centered", M=M, start_step_uc=start, num_steps_uc=num,
+                               predict_next=False, eta=0.0, num_zigzag=3, uncertainty_distance=1)
+        return get_uncertainty_scheduler(a, None, m, base or init_scheduler_imagenet128())
+
+    for name, n, base in (("adm128", 10, None), ("adm128", 20, None), ("uvit", 50, load_uvit_scheduler())):
+        s = sched(2, 3, 4, base)
+        s.set_timesteps(n)
+        np.testing.assert_array_equal(s.timesteps.numpy(), g[f"tab_{name}_{n}_timesteps"])
+        np.testing.assert_allclose(s.sigmas.numpy(), g[f"tab_{name}_{n}_sigmas"], rtol=1e-5, atol=0)
+        assert (s.timestep_after_step, s.timestep_end_step) == tuple(g[f"tab_{name}_{n}_window"])
+        assert isinstance(s, SchedulerUncertaintyMixin)
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    s = sched(3, 5, 3)
+    with pytest.raises(ValueError):
+        s.step(x, 900, x)                                            # set_timesteps not called (:919-922)
+    s.set_timesteps(10)
+    s.prompt_embeds = y
+    cur, seen = x, 0
+    for i, t in enumerate(s.timesteps.tolist()):
+        torch.manual_seed(4000 + i)
+        o = s.step(T(g[f"traj{i}_eps"]).to(dev), t, cur)
+        # schedule scalars are rebuilt on this host: an ulp of table difference is amplified by 1/alpha_t at high noise
+        np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"traj{i}_prev"], rtol=2e-5, atol=2e-5)
+        assert ("uncertainty" in o) == (f"traj{i}_unc" in g)
+        if "uncertainty" in o:
+            seen += 1
+            np.testing.assert_allclose(o.pred_original_sample.cpu().numpy(), g[f"traj{i}_x0"], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(o.pred_epsilon.cpu().numpy(), g[f"traj{i}_score"], rtol=2e-5, atol=2e-5)
+            u, ref = o.uncertainty.cpu().numpy(), g[f"traj{i}_unc"]
+            assert np.abs(u - ref).max() <= 2e-3 * ref.max(), (np.abs(u - ref).max(), ref.max())
+        cur = T(g[f"traj{i}_prev"]).to(dev)
+    assert seen == 3 and s.denoiser_calls == 9
+    s = sched(2, 6, 3)
+    s.set_timesteps(10)
+    torch.manual_seed(0)
+    r = gen(T(g["X_T"]), T(g["yy"]), 2, torch.device(dev), m, s)
+    np.testing.assert_allclose(r["score"].numpy(), g["drv_score"], rtol=0, atol=TOL)
+    ref = g["drv_uncertainty"]
+    assert np.abs(r["uncertainty"].numpy() - ref).max() <= 1e-2 * ref.max()
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["drv_gen_images"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-2
+    s2 = sched(2, 6, 3)
+    s2.predict_next = True
+    s2.set_timesteps(10)
+    s2.prompt_embeds = T(g["yy"])[:2].to(dev)
+    cur = T(g["X_T"])[:2].to(dev)
+    with pytest.raises(NotImplementedError):                         # :955
+        for t in s2.timesteps.tolist():
+            cur = s2.step(torch.zeros_like(cur), t, cur).prev_sample

@@ -62,6 +62,13 @@ def test_elementwise_sizes(ops, n):
         u8 = ops.to_uint8((a * 1.2).to(dev))
         ref = (((a * 1.2) / 2 + 0.5).clamp(0, 1) * 255.0).round().to(torch.uint8)
         np.testing.assert_array_equal(u8.cpu().numpy(), ref.numpy())
+    # DPM-Solver++ kernels: same operation order as the reference's separate torch ops -> bit-exact
+    c = rnd(3, n)
+    st, at, c1, c2, rinv = (torch.tensor(v, dtype=torch.float32) for v in (0.83, 0.55, 0.91, -0.37, 1.7))
+    x0 = ops.x0_from_eps(a.to(dev), b.to(dev), st, at)
+    np.testing.assert_array_equal(x0.cpu().numpy(), ((b - st * a) / at).numpy())
+    up = ops.dpmpp_2m_update(a.to(dev), b.to(dev), c.to(dev), c1, c2, 0.5 * c2, rinv)
+    np.testing.assert_array_equal(up.cpu().numpy(), (c1 * a - c2 * b - 0.5 * c2 * (rinv * (b - c))).numpy())
 
 
 @pytest.mark.parametrize("M", [2, 5, 10])

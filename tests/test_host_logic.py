@@ -48,9 +48,15 @@ def test_factory_semantics():
         assert isinstance(s, SchedulerUncertaintyMixin) and isinstance(s, SchedulerUncertaintyClassConditionedMixin)
     u = load_uvit_scheduler()
     assert "set_alpha_to_one" not in u.config and u.config.steps_offset == 1 and u.config.clip_sample is False
-    for kind in ("flip", "flip_grad", "dpm_2_uncertainty_centered"):
+    for kind in ("flip", "flip_grad"):
         with pytest.raises(NotImplementedError):
             get_uncertainty_scheduler(args(kind), y, None, base)
+    k = get_uncertainty_scheduler(args("dpm_2_uncertainty_centered"), y, "UNET", base)     # y= / eta= are dropped by from_config
+    assert (k.M, k.unet, k.prompt_embeds, k.config.solver_order, k.config.timestep_spacing) == (5, "UNET", None, 2, "leading")
+    assert k.config.variance_type == "fixed_small" and k.config.final_sigmas_type == "zero"
+    k.set_timesteps(10)                                                      # N + 1 in the 'leading' grid (:305-310)
+    assert k.timesteps.tolist() == [900, 810, 720, 630, 540, 450, 360, 270, 180, 90] and float(k.sigmas[-1]) == 0.0
+    assert isinstance(k, SchedulerUncertaintyMixin) and (k.timestep_after_step, k.timestep_end_step) == (540, 360)
     d = get_uncertainty_scheduler(args("uncertainty_centered_d", uncertainty_distance=3), y, None, base)
     assert d.prompt_embeds is None and d.uncertainty_distance == 3       # y= is dropped: this __init__ takes prompt_embed
     d.set_timesteps(10)

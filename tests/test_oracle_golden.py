@@ -359,3 +359,43 @@ def test_g11_more_estimators(golden):
             o = ddim.step_centered_d(tab, den, eps, t, x, 10, window, M, ts, int(kind[-1]))
         np.testing.assert_array_equal(o["prev_sample"].numpy(), g[f"c{c}_prev"])
         np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"c{c}_unc"], rtol=2e-3, atol=1e-8, err_msg=str(kind))
+
+
+def test_g12_dpm_solver(golden):
+    """`dpm_2_uncertainty_centered`: grids / sigmas, a teacher-forced trajectory and a driver run of the reference's class."""
+    from oracle import dpm
+    g = golden("g12_dpm_solver")
+    for name, n in (("adm128", 10), ("adm128", 20), ("uvit", 50)):
+        st = dpm.DPMState(TABLES[name](), n, 3, 4, steps_offset=OFFSET[name])
+        np.testing.assert_array_equal(st.timesteps, g[f"tab_{name}_{n}_timesteps"])
+        np.testing.assert_allclose(st.sigmas.numpy(), g[f"tab_{name}_{n}_sigmas"], rtol=1e-5, atol=0)
+        assert st.window == tuple(g[f"tab_{name}_{n}_window"])
+    x, y = T(g["x"]), T(g["y"])
+    sd = tiny_adm(TINY_ADM, seed=5)
+
+    def den(xx, t):
+        tv = torch.full((xx.shape[0],), int(t), dtype=torch.long)
+        return adm.forward(sd, TINY_ADM, xx, tv, y)[:, :3]
+
+    st = dpm.DPMState(TABLES["adm128"](), 10, 5, 3)
+    np.testing.assert_array_equal(st.timesteps, g["traj_timesteps"])
+    cur, seen = x, 0
+    for i, t in enumerate(st.timesteps.tolist()):
+        torch.manual_seed(4000 + i)
+        o = dpm.step(st, den, T(g[f"traj{i}_eps"]), t, cur, 3)
+        np.testing.assert_allclose(o["prev_sample"].numpy(), g[f"traj{i}_prev"], rtol=1e-6, atol=1e-6)
+        assert ("uncertainty" in o) == (f"traj{i}_unc" in g)
+        if "uncertainty" in o:
+            seen += 1
+            np.testing.assert_allclose(o["pred_original_sample"].numpy(), g[f"traj{i}_x0"], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(o["pred_epsilon"].numpy(), g[f"traj{i}_score"], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"traj{i}_unc"], rtol=2e-3, atol=1e-8)
+        cur = T(g[f"traj{i}_prev"])                                    # teacher-forced trajectory
+    assert seen == 3
+    torch.manual_seed(0)
+    r = driver.generate(T(g["X_T"]), T(g["yy"]), 2, lambda a, tv, yy, train=False: adm.forward(sd, TINY_ADM, a, tv, yy),
+                        TABLES["adm128"](), 10, "dpm", M=2, after_step=6, num_steps_uc=3)
+    np.testing.assert_allclose(r["score"].numpy(), g["drv_score"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(r["uncertainty"].numpy(), g["drv_uncertainty"], rtol=5e-3, atol=1e-6)
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["drv_gen_images"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
