@@ -13,8 +13,9 @@ weights and warms the allocator.  Ranks shard independent batches (weak scaling)
 one RCCL all_gather of the uint8 images at the end of each step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     - dominant kernel (fp32 MFMA implicit-GEMM conv3x3): algorithmic FLOPs per launch / mean launch
-                 duration, HIP events on the launch stream, over the timed region; peak = 157.3 TFLOP/s (fp32 MFMA).
+  roofline     - dominant kernel (implicit-GEMM conv3x3 of the selected precision mode): algorithmic FLOPs per launch / mean
+                 launch duration, HIP events on the launch stream, over the timed region; peak = 2.5 PFLOP/s (fp16 / bf16 MFMA)
+                 for the split modes, 157.3 TFLOP/s (fp32-input MFMA) for --precision fp32.
   cpu_baseline - the CPU oracle (port of the reference path, fp32, all host cores) timed on rank 0 at N=1 on a bounded
                  sample and extrapolated with the reference's exact forward count (200 / image for W10).
 """
@@ -45,6 +46,7 @@ class ConvProfile:
     # HBM-side bytes per conv launch from the PMC passes of profiles/r01d_pmc_traffic_conv.json (FETCH_SIZE doubled per the
     # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
     PMC_TRAFFIC_BF16X3 = 2.145e9
+    PMC_TRAFFIC_F16F8 = None          # filled from profiles/r01h_pmc_traffic_conv.json once collected
 
     def summary(self):
         if not self.items:
@@ -64,6 +66,16 @@ class ConvProfile:
                         frac=round(cs["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                         kernel="k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)",
                         launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
+        if precision == "f16f8":
+            return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_F16F8,
+                        traffic_source="profiles/r01h_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                        kernel="k_xconv_dma<NT, 1> (LDS-DMA implicit-GEMM conv3x3, fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross "
+                               "terms on one block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per 32-deep K block)",
+                        launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
+                        executed_mfma_tflops=round(2 * cs["tflops"], 1), executed_frac=round(2 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
+                        note="achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of 2 bf16-rate products (one fp16 "
+                             "product + two fp8 products at twice the rate), so frac <= 1/2 against the 2.5 PF bf16/fp16 peak by construction")
         return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_BF16X3,
                     traffic_source="profiles/r01d_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
@@ -134,9 +146,9 @@ def main():
     ap.add_argument("--start-step-uc", type=int, default=40)
     ap.add_argument("--num-steps-uc", type=int, default=10)
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="bf16x3: convs / weight GEMMs on the bf16 matrix cores with split fp32 operands (parity ~3e-5); "
-                         "fp32: exact fp32 MFMA (parity ~7e-6)")
+    ap.add_argument("--precision", choices=["f16f8", "bf16x3", "fp32"], default="f16f8",
+                    help="f16f8: 3x3 convs / qkv on fp16 + block-scaled fp8 matrix-core products (parity ~5e-5); bf16x3: convs / weight "
+                         "GEMMs on the bf16 matrix cores with split fp32 operands (parity ~3e-5); fp32: exact fp32 MFMA (parity ~7e-6)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-step run of the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -196,7 +208,7 @@ def main():
     dt, uc_calls, prof = timed(a.precision, a.steps, a.warmup)
     secondary = None
     if world == 1 and not a.no_secondary:
-        other = "fp32" if a.precision == "bf16x3" else "bf16x3"
+        other = "fp32" if a.precision != "fp32" else "f16f8"
         dt2, uc2, prof2 = timed(other, 1, 1)
         secondary = dict(precision=other, value=round(a.batch / dt2, 4), unit="images/sec", steps=1, ms_per_step=round(dt2 * 1e3, 1),
                          end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
@@ -211,8 +223,10 @@ def main():
             "metric": "images/sec @ ADM ImageNet-128, 50 steps, M=5, bs=128; 1/2/4/8 GPU",
             "value": round(images / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16x3 (fp32 operands split into 2 bf16 terms, 3 bf16 MFMA products, fp32 accumulate; norms/softmax/attention "
-                      "products/sampler in fp32)" if a.precision == "bf16x3" else "f32"), "data": "synthetic",
+            "dtype": {"f16f8": "f16f8 (fp32 operands split a = fp16 hi + lo; hi*hi on fp16 MFMA, both cross terms on one block-scaled fp8 "
+                               "MFMA, fp32 accumulate: ~2^-15 per product; 1x1 / attention products split-bf16; norms/softmax/sampler fp32)",
+                      "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 terms, 3 bf16 MFMA products, fp32 accumulate; norms/softmax/"
+                                "attention products/sampler in fp32)", "fp32": "f32"}[a.precision], "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ADM ImageNet-128, 50 DDIM steps, M=5, uncertainty_zigzag_centered, "
                                    "num_zigzag=3, UC window W10 (start 40, 10 steps), batch 128 per GPU",
                        "global_batch": a.batch * world, "parallelism": f"independent batches x{world} (no data-path collective; "
@@ -221,8 +235,8 @@ def main():
                                       "skip_dead_zigzag (outputs identical; noise draws still consumed)",
                        "executed_forwards_per_image": fwd_per_img, "noise": "device Philox (dua_randn)",
                        "precision": a.precision,
-                       "parity": ("full-size ADM-128 forward vs the reference CPU output: max abs err 2.9e-5 (bf16x3), 7.4e-6 (fp32); "
-                                  "tolerance 1e-3 (tests/test_gpu_models.py)"),
+                       "parity": ("full-size ADM-128 forward vs the reference CPU output: max abs err 5.3e-5 (f16f8), 3.1e-5 (bf16x3), "
+                                  "7.4e-6 (fp32); tolerance 1e-3 (tests/test_gpu_models.py)"),
                        "warmup_pass": "3-timestep truncated job"},
             "end_to_end_tflops": round(exec_flops / dt / 1e12, 2),
             "roofline": roof,

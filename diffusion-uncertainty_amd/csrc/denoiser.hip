@@ -182,6 +182,7 @@ struct GnApplyP {
     float* y;
     int C1, C2, N, H, W, G, act, resample;
     int split;               // 1: y is two bf16 planes (hi | lo) of the output shape, for the bf16x3 conv
+                             // 2: f16f8 planes: fp16 hi | per 32-channel block [32 x fp8(lo * 2^12) | 32 x fp8(x)]
     long plane;              // elements per plane
 };
 
@@ -189,6 +190,26 @@ typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gn_store(const GnApplyP& p, size_t off, float4 v) {
     if (!p.split) {
         *(float4*)(p.y + off) = v;
+    } else if (p.split == 2) {
+        // C % 32 == 0, so the 32-channel block and the position inside it follow from the element offset alone
+        typedef _Float16 gn_f16x4 __attribute__((ext_vector_type(4)));
+        float f[4] = {v.x, v.y, v.z, v.w}, l[4], c8[4];
+        gn_f16x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 t = (_Float16)f[j];
+            h[j] = t;
+            l[j] = fminf(fmaxf((f[j] - (float)t) * 4096.0f, -448.f), 448.f);
+            c8[j] = fminf(fmaxf(f[j], -448.f), 448.f);
+        }
+        *(gn_f16x4*)((_Float16*)p.y + off) = h;
+        unsigned char* x8 = (unsigned char*)((_Float16*)p.y + p.plane) + (off >> 5) * 64 + (off & 31);
+        int lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false);
+        lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo8, true);
+        int hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], 0, false);
+        hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], hi8, true);
+        *(int*)x8 = lo8;
+        *(int*)(x8 + 32) = hi8;
     } else {
         __bf16* hi = (__bf16*)p.y + off;
         float f[4] = {v.x, v.y, v.z, v.w};
@@ -305,6 +326,13 @@ extern "C" int dua_groupnorm_apply_split(const float* x1, int C1, const float* x
                                          const float* stats, const float* gamma, const float* beta, const float* film, int act,
                                          int resample, const float* dropmask, void* yplanes, void* stream) {
     return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, (float*)yplanes, 1, stream);
+}
+
+extern "C" int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                               const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                               int resample, const float* dropmask, void* yplanes, void* stream) {
+    DUA_REQUIRE((C1 + C2) % 32 == 0, "dua_groupnorm_apply_split_f16f8: channels must be a multiple of 32");
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, (float*)yplanes, 2, stream);
 }
 
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,

@@ -415,6 +415,9 @@ struct DConvP {
     int ntaps;               // 9 = 3x3 convolution, 1 = plain GEMM over rows (1x1 convolution / linear layer)
     int act_out;             // 2 = GELU on the output (U-ViT fc1)
     __bf16* Csplit;          // optional: write the output as split bf16 planes (hi | lo, [M][N] each) instead of fp32 C
+    const signed char* Bscale;  // FMT 1 (f16f8): per weight row r, w_hi8 = fp8(w * 2^Bscale[r]), w_lo8 = fp8(w_lo * 2^(Bscale[r] + 12))
+    int stagger_phases;      // > 1: workgroup start-up stagger (see k_xconv_dma); stagger_sleeps = s_sleep(127) per phase step
+    int stagger_sleeps;
 };
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
@@ -488,7 +491,15 @@ extern "C" int dua_debug_tile_times(unsigned long long* host) {
 #define DUA_STAMP(k)
 #endif
 
-template <int NT>
+// FMT selects the operand format of the two planes (same bytes, same DMA):
+//   0 "bf16x3": plane 0 = bf16 hi, plane 1 = bf16 lo; product = hi*hi + hi*lo + lo*hi, three v_mfma_f32_32x32x16_bf16 per 16 k.
+//   1 "f16f8":  plane 0 = fp16 hi; plane 1 = per 32-k block [32 x fp8 lo*2^12 | 32 x fp8 hi] (activations) resp.
+//               [32 x fp8 w*2^s | 32 x fp8 w_lo*2^(s+12)] (weights, s per output row).  hi*hi runs on v_mfma_f32_32x32x16_f16;
+//               BOTH cross terms of a 32-k block run as ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4: its k-block 0
+//               (lanes 0-31) holds a_lo8 x w_hi8 with E8M0 scales 2^-12, 2^-s, its k-block 1 (lanes 32-63) a_hi8 x w_lo8 with
+//               scales 1, 2^-(s+12).  The cross terms are 2^-11 of the product and fp8 keeps 2^-4 of them: 2^-15 per
+//               product, like the bf16 split, at 2/3 of its matrix-core cycles (128 instead of 192 per 32x32x32 block).
+template <int NT, int FMT>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
     constexpr int DBN = 64 * NT;
@@ -509,6 +520,14 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
     const int cq = ntiles >> 3, cr = ntiles & 7;
     const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
+    // Start-up stagger.  All workgroups run equally long tiles, so left alone they reach their epilogues together: the
+    // output / residual traffic of the whole chip (0.5 MB per tile and CU) then hits HBM in one burst while the matrix
+    // cores idle, and HBM idles during the K loops.  Delaying the workgroups of an XCD by phase/P of a tile period spreads
+    // the epilogues over the period; the phase persists because every tile takes the same time.
+    if (p.stagger_phases > 1) {
+        const int ph = slot % p.stagger_phases;
+        for (int i = 0; i < ph * p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
   for (int ti = slot; ti < chunk_n; ti += nslot) {
     const int lid = chunk0 + ti;
     const int tn = lid % p.ntn, tm = lid / p.ntn;
@@ -599,6 +618,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
+  if constexpr (FMT == 0) {
     // Fragment registers of ONE half step (16 of the 32 K columns of a stage); they are refilled in place while the
     // MFMA group that no longer needs them is executing, so the matrix pipe always has a full group queued when the
     // next one's operands arrive (no extra registers: the accumulators already take 128 of the 256):
@@ -689,7 +709,172 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #undef MM
 #undef DMA_GROUP
 #undef SBAR
+#undef DWAIT_TILE
 
+  } else {
+    // ---------------- f16f8: fp16 hi*hi + one block-scaled fp8 MFMA for both cross terms ----------------
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    f16x8 ah[2][2], bh[2][NT];          // [k16 half][tile]
+    i32x8 ax[2], bx[NT];
+    // Four lane-varying LDS byte offsets serve every fragment read: the A and the B side differ by a wave-uniform amount
+    // (kept in SGPRs), tiles by an immediate.  hi plane: chunk 2s + kh of the row; cross plane: chunks 2kh, 2kh + 1.
+    const int sw_ = (lr >> 2) & 3;
+    const int o_h0 = (lr * LDH + 8 * ((0 + kh) ^ sw_)) * 2, o_h1 = (lr * LDH + 8 * ((2 + kh) ^ sw_)) * 2;
+    const int o_x0 = (lr * LDH + 8 * ((2 * kh) ^ sw_)) * 2, o_x1 = (lr * LDH + 8 * ((2 * kh + 1) ^ sw_)) * 2;
+    const int a_row0 = wm * 64 * LDH * 2, b_row0 = (BOFF + wn * 32 * NT * LDH) * 2;      // bytes, wave-uniform
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const int sca = kh ? 127 : 115;                                                  // E8M0: 2^0 (a_hi8) / 2^-12 (a_lo8 * 2^12)
+    int scbp = 0;                                                                    // the NT column-tile scales, one byte each
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        scbp |= ((127 - (int)p.Bscale[n0 + wn * 32 * NT + 32 * j + lr] - (kh ? 12 : 0)) & 0xff) << (8 * j);
+    // ---- single operations; the step below lays them out one by one (every ds_read / DMA sits between two MFMAs)
+    auto rd_ah = [&](int st, int s_, int i_) {
+        ah[s_][i_] = *(const f16x8*)(ldsb + (st * 2 * SA * 2 + a_row0 + 32 * i_ * LDH * 2) + (s_ ? o_h1 : o_h0));
+    };
+    auto rd_bh = [&](int st, int s_, int j_) {
+        bh[s_][j_] = *(const f16x8*)(ldsb + (st * 2 * SB * 2 + b_row0 + 32 * j_ * LDH * 2) + (s_ ? o_h1 : o_h0));
+    };
+    auto rd_x = [&](int uni) -> i32x8 {
+        const i32x4 u0_ = *(const i32x4*)(ldsb + uni + o_x0), u1_ = *(const i32x4*)(ldsb + uni + o_x1);
+        return (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
+    };
+    auto rd_ax = [&](int st, int i_) { ax[i_] = rd_x((st * 2 * SA + SA) * 2 + a_row0 + 32 * i_ * LDH * 2); };
+    auto rd_bx = [&](int st, int j_) { bx[j_] = rd_x((st * 2 * SB + SB) * 2 + b_row0 + 32 * j_ * LDH * 2); };
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+    constexpr int KEEP = NT == 4 ? 4 : 6;
+#define DWAIT_TILE(more) \
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int NM = 2 * NT;                       // MFMAs per group (wave tile 64 x 32*NT)
+    constexpr int NPIECE = NT == 4 ? 8 : 6;          // DMA pieces per step: NT=4 [B0..B3 A0..A3], NT=2 [A0..A3 B0 B1]
+    issue_a(0);
+    issue_b(0);
+    if (nk > 1) {
+        issue_a(1);
+        if (NT == 2) issue_b(1);
+    }
+    DWAIT_TILE(nk > 1)
+    __builtin_amdgcn_s_barrier();
+    DUA_STAMP(1)
+    int sa = 0, sb = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        rd_ah(0, s_, 0); rd_ah(0, s_, 1);
+#pragma unroll
+        for (int j_ = 0; j_ < NT; ++j_) rd_bh(0, s_, j_);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // Per K step:  [hi*hi k 0..15 | hi*hi k 16..31]  wait + barrier  [cross MFMA].  The cross fragments of the step are read
+    // between the hi*hi MFMAs, the hi fragments of the NEXT stage between the cross MFMAs (after the barrier that publishes
+    // it), the DMA pieces of tile kt+2 between the MFMAs of the second hi*hi group and the cross group: at most two
+    // ds_read_b128 or one DMA piece per MFMA gap, never a burst of reads that would hold the matrix pipe of the wave.
+    for (int kt = 0; kt < nk; ++kt) {
+        int sa2 = sa + 2;
+        if (sa2 >= RA) sa2 -= RA;
+        int sbn = sb + (RB - 1);
+        if (sbn >= RB) sbn -= RB;
+        const bool preA = kt + 2 < nk;
+        const bool preB = NT == 4 ? kt + 1 < nk : kt + 2 < nk;
+        if (preA) dma_setup();
+        auto dma_piece = [&](int piece) {
+            if (NT == 4) {
+                if (piece < 4) { if (preB) dma_b(sbn, piece); }
+                else if (piece < 8) { if (preA) dma_a(sa2, piece - 4); }
+            } else {
+                if (piece < 4) { if (preA) dma_a(sa2, piece); }
+                else if (piece < 6) { if (preB) dma_b(sbn, piece - 4); }
+            }
+        };
+        SBAR();
+        // hi fragments in consumption order: ah[s][0], bh[s][0..NT-1], ah[s][1] for s = 0, 1
+        auto rd_hi = [&](int st_a, int st_b, int r_) {
+            const int s_ = r_ / (2 + NT), q_ = r_ % (2 + NT);
+            if (q_ == 0) rd_ah(st_a, s_, 0);
+            else if (q_ <= NT) rd_bh(st_b, s_, q_ - 1);
+            else rd_ah(st_a, s_, 1);
+        };
+        constexpr int NR = 4 + 2 * NT;
+#ifndef DUA_SCHED
+#define DUA_SCHED 2      // 1 = grouped reads / DMA bursts, 2 = one read or DMA piece per MFMA gap (+1 % on the ADM-128 mix)
+#endif
+#if DUA_SCHED == 1
+        // ---- grouped schedule: [cross reads | hi*hi 0 | DMA | hi*hi 1 | DMA] wait + barrier [next hi reads | cross MFMA]
+        rd_ax(sa, 0); rd_ax(sa, 1);
+#pragma unroll
+        for (int j_ = 0; j_ < NT; ++j_) rd_bx(sb, j_);
+        SBAR();
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_)
+            acc[m_ / NT][m_ % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][m_ / NT], bh[0][m_ % NT], acc[m_ / NT][m_ % NT], 0, 0, 0);
+        SBAR();
+#pragma unroll
+        for (int u_ = 0; u_ < NPIECE / 2; ++u_) dma_piece(u_);
+        SBAR();
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_)
+            acc[m_ / NT][m_ % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][m_ / NT], bh[1][m_ % NT], acc[m_ / NT][m_ % NT], 0, 0, 0);
+        SBAR();
+#pragma unroll
+        for (int u_ = NPIECE / 2; u_ < NPIECE; ++u_) dma_piece(u_);
+        SBAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DWAIT_TILE(preA)
+        __builtin_amdgcn_s_barrier();
+        if (++sa == RA) sa = 0;
+        if (++sb == RB) sb = 0;
+        SBAR();
+#pragma unroll
+        for (int r_ = 0; r_ < NR; ++r_) rd_hi(sa, sb, r_);
+        SBAR();
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_)
+            acc[m_ / NT][m_ % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[m_ / NT], bx[m_ % NT], acc[m_ / NT][m_ % NT], 0, 0, 0, sca, 0, scbp >> (8 * (m_ % NT)));
+        SBAR();
+#else
+        // ---- interleaved schedule: one read / DMA piece per MFMA gap
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int i_ = m_ / NT, j_ = m_ % NT;
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i_], bh[0][j_], acc[i_][j_], 0, 0, 0);
+            SBAR();
+            if (m_ < 2) rd_ax(sa, m_);
+            else if (m_ - 2 < NT) rd_bx(sb, m_ - 2);
+            else dma_piece(m_ - 2 - NT);                                   // NT = 4: gaps 6, 7 -> pieces 0, 1
+            SBAR();
+        }
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int i_ = m_ / NT, j_ = m_ % NT;
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i_], bh[1][j_], acc[i_][j_], 0, 0, 0);
+            SBAR();
+            if (NT == 4) { if (m_ < 6) dma_piece(2 + m_); }
+            else if (m_ < 2) { dma_piece(2 * m_); dma_piece(2 * m_ + 1); }
+            else dma_piece(2 + m_);
+            SBAR();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        DWAIT_TILE(preA)
+        __builtin_amdgcn_s_barrier();
+        if (++sa == RA) sa = 0;
+        if (++sb == RB) sb = 0;
+        SBAR();
+        constexpr int NDBL = NR - NM;                   // gaps m < NDBL carry two reads, the rest one
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int i_ = m_ / NT, j_ = m_ % NT;
+            acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 0, 0, 0, sca, 0, scbp >> (8 * j_));
+            SBAR();
+            if (m_ < NDBL) { rd_hi(sa, sb, 2 * m_); rd_hi(sa, sb, 2 * m_ + 1); }
+            else rd_hi(sa, sb, 2 * NDBL + (m_ - NDBL));
+            SBAR();
+        }
+#endif
+    }
+#undef SBAR
+#undef DWAIT_TILE
+  }
     DUA_STAMP(2)
     // The epilogue's lane-derived addresses must not be hoisted above the K loop (the loop owns every VGPR: hoisted
     // values end up in scratch, and their reload waits on vmcnt(0), i.e. on the whole DMA pipeline).
@@ -821,27 +1006,68 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ---- weight splitting: fp32 [N][K] (or OIHW conv weights) -> two bf16 planes [Npad128][K] -------------------
+__device__ __forceinline__ float split_weight_src(const float* __restrict__ w, int n, int k, int N, int K, int conv_cin) {
+    if (n >= N) return 0.f;
+    if (conv_cin) {                       // OIHW -> k = cb*288 + tap*32 + c  (channel-block major, tap minor)
+        int tap = (k % 288) / 32, ci = (k / 288) * 32 + k % 32;
+        return w[((size_t)n * conv_cin + ci) * 9 + tap];
+    }
+    return w[(size_t)n * K + k];
+}
 __global__ void k_split_weight(const float* __restrict__ w, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int N, int K,
                                int Npad, int conv_cin) {
     size_t total = (size_t)Npad * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         int n = (int)(i / K), k = (int)(i % K);
-        float v = 0.f;
-        if (n < N) {
-            if (conv_cin) {                       // OIHW -> k = cb*288 + tap*32 + c  (channel-block major, tap minor)
-                int tap = (k % 288) / 32, ci = (k / 288) * 32 + k % 32;
-                v = w[((size_t)n * conv_cin + ci) * 9 + tap];
-            } else {
-                v = w[(size_t)n * K + k];
-            }
-        }
+        float v = split_weight_src(w, n, k, N, K, conv_cin);
         __bf16 h = (__bf16)v;
         hi[i] = h;
         lo[i] = (__bf16)(v - (float)h);
     }
 }
 
+// f16f8 weight format: plane 0 = fp16(w); plane 1 = per (row, 32-k block) 64 bytes [32 x fp8(w * 2^s) | 32 x fp8((w - fp16(w)) * 2^(s+12))]
+// with s = 7 - floor(log2(max |row|)) (the row maximum lands in [128, 256), below the e4m3 maximum 448); s per row in `scale`.
+__device__ __forceinline__ unsigned char to_fp8(float v) {
+    v = fminf(fmaxf(v, -448.f), 448.f);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
+__global__ void k_weight_row_scale(const float* __restrict__ w, signed char* __restrict__ scale, int N, int K, int Npad) {
+    const int n = blockIdx.x;              // one workgroup per padded row (the K order does not matter for the maximum)
+    float m = 0.f;
+    if (n < N)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, fabsf(w[(size_t)n * K + k]));
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (red[0] > 0.f) e = 7 - (int)floorf(log2f(red[0]));
+        scale[n] = (signed char)max(-60, min(60, e));
+    }
+}
+__global__ void k_split_weight_f16f8(const float* __restrict__ w, _Float16* __restrict__ hi, unsigned char* __restrict__ x8,
+                                     const signed char* __restrict__ scale, int N, int K, int Npad, int conv_cin) {
+    size_t total = (size_t)Npad * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int n = (int)(i / K), k = (int)(i % K);
+        float v = split_weight_src(w, n, k, N, K, conv_cin);
+        _Float16 h = (_Float16)v;
+        hi[i] = h;
+        const float sc = exp2f((float)scale[n]);
+        unsigned char* o = x8 + ((size_t)n * K + (k & ~31)) * 2 + (k & 31);
+        o[0] = to_fp8(v * sc);
+        o[32] = to_fp8((v - (float)h) * sc * 4096.f);
+    }
+}
+
 extern "C" size_t dua_bf16x3_plane_elems(int N, int K) { return (size_t)round_up(N, BN) * K; }
+// bytes of a packed f16f8 weight: two planes of Npad x K 2-byte elements + Npad row-scale bytes (padded to 16)
+extern "C" size_t dua_f16f8_weight_bytes(int N, int K) { return 4 * dua_bf16x3_plane_elems(N, K) + (size_t)round_up(round_up(N, BN), 16); }
 
 extern "C" int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K, int conv_cin, void* stream) {
     DUA_REQUIRE(w && planes && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_bf16x3: K must be a positive multiple of 32 (got %d)", K);
@@ -851,6 +1077,19 @@ extern "C" int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K
     __bf16* hi = (__bf16*)planes;
     hipLaunchKernelGGL(k_split_weight, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, hi + plane, N, K, Npad, conv_cin);
     return dua_check_launch("dua_pack_weight_bf16x3");
+}
+
+extern "C" int dua_pack_weight_f16f8(const float* w, void* packed, int N, int K, int conv_cin, void* stream) {
+    DUA_REQUIRE(w && packed && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_f16f8: K must be a positive multiple of 32 (got %d)", K);
+    DUA_REQUIRE(conv_cin == 0 || (K == 9 * conv_cin && conv_cin % BK == 0), "dua_pack_weight_f16f8: conv K must be 9*Cin, Cin %% 32 == 0");
+    int Npad = round_up(N, BN);
+    size_t plane = (size_t)Npad * K;
+    _Float16* hi = (_Float16*)packed;
+    unsigned char* x8 = (unsigned char*)(hi + plane);
+    signed char* scale = (signed char*)(x8 + 2 * plane);
+    hipLaunchKernelGGL(k_weight_row_scale, dim3(Npad), 256, 0, as_stream(stream), w, scale, N, K, Npad);
+    hipLaunchKernelGGL(k_split_weight_f16f8, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, x8, scale, N, K, Npad, conv_cin);
+    return dua_check_launch("dua_pack_weight_f16f8");
 }
 
 extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
@@ -872,59 +1111,102 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
 static int dua_dma_conv_enabled = 1;
 extern "C" int dua_set_dma_conv(int on) { int o = dua_dma_conv_enabled; dua_dma_conv_enabled = on; return o; }
 
-extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
-                                           float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
-    DUA_REQUIRE(!colsum || (!nchw_out && Cout % 4 == 0), "dua_conv3x3_bf16x3_presplit: colsum needs an NHWC output with Cout %% 4 == 0");
-    DUA_REQUIRE(xplanes && planes && y, "dua_conv3x3_bf16x3_presplit: null pointer");
-    DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3_bf16x3_presplit: Cin must be a multiple of 32 (got %d)", Cin);
-    DUA_REQUIRE((long)N * H * W < (1L << 31), "dua_conv3x3_bf16x3_presplit: too many pixels");
-    XTileP p{};
+// Start-up stagger of the persistent LDS-DMA workgroups: `phases` phases per XCD (0 / 1 = off), each `percent` % of 1/phases
+// of the estimated tile period.  Applied only when every workgroup owns at least `min_tiles` tiles.
+static int dua_stagger_phases = 0, dua_stagger_percent = 100, dua_stagger_min_tiles = 6;
+extern "C" int dua_set_conv_stagger(int phases, int percent, int min_tiles) {
+    dua_stagger_phases = phases; dua_stagger_percent = percent; dua_stagger_min_tiles = min_tiles;
+    return 0;
+}
+static void dconv_set_stagger(DConvP& d, bool wide, int ntiles, int grid) {
+    d.stagger_phases = 0; d.stagger_sleeps = 0;
+    if (dua_stagger_phases <= 1 || ntiles < (long)dua_stagger_min_tiles * grid) return;
+    // tile period in shader cycles: K steps of ~3840 (256x256) / ~1920 (256x128) cycles plus the epilogue
+    const long period = (long)(d.K / BK) * (wide ? 3840 : 1920) + (wide ? 68000 : 34000);
+    const long step = period * dua_stagger_percent / 100 / dua_stagger_phases;
+    d.stagger_phases = dua_stagger_phases;
+    d.stagger_sleeps = (int)((step + 4064) / 8128);
+}
+
+static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
+    d.ntm = (d.M + DBM - 1) / DBM;
+    // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile N exactly and still give every CU
+    // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
+    const bool wide = dua_dma_conv_enabled != 2 && d.N % 256 == 0 && (long)d.ntm * (d.N / 256) >= 512;
+    d.ntn = wide ? d.N / 256 : (d.N + BN - 1) / BN;
+    const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
+    d.dbg_norec = dua_dma_conv_enabled == 3;
+    dconv_set_stagger(d, wide, ntiles, grid);
+    if (fmt == 0) {
+        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
+        else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
+    } else {
+        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 1>), dim3(grid), 512, 0, st, d);
+        else hipLaunchKernelGGL((k_xconv_dma<2, 1>), dim3(grid), 512, 0, st, d);
+    }
+    return dua_check_launch(what);
+}
+
+static int conv3x3_presplit_impl(const void* xplanes, const void* planes, const float* bias, const float* residual, float* y, int N,
+                                 int H, int W, int Cin, int Cout, int nchw_out, float* colsum, int fmt, void* stream) {
+    DUA_REQUIRE(!colsum || (!nchw_out && Cout % 4 == 0), "dua_conv3x3 presplit: colsum needs an NHWC output with Cout %% 4 == 0");
+    DUA_REQUIRE(xplanes && planes && y, "dua_conv3x3 presplit: null pointer");
+    DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3 presplit: Cin must be a multiple of 32 (got %d)", Cin);
+    DUA_REQUIRE((long)N * H * W < (1L << 31), "dua_conv3x3 presplit: too many pixels");
     size_t plane = dua_bf16x3_plane_elems(Cout, 9 * Cin);
-    p.Ahi = (const __bf16*)xplanes; p.Alo = p.Ahi + (size_t)N * H * W * Cin;
+    const size_t a_plane = (size_t)N * H * W * Cin;
+    const bool dma_ok = 4 * plane < 0x7FFFFFF0ull && (size_t)(2 * W + 260) * Cin * 2 < 0x7FFFFFF0ull;
+    if (fmt == 1) DUA_REQUIRE(dma_ok, "dua_conv3x3_f16f8_presplit: operand too large for the LDS-DMA kernel");
+    if ((dua_dma_conv_enabled != 0 || fmt == 1) && dma_ok) {
+        DConvP d{};
+        d.A = (const __bf16*)xplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = y;
+        d.a_plane = (long)a_plane; d.b_plane = (long)plane;
+        d.M = N * H * W; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
+        d.ntaps = 9;
+        d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
+        return launch_dconv(d, fmt, as_stream(stream), "dua_conv3x3 presplit (dma)");
+    }
+    XTileP p{};
+    p.Ahi = (const __bf16*)xplanes; p.Alo = p.Ahi + a_plane;
     p.Bhi = (const __bf16*)planes; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = y;
     p.M = N * H * W; p.N = Cout; p.ldc = Cout; p.ldr = Cout; p.alpha = 1.0f;
     p.H = H; p.W = W; p.Cin = Cin; p.nchw_out = nchw_out; p.colsum = colsum;
-    const size_t a_plane = (size_t)N * H * W * Cin;
-    if (dua_dma_conv_enabled != 0 && 4 * plane < 0x7FFFFFF0ull && (size_t)(2 * W + 260) * Cin * 2 < 0x7FFFFFF0ull) {
-        DConvP d{};
-        d.A = p.Ahi; d.B = p.Bhi; d.bias = bias; d.res = residual; d.C = y; d.a_plane = (long)a_plane; d.b_plane = (long)plane;
-        d.M = p.M; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
-        d.dbg_norec = dua_dma_conv_enabled == 3;
-        d.ntaps = 9;
-        d.ntm = (d.M + DBM - 1) / DBM;
-        // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile Cout exactly and still give every CU
-        // at least two workgroups; otherwise 128-wide tiles keep the 256 CUs busy.
-        const bool wide = dua_dma_conv_enabled != 2 && Cout % 256 == 0 && (long)d.ntm * (Cout / 256) >= 512;
-        d.ntn = wide ? Cout / 256 : (Cout + BN - 1) / BN;
-        const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
-        if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(grid), 512, 0, as_stream(stream), d);
-        else hipLaunchKernelGGL(k_xconv_dma<2>, dim3(grid), 512, 0, as_stream(stream), d);
-        return dua_check_launch("dua_conv3x3_bf16x3_presplit (dma)");
-    }
     return launch_x<XMODE_CONV, false, true>(p, as_stream(stream));
 }
 
-// C[M][N] = A * W^T (+ bias) (+ residual) with A given as split bf16 planes (hi | lo, [M][K] each, written by
-// dua_groupnorm_apply_split) and W pre-split by dua_pack_weight_bf16x3: the LDS-DMA kernel with a single tap.
-extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
-                                        void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
-    DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm_bf16x3_presplit: K must be a multiple of 32 (got %d)", K);
-    DUA_REQUIRE(N % 4 == 0, "dua_gemm_bf16x3_presplit: N must be a multiple of 4");
+extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
+                                           float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
+    return conv3x3_presplit_impl(xplanes, planes, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 0, stream);
+}
+extern "C" int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,
+                                          float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
+    return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 1, stream);
+}
+
+// C[M][N] = A * W^T (+ bias) (+ residual) with A given as split planes (written by dua_groupnorm_apply_split / _f16f8) and W
+// packed by dua_pack_weight_bf16x3 / _f16f8: the LDS-DMA kernel with a single tap.
+static int gemm_presplit_impl(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
+                              void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream) {
+    DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm presplit: K must be a multiple of 32 (got %d)", K);
+    DUA_REQUIRE(N % 4 == 0, "dua_gemm presplit: N must be a multiple of 4");
+    DUA_REQUIRE(fmt == 0 || !Csplit, "dua_gemm_f16f8_presplit: split output is not available in this format");
     size_t plane = dua_bf16x3_plane_elems(N, K);
-    DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm_bf16x3_presplit: operand too large");
+    DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm presplit: operand too large");
     DConvP d{};
     d.A = (const __bf16*)aplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = C;
     d.a_plane = (long)M * K; d.b_plane = (long)plane;
     d.M = M; d.N = N; d.K = K; d.H = 1; d.W = 1; d.Cin = K; d.nchw_out = 0; d.colsum = colsum; d.ntaps = 1;
     d.act_out = act_out; d.Csplit = (__bf16*)Csplit;
-    d.dbg_norec = dua_dma_conv_enabled == 3;
-    d.ntm = (M + DBM - 1) / DBM;
-    const bool wide = dua_dma_conv_enabled != 2 && N % 256 == 0 && (long)d.ntm * (N / 256) >= 512;
-    d.ntn = wide ? N / 256 : (N + BN - 1) / BN;
-    const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;
-    if (wide) hipLaunchKernelGGL(k_xconv_dma<4>, dim3(grid), 512, 0, as_stream(stream), d);
-    else hipLaunchKernelGGL(k_xconv_dma<2>, dim3(grid), 512, 0, as_stream(stream), d);
-    return dua_check_launch("dua_gemm_bf16x3_presplit");
+    d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
+    return launch_dconv(d, fmt, as_stream(stream), "dua_gemm presplit");
+}
+extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
+                                        void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
+    return gemm_presplit_impl(aplanes, planes, bias, residual, C, Csplit, M, N, K, act_out, colsum, 0, stream);
+}
+extern "C" int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
+                                       int M, int N, int K, int act_out, float* colsum, void* stream) {
+    return gemm_presplit_impl(aplanes, packed, bias, residual, C, nullptr, M, N, K, act_out, colsum, 1, stream);
 }
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,

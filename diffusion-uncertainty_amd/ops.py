@@ -259,8 +259,9 @@ def groupnorm_stats(x1, x2=None, groups=32, eps=1e-5):
 class SplitPlanes:
     """Activation tensor stored as two bf16 NHWC planes (hi | lo) - the operand format of the bf16x3 conv."""
 
-    def __init__(self, buf, shape):
-        self.buf, self.shape, self.device = buf, tuple(shape), buf.device
+    def __init__(self, buf, shape, fmt="bf16x3"):
+        # fmt "bf16x3": bf16 hi | bf16 lo;  "f16f8": fp16 hi | per 32-channel block [32 x e4m3(lo * 2^12) | 32 x e4m3(x)]
+        self.buf, self.shape, self.device, self.fmt = buf, tuple(shape), buf.device, fmt
 
 
 def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32, split=False):
@@ -268,13 +269,14 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
     if split:
+        fmt = "f16f8" if split == "f16f8" else "bf16x3"
         buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
-        check(_lib.lib().dua_groupnorm_apply_split(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
-                                                   int(act), int(resample), _p(dropmask), _p(buf), _stream()),
-              "dua_groupnorm_apply_split")
-        return SplitPlanes(buf, (N, Ho, Wo, C1 + C2))
+        fn = _lib.lib().dua_groupnorm_apply_split_f16f8 if fmt == "f16f8" else _lib.lib().dua_groupnorm_apply_split
+        check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                 int(act), int(resample), _p(dropmask), _p(buf), _stream()), "dua_groupnorm_apply_split")
+        return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt)
     y = torch.empty((N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.float32)
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
         _req(t, name=nm)
@@ -371,7 +373,24 @@ def pack_weight_bf16x3(w):
     return planes
 
 
+def pack_weight_f16f8(w):
+    """fp32 [N][K] linear / 1x1 weight, or OIHW 3x3 conv weight -> the packed f16f8 weight (fp16 plane, fp8 cross plane, row
+    exponents) in one uint8 buffer."""
+    _req(w, name="w")
+    L = _lib.lib()
+    if w.ndim == 4 and w.shape[2] == 3:
+        N, cin = w.shape[0], w.shape[1]
+        K = 9 * cin
+    else:
+        N, cin = w.shape[0], 0
+        K = w.numel() // N
+    packed = torch.empty(L.dua_f16f8_weight_bytes(N, K), device=w.device, dtype=torch.uint8)
+    check(L.dua_pack_weight_f16f8(_p(w), _p(packed), N, K, cin, _stream()), "dua_pack_weight_f16f8")
+    return packed
+
+
 def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=False):
+    """Split-operand 3x3 convolution; a SplitPlanes input selects the kernel by its format (the weight must be packed to match)."""
     pre = isinstance(x, SplitPlanes)
     if not pre:
         _req(x, name="x")
@@ -383,8 +402,9 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if pre:
-        check(_lib.lib().dua_conv3x3_bf16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout,
-                                                     int(nchw_out), _p(ws), _stream()), "dua_conv3x3_bf16x3_presplit")
+        fn = _lib.lib().dua_conv3x3_f16f8_presplit if x.fmt == "f16f8" else _lib.lib().dua_conv3x3_bf16x3_presplit
+        check(fn(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _p(ws), _stream()),
+              "dua_conv3x3 presplit")
     else:
         check(_lib.lib().dua_conv3x3_bf16x3(_p(x), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
                                             _p(ws), _stream()), "dua_conv3x3_bf16x3")
@@ -413,6 +433,12 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
     M = 1
     for d in a.shape[:-1]:
         M *= d
+    if a.fmt == "f16f8":
+        assert not split_out, "split output is not available in the f16f8 format"
+        c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
+        check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), M, n_out, K, int(act_out), None,
+                                                 _stream()), "dua_gemm_f16f8_presplit")
+        return c
     if split_out:
         buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
         check(_lib.lib().dua_gemm_bf16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), None, _p(buf), M, n_out, K, int(act_out),

@@ -219,10 +219,31 @@ int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const floa
 /* LayerNorm writing split bf16 planes ([rows][D] hi | lo): operand of the presplit GEMM (uvit/uvit.py:108-110). */
 int dua_layernorm_split(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                         void* stream);
+/* ---- "f16f8" operand format: fp16 hi plane + one fp8 plane carrying both cross-term operands -----------------------
+ * Same role, bytes and call shapes as the bf16x3 entry points above (conv / 1x1 / linear products of
+ * guided_diffusion/unet_openai.py:186,212,223,287,483,616 evaluated to ~2^-15 per product), 2/3 of their matrix-core
+ * cycles: product = fp16(a)*fp16(w) on v_mfma_f32_32x32x16_f16 + [a_lo*w + a*w_lo] on ONE block-scaled
+ * v_mfma_scale_f32_32x32x64_f8f6f4 per 32-deep K block (csrc/mfma_bf16x3.hip, FMT 1).
+ * Activation planes ([rows][C] each 2 bytes per element): plane 0 fp16(x); plane 1 per 32-channel block
+ * [32 x e4m3((x - fp16 x) * 2^12) | 32 x e4m3(x)].  Packed weights (dua_f16f8_weight_bytes): plane 0 fp16(w) [Npad128][K];
+ * plane 1 per (row, 32-k block) [32 x e4m3(w * 2^s) | 32 x e4m3((w - fp16 w) * 2^(s+12))]; then Npad row exponents s. */
+size_t dua_f16f8_weight_bytes(int N, int K);
+int dua_pack_weight_f16f8(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
+int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                    const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                    int resample, const float* dropmask, void* yplanes, void* stream);
+int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
+                               int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
+int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
+                            int M, int N, int K, int act_out, float* colsum, void* stream);
 /* Diagnostic engine selector for dua_conv3x3_bf16x3_presplit (returns the previous mode): 1 = LDS-DMA kernels, 256x256
  * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
  * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */
 int dua_set_dma_conv(int mode);
+/* Start-up stagger of the persistent LDS-DMA workgroups (tuning knob): `phases` phases per XCD (0 / 1 = off), each
+ * `percent` % of 1/phases of the estimated tile period; applied when every workgroup owns >= min_tiles tiles.  Spreads
+ * the epilogues (output / residual HBM traffic) of the 256 workgroups over the tile period instead of one burst. */
+int dua_set_conv_stagger(int phases, int percent, int min_tiles);
 int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,
                     const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                     int act_out, float alpha, float* colsum, void* stream);

@@ -126,7 +126,7 @@ def parse_args(argv=None):
     p.add_argument("--uncertainty-distance", type=int, default=20, dest="uncertainty_distance")
     p.add_argument("--num-zigzag", "--num-zigzags", "--num-zig-zag", "--num-zig-zags", type=int, default=3, dest="num_zigzag")
     # engine options (not in the reference)
-    p.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3")
+    p.add_argument("--precision", choices=["f16f8", "bf16x3", "fp32"], default="bf16x3")
     p.add_argument("--noise", choices=["host", "device"], default="host", help="host: CPU-generator noise tape in the reference's draw order")
     p.add_argument("--synthetic", action="store_true", help="generate X_T / y like scripts/generate_diffusion_starting_data.py")
     p.add_argument("--random-weights", action="store_true", help="seeded random weights instead of checkpoints")

@@ -267,6 +267,46 @@ def test_conv3x3_bf16x3(ops, N, H, W, Cin, Cout):
     assert (y.cpu().double() - ref).abs().max().item() < 1e-4
 
 
+def _f16f8_planes(ops, x_nhwc):
+    """x in the f16f8 plane format, written by the product kernel itself (identity GroupNorm: mean 0, rstd 1, gamma 1)."""
+    N, C = x_nhwc.shape[0], x_nhwc.shape[3]
+    st = torch.tensor([0.0, 1.0]).repeat(N * 32, 1).contiguous().to(dev)
+    return ops.groupnorm_apply(x_nhwc.to(dev), st, torch.ones(C, device=dev), torch.zeros(C, device=dev), act=0, split="f16f8")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 16, 32, 6),
+                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (5, 16, 16, 128, 512)])
+def test_conv3x3_f16f8(ops, N, H, W, Cin, Cout):
+    """fp16 hi*hi + block-scaled fp8 cross terms (dua_conv3x3_f16f8_presplit): plane format, packing and kernel vs fp64."""
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xs = _f16f8_planes(ops, nhwc(x))
+    assert xs.fmt == "f16f8"
+    # the planes decode back to x: fp16(x) + e4m3((x - fp16 x) * 2^12) / 2^12, and e4m3(x) in the second half of each block
+    buf = xs.buf.view(torch.uint8).reshape(2, -1).cpu()
+    hi = buf[0].view(torch.float16).reshape(N, H, W, Cin).float()
+    x8 = buf[1].reshape(N * H * W, Cin // 32, 2, 32)
+    lo = x8[:, :, 0].reshape(N, H, W, Cin).view(torch.float8_e4m3fn).float() / 4096
+    np.testing.assert_array_equal(hi.numpy(), nhwc(x).half().float().numpy())
+    assert (hi + lo - nhwc(x)).abs().max().item() < 1e-4          # e4m3 keeps 2^-4 of lo <= 2^-11 |x|
+    np.testing.assert_array_equal(x8[:, :, 1].reshape(N, H, W, Cin).view(torch.float8_e4m3fn).float().numpy(),
+                                  nhwc(x).to(torch.float8_e4m3fn).float().numpy())
+    packed = ops.pack_weight_f16f8(w.to(dev))
+    y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err = (nchw(y.cpu()).double() - (ref + res)).abs().max().item()
+    assert err < 2e-4, err                                   # ~2^-15 per product: 3e-5 on O(1) outputs
+    y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, nchw_out=True)
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-4
+    if Cout % 4:
+        return
+    # one tap: the presplit GEMM over pixel rows (qkv projection)
+    w1 = rnd(24, Cout, Cin) / math.sqrt(Cin)
+    c = ops.gemm_bf16x3_presplit(xs, ops.pack_weight_f16f8(w1.to(dev)), Cout, bias=b.to(dev))
+    ref1 = nhwc(x).reshape(-1, Cin).double() @ w1.double().t() + b.double()
+    assert (c.cpu().double() - ref1).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0)])
 def test_gemm_bf16x3(ops, M, N, K1, K2):
     a1, a2 = rnd(30, M, K1), (rnd(31, M, K2) if K2 else None)
