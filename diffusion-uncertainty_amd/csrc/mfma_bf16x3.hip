@@ -503,7 +503,14 @@ template <int NT, int FMT>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
     constexpr int DBN = 64 * NT;
-    constexpr int RA = 3, RB = NT == 2 ? 3 : 2;      // ring depths (stages) of the activation / weight operand
+    // Ring depths (stages) of the activation / weight operand.  With the 256x256 tile the 160 KB of LDS hold five 32 KB
+    // stages: the bf16x3 loop (matrix-core bound) keeps the activations two tiles ahead; the f16f8 loop is bound by the
+    // WEIGHT stream - every workgroup of the chip asks for the same 32 KB tile at the same time, and the activation
+    // stream has pushed it out of the 4 MB L2s since the previous M tile, so it comes from the Infinity Cache - and
+    // keeps the weights two tiles ahead instead (measured per 72-step tile: weight stream 36k cycles exposed, activation
+    // stream 7k).
+    constexpr bool BDEEP = NT == 4 && FMT == 1;
+    constexpr int RA = BDEEP ? 2 : 3, RB = NT == 2 || BDEEP ? 3 : 2;
     constexpr int SA = DBM * LDH;                    // bf16 elements per A plane of a stage
     constexpr int SB = DBN * LDH;
     constexpr int BOFF = RA * 2 * SA;                // start of the weight ring
@@ -564,10 +571,10 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
     for (int j = 0; j < NT / 2; ++j) boff[j] = (unsigned)(((long)(n0 + 16 * ((NT / 2) * wave + j) + lrow) * p.K + 8 * csrc) * 2);
     const long arem = ((long)p.M - mbase) * p.Cin * 2;                       // bytes from the rebased origin to the plane's end
-    const int arec = p.dbg_norec ? 0 : (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
+    const int arec = (p.dbg_norec & 1) ? 0 : (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
     const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)mbase * p.Cin), 0, arec, 0x00020000);
     const auto ral = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + p.a_plane + (long)mbase * p.Cin), 0, arec, 0x00020000);
-    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.dbg_norec ? 0 : (int)(2 * p.b_plane * 2), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (p.dbg_norec & 2) ? 0 : (int)(2 * p.b_plane * 2), 0x00020000);
     const int b_lo = (int)(p.b_plane * 2);                                   // byte distance hi -> lo weight plane
     int tap = 0, cb = 0;
     // The DMA pieces of a tile are issued one at a time so that the caller can spread them between MFMA groups
@@ -582,10 +589,13 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     };
     auto dma_a = [&](int sa, int i) {          // piece i = 0..3 of the activation tile whose offsets dma_setup() prepared
         __bf16* st = lds + sa * 2 * SA;
-        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH, 16, vo0, 0, 0, 0);
-        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave)) * LDH + SA, 16, vo0, 0, 0, 0);
-        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH, 16, vo1, 0, 0, 0);
-        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave + 1)) * LDH + SA, 16, vo1, 0, 0, 0);
+#ifndef DUA_A_AUX
+#define DUA_A_AUX 0
+#endif
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * LDH, 16, vo0, 0, 0, DUA_A_AUX);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave)) * LDH + SA, 16, vo0, 0, 0, DUA_A_AUX);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * LDH, 16, vo1, 0, 0, DUA_A_AUX);
+        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, st + (16 * (2 * wave + 1)) * LDH + SA, 16, vo1, 0, 0, DUA_A_AUX);
     };
     auto dma_b = [&](int sb, int i) {          // piece i = 0..NT-1 of the next weight tile (sequential in K)
         __bf16* st = lds + BOFF + sb * 2 * SB;
@@ -752,8 +762,8 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     issue_a(0);
     issue_b(0);
     if (nk > 1) {
-        issue_a(1);
-        if (NT == 2) issue_b(1);
+        if (!BDEEP) issue_a(1);
+        if (NT == 2 || BDEEP) issue_b(1);
     }
     DWAIT_TILE(nk > 1)
     __builtin_amdgcn_s_barrier();
@@ -768,23 +778,25 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     __builtin_amdgcn_sched_barrier(0);
     // Per K step:  [hi*hi k 0..15 | hi*hi k 16..31]  wait + barrier  [cross MFMA].  The cross fragments of the step are read
     // between the hi*hi MFMAs, the hi fragments of the NEXT stage between the cross MFMAs (after the barrier that publishes
-    // it), the DMA pieces of tile kt+2 between the MFMAs of the second hi*hi group and the cross group: at most two
-    // ds_read_b128 or one DMA piece per MFMA gap, never a burst of reads that would hold the matrix pipe of the wave.
+    // it), the DMA pieces of the tiles ahead between the hi*hi MFMAs: at most two ds_read_b128 or one DMA piece per MFMA
+    // gap, never a burst of reads that would hold the matrix pipe of the wave.
     for (int kt = 0; kt < nk; ++kt) {
-        int sa2 = sa + 2;
+        constexpr int AA = BDEEP ? 1 : 2, BA = NT == 4 && !BDEEP ? 1 : 2;      // tiles ahead of the step being multiplied
+        int sa2 = sa + AA;
         if (sa2 >= RA) sa2 -= RA;
-        int sbn = sb + (RB - 1);
+        int sbn = sb + BA;
         if (sbn >= RB) sbn -= RB;
-        const bool preA = kt + 2 < nk;
-        const bool preB = NT == 4 ? kt + 1 < nk : kt + 2 < nk;
+        const bool preA = kt + AA < nk, preB = kt + BA < nk;
         if (preA) dma_setup();
+        // piece order of a step = issue order = vmcnt order: the operand that is only ONE tile ahead goes first, so that the
+        // counted wait at the end of the step can leave the 4 (NT = 4) / 6 (NT = 2) pieces of the far tile in flight
         auto dma_piece = [&](int piece) {
-            if (NT == 4) {
+            if (NT == 4 && !BDEEP) {
                 if (piece < 4) { if (preB) dma_b(sbn, piece); }
                 else if (piece < 8) { if (preA) dma_a(sa2, piece - 4); }
             } else {
                 if (piece < 4) { if (preA) dma_a(sa2, piece); }
-                else if (piece < 6) { if (preB) dma_b(sbn, piece - 4); }
+                else if (piece < 4 + NT) { if (preB) dma_b(sbn, piece - 4); }
             }
         };
         SBAR();
@@ -820,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         for (int u_ = NPIECE / 2; u_ < NPIECE; ++u_) dma_piece(u_);
         SBAR();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        DWAIT_TILE(preA)
+        DWAIT_TILE(BDEEP ? preB : preA)
         __builtin_amdgcn_s_barrier();
         if (++sa == RA) sa = 0;
         if (++sb == RB) sb = 0;
@@ -855,7 +867,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             SBAR();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        DWAIT_TILE(preA)
+        DWAIT_TILE(BDEEP ? preB : preA)
         __builtin_amdgcn_s_barrier();
         if (++sa == RA) sa = 0;
         if (++sb == RB) sb = 0;
@@ -1135,7 +1147,7 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     const bool wide = dua_dma_conv_enabled != 2 && d.N % 256 == 0 && (long)d.ntm * (d.N / 256) >= 512;
     d.ntn = wide ? d.N / 256 : (d.N + BN - 1) / BN;
     const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
-    d.dbg_norec = dua_dma_conv_enabled == 3;
+    d.dbg_norec = dua_dma_conv_enabled == 3 ? 3 : (dua_dma_conv_enabled == 4 ? 1 : (dua_dma_conv_enabled == 5 ? 2 : 0));   // 4: A only, 5: B only
     dconv_set_stagger(d, wide, ntiles, grid);
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);

@@ -78,8 +78,10 @@ def main():
     for i in range(8):
         print(f" tile {i}: prologue {int(np.median(pro[:, i])):7d}  K loop {int(np.median(loop[:, i])):8d}  epilogue {int(np.median(epi[:, i])):7d}"
               + (f"  gap-to-next {int(np.median(gap[:, i])):6d}" if i < 7 else ""))
-    print(" start skew of tile 0 (max-min over workgroups):", int(t[:, 0, 0].max() - t[:, 0, 0].min()),
-          " tile 7 end skew:", int(t[:, 7, 3].max() - t[:, 7, 3].min()))
+    # the counter bases differ between XCDs: spread of the tile starts inside each XCD (workgroup b runs on XCD b % 8)
+    for i in (0, 3, 7):
+        sp = [int(t[x::8, i, 0].max() - t[x::8, i, 0].min()) for x in range(8)]
+        print(f" tile {i}: start-time spread inside an XCD (cycles): median {int(np.median(sp))}, max {max(sp)}")
     tot = t[:, 7, 3] - t[:, 0, 0]
     print(f" 8 tiles: {int(np.median(tot))} cycles; K loop share {np.median(loop.sum(1) / tot):.3f}, epilogue {np.median(epi.sum(1) / tot):.3f}, "
           f"prologue {np.median(pro.sum(1) / tot):.3f}")
