@@ -48,7 +48,7 @@ SIGNATURES = {
     "dua_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dua_groupnorm_ws_floats": (_Z, [_I, _I, _I, _I]),
     "dua_groupnorm_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
-    "dua_groupnorm_apply": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dua_groupnorm_apply": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dua_resample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dua_conv3x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_groupnorm_stats_from_colsums": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
@@ -64,10 +64,10 @@ SIGNATURES = {
     "dua_pack_weight_bf16x3": (_I, [_P, _P, _I, _I, _I, _P]),
     "dua_conv3x3_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_conv3x3_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "dua_groupnorm_apply_split": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dua_groupnorm_apply_split": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dua_f16f8_weight_bytes": (_Z, [_I, _I]),
     "dua_pack_weight_f16f8": (_I, [_P, _P, _I, _I, _I, _P]),
-    "dua_groupnorm_apply_split_f16f8": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dua_groupnorm_apply_split_f16f8": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dua_conv3x3_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_set_dma_conv": (_I, [_I]),

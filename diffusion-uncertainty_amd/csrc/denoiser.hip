@@ -184,6 +184,7 @@ struct GnApplyP {
     int split;               // 1: y is two bf16 planes (hi | lo) of the output shape, for the bf16x3 conv
                              // 2: f16f8 planes: fp16 hi | per 32-channel block [32 x fp8(lo * 2^12) | 32 x fp8(x)]
     long plane;              // elements per plane
+    long film_ld;            // row stride of film in floats (>= 2*C)
 };
 
 typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p, int chunk_px) {
             float a = st.y * p.gamma[ch];
             float b = p.beta[ch] - st.x * a;
             if (p.film) {
-                const float sc = 1.0f + p.film[(size_t)n * 2 * C + ch];
+                const float sc = 1.0f + p.film[(size_t)n * p.film_ld + ch];
                 a *= sc;
-                b = b * sc + p.film[(size_t)n * 2 * C + C + ch];
+                b = b * sc + p.film[(size_t)n * p.film_ld + C + ch];
             }
             ca[u][j] = a;
             cb[u][j] = b;
@@ -313,30 +314,30 @@ __global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p, int chunk_px) {
 }
 
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                         const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                         const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                          int resample, const float* dropmask, float* y, int split, void* stream);
 
 extern "C" int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                   const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                   const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                    int resample, const float* dropmask, float* y, void* stream) {
-    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, y, 0, stream);
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, y, 0, stream);
 }
 
 extern "C" int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                         const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                         const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                          int resample, const float* dropmask, void* yplanes, void* stream) {
-    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, (float*)yplanes, 1, stream);
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 1, stream);
 }
 
 extern "C" int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                               const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                                int resample, const float* dropmask, void* yplanes, void* stream) {
     DUA_REQUIRE((C1 + C2) % 32 == 0, "dua_groupnorm_apply_split_f16f8: channels must be a multiple of 32");
-    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, act, resample, dropmask, (float*)yplanes, 2, stream);
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 2, stream);
 }
 
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                         const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                         const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                          int resample, const float* dropmask, float* y, int split, void* stream) {
     int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && y, "dua_groupnorm_apply: null pointer");
@@ -344,7 +345,8 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply: x2/C2 mismatch");
     DUA_REQUIRE(resample >= 0 || (H % 2 == 0 && W % 2 == 0), "dua_groupnorm_apply: pooling needs even H, W");
     DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply: dropout mask with resampling unsupported");
-    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0};
+    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0, film_ld ? film_ld : 2L * (C1 + C2)};
+    DUA_REQUIRE(p.film_ld >= 2L * (C1 + C2), "dua_groupnorm_apply: film_ld < 2*C");
     {
         long Hy = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wy = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
         p.plane = (long)N * Hy * Wy * C;

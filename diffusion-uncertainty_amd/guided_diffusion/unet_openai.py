@@ -95,7 +95,7 @@ class ResBlock(TimestepBlock):
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
         h = ctx.conv3x3(h, conv1, self.out_channels, colsum=True)      # epilogue leaves GroupNorm statistics for out_layers[0]
-        film = ops.gemm(ctx.emb, self.emb_layers[1].weight, bias=self.emb_layers[1].bias, act_in=1)   # :245
+        film = ctx.film(self)                                                              # :245 emb_layers(emb)
         st2 = ops.groupnorm_stats(h)
         mask = None
         if drop.training and drop.p > 0:
@@ -169,6 +169,7 @@ class _Ctx:
     def __init__(self, model):
         self.model = model
         self.emb = None
+        self.film_all = None
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
         # (False | True = bf16x3 planes | "f16f8" planes)
         assert model.precision in ("fp32", "bf16x3", "f16f8"), model.precision
@@ -207,6 +208,16 @@ class _Ctx:
                     b = b.reshape(Hh, 3, ch).permute(1, 0, 2).reshape(-1)
                 cache[key] = (w.contiguous(), b.contiguous())
         return cache[key]
+
+    def film(self, blk):
+        """(scale | shift) rows of one ResBlock: a column block of the FiLM table.  `emb_layers` of EVERY ResBlock is the same
+        Linear(SiLU(emb)) on the same [B, 4*model_channels] embedding (unet_openai.py:200-206,245), so the forward evaluates
+        all of them with ONE GEMM against the row-concatenated weights (36 launches of ~0.1 ms -> 1 for ADM-128)."""
+        tab = self.model._film_table()
+        if self.film_all is None:
+            self.film_all = ops.gemm(self.emb, tab["w"], bias=tab["b"], act_in=1)
+        o, n = tab["slices"][id(blk)]
+        return self.film_all[:, o:o + n]
 
     def dropout_mask(self, shape_nhwc, p):
         return self.model.dropout_mask_source(shape_nhwc, p)
@@ -326,6 +337,21 @@ class UNetModel(nn.Module):
     # ---- weight cache hygiene
     def invalidate_packed_weights(self):
         self._packed = {}
+
+    def _film_table(self):
+        """Row-concatenated emb_layers weights / biases of all ResBlocks (cached with the packed weights)."""
+        tab = self._packed.get("film_table")
+        if tab is None:
+            blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+            slices, o = {}, 0
+            for b in blocks:
+                n = b.emb_layers[1].weight.shape[0]
+                slices[id(b)] = (o, n)
+                o += n
+            tab = dict(w=torch.cat([b.emb_layers[1].weight.detach() for b in blocks]).contiguous(),
+                       b=torch.cat([b.emb_layers[1].bias.detach() for b in blocks]).contiguous(), slices=slices)
+            self._packed["film_table"] = tab
+        return tab
 
     def _apply(self, fn, *a, **k):
         self._packed = {}

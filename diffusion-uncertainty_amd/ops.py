@@ -264,6 +264,14 @@ class SplitPlanes:
         self.buf, self.shape, self.device, self.fmt = buf, tuple(shape), buf.device, fmt
 
 
+def _film_ld(film, N, C):
+    """Row stride of the FiLM operand: a dense [N, 2C] tensor or a column block (view) of a wider row-major table."""
+    if film is None:
+        return 0
+    assert film.is_cuda and film.dtype == torch.float32 and film.shape == (N, 2 * C) and film.stride(1) == 1, "film: [N, 2C] fp32 rows"
+    return film.stride(0)
+
+
 def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32, split=False):
     N, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
@@ -274,17 +282,15 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
         fn = _lib.lib().dua_groupnorm_apply_split_f16f8 if fmt == "f16f8" else _lib.lib().dua_groupnorm_apply_split
-        check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+        check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film), _film_ld(film, N, C1 + C2),
                  int(act), int(resample), _p(dropmask), _p(buf), _stream()), "dua_groupnorm_apply_split")
         return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt)
     y = torch.empty((N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.float32)
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
         _req(t, name=nm)
-    if film is not None:
-        _req(film, name="film")
-        assert film.shape == (N, 2 * (C1 + C2))
     check(_lib.lib().dua_groupnorm_apply(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
-                                         int(act), int(resample), _p(dropmask), _p(y), _stream()), "dua_groupnorm_apply")
+                                         _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask), _p(y), _stream()),
+          "dua_groupnorm_apply")
     return y
 
 

@@ -125,10 +125,11 @@ int dua_groupnorm_stats(const float* x1, int C1, const float* x2, int C2, int N,
 
 /* y = act(GN(x)*gamma+beta [*(1+scale)+shift]) [*dropmask], optionally followed by 2x2 average pooling
  * (resample=-1) or nearest x2 upsampling (resample=+1): unet_openai.py:183-187 (in_layers), :207-214 and
- * :249-253 (FiLM out_layers), :191-196 (h_upd).  film: [N][2*C] (scale | shift) or NULL. act: 1 = SiLU.
+ * :249-253 (FiLM out_layers), :191-196 (h_upd).  film: [N][2*C] (scale | shift) rows film_ld floats apart (0 = dense 2*C; a column block of the
+ * one-GEMM FiLM table of all ResBlocks, :245 for every block at once) or NULL. act: 1 = SiLU.
  * dropmask: [N][H][W][C] float keep/(1-p) or NULL.  y: NHWC at the resampled size. */
 int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                        const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                        const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                         int resample, const float* dropmask, float* y, void* stream);
 
 /* x_upd of an up/down ResBlock (unet_openai.py:191-196,243): resample=-1 avg-pool 2x2, +1 nearest x2. */
@@ -208,7 +209,7 @@ int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const f
 /* dua_groupnorm_apply writing its result as two bf16 planes (hi = bf16(v), lo = bf16(v - hi)), N*Hy*Wy*C elements
  * each (Hy, Wy = resampled size): the same bytes as the fp32 tensor, already in the bf16x3 conv's operand format. */
 int dua_groupnorm_apply_split(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                              const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                              const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                               int resample, const float* dropmask, void* yplanes, void* stream);
 /* C[M][N] = A W^T (+bias) (+residual) with A as split bf16 planes [M][K] (hi | lo) from dua_groupnorm_apply_split and W
  * from dua_pack_weight_bf16x3: the LDS-DMA kernel with one tap (qkv projection after the attention GroupNorm). */
@@ -230,7 +231,7 @@ int dua_layernorm_split(const float* x, const float* gamma, const float* beta, v
 size_t dua_f16f8_weight_bytes(int N, int K);
 int dua_pack_weight_f16f8(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
 int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                    const float* stats, const float* gamma, const float* beta, const float* film, int act,
+                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                     int resample, const float* dropmask, void* yplanes, void* stream);
 int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
