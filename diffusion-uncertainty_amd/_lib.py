@@ -71,6 +71,7 @@ SIGNATURES = {
     "dua_conv3x3_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_set_dma_conv": (_I, [_I]),
+    "dua_set_gn_apply_wide": (_I, [_I]),
     "dua_set_conv_stagger": (_I, [_I, _I, _I]),
     "dua_gemm_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_layernorm_split": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),

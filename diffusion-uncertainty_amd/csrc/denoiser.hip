@@ -313,6 +313,126 @@ __global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p, int chunk_px) {
     }
 }
 
+// ---- 8 channels per lane: every plane is written 16 B per lane (two float4 for the fp32 output).  Used when both
+// sources have a multiple of 8 channels (f16f8: of 32, so that the lane pair 2i / 2i+1 sits in one 32-channel block).
+// f16f8 plane 1 holds per 32-channel block [32 x lo8 | 32 x hi8]: a lane owns 8 B of each half, so lane pairs swap one
+// half (even lane: the 16 lo8 bytes of both, odd lane: the 16 hi8 bytes) and store 16 contiguous bytes.
+typedef __bf16 gn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gn_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const float (&f)[8], int lane_odd) {
+    if (!p.split) {
+        *(float4*)(p.y + off) = make_float4(f[0], f[1], f[2], f[3]);
+        *(float4*)(p.y + off + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else if (p.split == 1) {
+        gn_bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 t = (__bf16)f[j];
+            h[j] = t;
+            l[j] = (__bf16)(f[j] - (float)t);
+        }
+        __bf16* hi = (__bf16*)p.y + off;
+        *(gn_bf16x8*)hi = h;
+        *(gn_bf16x8*)(hi + p.plane) = l;
+    } else {
+        gn_f16x8 h;
+        float l[8], c8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 t = (_Float16)f[j];
+            h[j] = t;
+            l[j] = fminf(fmaxf((f[j] - (float)t) * 4096.0f, -448.f), 448.f);
+            c8[j] = fminf(fmaxf(f[j], -448.f), 448.f);
+        }
+        *(gn_f16x8*)((_Float16*)p.y + off) = h;
+        int lo0 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false), lo1 = __builtin_amdgcn_cvt_pk_fp8_f32(l[4], l[5], 0, false);
+        lo0 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo0, true);
+        lo1 = __builtin_amdgcn_cvt_pk_fp8_f32(l[6], l[7], lo1, true);
+        int hi0 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], 0, false), hi1 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[4], c8[5], 0, false);
+        hi0 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], hi0, true);
+        hi1 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[6], c8[7], hi1, true);
+        // even lane keeps its lo8 and receives the partner's lo8; odd lane keeps hi8 and receives the partner's hi8
+        const int give0 = lane_odd ? lo0 : hi0, give1 = lane_odd ? lo1 : hi1;
+        const int got0 = __shfl_xor(give0, 1), got1 = __shfl_xor(give1, 1);
+        const size_t eoff = off & ~(size_t)15;                       // element offset of the pair's 16 channels
+        unsigned char* x8 = (unsigned char*)((_Float16*)p.y + p.plane) + (eoff >> 5) * 64 + (eoff & 31) + (lane_odd ? 32 : 0);
+        *(int4*)x8 = lane_odd ? make_int4(got0, got1, hi0, hi1) : make_int4(lo0, lo1, got0, got1);
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_gn_apply8(GnApplyP p, int chunk_px) {
+    const int C = p.C1 + p.C2, O = C / 8, cpg = C / p.G;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int Ho = p.resample < 0 ? p.H / 2 : p.H, Wo = p.resample < 0 ? p.W / 2 : p.W;   // iteration space
+    const int npx = Ho * Wo;
+    const int p0 = blockIdx.x * chunk_px, p1 = min(npx, p0 + chunk_px);
+    const int PP = BLK / O, pl = tid / O;
+    if (pl >= PP) return;                          // (O even: a lane pair is never split by this exit)
+    const int c = 8 * (tid % O);
+    const bool second = c >= p.C1;
+    const float* src = second ? p.x2 : p.x1;
+    const int cs = second ? p.C2 : p.C1, cq = second ? c - p.C1 : c;
+    float ca[8], cb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = c + j;
+        const float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + ch / cpg));
+        float a = st.y * p.gamma[ch];
+        float b = p.beta[ch] - st.x * a;
+        if (p.film) {
+            const float sc = 1.0f + p.film[(size_t)n * p.film_ld + ch];
+            a *= sc;
+            b = b * sc + p.film[(size_t)n * p.film_ld + C + ch];
+        }
+        ca[j] = a;
+        cb[j] = b;
+    }
+    auto xf = [&](size_t pix, float (&r)[8]) {
+        const float4 v0 = *(const float4*)(src + pix * cs + cq), v1 = *(const float4*)(src + pix * cs + cq + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r[j] = v[j] * ca[j] + cb[j];
+            if (p.act == 1) r[j] = silu_f(r[j]);
+        }
+        if (p.drop) {
+            const float4 d0 = *(const float4*)(p.drop + pix * C + c), d1 = *(const float4*)(p.drop + pix * C + c + 4);
+            r[0] *= d0.x; r[1] *= d0.y; r[2] *= d0.z; r[3] *= d0.w; r[4] *= d1.x; r[5] *= d1.y; r[6] *= d1.z; r[7] *= d1.w;
+        }
+    };
+    const int odd = tid & 1;
+    const size_t img_in = (size_t)n * p.H * p.W;
+    // every lane of a pair runs the same number of iterations (same pl), so the pair exchange in gn_store8 is safe
+    for (int px = p0 + pl; px < p1; px += PP) {
+        float r[8];
+        if (p.resample == 0) {
+            const size_t pix = img_in + px;
+            xf(pix, r);
+            gn_store8(p, pix * C + c, r, odd);
+        } else {
+            const int yo = px / Wo, xo = px - yo * Wo;
+            if (p.resample > 0) {
+                xf(img_in + px, r);
+                const int W2 = 2 * p.W;
+                const size_t o = (((size_t)n * 2 * p.H + 2 * yo) * W2 + 2 * xo) * C + c;
+                gn_store8(p, o, r, odd);
+                gn_store8(p, o + C, r, odd);
+                gn_store8(p, o + (size_t)W2 * C, r, odd);
+                gn_store8(p, o + (size_t)W2 * C + C, r, odd);
+            } else {
+                const size_t pix = img_in + (size_t)(2 * yo) * p.W + 2 * xo;
+                float a[8], b[8], d[8], e[8];
+                xf(pix, a); xf(pix + 1, b); xf(pix + p.W, d); xf(pix + p.W + 1, e);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = (a[j] + b[j] + d[j] + e[j]) * 0.25f;
+                gn_store8(p, (((size_t)n * Ho + yo) * Wo + xo) * C + c, r, odd);
+            }
+        }
+    }
+}
+
+static int gn_apply_wide = 1;          // 0: always the 4-channel-per-lane kernel (A/B switch)
+extern "C" int dua_set_gn_apply_wide(int on) { int o = gn_apply_wide; gn_apply_wide = on; return o; }
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                          const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                          int resample, const float* dropmask, float* y, int split, void* stream);
@@ -356,7 +476,12 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     if ((size_t)N * Ho * Wo == 0) return DUA_OK;
     int cp, nc;
     gn_chunking(N, Ho * Wo, &cp, &nc);
-    if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    // the 16-byte-store kernel wins on the large maps (+11 % at 128^2, +5 % at 64^2) and loses on the small ones, where its
+    // fewer, fatter lanes leave part of a workgroup idle
+    const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && (split != 2 || (C1 % 16 == 0 && C2 % 16 == 0)) &&
+                      (long)Ho * Wo >= 4096 && BLK % (C / 8) == 0;
+    if (wide && gn_apply_wide) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    else if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     return dua_check_launch("dua_groupnorm_apply");
 }

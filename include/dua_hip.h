@@ -241,6 +241,9 @@ int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float
  * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
  * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */
 int dua_set_dma_conv(int mode);
+/* A/B switch of the GroupNorm-apply kernels (returns the previous value): 1 = 8 channels per lane with 16-byte stores on
+ * every plane where the channel counts allow (default), 0 = always the 4-channel-per-lane kernel. */
+int dua_set_gn_apply_wide(int on);
 /* Start-up stagger of the persistent LDS-DMA workgroups (tuning knob): `phases` phases per XCD (0 / 1 = off), each
  * `percent` % of 1/phases of the estimated tile period; applied when every workgroup owns >= min_tiles tiles.  Spreads
  * the epilogues (output / residual HBM traffic) of the 256 workgroups over the tile period instead of one burst. */

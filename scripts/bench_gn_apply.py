@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GroupNorm-apply kernel (HBM-bound: reads fp32, writes the conv operand planes) at ADM-128 shapes."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusion_uncertainty_amd import _lib, ops
+
+dev = "cuda"
+L = _lib.lib()
+for H, C in ((128, 256), (64, 256), (32, 512), (16, 768), (128, 512)):
+    N = 128
+    C1 = C if C != 512 or H != 128 else 256
+    x = torch.randn(N, H, H, C1, device=dev)
+    x2 = torch.randn(N, H, H, C - C1, device=dev) if C1 != C else None
+    st = torch.tensor([0.1, 0.9], device=dev).repeat(N * 32, 1).contiguous()
+    g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    film = torch.randn(N, 2 * C, device=dev)
+    for split in (False, True, "f16f8"):
+        for wide in (0, 1):
+            L.dua_set_gn_apply_wide(wide)
+            ops.groupnorm_apply(x, st, g, b, x2=x2, film=film, act=1, split=split)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.groupnorm_apply(x, st, g, b, x2=x2, film=film, act=1, split=split)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            by = N * H * H * C * 8.0
+            print(f"H={H:4d} C={C:4d} split={str(split):6s} wide={wide}: {ms:7.3f} ms  {by / ms / 1e9:6.2f} TB/s", flush=True)
