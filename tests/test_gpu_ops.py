@@ -147,7 +147,8 @@ def test_layout_roundtrip(ops):
     assert torch.equal(z.cpu(), x[:, :3])
 
 
-@pytest.mark.parametrize("C1,C2,H", [(32, 0, 8), (64, 32, 8), (192, 0, 16), (256, 0, 32), (576, 384, 4), (1024, 1024, 8), (1280, 0, 4)])
+@pytest.mark.parametrize("C1,C2,H", [(32, 0, 8), (64, 32, 8), (192, 0, 16), (256, 0, 32), (576, 384, 4), (1024, 1024, 8), (1280, 0, 4),
+                                     (64, 0, 64), (32, 32, 64), (64, 0, 128)])       # >= 64^2: the 8-channel-per-lane kernel
 def test_groupnorm(ops, C1, C2, H):
     N = 2
     x1 = rnd(10, N, C1, H, H) * 2 + 0.5
@@ -179,6 +180,21 @@ def test_groupnorm(ops, C1, C2, H):
         np.testing.assert_allclose(nchw(y.cpu()).numpy(), F.interpolate(F.silu(gn), scale_factor=2, mode="nearest").numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_array_equal(nchw(ops.resample2x(d1, -1).cpu()).numpy(), F.avg_pool2d(x1, 2, 2).numpy())
         np.testing.assert_array_equal(nchw(ops.resample2x(d1, 1).cpu()).numpy(), F.interpolate(x1, scale_factor=2, mode="nearest").numpy())
+    if C % 32 == 0:
+        # split outputs decode to the fp32 result: bf16 hi + lo (2^-17), fp16 hi + e4m3 lo (2^-15)
+        want = nhwc(F.silu(gn * (1 + sc) + sh))
+        for split, tol in ((True, 2e-5), ("f16f8", 1e-4)):
+            for res, ref in ((0, want), (1, nhwc(F.interpolate(nchw(want), scale_factor=2, mode="nearest")))) if C2 == 0 else ((0, want),):
+                sp = ops.groupnorm_apply(d1, stats, ga.to(dev), be.to(dev), x2=d2, film=film.to(dev), act=1, split=split, resample=res)
+                buf = sp.buf.view(torch.uint8).reshape(2, -1).cpu()
+                if split is True:
+                    dec = buf[0].view(torch.bfloat16).float() + buf[1].view(torch.bfloat16).float()
+                else:
+                    x8 = buf[1].reshape(-1, 2, 32)
+                    dec = buf[0].view(torch.float16).float() + x8[:, 0].reshape(-1).view(torch.float8_e4m3fn).float() / 4096
+                    h8 = x8[:, 1].reshape(-1).view(torch.float8_e4m3fn).float()
+                    assert (h8 - ref.reshape(-1)).abs().max().item() <= 0.0625 * ref.abs().max().item() + 1e-3
+                assert (dec.reshape(ref.shape) - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 8, 3, 32),
