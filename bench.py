@@ -46,7 +46,7 @@ class ConvProfile:
     # HBM-side bytes per conv launch from the PMC passes of profiles/r01d_pmc_traffic_conv.json (FETCH_SIZE doubled per the
     # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
     PMC_TRAFFIC_BF16X3 = 2.145e9
-    PMC_TRAFFIC_F16F8 = None          # filled from profiles/r01h_pmc_traffic_conv.json once collected
+    PMC_TRAFFIC_F16F8 = 2.066e9       # profiles/r01h_pmc_traffic_conv.json (mean over the conv and 1-tap GEMM launches of the kernel)
 
     def summary(self):
         if not self.items:

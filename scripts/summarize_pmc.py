@@ -31,7 +31,7 @@ def pmc(out, tag):
             for name, value in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
                 if "k_xconv_dma" not in name:
                     continue
-                key = "k_xconv_dma<4>" if "<4>" in name else "k_xconv_dma<2>"
+                key = "k_xconv_dma<4>" if ("<4>" in name or "<4," in name) else "k_xconv_dma<2>"
                 for k in (key, "k_xconv_dma"):
                     acc[k] += float(value)
                     cnt[k] += 1
