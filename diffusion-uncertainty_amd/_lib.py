@@ -49,6 +49,9 @@ SIGNATURES = {
     "dua_groupnorm_ws_floats": (_Z, [_I, _I, _I, _I]),
     "dua_groupnorm_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dua_groupnorm_apply": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "dua_add_channel_bias": (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    "dua_geglu": (_I, [_P, _P, _L, _I, _P]),
+    "dua_pick_even": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dua_resample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dua_conv3x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_groupnorm_stats_from_colsums": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P]),

@@ -471,7 +471,7 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
         long Hy = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wy = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
         p.plane = (long)N * Hy * Wy * C;
     }
-    DUA_REQUIRE(C <= 2048, "dua_groupnorm_apply: at most 2048 channels");
+    DUA_REQUIRE(C <= 3072, "dua_groupnorm_apply: at most 3072 channels");
     int Ho = resample < 0 ? H / 2 : H, Wo = resample < 0 ? W / 2 : W;
     if ((size_t)N * Ho * Wo == 0) return DUA_OK;
     int cp, nc;
@@ -482,8 +482,67 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
                       (long)Ho * Wo >= 4096 && BLK % (C / 8) == 0;
     if (wide && gn_apply_wide) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
-    else hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    else if (C / 4 <= 2 * BLK) hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    else hipLaunchKernelGGL(k_gn_apply<3>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);    // SD-1.5 up blocks: 1280 + 1280
     return dua_check_launch("dua_groupnorm_apply");
+}
+
+// =================================== latent-UNet (SD-1.5) helpers ===============================
+// x[n][p][c] += bias[n][c]  (ResnetBlock2D: hidden + time_emb_proj(silu(emb))[:, :, None, None]), in place
+__global__ __launch_bounds__(BLK) void k_add_channel_bias(float* __restrict__ x, const float* __restrict__ b, long bld, int N, int HW, int C) {
+    const int Q = C / 4;
+    size_t total = (size_t)N * HW * Q, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int q = (int)(i % Q);
+        const int n = (int)(i / ((size_t)HW * Q));
+        float4 v = ((float4*)x)[i];
+        const float4 bb = *(const float4*)(b + (size_t)n * bld + 4 * q);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        ((float4*)x)[i] = v;
+    }
+}
+extern "C" int dua_add_channel_bias(float* x, const float* bias, long bias_ld, int N, int HW, int C, void* stream) {
+    DUA_REQUIRE(x && bias && N > 0 && HW > 0 && C > 0 && C % 4 == 0 && bias_ld % 4 == 0 && bias_ld >= C, "dua_add_channel_bias: bad arguments");
+    hipLaunchKernelGGL(k_add_channel_bias, stream_grid((size_t)N * HW * (C / 4), BLK), BLK, 0, as_stream(stream), x, bias, bias_ld, N, HW, C);
+    return dua_check_launch("dua_add_channel_bias");
+}
+
+// GEGLU (diffusers activations.GEGLU): y[m][f] = x[m][f] * gelu(x[m][F + f]), exact erf GELU
+__global__ __launch_bounds__(BLK) void k_geglu(const float* __restrict__ x, float* __restrict__ y, long M, int F) {
+    const int Q = F / 4;
+    size_t total = (size_t)M * Q, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t m = i / Q;
+        const int q = (int)(i % Q);
+        const float4 a = *(const float4*)(x + m * 2 * F + 4 * q), g = *(const float4*)(x + m * 2 * F + F + 4 * q);
+        auto ge = [](float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); };
+        ((float4*)y)[i] = make_float4(a.x * ge(g.x), a.y * ge(g.y), a.z * ge(g.z), a.w * ge(g.w));
+    }
+}
+extern "C" int dua_geglu(const float* x, float* y, long M, int F, void* stream) {
+    DUA_REQUIRE(x && y && M > 0 && F > 0 && F % 4 == 0, "dua_geglu: F must be a positive multiple of 4");
+    hipLaunchKernelGGL(k_geglu, stream_grid((size_t)M * (F / 4), BLK), BLK, 0, as_stream(stream), x, y, M, F);
+    return dua_check_launch("dua_geglu");
+}
+
+// y[n][i][j][c] = x[n][2i][2j][c]: the stride-2 / pad-1 3x3 convolution of diffusers' Downsample2D is the stride-1 result
+// sampled at the even pixels
+__global__ __launch_bounds__(BLK) void k_pick_even(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int Q = C / 4, Ho = H / 2, Wo = W / 2;
+    size_t total = (size_t)N * Ho * Wo * Q, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int q = (int)(i % Q);
+        size_t pp = i / Q;
+        const int xo = (int)(pp % Wo);
+        pp /= Wo;
+        const int yo = (int)(pp % Ho), n = (int)(pp / Ho);
+        ((float4*)y)[i] = *(const float4*)(x + ((((size_t)n * H + 2 * yo) * W + 2 * xo) * C + 4 * q));
+    }
+}
+extern "C" int dua_pick_even(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    DUA_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "dua_pick_even: even H, W and C %% 4 == 0");
+    hipLaunchKernelGGL(k_pick_even, stream_grid((size_t)N * (H / 2) * (W / 2) * (C / 4), BLK), BLK, 0, as_stream(stream), x, y, N, H, W, C);
+    return dua_check_launch("dua_pick_even");
 }
 
 // =================================== 2x resampling of the skip path ============================

@@ -568,8 +568,18 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         abits[j] = bits;
     }
     unsigned boff[NT / 2];
+    // Every workgroup of the chip streams the SAME weight tile at about the same time: rotate which 16-row group a wave
+    // fetches by the workgroup's slot, so that at a given moment the workgroups of an XCD ask different L2 channels.
+#ifndef DUA_B_ROT
+#define DUA_B_ROT 1
+#endif
+    const int brot = DUA_B_ROT ? (slot * 5) % (4 * NT) : 0;
+    int bgrp[NT / 2];
 #pragma unroll
-    for (int j = 0; j < NT / 2; ++j) boff[j] = (unsigned)(((long)(n0 + 16 * ((NT / 2) * wave + j) + lrow) * p.K + 8 * csrc) * 2);
+    for (int j = 0; j < NT / 2; ++j) {
+        bgrp[j] = ((NT / 2) * wave + j + brot) % (4 * NT);
+        boff[j] = (unsigned)(((long)(n0 + 16 * bgrp[j] + lrow) * p.K + 8 * csrc) * 2);
+    }
     const long arem = ((long)p.M - mbase) * p.Cin * 2;                       // bytes from the rebased origin to the plane's end
     const int arec = (p.dbg_norec & 1) ? 0 : (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
     const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)mbase * p.Cin), 0, arec, 0x00020000);
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         __bf16* st = lds + BOFF + sb * 2 * SB;
 #pragma unroll
         for (int j = 0; j < NT / 2; ++j) {
-            __bf16* dst = st + (16 * ((NT / 2) * wave + j)) * LDH;
+            __bf16* dst = st + (16 * bgrp[j]) * LDH;
             if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
             if (i == 2 * j + 1) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);

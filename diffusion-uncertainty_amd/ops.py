@@ -303,6 +303,56 @@ def resample2x(x, mode):
     return y
 
 
+def add_channel_bias_(x, bias):
+    """x [N, H, W, C] += bias [N, C] (a dense tensor or a column block of a wider table), in place."""
+    _req(x, name="x")
+    N, H, W, C = x.shape
+    assert bias.is_cuda and bias.dtype == torch.float32 and bias.shape == (N, C) and bias.stride(1) == 1
+    check(_lib.lib().dua_add_channel_bias(_p(x), _p(bias), bias.stride(0), N, H * W, C, _stream()), "dua_add_channel_bias")
+    return x
+
+
+def geglu(x):
+    """[M, 2F] -> [M, F]: x[:, :F] * gelu(x[:, F:])."""
+    _req(x, name="x")
+    M, F2 = x.shape
+    y = torch.empty((M, F2 // 2), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_geglu(_p(x), _p(y), M, F2 // 2, _stream()), "dua_geglu")
+    return y
+
+
+def pick_even(x):
+    """NHWC [N, H, W, C] -> [N, H/2, W/2, C]: the even pixels."""
+    _req(x, name="x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=torch.float32)
+    check(_lib.lib().dua_pick_even(_p(x), _p(y), N, H, W, C, _stream()), "dua_pick_even")
+    return y
+
+
+def attention(q, k, v, heads):
+    """Multi-head attention with separate operands (cross-attention): q [B, Tq, C], k / v [B, Tk, C], heads of C/heads
+    channels, softmax(q k^T / sqrt(ch)) v -> [B, Tq, C].  fp32 MFMA products with the logits in HBM (the SD-1.5 shapes
+    are small: Tk = 77 for the text context)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        _req(t, name=nm)
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    ch = C // heads
+    assert k.shape == (B, Tk, C) and v.shape == (B, Tk, C) and C % heads == 0 and ch % 4 == 0 and B * heads <= 65535
+    Tp = (Tk + 3) // 4 * 4
+    S = torch.empty((B * heads, Tq, Tp), device=q.device, dtype=torch.float32)
+    out = torch.empty((B, Tq, C), device=q.device, dtype=torch.float32)
+    gemm_raw(A1=q.data_ptr(), B=k.data_ptr(), C=S.data_ptr(), M=Tq, N=Tk, K1=ch, K2=0, lda1=C, lda2=4, ldb=C, ldc=Tp, ldr=Tp,
+             sA1=Tq * C, sB=Tk * C, sC=heads * Tq * Tp, batch=B * heads, batch_inner=heads, sA1i=ch, sBi=ch, sCi=Tq * Tp,
+             transB=1, alpha=1.0 / math.sqrt(ch))
+    softmax_rows_(S, B * heads * Tq, Tk, Tp)
+    gemm_raw(A1=S.data_ptr(), B=v.data_ptr(), C=out.data_ptr(), M=Tq, N=ch, K1=Tk, K2=0, lda1=Tp, lda2=4, ldb=C, ldc=C, ldr=C,
+             sA1=heads * Tq * Tp, sB=Tk * C, sC=Tq * C, batch=B * heads, batch_inner=heads, sA1i=Tq * Tp, sBi=ch, sCi=ch,
+             transB=0, alpha=1.0)
+    return out
+
+
 def pack_conv3x3_weight(w):
     """OIHW -> packed device layout consumed by conv3x3."""
     _req(w, name="w")

@@ -1,0 +1,320 @@
+"""Latent UNet of Stable Diffusion 1.5 on the gfx950 HIP library (BASELINE configs[4]).
+
+The reference takes this network from the un-vendored ``diffusers==0.31.0`` (``UNet2DConditionModel``,
+``pipeline_uncertainty/pipeline_stable_diffusion_uncertainty_guided.py:747-753``); this module holds parameters under
+diffusers' state-dict keys (``down_blocks.0.resnets.0.norm1.weight``, ``...attentions.0.transformer_blocks.0.attn2.to_k.weight``
+...) so the ``runwayml/stable-diffusion-v1-5`` UNet checkpoint loads strictly, keeps its call convention
+``unet(sample[B,4,h,w], timestep, encoder_hidden_states=[B,77,768], return_dict=False)[0]`` and drives the C ABI
+(include/dua_hip.h): NHWC activations, 3x3 convs / 1x1 convs / linears on the MFMA tile engines in the model's precision
+mode, GroupNorm+SiLU fused with the operand split, the skip concat of the up blocks never materialised, self-attention in the
+fused flash kernel, cross-attention (77 text tokens) through the batched GEMM + softmax path, GEGLU / time-embedding add as
+small HBM-bound kernels.  PARITY UNPINNED: no diffusers here and no vector in /root/reference; checked against
+oracle/sd_unet.py (a restatement of the published architecture) only.  There is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb, groups):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.norm1, self.conv1 = nn.GroupNorm(groups, cin), nn.Conv2d(cin, cout, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb, cout)
+        self.norm2, self.conv2 = nn.GroupNorm(groups, cout), nn.Conv2d(cout, cout, 3, padding=1)
+        if cin != cout:
+            self.conv_shortcut = nn.Conv2d(cin, cout, 1)
+
+    def run(self, ctx, x, skip=None):
+        """x (+ skip = second half of the channel concat of the up blocks): NHWC."""
+        N, H, W, _ = x.shape
+        G = self.norm1.num_groups
+        st = ops.groupnorm_stats(x, skip, groups=G, eps=self.norm1.eps)
+        h = ops.groupnorm_apply(x, st, self.norm1.weight, self.norm1.bias, x2=skip, act=1, groups=G, split=ctx.split_acts)
+        h = ctx.conv3x3(h, self.conv1, self.cout)
+        ops.add_channel_bias_(h, ctx.temb(self))                       # + time_emb_proj(silu(emb))[:, :, None, None]
+        st2 = ops.groupnorm_stats(h, groups=G, eps=self.norm2.eps)
+        h = ops.groupnorm_apply(h, st2, self.norm2.weight, self.norm2.bias, act=1, groups=G, split=ctx.split_acts)
+        if hasattr(self, "conv_shortcut"):
+            res = ctx.linear(x.view(N * H * W, -1), self.conv_shortcut, a2=(skip.view(N * H * W, -1) if skip is not None else None))
+            res = res.view(N, H, W, self.cout)
+        else:
+            assert skip is None
+            res = x
+        return ctx.conv3x3(h, self.conv2, self.cout, residual=res)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q, self.to_k, self.to_v = nn.Linear(dim, dim, bias=False), nn.Linear(ctx_dim, dim, bias=False), nn.Linear(ctx_dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, 2 * inner)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, 4 * dim), nn.Dropout(0.0), nn.Linear(4 * dim, dim)])
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.norm1, self.attn1 = nn.LayerNorm(dim), Attention(dim, dim, heads)
+        self.norm2, self.attn2 = nn.LayerNorm(dim), Attention(dim, ctx_dim, heads)
+        self.norm3, self.ff = nn.LayerNorm(dim), FeedForward(dim)
+
+    def run(self, ctx, h, B, T, enc):
+        """h: [B*T, C] token rows; enc: [B, Tk, ctx_dim]."""
+        C = h.shape[1]
+        heads = self.attn1.heads
+        n1 = ops.layernorm(h, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        qkv = ctx.gemm(n1, ctx.cat_weight(self.attn1, ("to_q", "to_k", "to_v")), None)
+        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision)
+        h = ctx.gemm(a, self.attn1.to_out[0].weight, self.attn1.to_out[0].bias, residual=h)
+        n2 = ops.layernorm(h, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
+        q = ctx.gemm(n2, self.attn2.to_q.weight, None)
+        Tk = enc.shape[1]
+        e2 = enc.reshape(B * Tk, -1)
+        k, v = ctx.gemm(e2, self.attn2.to_k.weight, None), ctx.gemm(e2, self.attn2.to_v.weight, None)
+        a = ops.attention(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), heads).view(B * T, C)
+        h = ctx.gemm(a, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, residual=h)
+        n3 = ops.layernorm(h, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
+        g = ops.geglu(ctx.gemm(n3, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias))
+        return ctx.gemm(g, self.ff.net[2].weight, self.ff.net[2].bias, residual=h)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, dim, ctx_dim, heads, groups):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.proj_in = nn.Conv2d(dim, dim, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads)])
+        self.proj_out = nn.Conv2d(dim, dim, 1)
+
+    def run(self, ctx, x, enc):
+        N, H, W, C = x.shape
+        st = ops.groupnorm_stats(x, groups=self.norm.num_groups, eps=self.norm.eps)
+        xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0, groups=self.norm.num_groups)
+        h = ctx.linear(xn.view(N * H * W, C), self.proj_in)
+        for blk in self.transformer_blocks:
+            h = blk.run(ctx, h, N, H * W, enc)
+        return ctx.linear(h, self.proj_out, residual=x.view(N * H * W, C)).view(N, H, W, C)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+
+
+class _Block(nn.Module):
+    """One down / mid / up block: ``resnets`` (+ ``attentions``) (+ ``downsamplers`` / ``upsamplers``)."""
+
+    def __init__(self, resnets, attentions=None, down=None, up=None):
+        super().__init__()
+        self.resnets = nn.ModuleList(resnets)
+        if attentions is not None:
+            self.attentions = nn.ModuleList(attentions)
+        if down is not None:
+            self.downsamplers = nn.ModuleList([down])
+        if up is not None:
+            self.upsamplers = nn.ModuleList([up])
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, ted):
+        super().__init__()
+        self.linear_1, self.linear_2 = nn.Linear(cin, ted), nn.Linear(ted, ted)
+
+
+class _Ctx:
+    def __init__(self, model):
+        self.model = model
+        assert model.precision in ("fp32", "bf16x3", "f16f8"), model.precision
+        self.split_mode = model.precision != "fp32"
+        self.split_acts = "f16f8" if model.precision == "f16f8" else model.precision == "bf16x3"
+        self.attn_precision = "fp32" if model.precision == "fp32" else "bf16x3"
+        self.emb = None
+        self.temb_all = None
+
+    def packed(self, key, make):
+        cache = self.model._packed
+        if key not in cache:
+            cache[key] = make()
+        return cache[key]
+
+    def conv3x3(self, h, conv, cout, residual=None, nchw_out=False):
+        if isinstance(h, ops.SplitPlanes):
+            if h.fmt == "f16f8":
+                w = self.packed((id(conv), "w3f"), lambda: ops.pack_weight_f16f8(conv.weight.detach().contiguous()))
+            else:
+                w = self.packed((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
+            return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out)
+        if self.split_mode and h.shape[3] % 32 == 0:
+            w = self.packed((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
+            return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out)
+        w = self.packed((id(conv), "w3"), lambda: ops.pack_conv3x3_weight(conv.weight.detach().contiguous()))
+        return ops.conv3x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out)
+
+    def gemm(self, a, weight, bias, a2=None, residual=None):
+        """rows x weight^T in the model's precision (fp32 MFMA, or the split-bf16 tile engine with the operand split on the fly)."""
+        n_out, K = weight.shape[0], a.shape[1] + (0 if a2 is None else a2.shape[1])
+        if self.split_mode and K % 32 == 0 and a.shape[1] % 32 == 0:
+            planes = self.packed((id(weight), "w1x"), lambda: ops.pack_weight_bf16x3(weight.detach().reshape(n_out, K).contiguous()))
+            return ops.gemm_bf16x3(a, planes, n_out, bias=bias, a2=a2, residual=residual)
+        w = self.packed((id(weight), "w1"), lambda: weight.detach().reshape(n_out, K).contiguous())
+        return ops.gemm(a, w, bias=bias, a2=a2, residual=residual)
+
+    def linear(self, a, conv1x1, a2=None, residual=None):
+        return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual)
+
+    def cat_weight(self, attn, names):
+        """Row-concatenated projection weights (q | k | v of a self-attention): one GEMM, packed qkv rows for dua_attention."""
+        key = (id(attn), names)
+        if key not in self.model._packed:
+            self.model._packed[key] = torch.cat([getattr(attn, n).weight.detach() for n in names]).contiguous()
+        return self.model._packed[key]
+
+    def temb(self, resnet):
+        """time_emb_proj(silu(emb)) of one ResnetBlock2D: a column block of ONE GEMM over all blocks (same emb everywhere)."""
+        tab = self.model._temb_table()
+        if self.temb_all is None:
+            self.temb_all = ops.gemm(self.emb, tab["w"], bias=tab["b"], act_in=1)
+        o, n = tab["slices"][id(resnet)]
+        return self.temb_all[:, o:o + n]
+
+
+class UNet2DConditionModel(nn.Module):
+    """diffusers.UNet2DConditionModel for the SD-1.x configuration family (conv proj_in/out, one transformer block per
+    attention, additive time embedding, 8 heads)."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                 down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                 up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+                 attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32, norm_eps=1e-5):
+        super().__init__()
+        assert norm_eps == 1e-5, "GroupNorm eps of the resnets is the nn.GroupNorm default in this build"
+        boc, L, G, heads, cd = tuple(block_out_channels), layers_per_block, norm_num_groups, attention_head_dim, cross_attention_dim
+        self.config = dict(in_channels=in_channels, out_channels=out_channels, block_out_channels=boc, layers_per_block=L,
+                           down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+                           attention_head_dim=heads, cross_attention_dim=cd, norm_num_groups=G, norm_eps=norm_eps)
+        ted = boc[0] * 4
+        self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(boc[0], ted)
+        self.down_blocks = nn.ModuleList()
+        ch = boc[0]
+        for i, (bt, co) in enumerate(zip(down_block_types, boc)):
+            rs, at = [], []
+            for _ in range(L):
+                rs.append(ResnetBlock2D(ch, co, ted, G))
+                ch = co
+                if bt.startswith("CrossAttn"):
+                    at.append(Transformer2DModel(co, cd, heads, G))
+            self.down_blocks.append(_Block(rs, at or None, down=Downsample2D(co) if i != len(boc) - 1 else None))
+        self.mid_block = _Block([ResnetBlock2D(ch, ch, ted, G), ResnetBlock2D(ch, ch, ted, G)], [Transformer2DModel(ch, cd, heads, G)])
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        for i, bt in enumerate(up_block_types):
+            prev, out_ch = out_ch, rev[i]
+            skip_in = rev[min(i + 1, len(boc) - 1)]
+            rs, at = [], []
+            for j in range(L + 1):
+                rs.append(ResnetBlock2D((prev if j == 0 else out_ch) + (skip_in if j == L else out_ch), out_ch, ted, G))
+                if bt.startswith("CrossAttn"):
+                    at.append(Transformer2DModel(out_ch, cd, heads, G))
+            self.up_blocks.append(_Block(rs, at or None, up=Upsample2D(out_ch) if i != len(boc) - 1 else None))
+        self.conv_norm_out = nn.GroupNorm(G, boc[0])
+        self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
+        self._packed = {}
+        self.precision = "fp32"          # "fp32" | "bf16x3" | "f16f8" (see guided_diffusion/unet_openai.py)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = {}
+        return super().load_state_dict(*a, **k)
+
+    def _temb_table(self):
+        tab = self._packed.get("temb_table")
+        if tab is None:
+            blocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+            slices, o = {}, 0
+            for b in blocks:
+                slices[id(b)] = (o, b.cout)
+                o += b.cout
+            tab = dict(w=torch.cat([b.time_emb_proj.weight.detach() for b in blocks]).contiguous(),
+                       b=torch.cat([b.time_emb_proj.bias.detach() for b in blocks]).contiguous(), slices=slices)
+            self._packed["temb_table"] = tab
+        return tab
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=True, **kw):
+        if not sample.is_cuda:
+            raise RuntimeError("UNet2DConditionModel.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        assert encoder_hidden_states is not None, "encoder_hidden_states is required (cross-attention UNet)"
+        B = sample.shape[0]
+        t = torch.as_tensor(timestep, device=sample.device)
+        t = (t.reshape(1).expand(B) if t.ndim == 0 else t).to(torch.int64).contiguous()
+        enc = encoder_hidden_states.to(torch.float32).contiguous()
+        ctx = _Ctx(self)
+        te = self.time_embedding
+        emb = ops.timestep_embedding(t, self.conv_in.out_channels)        # [cos | sin], freq_shift 0: the ADM embedding
+        emb = ops.gemm(emb, te.linear_1.weight, bias=te.linear_1.bias)
+        ctx.emb = ops.gemm(emb, te.linear_2.weight, bias=te.linear_2.bias, act_in=1)
+        h = ops.nchw_to_nhwc(sample.float().contiguous(), 4)
+        h = ops.conv3x3(h, ctx.packed((id(self.conv_in), "w3"), lambda: ops.pack_conv3x3_weight(self.conv_in.weight.detach().contiguous())),
+                        self.conv_in.bias, self.conv_in.out_channels)
+        res = [h]
+        for blk in self.down_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = r.run(ctx, h)
+                if hasattr(blk, "attentions"):
+                    h = blk.attentions[j].run(ctx, h, enc)
+                res.append(h)
+            if hasattr(blk, "downsamplers"):
+                conv = blk.downsamplers[0].conv
+                h = ops.pick_even(ctx.conv3x3(h, conv, conv.out_channels))      # stride 2 / pad 1 = stride 1 at the even pixels
+                res.append(h)
+        h = self.mid_block.resnets[0].run(ctx, h)
+        h = self.mid_block.attentions[0].run(ctx, h, enc)
+        h = self.mid_block.resnets[1].run(ctx, h)
+        for blk in self.up_blocks:
+            for j, r in enumerate(blk.resnets):
+                h = r.run(ctx, h, res.pop())
+                if hasattr(blk, "attentions"):
+                    h = blk.attentions[j].run(ctx, h, enc)
+            if hasattr(blk, "upsamplers"):
+                conv = blk.upsamplers[0].conv
+                h = ctx.conv3x3(ops.resample2x(h, 1), conv, conv.out_channels)
+        G = self.conv_norm_out.num_groups
+        st = ops.groupnorm_stats(h, groups=G, eps=self.conv_norm_out.eps)
+        h = ops.groupnorm_apply(h, st, self.conv_norm_out.weight, self.conv_norm_out.bias, act=1, groups=G, split=ctx.split_acts)
+        out = ctx.conv3x3(h, self.conv_out, self.conv_out.out_channels, nchw_out=True)
+        if return_dict:
+            return UNet2DConditionOutput(sample=out)
+        return (out,)
+
+
+class UNet2DConditionOutput(dict):
+    def __init__(self, sample):
+        super().__init__(sample=sample)
+        self.sample = sample

@@ -135,6 +135,16 @@ int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N,
 /* x_upd of an up/down ResBlock (unet_openai.py:191-196,243): resample=-1 avg-pool 2x2, +1 nearest x2. */
 int dua_resample2x(const float* x, float* y, int N, int H, int W, int C, int resample, void* stream);
 
+/* ---- latent UNet of Stable Diffusion 1.5 (diffusers==0.31.0 UNet2DConditionModel, un-vendored dependency of
+ * pipeline_uncertainty/pipeline_stable_diffusion_uncertainty_guided.py:747-753; parity unpinned) ----
+ * x[n][p][c] += bias[n][c] in place (ResnetBlock2D: hidden_states + time_emb_proj(silu(emb))[:, :, None, None]);
+ * bias rows are bias_ld floats apart. */
+int dua_add_channel_bias(float* x, const float* bias, long bias_ld, int N, int HW, int C, void* stream);
+/* GEGLU feed-forward gate: y[m][f] = x[m][f] * gelu(x[m][F + f]) for x [M][2F] (exact erf GELU). */
+int dua_geglu(const float* x, float* y, long M, int F, void* stream);
+/* y[n][i][j][c] = x[n][2i][2j][c]  (Downsample2D's stride-2 / pad-1 conv = the stride-1 conv at the even pixels). */
+int dua_pick_even(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on fp32 MFMA (unet_openai.py:186,212,483,616).
  * x: NHWC [N][H][W][Cin]; wp: weights packed by dua_pack_conv3x3_weight ([CoutPad][9][Cin], Cin%32==0, or the
  * small-Cin form [CoutPad][16][4] when Cin == 4); bias [Cout]; residual NHWC [N][H][W][Cout] or NULL (the
