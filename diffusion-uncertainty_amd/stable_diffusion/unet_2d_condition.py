@@ -244,13 +244,25 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
         self._packed = {}
         self.precision = "fp32"          # "fp32" | "bf16x3" | "f16f8" (see guided_diffusion/unet_openai.py)
+        # hipGraph replay of the forward (enable_hip_graph): at the CFG batch of 2 one forward is ~1000 launches of a few
+        # microseconds each and the host cannot issue them fast enough; a captured graph removes the launch path.
+        self._graphs = None
+
+    def enable_hip_graph(self, on=True):
+        """Capture the forward once per (input shapes, precision) into a HIP graph and replay it afterwards."""
+        self._graphs = {} if on else None
+        return self
 
     def _apply(self, fn, *a, **k):
         self._packed = {}
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = {}
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs = {}
         return super().load_state_dict(*a, **k)
 
     def _temb_table(self):
@@ -275,12 +287,35 @@ class UNet2DConditionModel(nn.Module):
         t = torch.as_tensor(timestep, device=sample.device)
         t = (t.reshape(1).expand(B) if t.ndim == 0 else t).to(torch.int64).contiguous()
         enc = encoder_hidden_states.to(torch.float32).contiguous()
+        sample = sample.float().contiguous()
+        if self._graphs is None:
+            out = self._forward_impl(sample, t, enc)
+        else:
+            key = (tuple(sample.shape), tuple(enc.shape), self.precision)
+            entry = self._graphs.get(key)
+            if entry is None:
+                self._forward_impl(sample, t, enc)                     # eager once: packs the weights, warms the allocator
+                sx, st, se = sample.clone(), t.clone(), enc.clone()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    so = self._forward_impl(sx, st, se)
+                entry = self._graphs[key] = (graph, sx, st, se, so)
+            graph, sx, st, se, so = entry
+            sx.copy_(sample), st.copy_(t), se.copy_(enc)
+            graph.replay()
+            out = so.clone()
+        if return_dict:
+            return UNet2DConditionOutput(sample=out)
+        return (out,)
+
+    def _forward_impl(self, sample, t, enc):
+        """sample [B,4,h,w] fp32, t [B] int64, enc [B,Tk,ctx] fp32, all on the GPU -> [B,4,h,w]."""
         ctx = _Ctx(self)
         te = self.time_embedding
         emb = ops.timestep_embedding(t, self.conv_in.out_channels)        # [cos | sin], freq_shift 0: the ADM embedding
         emb = ops.gemm(emb, te.linear_1.weight, bias=te.linear_1.bias)
         ctx.emb = ops.gemm(emb, te.linear_2.weight, bias=te.linear_2.bias, act_in=1)
-        h = ops.nchw_to_nhwc(sample.float().contiguous(), 4)
+        h = ops.nchw_to_nhwc(sample, 4)
         h = ops.conv3x3(h, ctx.packed((id(self.conv_in), "w3"), lambda: ops.pack_conv3x3_weight(self.conv_in.weight.detach().contiguous())),
                         self.conv_in.bias, self.conv_in.out_channels)
         res = [h]
@@ -308,10 +343,7 @@ class UNet2DConditionModel(nn.Module):
         G = self.conv_norm_out.num_groups
         st = ops.groupnorm_stats(h, groups=G, eps=self.conv_norm_out.eps)
         h = ops.groupnorm_apply(h, st, self.conv_norm_out.weight, self.conv_norm_out.bias, act=1, groups=G, split=ctx.split_acts)
-        out = ctx.conv3x3(h, self.conv_out, self.conv_out.out_channels, nchw_out=True)
-        if return_dict:
-            return UNet2DConditionOutput(sample=out)
-        return (out,)
+        return ctx.conv3x3(h, self.conv_out, self.conv_out.out_channels, nchw_out=True)
 
 
 class UNet2DConditionOutput(dict):

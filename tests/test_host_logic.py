@@ -140,3 +140,17 @@ def test_plain_ddim_scheduler_and_pipeline_surface():
         Guided(model, s, 0.9, 16, torch.device("cpu"), 2, 0)
     with pytest.raises(AssertionError):
         Guided(model, s, 2, 16, torch.device("cuda"), 2, 0)            # threshold must be a float or a tensor
+
+
+def test_pndm_scheduler_tables():
+    """SD-1.5 scheduler_config: scaled_linear 0.00085..0.012, steps_offset 1, skip_prk_steps (second timestep twice)."""
+    from diffusion_uncertainty_amd.schedulers_uncertainty.scheduling_pndm import PNDMScheduler
+    s = PNDMScheduler()
+    with pytest.raises(ValueError):
+        s.step(torch.zeros(1), 1, torch.zeros(1))
+    s.set_timesteps(20)
+    assert s.timesteps.tolist() == [951, 901, 901] + list(range(851, 0, -50))
+    assert len(s) == 1000 and abs(float(s.alphas_cumprod[0]) - 0.99915) < 1e-6 and abs(float(s.alphas_cumprod[-1]) - 0.004660) < 1e-5
+    assert float(s.final_alpha_cumprod) == float(s.alphas_cumprod[0])
+    with pytest.raises(NotImplementedError):
+        PNDMScheduler(skip_prk_steps=False)
