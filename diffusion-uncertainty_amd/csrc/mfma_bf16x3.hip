@@ -499,7 +499,12 @@ extern "C" int dua_debug_tile_times(unsigned long long* host) {
 //               (lanes 0-31) holds a_lo8 x w_hi8 with E8M0 scales 2^-12, 2^-s, its k-block 1 (lanes 32-63) a_hi8 x w_lo8 with
 //               scales 1, 2^-(s+12).  The cross terms are 2^-11 of the product and fp8 keeps 2^-4 of them: 2^-15 per
 //               product, like the bf16 split, at 2/3 of its matrix-core cycles (128 instead of 192 per 32x32x32 block).
-template <int NT, int FMT>
+//   RS ("row shift", f16f8 3x3 convolutions whose image width divides 256): ONE activation stage per (channel block, dy) serves
+//   the three dx taps.  The 256-row tile is whole image rows, so the pixel a dx = -1 / +1 tap reads outside the tile is always
+//   outside the image (zero): the taps read the same LDS stage at rows r-1, r, r+1 and zero the lanes at the image's left /
+//   right edge in registers.  Activation traffic L2 -> LDS drops to a third (the taps of a stage used to be re-fetched from L2:
+//   92 % L2 hits but 8 TB/s through the L2s, the limiter of the f16f8 K loop next to the matrix cores).
+template <int NT, int FMT, bool RS = false>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
     constexpr int DBN = 64 * NT;
@@ -509,11 +514,13 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // stream has pushed it out of the 4 MB L2s since the previous M tile, so it comes from the Infinity Cache - and
     // keeps the weights two tiles ahead instead (measured per 72-step tile: weight stream 36k cycles exposed, activation
     // stream 7k).
-    constexpr bool BDEEP = NT == 4 && FMT == 1;
+    constexpr bool BDEEP = (NT == 4 && FMT == 1) || RS;
     constexpr int RA = BDEEP ? 2 : 3, RB = NT == 2 || BDEEP ? 3 : 2;
     constexpr int SA = DBM * LDH;                    // bf16 elements per A plane of a stage
     constexpr int SB = DBN * LDH;
-    constexpr int BOFF = RA * 2 * SA;                // start of the weight ring
+    // RS puts the weight ring first: a fragment row -1 of activation stage 0 then reads (masked) weight bytes, not a negative address
+    constexpr int BOFF = RS ? 0 : RA * 2 * SA;       // start of the weight ring
+    constexpr int AOFF = RS ? RB * 2 * SB : 0;       // start of the activation ring
     __shared__ __attribute__((aligned(16))) __bf16 lds[RA * 2 * SA + RB * 2 * SB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // The buffer descriptors are rebased per workgroup at the first pixel its taps can touch (tile start minus one
     // image row and one pixel), so the 32-bit buffer offsets stay tiny whatever the size of the activation planes.
     const int mbase = p.ntaps == 9 ? max(0, m0 - (p.W + 1)) : m0;
-    unsigned abase[2], abits[2];
+    unsigned abase[2], abits[2], rsy = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = min(m0 + 16 * (2 * wave + j) + lrow, p.M - 1);
@@ -566,6 +573,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             }
         }
         abits[j] = bits;
+        if (RS) rsy |= ((bits >> 1) & 1u ? 0u : 1u) << j | ((bits >> 7) & 1u ? 0u : 1u) << (2 + j);   // taps (-1, 0) / (+1, 0) outside
     }
     unsigned boff[NT / 2];
     // Every workgroup of the chip streams the SAME weight tile at about the same time: rotate which 16-row group a wave
@@ -591,6 +599,15 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // (an LDS-DMA issue holds the wave for ~60-180 cycles).
     unsigned vo0 = 0, vo1 = 0;
     auto dma_setup = [&]() {
+        if (RS) {      // one stage per (channel block, dy): the dx = 0 tap's rows; `tap` counts dy + 1 here
+            const int toff = (((tap - 1) * p.W) * p.Cin + cb * BK) * 2;
+            // rows whose dy neighbour lies outside the image: rsy bit j = row group j at y == 0, bit 2 + j = at y == H - 1
+            const unsigned out_ = tap == 0 ? rsy : (tap == 2 ? rsy >> 2 : 0u);
+            vo0 = (out_ & 1u) ? OOB : abase[0] + (unsigned)toff;
+            vo1 = (out_ & 2u) ? OOB : abase[1] + (unsigned)toff;
+            if (++tap == 3) { tap = 0; ++cb; }
+            return;
+        }
         const int dy = p.ntaps == 9 ? tap / 3 - 1 : 0, dx = p.ntaps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
         const int toff = ((dy * p.W + dx) * p.Cin + cb * BK) * 2;           // byte offset of this (tap, channel block)
         vo0 = ((abits[0] >> tap) & 1u) ? abase[0] + (unsigned)toff : OOB;
@@ -598,7 +615,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         if (++tap == p.ntaps) { tap = 0; ++cb; }
     };
     auto dma_a = [&](int sa, int i) {          // piece i = 0..3 of the activation tile whose offsets dma_setup() prepared
-        __bf16* st = lds + sa * 2 * SA;
+        __bf16* st = lds + AOFF + sa * 2 * SA;
 #ifndef DUA_A_AUX
 #define DUA_A_AUX 0
 #endif
@@ -612,9 +629,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
         for (int j = 0; j < NT / 2; ++j) {
             __bf16* dst = st + (16 * bgrp[j]) * LDH;
-            if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
+#ifndef DUA_B_AUX
+#define DUA_B_AUX 0
+#endif
+            if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, DUA_B_AUX);
             if (i == 2 * j + 1) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, DUA_B_AUX);
                 boff[j] += BK * 2;
             }
         }
@@ -764,6 +784,147 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     auto rd_ax = [&](int st, int i_) { ax[i_] = rd_x((st * 2 * SA + SA) * 2 + a_row0 + 32 * i_ * LDH * 2); };
     auto rd_bx = [&](int st, int j_) { bx[j_] = rd_x((st * 2 * SB + SB) * 2 + b_row0 + 32 * j_ * LDH * 2); };
 #define SBAR() __builtin_amdgcn_sched_barrier(0)
+  if constexpr (RS) {
+    // ================= row-shift loop: one activation stage per (channel block, dy), three dx steps on it =================
+    constexpr int NM = 2 * NT;
+    const int a_stage0 = AOFF * 2 + a_row0;                                            // bytes
+    // lane offset (bytes) of chunk c of the fragment row shifted by dx; the swizzle follows the ACTUAL LDS row
+    // Every lane-derived offset of the loop is recomputed per step from the lane id (a handful of VALU operations):
+    // the accumulators and fragments take 224 of the 256 registers, and a loop-invariant offset that ends up in scratch
+    // costs a vmcnt(0) at its reload, i.e. the whole DMA pipeline.
+    auto loff = [&](int lr_, int dx, int c) -> int {
+        const int r_ = lr_ + dx;
+        return (r_ * LDH + 8 * (c ^ ((r_ >> 2) & 3))) * 2;
+    };
+    // image-edge lanes: bit i = row block i sits at x == 0, bit 2 + i = at x == W - 1
+    // (kept in bits 4..7 of the lane word that already holds the y-edge bits of the DMA rows)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int x_ = (m0 + wm * 64 + 32 * i + lr) % p.W;
+        rsy |= (x_ == 0 ? 1u : 0u) << (4 + i);
+        rsy |= (x_ == p.W - 1 ? 1u : 0u) << (6 + i);
+    }
+    asm volatile("" : "+v"(rsy));
+    // Edge lanes read ZEROS instead of their shifted row: their fragment address is replaced by one beyond the workgroup's
+    // LDS allocation (out-of-range DS reads return 0), four address selects per step instead of 32 data selects that would
+    // sit between the ds_reads and the MFMAs that consume them (measured: 29k of 220k cycles per tile).
+    constexpr int OOBL = 0x40000;
+    auto edge = [&](int dx, int i) -> bool { return (dx < 0 && ((rsy >> (4 + i)) & 1u)) || (dx > 0 && ((rsy >> (6 + i)) & 1u)); };
+    auto wait_vm = [&](int n) {        // counted wait with a run-time choice among the few counts that occur
+        if (n >= NT + 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT + 4) : "memory");
+        else if (n >= 4 && NT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n >= NT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int ngroups = nk / 3;
+    // prologue: stage of group 0, weight tiles 0 and 1
+    dma_setup();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_a(0, i);
+    issue_b(0);
+    if (nk > 1) issue_b(1);
+    wait_vm(nk > 1 ? NT : 0);
+    __builtin_amdgcn_s_barrier();
+    DUA_STAMP(1)
+    int sa = 0, sb = 0, dxi = 0, grp = 0;
+    bool a_inflight = false;
+    {
+        const int oh0 = loff(lr, -1, kh);
+        const int oha[2] = {edge(-1, 0) ? OOBL : oh0, edge(-1, 1) ? OOBL : oh0};
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+            for (int i_ = 0; i_ < 2; ++i_) ah[s_][i_] = *(const f16x8*)(ldsb + (a_stage0 + 32 * i_ * LDH * 2) + (s_ ? oha[i_] ^ 32 : oha[i_]));
+#pragma unroll
+            for (int j_ = 0; j_ < NT; ++j_) rd_bh(0, s_, j_);
+        }
+    }
+    SBAR();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int dxc = dxi - 1;
+        int sbn = sb + 2;
+        if (sbn >= RB) sbn -= RB;
+        const bool preB = kt + 2 < nk;
+        const bool issueA = dxi == 0 && grp + 1 < ngroups;
+        if (issueA) dma_setup();
+        auto dma_piece = [&](int piece) {          // issue order of a step: weight pieces first, then the next activation stage
+            if (piece < NT) { if (preB) dma_b(sbn, piece); }
+            else if (piece < NT + 4) { if (issueA) dma_a(sa ^ 1, piece - NT); }
+        };
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));                 // keeps the derived values below inside the step
+        const int lr_k = lane_k & 31, kh_k = lane_k >> 5;
+        const int ob_h = loff(lr_k, 0, kh_k), ob_x = loff(lr_k, 0, 2 * kh_k);      // weight side: chunk kh (s = 1: ^ 32), chunk 2kh (^ 16)
+        const int sca_k = kh_k ? 127 : 115;
+        auto rd_bh_k = [&](int st, int s_, int j_) {
+            bh[s_][j_] = *(const f16x8*)(ldsb + (st * 2 * SB * 2 + b_row0 + 32 * j_ * LDH * 2) + (s_ ? ob_h ^ 32 : ob_h));
+        };
+        auto rd_bx_k = [&](int st, int j_) {
+            const char* b_ = ldsb + ((st * 2 * SB + SB) * 2 + b_row0 + 32 * j_ * LDH * 2);
+            const i32x4 u0_ = *(const i32x4*)(b_ + ob_x), u1_ = *(const i32x4*)(b_ + (ob_x ^ 16));
+            bx[j_] = (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
+        };
+        const int ox0 = loff(lr_k, dxc, 2 * kh_k);                      // chunk 2kh + 1 sits at ox0 ^ 16
+        const int oxa[2] = {edge(dxc, 0) ? OOBL : ox0, edge(dxc, 1) ? OOBL : ox0};
+        const int a_st = a_stage0 + sa * 2 * SA * 2;
+        SBAR();
+        // ---- hi*hi, k 0..15: cross fragments of this step (rows shifted by dx), first DMA pieces
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int i_ = m_ / NT, j_ = m_ % NT;
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i_], bh[0][j_], acc[i_][j_], 0, 0, 0);
+            SBAR();
+            if (m_ < 2) {
+                const char* a_ = ldsb + (a_st + SA * 2 + 32 * m_ * LDH * 2);
+                const i32x4 u0_ = *(const i32x4*)(a_ + oxa[m_]), u1_ = *(const i32x4*)(a_ + (oxa[m_] ^ 16));
+                ax[m_] = (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
+            } else if (m_ - 2 < NT) rd_bx_k(sb, m_ - 2);
+            else dma_piece(m_ - 2 - NT);                                   // NT = 4: gaps 6, 7 -> pieces 0, 1
+            SBAR();
+        }
+        // ---- hi*hi, k 16..31: the remaining DMA pieces
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int i_ = m_ / NT, j_ = m_ % NT;
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i_], bh[1][j_], acc[i_][j_], 0, 0, 0);
+            SBAR();
+            if (NT == 4) { if (m_ < 6) dma_piece(2 + m_); }
+            else if (m_ < 2) { dma_piece(2 * m_); dma_piece(2 * m_ + 1); }
+            else dma_piece(2 + m_);
+            SBAR();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // what may stay in flight: the weight tile two steps ahead, and the next activation stage until its group starts
+        if (issueA) a_inflight = true;
+        wait_vm((preB ? NT : 0) + ((a_inflight && dxi != 2) ? 4 : 0));
+        __builtin_amdgcn_s_barrier();
+        if (++sb == RB) sb = 0;
+        int dxn = dxc + 1;                          // dx of the next step, and the stage it reads
+        if (dxi == 2) { sa ^= 1; dxn = -1; dxi = 0; ++grp; a_inflight = false; } else ++dxi;
+        SBAR();
+        const int oh0 = loff(lr_k, dxn, kh_k);                          // chunk 2 + kh sits at oh0 ^ 32
+        const int oha[2] = {edge(dxn, 0) ? OOBL : oh0, edge(dxn, 1) ? OOBL : oh0};
+        const int a_sn = a_stage0 + sa * 2 * SA * 2;
+        SBAR();
+        // ---- cross terms of this step (registers); between them the hi fragments of the next step
+        auto rd_hi = [&](int r_) {
+            const int s_ = r_ / (2 + NT), q_ = r_ % (2 + NT);
+            if (q_ == 0) ah[s_][0] = *(const f16x8*)(ldsb + a_sn + (s_ ? oha[0] ^ 32 : oha[0]));
+            else if (q_ <= NT) rd_bh_k(sb, s_, q_ - 1);
+            else ah[s_][1] = *(const f16x8*)(ldsb + (a_sn + 32 * LDH * 2) + (s_ ? oha[1] ^ 32 : oha[1]));
+        };
+        constexpr int NR = 4 + 2 * NT, NDBL = NR - NM;
+#pragma unroll
+        for (int m_ = 0; m_ < NM; ++m_) {
+            const int i_ = m_ / NT, j_ = m_ % NT;
+            acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 0, 0, 0, sca_k, 0, scbp >> (8 * j_));
+            SBAR();
+            if (m_ < NDBL) { rd_hi(2 * m_); rd_hi(2 * m_ + 1); }
+            else rd_hi(2 * NDBL + (m_ - NDBL));
+            SBAR();
+        }
+    }
+  } else {
     constexpr int KEEP = NT == 4 ? 4 : 6;
 #define DWAIT_TILE(more) \
     if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -894,8 +1055,9 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         }
 #endif
     }
-#undef SBAR
 #undef DWAIT_TILE
+  }
+#undef SBAR
   }
     DUA_STAMP(2)
     // The epilogue's lane-derived addresses must not be hoisted above the K loop (the loop owns every VGPR: hoisted
@@ -1162,6 +1324,9 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
+    } else if (d.ntaps == 9 && 256 % d.W == 0 && dua_dma_conv_enabled != 6) {     // row-shift form (6: A/B switch to the per-tap form)
+        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 1, true>), dim3(grid), 512, 0, st, d);
+        else hipLaunchKernelGGL((k_xconv_dma<2, 1, true>), dim3(grid), 512, 0, st, d);
     } else {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 1>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 1>), dim3(grid), 512, 0, st, d);
