@@ -767,9 +767,11 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const char* ldsb = reinterpret_cast<const char*>(lds);
     const int sca = kh ? 127 : 115;                                                  // E8M0: 2^0 (a_hi8) / 2^-12 (a_lo8 * 2^12)
     int scbp = 0;                                                                    // the NT column-tile scales, one byte each
+    auto load_scales = [&]() {       // called AFTER the prologue DMA has been issued: its latency then runs under that of the DMA
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-        scbp |= ((127 - (int)p.Bscale[n0 + wn * 32 * NT + 32 * j + lr] - (kh ? 12 : 0)) & 0xff) << (8 * j);
+        for (int j = 0; j < NT; ++j)
+            scbp |= ((127 - (int)p.Bscale[n0 + wn * 32 * NT + 32 * j + lr] - (kh ? 12 : 0)) & 0xff) << (8 * j);
+    };
     // ---- single operations; the step below lays them out one by one (every ds_read / DMA sits between two MFMAs)
     auto rd_ah = [&](int st, int s_, int i_) {
         ah[s_][i_] = *(const f16x8*)(ldsb + (st * 2 * SA * 2 + a_row0 + 32 * i_ * LDH * 2) + (s_ ? o_h1 : o_h0));
@@ -823,6 +825,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     for (int i = 0; i < 4; ++i) dma_a(0, i);
     issue_b(0);
     if (nk > 1) issue_b(1);
+    load_scales();
     wait_vm(nk > 1 ? NT : 0);
     __builtin_amdgcn_s_barrier();
     DUA_STAMP(1)
@@ -936,6 +939,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         if (!BDEEP) issue_a(1);
         if (NT == 2 || BDEEP) issue_b(1);
     }
+    load_scales();
     DWAIT_TILE(nk > 1)
     __builtin_amdgcn_s_barrier();
     DUA_STAMP(1)
