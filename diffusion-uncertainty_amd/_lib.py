@@ -72,7 +72,8 @@ SIGNATURES = {
     "dua_pack_weight_f16f8": (_I, [_P, _P, _I, _I, _I, _P]),
     "dua_groupnorm_apply_split_f16f8": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dua_conv3x3_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),
     "dua_set_gn_apply_wide": (_I, [_I]),
     "dua_set_conv_stagger": (_I, [_I, _I, _I]),

@@ -667,7 +667,14 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
         if (c < D) {
             const float o = (v[j] - mean) * rstd * ga[c] + be[c];
             if (!split) y[row * (long)D + c] = o;
-            else {
+            else if (split == 2) {           // f16f8 planes: fp16 hi | per 32-column block [32 x e4m3(lo * 2^12) | 32 x e4m3(o)]
+                const _Float16 h = (_Float16)o;
+                ((_Float16*)y)[row * (long)D + c] = h;
+                unsigned char* x8 = (unsigned char*)((_Float16*)y + rows * (long)D) + (row * (long)D + (c & ~31)) * 2 + (c & 31);
+                const float l = fminf(fmaxf((o - (float)h) * 4096.0f, -448.f), 448.f), g = fminf(fmaxf(o, -448.f), 448.f);
+                x8[0] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(l, 0.f, 0, false) & 0xff);
+                x8[32] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(g, 0.f, 0, false) & 0xff);
+            } else {
                 __bf16* hi = (__bf16*)y;
                 const __bf16 h = (__bf16)o;
                 hi[row * (long)D + c] = h;
@@ -691,6 +698,11 @@ extern "C" int dua_layernorm(const float* x, const float* gamma, const float* be
 extern "C" int dua_layernorm_split(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                                    void* stream) {
     return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 1, stream);
+}
+extern "C" int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
+                                         void* stream) {
+    DUA_REQUIRE(D % 32 == 0, "dua_layernorm_split_f16f8: D must be a multiple of 32");
+    return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 2, stream);
 }
 
 // =================================== embeddings ================================================

@@ -430,16 +430,42 @@ struct DConvP {
 // floats: the two half-waves write rows 4 apart and must land on different banks), then moves whole rows, 16 B per lane.
 // All residual rows of the half are requested BEFORE the transposition so that their latency runs under it (read one by
 // one they cost a full memory round trip per row group: 55k of the 87k epilogue cycles of a 256x256 tile).
-template <int ACT, bool RES, bool SPLIT>
+// four consecutive columns of one output row as f16f8 planes (the operand format of the next presplit GEMM); N % 32 == 0
+__device__ __forceinline__ void store_f16f8_quad(__bf16* planes, long plane_elems, long o, float4 w) {
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    const float f[4] = {w.x, w.y, w.z, w.w};
+    float l[4], g[4];
+    f16x4_t h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 t = (_Float16)f[j];
+        h[j] = t;
+        l[j] = fminf(fmaxf((f[j] - (float)t) * 4096.0f, -448.f), 448.f);
+        g[j] = fminf(fmaxf(f[j], -448.f), 448.f);
+    }
+    *(f16x4_t*)((_Float16*)planes + o) = h;
+    unsigned char* x8 = (unsigned char*)((_Float16*)planes + plane_elems) + (o >> 5) * 64 + (o & 31);
+    int lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false), hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(g[0], g[1], 0, false);
+    lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo8, true);
+    hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(g[2], g[3], hi8, true);
+    *(int*)x8 = lo8;
+    *(int*)(x8 + 32) = hi8;
+}
+
+template <int ACT, bool RES, bool SPLIT, int FMT = 0>
 __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const float4 q, const float4 bq, long o, float4& cs, float4& cq) {
     w.x += bq.x; w.y += bq.y; w.z += bq.z; w.w += bq.w;
     if (ACT == 2) { w.x = gelu_x(w.x); w.y = gelu_x(w.y); w.z = gelu_x(w.z); w.w = gelu_x(w.w); }
     if (RES) { w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
-    if (SPLIT) {               // the consumer is another bf16x3 GEMM: hand it the operand format directly
-        bf16x4 hi, lo;
-        split4(w, hi, lo);
-        *(bf16x4*)(p.Csplit + o) = hi;
-        *(bf16x4*)(p.Csplit + o + (long)p.M * p.N) = lo;
+    if (SPLIT) {               // the consumer is another split-operand GEMM: hand it the operand format directly
+        if (FMT == 1) {
+            store_f16f8_quad(p.Csplit, (long)p.M * p.N, o, w);
+        } else {
+            bf16x4 hi, lo;
+            split4(w, hi, lo);
+            *(bf16x4*)(p.Csplit + o) = hi;
+            *(bf16x4*)(p.Csplit + o + (long)p.M * p.N) = lo;
+        }
     } else {
         *(float4*)(p.C + o) = w;
     }
@@ -447,7 +473,7 @@ __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const f
     cq.x += w.x * w.x; cq.y += w.y * w.y; cq.z += w.z * w.z; cq.w += w.w * w.w;
 }
 
-template <int NT, bool RES, int ACT, bool SPLIT>
+template <int NT, bool RES, int ACT, bool SPLIT, int FMT = 0>
 __device__ __forceinline__ void dconv_rows_full(const DConvP& p, f32x16 (&acc)[2][NT], float* patch, int lane, int row0, int colq,
                                                 float4 bq, float4& cs, float4& cq) {
     constexpr int WC = 32 * NT, WCP = WC + 8, RPI = 64 / (WC / 4), NIT = 32 / RPI;
@@ -476,7 +502,7 @@ __device__ __forceinline__ void dconv_rows_full(const DConvP& p, f32x16 (&acc)[2
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(rd + (g + u) * RPI * WCP);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dconv_row_out<ACT, RES, SPLIT>(p, v[u], RES ? q[g + u] : z4, bq, rb + (g + u) * rstep, cs, cq);
+            for (int u = 0; u < 4; ++u) dconv_row_out<ACT, RES, SPLIT, FMT>(p, v[u], RES ? q[g + u] : z4, bq, rb + (g + u) * rstep, cs, cq);
         }
     }
 }
@@ -1080,8 +1106,8 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
         const int row0 = m0 + wm * 64;
         if (p.Csplit) {
-            if (p.act_out == 2) dconv_rows_full<NT, false, 2, true>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
-            else dconv_rows_full<NT, false, 0, true>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            if (p.act_out == 2) dconv_rows_full<NT, false, 2, true, FMT>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            else dconv_rows_full<NT, false, 0, true, FMT>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
         } else if (p.res) {
             dconv_rows_full<NT, true, 0, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
         } else if (p.act_out == 2) {
@@ -1135,12 +1161,16 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                         const float4 q = *(const float4*)(p.res + (long)row * p.N + colq);
                         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                     }
-                    if (p.Csplit) {        // the consumer is another bf16x3 GEMM: hand it the operand format directly
-                        bf16x4 hi, lo;
-                        split4(v, hi, lo);
-                        __bf16* o = p.Csplit + (long)row * p.N + colq;
-                        *(bf16x4*)o = hi;
-                        *(bf16x4*)(o + (long)p.M * p.N) = lo;
+                    if (p.Csplit) {        // the consumer is another split-operand GEMM: hand it the operand format directly
+                        if (FMT == 1) {
+                            store_f16f8_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v);
+                        } else {
+                            bf16x4 hi, lo;
+                            split4(v, hi, lo);
+                            __bf16* o = p.Csplit + (long)row * p.N + colq;
+                            *(bf16x4*)o = hi;
+                            *(bf16x4*)(o + (long)p.M * p.N) = lo;
+                        }
                     } else {
                         *(float4*)(p.C + (long)row * p.N + colq) = v;
                     }
@@ -1380,7 +1410,7 @@ static int gemm_presplit_impl(const void* aplanes, const void* planes, const flo
                               void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream) {
     DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm presplit: K must be a multiple of 32 (got %d)", K);
     DUA_REQUIRE(N % 4 == 0, "dua_gemm presplit: N must be a multiple of 4");
-    DUA_REQUIRE(fmt == 0 || !Csplit, "dua_gemm_f16f8_presplit: split output is not available in this format");
+    DUA_REQUIRE(!Csplit || fmt == 0 || N % 32 == 0, "dua_gemm_f16f8_presplit: a split output needs N %% 32 == 0");
     size_t plane = dua_bf16x3_plane_elems(N, K);
     DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm presplit: operand too large");
     DConvP d{};
@@ -1396,8 +1426,8 @@ extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes,
     return gemm_presplit_impl(aplanes, planes, bias, residual, C, Csplit, M, N, K, act_out, colsum, 0, stream);
 }
 extern "C" int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
-                                       int M, int N, int K, int act_out, float* colsum, void* stream) {
-    return gemm_presplit_impl(aplanes, packed, bias, residual, C, nullptr, M, N, K, act_out, colsum, 1, stream);
+                                       void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
+    return gemm_presplit_impl(aplanes, packed, bias, residual, C, Csplit, M, N, K, act_out, colsum, 1, stream);
 }
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,

@@ -490,9 +490,13 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
     for d in a.shape[:-1]:
         M *= d
     if a.fmt == "f16f8":
-        assert not split_out, "split output is not available in the f16f8 format"
+        if split_out:
+            buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
+            check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), None, _p(buf), M, n_out, K, int(act_out),
+                                                     None, _stream()), "dua_gemm_f16f8_presplit")
+            return SplitPlanes(buf, (M, n_out), "f16f8")
         c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
-        check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), M, n_out, K, int(act_out), None,
+        check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), None, M, n_out, K, int(act_out), None,
                                                  _stream()), "dua_gemm_f16f8_presplit")
         return c
     if split_out:
@@ -583,10 +587,11 @@ def layernorm(x, gamma, beta, eps=1e-5, split=False):
     _req(x, name="x")
     D = x.shape[-1]
     if split:
+        fmt = "f16f8" if split == "f16f8" else "bf16x3"
         buf = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.int16)
-        check(_lib.lib().dua_layernorm_split(_p(x), _p(gamma), _p(beta), _p(buf), x.numel() // D, D, float(eps), _stream()),
-              "dua_layernorm_split")
-        return SplitPlanes(buf, tuple(x.shape))
+        fn = _lib.lib().dua_layernorm_split_f16f8 if fmt == "f16f8" else _lib.lib().dua_layernorm_split
+        check(fn(_p(x), _p(gamma), _p(beta), _p(buf), x.numel() // D, D, float(eps), _stream()), "dua_layernorm_split")
+        return SplitPlanes(buf, tuple(x.shape), fmt)
     y = torch.empty_like(x)
     check(_lib.lib().dua_layernorm(_p(x), _p(gamma), _p(beta), _p(y), x.numel() // D, D, float(eps), _stream()), "dua_layernorm")
     return y

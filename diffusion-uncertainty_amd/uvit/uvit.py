@@ -52,13 +52,15 @@ class Block(nn.Module):
         D = x.shape[1]
         if self.skip_linear is not None:
             x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
-        fast = precision == "bf16x3" and D % 32 == 0       # LayerNorm / GELU outputs go out as split bf16 planes (LDS-DMA GEMMs)
+        # split modes: LayerNorm / GELU outputs go out in the operand format of the LDS-DMA GEMMs (bf16 planes or f16f8 planes)
+        fast = (precision if precision == "f16f8" else precision == "bf16x3") if D % 32 == 0 else False
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=fast)
         qkv = lin(h, self.attn.qkv)
-        a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads, precision=precision)   # :69-73
+        a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads,
+                              precision="fp32" if precision == "fp32" else "bf16x3")                       # :69-73
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, split=fast)
-        h = lin(h, self.mlp.fc1, act_out=2, split_out=fast)                                        # fc1 + GELU
+        h = lin(h, self.mlp.fc1, act_out=2, split_out=bool(fast))                                  # fc1 + GELU
         return lin(h, self.mlp.fc2, residual=x)                                                    # :119
 
 
@@ -100,7 +102,7 @@ class UViT(nn.Module):
         self.apply(self._init_weights)
         self.img_size = img_size
         self.patch_size = patch_size
-        self.precision = "fp32"          # or "bf16x3" (see guided_diffusion/unet_openai.py)
+        self.precision = "fp32"          # or "bf16x3" / "f16f8" (see guided_diffusion/unet_openai.py)
         self._planes = {}
 
     def _apply(self, fn, *a, **k):
@@ -112,13 +114,15 @@ class UViT(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def _lin(self, a, mod, a2=None, residual=None, act_out=0, split_out=False):
-        if isinstance(a, ops.SplitPlanes):                # operand already in split-bf16 format: LDS-DMA GEMM
-            if id(mod) not in self._planes:
-                self._planes[id(mod)] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
-            return ops.gemm_bf16x3_presplit(a, self._planes[id(mod)], mod.weight.shape[0], bias=mod.bias, residual=residual,
+        if isinstance(a, ops.SplitPlanes):                # operand already in a split format: LDS-DMA GEMM
+            key = (id(mod), a.fmt)
+            if key not in self._planes:
+                pack = ops.pack_weight_f16f8 if a.fmt == "f16f8" else ops.pack_weight_bf16x3
+                self._planes[key] = pack(mod.weight.detach().contiguous())
+            return ops.gemm_bf16x3_presplit(a, self._planes[key], mod.weight.shape[0], bias=mod.bias, residual=residual,
                                             act_out=act_out, split_out=split_out)
         K = a.shape[1] + (0 if a2 is None else a2.shape[1])
-        if self.precision == "bf16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:
+        if self.precision != "fp32" and K % 32 == 0 and a.shape[1] % 32 == 0:
             if id(mod) not in self._planes:
                 self._planes[id(mod)] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
             return ops.gemm_bf16x3(a, self._planes[id(mod)], mod.weight.shape[0], bias=mod.bias, a2=a2, residual=residual, act_out=act_out)

@@ -246,7 +246,10 @@ int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, in
 int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
 int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
-                            int M, int N, int K, int act_out, float* colsum, void* stream);
+                            void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream);
+/* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
+int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
+                              void* stream);
 /* Diagnostic engine selector for dua_conv3x3_bf16x3_presplit (returns the previous mode): 1 = LDS-DMA kernels, 256x256
  * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
  * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */

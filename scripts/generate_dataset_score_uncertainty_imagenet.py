@@ -71,7 +71,8 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         ae = load_autoencoder_uvit(device="cpu", load_checkpoint=ckpt)
         if not ckpt:
             randomize_parameters_(ae, seed=9)
-        uvit.precision = ae.precision = args.precision
+        uvit.precision = args.precision
+        ae.precision = "fp32" if args.precision == "fp32" else "bf16x3"       # the VAE decoder has no f16f8 path (one call per batch)
         model = UViTAE(uvit, ae).to(device)
         scheduler = load_uvit_scheduler()
     uc_scheduler = get_uncertainty_scheduler(args, y.to(device), model, scheduler)
