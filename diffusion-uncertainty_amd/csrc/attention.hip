@@ -164,6 +164,212 @@ __global__ __launch_bounds__(64 * QW) void k_flash_attn(AttnP p) {
     }
 }
 
+// ================================================================================================================
+// Split-bf16 form of the same kernel (precision modes bf16x3 / f16f8 of the models): both products run as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (2^-17 per product), 16 channels / 16 keys per instruction instead
+// of 2, i.e. 96 instead of 512 matrix-core cycles per 32x32x16 block of the exact-fp32 form.
+//   S^T = K . Q^T : A = K tile (LDS, bf16 hi | lo planes, key rows, channel-contiguous), B = this wave's 32 queries, kept in
+//                   REGISTERS for the whole kernel (pre-scaled, split once): query on the lane as before.
+//   O^T += V^T.P^T: B = the exponentiated accumulator registers, split to bf16 where they stand; a 32x32x16 step sums over
+//                   accumulator ROWS 16s + 8(j>>2) + 4h + (j&3) (element j of lane half h), so V is staged TRANSPOSED with its
+//                   32 keys stored in exactly that order: the A fragment is one 16-byte LDS read, no lane exchange anywhere.
+// Head dims up to 128 (queries in registers); wider heads keep the GEMM path.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void asplit(float v, __bf16& h, __bf16& l) {
+    h = (__bf16)v;
+    l = (__bf16)(v - (float)h);
+}
+
+template <int CT16 /* 16-channel steps: ceil(ch/16) */, int QW>
+__global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
+    constexpr int CHP = CT16 * 16, CT32 = (CHP + 31) / 32;
+    constexpr int KP = CHP + 8;          // K tile row pitch (bf16): 16-byte reads of 16 consecutive rows hit distinct banks
+    constexpr int VP = 40;               // V^T row pitch (32 keys + 8)
+    __shared__ __attribute__((aligned(16))) __bf16 Kh[32 * KP], Kl[32 * KP], Vh[CT32 * 32 * VP], Vl[CT32 * 32 * VP];
+    const int ch = p.ch, C = p.heads * ch, T = p.T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
+    const int q0 = blockIdx.x * (QW * 32);
+    const float* base = p.qkv + (long)b * T * 3 * C + h * ch;
+    constexpr int nthr = 64 * QW;
+
+    // ---- this lane's query row, scaled and split once: element j of step c = channel 16c + 8kh + j
+    abf16x8 qh[CT16], ql[CT16];
+    {
+        const float* qrow = base + (long)min(q0 + wave * 32 + lr, T - 1) * 3 * C;
+#pragma unroll
+        for (int c = 0; c < CT16; ++c) {
+            const int c0 = 16 * c + 8 * kh;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j += 4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + j < ch) t = *(const float4*)(qrow + c0 + j);       // ch % 4 == 0: a float4 is all in or all out
+                v[j] = t.x * p.scale; v[j + 1] = t.y * p.scale; v[j + 2] = t.z * p.scale; v[j + 3] = t.w * p.scale;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { __bf16 a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; ql[c][j] = b_; }
+        }
+    }
+    // ---- zero the padded channel columns of the K tile (they meet zero Q channels: must not be NaN patterns) and all of V^T
+    for (int i = tid; i < 32 * KP; i += nthr) { Kh[i] = (__bf16)0.f; Kl[i] = (__bf16)0.f; }
+    for (int i = tid; i < CT32 * 32 * VP; i += nthr) { Vh[i] = (__bf16)0.f; Vl[i] = (__bf16)0.f; }
+
+    f32x16 o[CT32];
+#pragma unroll
+    for (int t = 0; t < CT32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // K/V staging plan: thread-owned float4 chunks of the 32 x ch tile, fetched one key tile ahead into registers
+    const int c4 = ch / 4;
+    constexpr int NL = (32 * (CHP / 4) + nthr - 1) / nthr;
+    int goff[NL], kcol[NL], krow[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int i = tid + j * nthr;
+        const bool live = i < 32 * c4;
+        const int r = live ? i / c4 : 0, c = live ? 4 * (i % c4) : 0;
+        goff[j] = r * 3 * C + C + c;
+        kcol[j] = c;
+        krow[j] = live ? r : (1 << 30);
+    }
+    float4 kr[NL], vr[NL];
+#define DUA_ATTNX_FETCH(KT)                                                                                          \
+    {                                                                                                                \
+        const long adv = (long)(KT) * 32 * 3 * C;                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NL; ++j) {                                                             \
+            const bool ok = (KT) * 32 + krow[j] < T;                                                                 \
+            kr[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
+            vr[j] = kr[j];                                                                                           \
+            if (ok) {                                                                                                \
+                kr[j] = *(const float4*)(base + adv + goff[j]);                                                      \
+                vr[j] = *(const float4*)(base + adv + goff[j] + C);                                                  \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+    DUA_ATTNX_FETCH(0)
+
+    const int nkt = (T + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                     // previous tile's readers are done
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+            if (krow[j] < 32) {
+                const int r = krow[j], c = kcol[j];
+                const float kf[4] = {kr[j].x, kr[j].y, kr[j].z, kr[j].w}, vf[4] = {vr[j].x, vr[j].y, vr[j].z, vr[j].w};
+                abf16x4 a_, b_;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { __bf16 x_, y_; asplit(kf[u], x_, y_); a_[u] = x_; b_[u] = y_; }
+                *(abf16x4*)(Kh + r * KP + c) = a_;
+                *(abf16x4*)(Kl + r * KP + c) = b_;
+                // V^T with the key order of the accumulator rows: key = 16s + 8(j>>2) + 4h + (j&3)  <->  position 16s + 8h + j
+                const int kk = r & 15, pos = (r & 16) + 8 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    __bf16 x_, y_;
+                    asplit(vf[u], x_, y_);
+                    Vh[(c + u) * VP + pos] = x_;
+                    Vl[(c + u) * VP + pos] = y_;
+                }
+            }
+        __syncthreads();
+        DUA_ATTNX_FETCH(kt + 1)
+
+        // ---- S^T tile: keys on rows, this wave's 32 queries on columns (scale folded into Q)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT16; ++c) {
+            const abf16x8 ah = *(const abf16x8*)(Kh + lr * KP + 16 * c + 8 * kh), al = *(const abf16x8*)(Kl + lr * KP + 16 * c + 8 * kh);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+        }
+        // ---- online softmax (query = lane; this lane holds keys (r&3) + 8(r>>2) + 4kh of the tile)
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            s[r] = key < T ? s[r] : -INFINITY;
+            mloc = fmaxf(mloc, s[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+        abf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(s[r] - m_new);
+            psum += e;
+            __bf16 x_, y_;
+            asplit(e, x_, y_);
+            ph[r >> 3][r & 7] = x_;
+            pl[r >> 3][r & 7] = y_;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < CT32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // ---- O^T += V^T . P^T: rows = channels 32t + lr, k = the 16 keys of step s2 in accumulator-row order
+#pragma unroll
+        for (int t = 0; t < CT32; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const abf16x8 vh = *(const abf16x8*)(Vh + (32 * t + lr) * VP + 16 * s2 + 8 * kh),
+                              vl = *(const abf16x8*)(Vl + (32 * t + lr) * VP + 16 * s2 + 8 * kh);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[t], 0, 0, 0);
+            }
+    }
+#undef DUA_ATTNX_FETCH
+    const float l_full = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_full;
+    const int q = q0 + wave * 32 + lr;
+    if (q < T) {
+        float* orow = p.out + ((long)b * T + q) * C + h * ch;
+#pragma unroll
+        for (int t = 0; t < CT32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 32 * t + 8 * g + 4 * kh;
+                if (c < ch) *(float4*)(orow + c) = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+            }
+    }
+}
+
+template <int CT16, int QW>
+static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
+    dim3 grid((p.T + QW * 32 - 1) / (QW * 32), B * p.heads);
+    hipLaunchKernelGGL((k_flash_attn_x<CT16, QW>), grid, 64 * QW, 0, s, p);
+    return dua_check_launch("dua_attention_bf16x3");
+}
+
+extern "C" int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream) {
+    DUA_REQUIRE(qkv && out && B > 0 && T > 0 && heads > 0, "dua_attention_bf16x3: bad arguments");
+    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_attention_bf16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
+    DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_bf16x3: B*heads must be <= 65535");
+    AttnP p{qkv, out, T, heads, ch, scale};
+    hipStream_t s = as_stream(stream);
+    const bool small = T <= 512;
+#define ATTNX_CASE(CTV) \
+    case CTV: return small ? launch_attn_x<CTV, 2>(p, B, s) : launch_attn_x<CTV, 4>(p, B, s);
+    switch ((ch + 15) / 16) {
+        ATTNX_CASE(1) ATTNX_CASE(2) ATTNX_CASE(3) ATTNX_CASE(4) ATTNX_CASE(5) ATTNX_CASE(6) ATTNX_CASE(7) ATTNX_CASE(8)
+    }
+    dua_set_error("dua_attention_bf16x3: unsupported head dim %d", ch);
+    return DUA_EINVAL;
+}
+
 template <int CT, int QW>
 static int launch_attn(const AttnP& p, int B, hipStream_t s) {
     const int chp = (CT * 32 > p.ch ? CT * 32 : p.ch) + 4;

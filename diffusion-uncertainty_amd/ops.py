@@ -535,6 +535,16 @@ def fused_attention(qkv, B, T, heads, ch):
     return out
 
 
+def fused_attention_bf16x3(qkv, B, T, heads, ch):
+    """Flash-style attention with both products on the bf16 matrix cores, split operands (dua_attention_bf16x3)."""
+    _req(qkv, name="qkv")
+    C = heads * ch
+    assert qkv.shape == (B * T, 3 * C)
+    out = torch.empty((B * T, C), device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().dua_attention_bf16x3(_p(qkv), _p(out), B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()), "dua_attention_bf16x3")
+    return out
+
+
 def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     """qkv: [B*T, 3*heads*ch] laid out (q | k | v), head-major inside each third -> [B*T, heads*ch].
 
@@ -549,6 +559,8 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     C = heads * ch
     assert qkv.shape == (B * T, 3 * C)
     assert B * heads <= 65535
+    if precision == "bf16x3" and ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
+        return fused_attention_bf16x3(qkv, B, T, heads, ch)       # split-bf16 flash kernel: 2-3x the GEMM pair / the fp32 flash kernel
     fast = precision == "bf16x3" and ch % 32 == 0 and T % 32 == 0
     fusable = ch % 8 == 0 and ch <= 256
     # measured (MI355X, B=128): fused fp32 117 TF vs 64 TF for the split-bf16 GEMM pair at ch=64, T=1024; at ch=128 the

@@ -192,6 +192,9 @@ int dua_softmax_rows(float* S, long rows, int cols, long ld, void* stream);
  * (guided_diffusion/unet_openai.py:338-355, :371-390; scale = ch^-1/2 = the two ch^-1/4 operand scales) and
  * F.scaled_dot_product_attention in uvit/uvit.py:69-73. */
 int dua_attention(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream);
+/* Same contract on the bf16 matrix cores with split operands (hi*hi + hi*lo + lo*hi, ~2^-17 per product, both q.k^T and P.v):
+ * the attention of the split precision modes.  ch a multiple of 4, <= 128 (the queries live in registers). */
+int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream);
 
 /* LayerNorm over the last axis (U-ViT, uvit/uvit.py:108-110,225): y = (x-mean)*rstd*gamma+beta, eps 1e-5. */
 int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps,

@@ -239,7 +239,7 @@ def test_qkv_attention(ops, B, T_, heads, ch):
     d = qkv.permute(0, 2, 1).reshape(B * T_, 3 * C).contiguous().to(dev)
     import diffusion_uncertainty_amd.ops as O
     try:
-        for mode in ("gemm", "fused", "auto"):        # materialised-logits GEMM pair, flash kernel, default dispatch
+        for mode in ("gemm", "fused", "fused_x", "auto"):   # materialised-logits GEMM pair, fp32 flash kernel, split-bf16 flash kernel, default
             O.ATTENTION_MODE = mode
             out = ops.qkv_attention(d, B, T_, heads, ch)
             np.testing.assert_allclose(out.cpu().reshape(B, T_, C).permute(0, 2, 1).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5, err_msg=mode)
