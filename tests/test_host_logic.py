@@ -154,3 +154,39 @@ def test_pndm_scheduler_tables():
     assert float(s.final_alpha_cumprod) == float(s.alphas_cumprod[0])
     with pytest.raises(NotImplementedError):
         PNDMScheduler(skip_prk_steps=False)
+
+
+def test_sd15_unet_key_layout_matches_diffusers_checkpoint():
+    """The SD-1.5 latent UNet holds its parameters under diffusers' UNet2DConditionModel keys (strict-loadable): 686
+    tensors, 859 520 964 parameters - the published size of runwayml/stable-diffusion-v1-5's UNet - and the host module
+    agrees with the oracle's independent enumeration of the layout."""
+    from diffusion_uncertainty_amd.stable_diffusion.unet_2d_condition import UNet2DConditionModel
+    from oracle import sd_unet
+    m = UNet2DConditionModel()
+    have = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    want = {k: tuple(v) for k, v in sd_unet.state_shapes(sd_unet.SD15).items()}
+    assert have == want and len(have) == 686
+    assert sum(p.numel() for p in m.parameters()) == 859520964
+    for k in ("down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight", "mid_block.resnets.1.time_emb_proj.bias",
+              "up_blocks.3.resnets.2.conv_shortcut.weight", "up_blocks.0.upsamplers.0.conv.weight", "conv_norm_out.weight"):
+        assert k in have
+    assert have["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 768)
+    assert have["up_blocks.0.resnets.0.conv1.weight"] == (1280, 2560, 3, 3)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, 8, 8), 1, encoder_hidden_states=torch.zeros(1, 77, 768))      # no CPU fallback
+
+
+def test_oracle_sd_unet_runs_on_cpu():
+    """The (unpinned) oracle restatement itself: a tiny configuration runs and is deterministic."""
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    from oracle import sd_unet
+    cfg = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64), layers_per_block=1,
+               down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+               attention_head_dim=4, cross_attention_dim=32, norm_num_groups=32, norm_eps=1e-5)
+    sd = seeded_state_dict(sd_unet.state_shapes(cfg), 3)
+    g = torch.Generator().manual_seed(0)
+    x, enc = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 5, 32, generator=g)
+    a = sd_unet.forward(sd, cfg, x, torch.tensor([10, 900]), enc)
+    b = sd_unet.forward(sd, cfg, x, torch.tensor([10, 900]), enc)
+    assert a.shape == (2, 4, 8, 8) and torch.equal(a, b) and torch.isfinite(a).all()
+    assert not torch.allclose(a[0], sd_unet.forward(sd, cfg, x, torch.tensor([900, 900]), enc)[0])     # the timestep matters
