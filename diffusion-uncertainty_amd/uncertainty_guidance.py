@@ -17,6 +17,10 @@ from .schedulers_uncertainty.noise import HostNoise
 
 use_posterior = True
 noise_source = HostNoise()
+# The M Monte-Carlo denoiser calls of one guided step are independent (same timestep, same prompt): run them as ONE call of
+# batch 2*M instead of M calls of batch 2 (the reference loops, uncertainty_guidance.py:87-99; same noise draws in the same
+# order, same per-sample results, ~3x the GPU efficiency at the CFG batch of 2).  False: one call per sample, as upstream.
+batch_mc_samples = True
 
 
 def predict_model_stable_diffusion(model, sample, t_tensor, y, guidance_scale: float, extra_diffusion_kwargs=None):
@@ -52,11 +56,23 @@ def get_uncertainty_guided_score_with_percentile(pred_epsilon, input, t_tensor, 
     # pred_x_0 = (input - sqrt(1-a) eps) / sqrt(a)   (:86)
     _, x0 = ops.ddim_step(eps_rep, ops._f32c(input), sb, sa, 0.0, 0.0, clip=False)
     samples = []
+    x_hats = []
     for _ in range(M):
         z = noise_source.draw(eps.shape, eps.device)                                        # randn_like(pred_epsilon) :88
         z_rep = z if reps == 1 else z.repeat(reps, *([1] * (z.ndim - 1)))
         x_hat = ops.axpby(x0, z_rep, sa, sb)
-        samples.append(predict_model_stable_diffusion(model, x_hat, t_tensor, y, guidance_scale, extra_diffusion_kwargs))
+        if batch_mc_samples and reps == 2 and M > 1:
+            x_hats.append(x_hat)
+        else:
+            samples.append(predict_model_stable_diffusion(model, x_hat, t_tensor, y, guidance_scale, extra_diffusion_kwargs))
+    if x_hats:
+        # rows [uncond of every sample | text of every sample], prompt embeddings repeated to match: chunk(2) of the output is
+        # again (uncond, text), now with M samples in each half
+        B1 = eps.shape[0]
+        xin = torch.cat([xh[:B1] for xh in x_hats] + [xh[B1:] for xh in x_hats])
+        yin = torch.cat([y[:y.shape[0] // 2].repeat(M, *([1] * (y.ndim - 1))), y[y.shape[0] // 2:].repeat(M, *([1] * (y.ndim - 1)))])
+        allm = predict_model_stable_diffusion(model, xin, t_tensor, yin, guidance_scale, extra_diffusion_kwargs)      # [M*B1, ...]
+        samples.extend(allm[m * B1:(m + 1) * B1] for m in range(M))
     samples.append(eps)                                                                     # :101-102
     u = ops.mc_reduce_var(torch.stack(samples, dim=0))                                      # torch.var :106
     mask, _q = ops.quantile_mask(u, percentile)                                             # :112

@@ -72,11 +72,11 @@ def main():
         out = pipe(generator=g, **kw)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
-    calls = (a.num_steps + 1) + a.num_steps_threshold * a.M
     best = min(times[1:]) if a.repeats else times[0]
     print(f"SD-1.5 latent UNet 512x512, {a.num_steps} PLMS steps (+1 repeated), guided steps {a.num_steps_threshold} x M={a.M}, "
-          f"percentile {a.percentile}, precision {a.precision}: {best:.3f} s per image ({1.0 / best:.3f} images/s, "
-          f"{calls} CFG UNet calls of batch 2, {best / calls * 1e3:.1f} ms per call); first run incl. weight packing {times[0]:.2f} s")
+          f"percentile {a.percentile}, precision {a.precision}: {best:.3f} s per image ({1.0 / best:.3f} images/s; "
+          f"{a.num_steps + 1} CFG UNet calls of batch 2 + {a.num_steps_threshold} Monte-Carlo calls of batch {2 * a.M}); "
+          f"first run incl. weight packing {times[0]:.2f} s")
     if a.out:
         torch.save(out.images.cpu(), a.out)
 

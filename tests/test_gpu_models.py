@@ -207,12 +207,15 @@ def test_posterior_guidance_vs_golden(golden):
             h = torch.nn.functional.conv2d(sample.cpu(), w, padding=1).to(dev)
             return (h + encoder_hidden_states.mean(dim=(1, 2))[:, None, None, None],)
 
-    for i, p in enumerate((0.85, 0.9, 0.95, 0.99)):
-        torch.manual_seed(700 + i)
-        fe = ug.get_uncertainty_guided_score_with_percentile(T(g["sd_eps"]).to(dev), T(g["sd_input"]).to(dev), torch.tensor([500]), ctx,
-                                                             FakeCFGUNet(), torch.tensor(0.3), p, "stable-diffusion",
-                                                             num_uncertainty_samples=5, guidance_scale=7.5)
-        np.testing.assert_allclose(fe.cpu().numpy(), g[f"sd_final_{p}"], rtol=2e-4, atol=1e-5)
+    for batched in (True, False):              # the M denoiser calls as one call of batch 2M, or one by one as upstream
+        ug.batch_mc_samples = batched
+        for i, p in enumerate((0.85, 0.9, 0.95, 0.99)):
+            torch.manual_seed(700 + i)
+            fe = ug.get_uncertainty_guided_score_with_percentile(T(g["sd_eps"]).to(dev), T(g["sd_input"]).to(dev), torch.tensor([500]), ctx,
+                                                                 FakeCFGUNet(), torch.tensor(0.3), p, "stable-diffusion",
+                                                                 num_uncertainty_samples=5, guidance_scale=7.5)
+            np.testing.assert_allclose(fe.cpu().numpy(), g[f"sd_final_{p}"], rtol=2e-4, atol=1e-5)
+    ug.batch_mc_samples = True
     ug.use_posterior = False
     try:
         with pytest.raises(NotImplementedError):
