@@ -46,7 +46,7 @@ class ConvProfile:
     # HBM-side bytes per conv launch from the PMC passes of profiles/r01d_pmc_traffic_conv.json (FETCH_SIZE doubled per the
     # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
     PMC_TRAFFIC_BF16X3 = 2.145e9
-    PMC_TRAFFIC_F16F8 = 1.942e9       # profiles/r01i_pmc_traffic_conv.json (mean over the conv and 1-tap GEMM launches of the kernel)
+    PMC_TRAFFIC_F16F8 = 1.999e9       # profiles/r01j_pmc_traffic_conv.json (mean over the conv and 1-tap GEMM launches of the kernel)
 
     def summary(self):
         if not self.items:
@@ -69,7 +69,7 @@ class ConvProfile:
         if precision == "f16f8":
             return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_F16F8,
-                        traffic_source="profiles/r01i_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                        traffic_source="profiles/r01j_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                         kernel="k_xconv_dma<NT, 1> (LDS-DMA implicit-GEMM conv3x3, fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross "
                                "terms on one block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per 32-deep K block)",
                         launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),

@@ -86,21 +86,29 @@ __global__ __launch_bounds__(BLK) void k_gn_partial(const float* __restrict__ x1
     (void)rows_per_iter;
 }
 
-__global__ void k_gn_finalize(const double* __restrict__ ws, int NG, int G, int nchunks, double count, float eps,
-                              float* __restrict__ stats) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (image, group): the lanes stride over the chunks and fold their partial sums with a butterfly, in double
+__global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ ws, int NG, int G, int nchunks, double count, float eps,
+                                                      float* __restrict__ stats) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= NG) return;
-    int n = i / G, g = i % G;
+    const int n = i / G, g = i % G;
     double a = 0, b = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = lane; c < nchunks; c += 64) {
         const double* o = ws + (((size_t)n * nchunks + c) * G + g) * 2;
         a += o[0];
         b += o[1];
     }
-    double mean = a / count, var = b / count - mean * mean;
-    if (var < 0) var = 0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if (lane == 0) {
+        double mean = a / count, var = b / count - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 static void gn_chunking(int N, int HW, int* chunk_px, int* nchunks) {
@@ -131,7 +139,7 @@ extern "C" int dua_groupnorm_stats(const float* x1, int C1, const float* x2, int
     gn_chunking(N, HW, &cp, &nc);
     hipLaunchKernelGGL(k_gn_partial, dim3(nc, N), BLK, 4096 * sizeof(float), as_stream(stream), x1, C1, x2, C2, HW, G, cp, nc, (double*)ws);
     int NG = N * G;
-    hipLaunchKernelGGL(k_gn_finalize, (NG + 255) / 256, 256, 0, as_stream(stream), (const double*)ws, NG, G, nc,
+    hipLaunchKernelGGL(k_gn_finalize, (NG + 3) / 4, 256, 0, as_stream(stream), (const double*)ws, NG, G, nc,
                        (double)HW * (double)(C / G), eps, stats);
     return dua_check_launch("dua_groupnorm_stats");
 }

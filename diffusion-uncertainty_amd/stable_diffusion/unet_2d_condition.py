@@ -43,7 +43,7 @@ class ResnetBlock2D(nn.Module):
         else:
             assert skip is None
             res = x
-        return ctx.conv3x3(h, self.conv2, self.cout, residual=res)
+        return ctx.conv3x3(h, self.conv2, self.cout, residual=res, colsum=True)     # epilogue leaves the next GroupNorm's statistics
 
 
 class Attention(nn.Module):
@@ -108,7 +108,12 @@ class Transformer2DModel(nn.Module):
         h = ctx.linear(xn.view(N * H * W, C), self.proj_in)
         for blk in self.transformer_blocks:
             h = blk.run(ctx, h, N, H * W, enc)
-        return ctx.linear(h, self.proj_out, residual=x.view(N * H * W, C)).view(N, H, W, C)
+        out2d = ctx.linear(h, self.proj_out, residual=x.view(N * H * W, C), colsum=True)
+        out = out2d.view(N, H, W, C)
+        ws = getattr(out2d, "_dua_colsums_rows", None)
+        if ws is not None and (H * W) % 64 == 0:
+            out._dua_colsums = ws                     # statistics for the next block's GroupNorm
+        return out
 
 
 class Downsample2D(nn.Module):
@@ -159,30 +164,30 @@ class _Ctx:
             cache[key] = make()
         return cache[key]
 
-    def conv3x3(self, h, conv, cout, residual=None, nchw_out=False):
+    def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         if isinstance(h, ops.SplitPlanes):
             if h.fmt == "f16f8":
                 w = self.packed((id(conv), "w3f"), lambda: ops.pack_weight_f16f8(conv.weight.detach().contiguous()))
             else:
                 w = self.packed((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
-            return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out)
+            return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         if self.split_mode and h.shape[3] % 32 == 0:
             w = self.packed((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
-            return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out)
+            return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         w = self.packed((id(conv), "w3"), lambda: ops.pack_conv3x3_weight(conv.weight.detach().contiguous()))
-        return ops.conv3x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out)
+        return ops.conv3x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
-    def gemm(self, a, weight, bias, a2=None, residual=None):
+    def gemm(self, a, weight, bias, a2=None, residual=None, colsum=False):
         """rows x weight^T in the model's precision (fp32 MFMA, or the split-bf16 tile engine with the operand split on the fly)."""
         n_out, K = weight.shape[0], a.shape[1] + (0 if a2 is None else a2.shape[1])
         if self.split_mode and K % 32 == 0 and a.shape[1] % 32 == 0:
             planes = self.packed((id(weight), "w1x"), lambda: ops.pack_weight_bf16x3(weight.detach().reshape(n_out, K).contiguous()))
-            return ops.gemm_bf16x3(a, planes, n_out, bias=bias, a2=a2, residual=residual)
+            return ops.gemm_bf16x3(a, planes, n_out, bias=bias, a2=a2, residual=residual, colsum=colsum)
         w = self.packed((id(weight), "w1"), lambda: weight.detach().reshape(n_out, K).contiguous())
-        return ops.gemm(a, w, bias=bias, a2=a2, residual=residual)
+        return ops.gemm(a, w, bias=bias, a2=a2, residual=residual, colsum=colsum)
 
-    def linear(self, a, conv1x1, a2=None, residual=None):
-        return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual)
+    def linear(self, a, conv1x1, a2=None, residual=None, colsum=False):
+        return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual, colsum=colsum)
 
     def cat_weight(self, attn, names):
         """Row-concatenated projection weights (q | k | v of a self-attention): one GEMM, packed qkv rows for dua_attention."""
@@ -317,7 +322,7 @@ class UNet2DConditionModel(nn.Module):
         ctx.emb = ops.gemm(emb, te.linear_2.weight, bias=te.linear_2.bias, act_in=1)
         h = ops.nchw_to_nhwc(sample, 4)
         h = ops.conv3x3(h, ctx.packed((id(self.conv_in), "w3"), lambda: ops.pack_conv3x3_weight(self.conv_in.weight.detach().contiguous())),
-                        self.conv_in.bias, self.conv_in.out_channels)
+                        self.conv_in.bias, self.conv_in.out_channels, colsum=True)
         res = [h]
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
@@ -339,7 +344,7 @@ class UNet2DConditionModel(nn.Module):
                     h = blk.attentions[j].run(ctx, h, enc)
             if hasattr(blk, "upsamplers"):
                 conv = blk.upsamplers[0].conv
-                h = ctx.conv3x3(ops.resample2x(h, 1), conv, conv.out_channels)
+                h = ctx.conv3x3(ops.resample2x(h, 1), conv, conv.out_channels, colsum=True)
         G = self.conv_norm_out.num_groups
         st = ops.groupnorm_stats(h, groups=G, eps=self.conv_norm_out.eps)
         h = ops.groupnorm_apply(h, st, self.conv_norm_out.weight, self.conv_norm_out.bias, act=1, groups=G, split=ctx.split_acts)
