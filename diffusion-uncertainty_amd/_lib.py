@@ -61,6 +61,7 @@ SIGNATURES = {
     "dua_softmax_rows": (_I, [_P, _L, _I, _L, _P]),
     "dua_attention": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dua_attention_bf16x3": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
+    "dua_attention_bf16x3_planes": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dua_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "dua_embedding_add": (_I, [_P, _P, _P, _P, _I, _I, _P]),

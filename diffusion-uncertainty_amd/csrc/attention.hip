@@ -23,6 +23,8 @@ struct AttnP {
     float* out;
     int T, heads, ch;
     float scale;
+    void* out_planes;        // split kernel only: write the result as f16f8 planes [B*T][C] (operand of the presplit proj GEMM)
+    long plane_elems;
 };
 
 template <int CT /* 32-channel tiles: ceil(ch/32) */, int QW /* waves (32 queries each) per workgroup */>
@@ -336,13 +338,17 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     const float inv = 1.0f / l_full;
     const int q = q0 + wave * 32 + lr;
     if (q < T) {
-        float* orow = p.out + ((long)b * T + q) * C + h * ch;
+        const long ro = ((long)b * T + q) * C + h * ch;
 #pragma unroll
         for (int t = 0; t < CT32; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = 32 * t + 8 * g + 4 * kh;
-                if (c < ch) *(float4*)(orow + c) = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+                if (c < ch) {
+                    const float4 w = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+                    if (p.out_planes) dua_store_f16f8_quad(p.out_planes, p.plane_elems, ro + c, w);
+                    else *(float4*)(p.out + ro + c) = w;
+                }
             }
     }
 }
@@ -354,11 +360,28 @@ static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
     return dua_check_launch("dua_attention_bf16x3");
 }
 
+static int attention_x_launch(const AttnP& p, int B, void* stream);
+
 extern "C" int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream) {
     DUA_REQUIRE(qkv && out && B > 0 && T > 0 && heads > 0, "dua_attention_bf16x3: bad arguments");
     DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_attention_bf16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
     DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_bf16x3: B*heads must be <= 65535");
-    AttnP p{qkv, out, T, heads, ch, scale};
+    AttnP p{qkv, out, T, heads, ch, scale, nullptr, 0};
+    return attention_x_launch(p, B, stream);
+}
+
+/* Same, with the result written as f16f8 planes [B*T][heads*ch] (needs heads*ch % 32 == 0): the next GEMM (attention proj_out /
+ * proj) then runs on the presplit LDS-DMA kernel without a conversion pass. */
+extern "C" int dua_attention_bf16x3_planes(const float* qkv, void* out_planes, int B, int T, int heads, int ch, float scale, void* stream) {
+    DUA_REQUIRE(qkv && out_planes && B > 0 && T > 0 && heads > 0, "dua_attention_bf16x3_planes: bad arguments");
+    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128 && (heads * ch) % 32 == 0, "dua_attention_bf16x3_planes: ch %% 4 == 0, ch <= 128, heads*ch %% 32 == 0");
+    DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_bf16x3_planes: B*heads must be <= 65535");
+    AttnP p{qkv, nullptr, T, heads, ch, scale, out_planes, (long)B * T * heads * ch};
+    return attention_x_launch(p, B, stream);
+}
+
+static int attention_x_launch(const AttnP& p, int B, void* stream) {
+    const int T = p.T, ch = p.ch;
     hipStream_t s = as_stream(stream);
     const bool small = T <= 512;
 #define ATTNX_CASE(CTV) \
@@ -387,7 +410,7 @@ extern "C" int dua_attention(const float* qkv, float* out, int B, int T, int hea
     DUA_REQUIRE(qkv && out && B > 0 && T > 0 && heads > 0, "dua_attention: bad arguments");
     DUA_REQUIRE(ch >= 8 && ch % 8 == 0 && ch <= 256, "dua_attention: head dim must be a multiple of 8 in [8, 256] (got %d)", ch);
     DUA_REQUIRE((long)B * heads <= 65535, "dua_attention: B*heads must be <= 65535");
-    AttnP p{qkv, out, T, heads, ch, scale};
+    AttnP p{qkv, out, T, heads, ch, scale, nullptr, 0};
     hipStream_t s = as_stream(stream);
     const int ct = (ch + 31) / 32;
     const bool small = T <= 512 || ch > 128;             // fewer queries per workgroup: less tail waste / LDS for wide heads

@@ -691,10 +691,69 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
         }
     }
 }
+// D % 4 == 0: four consecutive channels per lane and iteration (16-byte loads; 16 / 8 + 8 / 8 + 4 + 4 byte stores)
+template <int PER4>
+__global__ __launch_bounds__(BLK) void k_layernorm4(const float* __restrict__ x, const float* __restrict__ ga,
+                                                    const float* __restrict__ be, float* __restrict__ y, long rows, int D, float eps,
+                                                    int split) {
+    long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* r = x + row * (long)D;
+    float4 v[PER4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER4; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        v[j] = c < D ? *(const float4*)(r + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER4; ++j)
+        if (4 * (lane + 64 * j) < D) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c_ = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (c_ * c_ + d * d);
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < PER4; ++j) {
+        const int c = 4 * (lane + 64 * j);
+        if (c < D) {
+            const float4 g = *(const float4*)(ga + c), b = *(const float4*)(be + c);
+            const float4 o = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                                         (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+            const long off = row * (long)D + c;
+            if (!split) *(float4*)(y + off) = o;
+            else if (split == 2) dua_store_f16f8_quad(y, rows * (long)D, off, o);
+            else {
+                typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+                const float f[4] = {o.x, o.y, o.z, o.w};
+                ln_bf16x4 h, l;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const __bf16 t = (__bf16)f[u];
+                    h[u] = t;
+                    l[u] = (__bf16)(f[u] - (float)t);
+                }
+                *(ln_bf16x4*)((__bf16*)y + off) = h;
+                *(ln_bf16x4*)((__bf16*)y + rows * (long)D + off) = l;
+            }
+        }
+    }
+}
+
 static int layernorm_impl(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, int split, void* stream) {
     DUA_REQUIRE(x && gamma && beta && y && D >= 1 && D <= 2048, "dua_layernorm: D must be in [1, 2048]");
     if (rows == 0) return DUA_OK;
     unsigned grid = (unsigned)((rows + 3) / 4);
+    if (D % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
+        if (D <= 256) hipLaunchKernelGGL(k_layernorm4<1>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+        else if (D <= 1024) hipLaunchKernelGGL(k_layernorm4<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+        else hipLaunchKernelGGL(k_layernorm4<8>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+        return dua_check_launch("dua_layernorm");
+    }
     if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
     else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
     else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);

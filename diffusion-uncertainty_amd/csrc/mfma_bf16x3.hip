@@ -430,28 +430,6 @@ struct DConvP {
 // floats: the two half-waves write rows 4 apart and must land on different banks), then moves whole rows, 16 B per lane.
 // All residual rows of the half are requested BEFORE the transposition so that their latency runs under it (read one by
 // one they cost a full memory round trip per row group: 55k of the 87k epilogue cycles of a 256x256 tile).
-// four consecutive columns of one output row as f16f8 planes (the operand format of the next presplit GEMM); N % 32 == 0
-__device__ __forceinline__ void store_f16f8_quad(__bf16* planes, long plane_elems, long o, float4 w) {
-    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-    const float f[4] = {w.x, w.y, w.z, w.w};
-    float l[4], g[4];
-    f16x4_t h;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 t = (_Float16)f[j];
-        h[j] = t;
-        l[j] = fminf(fmaxf((f[j] - (float)t) * 4096.0f, -448.f), 448.f);
-        g[j] = fminf(fmaxf(f[j], -448.f), 448.f);
-    }
-    *(f16x4_t*)((_Float16*)planes + o) = h;
-    unsigned char* x8 = (unsigned char*)((_Float16*)planes + plane_elems) + (o >> 5) * 64 + (o & 31);
-    int lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false), hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(g[0], g[1], 0, false);
-    lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo8, true);
-    hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(g[2], g[3], hi8, true);
-    *(int*)x8 = lo8;
-    *(int*)(x8 + 32) = hi8;
-}
-
 template <int ACT, bool RES, bool SPLIT, int FMT = 0>
 __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const float4 q, const float4 bq, long o, float4& cs, float4& cq) {
     w.x += bq.x; w.y += bq.y; w.z += bq.z; w.w += bq.w;
@@ -459,7 +437,7 @@ __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const f
     if (RES) { w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
     if (SPLIT) {               // the consumer is another split-operand GEMM: hand it the operand format directly
         if (FMT == 1) {
-            store_f16f8_quad(p.Csplit, (long)p.M * p.N, o, w);
+            dua_store_f16f8_quad(p.Csplit, (long)p.M * p.N, o, w);
         } else {
             bf16x4 hi, lo;
             split4(w, hi, lo);
@@ -1163,7 +1141,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                     }
                     if (p.Csplit) {        // the consumer is another split-operand GEMM: hand it the operand format directly
                         if (FMT == 1) {
-                            store_f16f8_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v);
+                            dua_store_f16f8_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v);
                         } else {
                             bf16x4 hi, lo;
                             split4(v, hi, lo);

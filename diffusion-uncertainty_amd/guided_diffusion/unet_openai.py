@@ -154,8 +154,17 @@ class AttentionBlock(nn.Module):
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0,
                                  split=ctx.split_acts if (ctx.model.presplit_qkv and C % 32 == 0) else False)
         qkv = ctx.qkv(xn if isinstance(xn, ops.SplitPlanes) else xn.view(N * T, C), self)
-        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision="fp32" if ctx.model.precision == "fp32" else "bf16x3")
-        out2d = ctx.linear(a, self.proj_out, residual=x.view(N * T, C), colsum=True)
+        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision="fp32" if ctx.model.precision == "fp32" else "bf16x3",
+                              planes_out=(ctx.model.precision == "f16f8"))
+        if isinstance(a, ops.SplitPlanes):        # attention output already in the operand format: proj_out on the LDS-DMA kernel
+            key = (id(self.proj_out), "w1f")
+            if key not in ctx.model._packed:
+                w = self.proj_out.weight.detach()
+                ctx.model._packed[key] = ops.pack_weight_f16f8(w.reshape(w.shape[0], w.shape[1]).contiguous())
+            out2d = ops.gemm_bf16x3_presplit(a, ctx.model._packed[key], C, bias=self.proj_out.bias, residual=x.view(N * T, C),
+                                             colsum=ctx.model.fuse_gn_stats)
+        else:
+            out2d = ctx.linear(a, self.proj_out, residual=x.view(N * T, C), colsum=True)
         out = out2d.view(N, H, W, C)
         ws = getattr(out2d, "_dua_colsums_rows", None)
         if ws is not None and T % 64 == 0:

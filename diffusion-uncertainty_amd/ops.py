@@ -483,7 +483,7 @@ def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, 
     return c
 
 
-def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, split_out=False):
+def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, split_out=False, colsum=False):
     """a: SplitPlanes whose trailing dim is K (rows = all leading dims) -> [rows, n_out] fp32, or SplitPlanes if split_out."""
     K = a.shape[-1]
     M = 1
@@ -496,8 +496,11 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
                                                      None, _stream()), "dua_gemm_f16f8_presplit")
             return SplitPlanes(buf, (M, n_out), "f16f8")
         c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
-        check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), None, M, n_out, K, int(act_out), None,
-                                                 _stream()), "dua_gemm_f16f8_presplit")
+        ws = _colsum_ws(M, n_out, a.device, colsum)
+        if ws is not None:
+            c._dua_colsums_rows = ws
+        check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), None, M, n_out, K, int(act_out),
+                                                 _p(ws), _stream()), "dua_gemm_f16f8_presplit")
         return c
     if split_out:
         buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
@@ -545,7 +548,7 @@ def fused_attention_bf16x3(qkv, B, T, heads, ch):
     return out
 
 
-def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
+def qkv_attention(qkv, B, T, heads, ch, precision="fp32", planes_out=False):
     """qkv: [B*T, 3*heads*ch] laid out (q | k | v), head-major inside each third -> [B*T, heads*ch].
 
     Reference: QKVAttentionLegacy / QKVAttention (unet_openai.py:338-355 / :371-390); the q/k scale
@@ -560,6 +563,11 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32"):
     assert qkv.shape == (B * T, 3 * C)
     assert B * heads <= 65535
     if precision == "bf16x3" and ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
+        if planes_out and C % 32 == 0:       # result straight in the operand format of the presplit proj GEMM
+            buf = torch.empty((2, B * T, C), device=qkv.device, dtype=torch.int16)
+            check(_lib.lib().dua_attention_bf16x3_planes(_p(qkv), _p(buf), B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()),
+                  "dua_attention_bf16x3_planes")
+            return SplitPlanes(buf, (B * T, C), "f16f8")
         return fused_attention_bf16x3(qkv, B, T, heads, ch)       # split-bf16 flash kernel: 2-3x the GEMM pair / the fp32 flash kernel
     fast = precision == "bf16x3" and ch % 32 == 0 and T % 32 == 0
     fusable = ch % 8 == 0 and ch <= 256

@@ -79,7 +79,7 @@ class BasicTransformerBlock(nn.Module):
         heads = self.attn1.heads
         n1 = ops.layernorm(h, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
         qkv = ctx.gemm(n1, ctx.cat_weight(self.attn1, ("to_q", "to_k", "to_v")), None)
-        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision)
+        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision, planes_out=(ctx.split_acts == "f16f8"))
         h = ctx.gemm(a, self.attn1.to_out[0].weight, self.attn1.to_out[0].bias, residual=h)
         n2 = ops.layernorm(h, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
         q = ctx.gemm(n2, self.attn2.to_q.weight, None)
@@ -179,6 +179,10 @@ class _Ctx:
 
     def gemm(self, a, weight, bias, a2=None, residual=None, colsum=False):
         """rows x weight^T in the model's precision (fp32 MFMA, or the split-bf16 tile engine with the operand split on the fly)."""
+        if isinstance(a, ops.SplitPlanes):           # operand already in the f16f8 format (attention output): LDS-DMA GEMM
+            n_out = weight.shape[0]
+            packed = self.packed((id(weight), "w1f"), lambda: ops.pack_weight_f16f8(weight.detach().reshape(n_out, -1).contiguous()))
+            return ops.gemm_bf16x3_presplit(a, packed, n_out, bias=bias, residual=residual, colsum=colsum)
         n_out, K = weight.shape[0], a.shape[1] + (0 if a2 is None else a2.shape[1])
         if self.split_mode and K % 32 == 0 and a.shape[1] % 32 == 0:
             planes = self.packed((id(weight), "w1x"), lambda: ops.pack_weight_bf16x3(weight.detach().reshape(n_out, K).contiguous()))

@@ -57,7 +57,7 @@ class Block(nn.Module):
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=fast)
         qkv = lin(h, self.attn.qkv)
         a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads,
-                              precision="fp32" if precision == "fp32" else "bf16x3")                       # :69-73
+                              precision="fp32" if precision == "fp32" else "bf16x3", planes_out=(fast == "f16f8"))   # :69-73
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, split=fast)
         h = lin(h, self.mlp.fc1, act_out=2, split_out=bool(fast))                                  # fc1 + GELU

@@ -195,6 +195,9 @@ int dua_attention(const float* qkv, float* out, int B, int T, int heads, int ch,
 /* Same contract on the bf16 matrix cores with split operands (hi*hi + hi*lo + lo*hi, ~2^-17 per product, both q.k^T and P.v):
  * the attention of the split precision modes.  ch a multiple of 4, <= 128 (the queries live in registers). */
 int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream);
+/* Same, writing the result as f16f8 planes [B*T][heads*ch] (heads*ch % 32 == 0) for the presplit proj GEMM that follows
+ * (unet_openai.py:295 proj_out, uvit/uvit.py:76 proj). */
+int dua_attention_bf16x3_planes(const float* qkv, void* out_planes, int B, int T, int heads, int ch, float scale, void* stream);
 
 /* LayerNorm over the last axis (U-ViT, uvit/uvit.py:108-110,225): y = (x-mean)*rstd*gamma+beta, eps 1e-5. */
 int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps,
