@@ -291,7 +291,11 @@ def _f16f8_planes(ops, x_nhwc):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 16, 32, 6),
-                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (5, 16, 16, 128, 512)])
+                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (5, 16, 16, 128, 512),
+                                             (1, 24, 24, 64, 64),        # 256 % W != 0: the per-tap loop, not the row-shift loop
+                                             (1, 256, 256, 32, 32),      # W = 256: one image row per tile (row-shift loop)
+                                             (8, 128, 128, 32, 256),     # >= 512 tiles of 256 x 256: the wide-tile kernel
+                                             (3, 64, 64, 64, 256)])      # wide tiles, several images, partial last tile row count
 def test_conv3x3_f16f8(ops, N, H, W, Cin, Cout):
     """fp16 hi*hi + block-scaled fp8 cross terms (dua_conv3x3_f16f8_presplit): plane format, packing and kernel vs fp64."""
     x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
@@ -299,6 +303,11 @@ def test_conv3x3_f16f8(ops, N, H, W, Cin, Cout):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     xs = _f16f8_planes(ops, nhwc(x))
     assert xs.fmt == "f16f8"
+    if N * H * W > 70000:            # large cases: kernel check only (fp64 reference on the GPU box's CPU stays in seconds)
+        packed = ops.pack_weight_f16f8(w.to(dev))
+        y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+        assert (nchw(y.cpu()).double() - (ref + res)).abs().max().item() < 2e-4
+        return
     # the planes decode back to x: fp16(x) + e4m3((x - fp16 x) * 2^12) / 2^12, and e4m3(x) in the second half of each block
     buf = xs.buf.view(torch.uint8).reshape(2, -1).cpu()
     hi = buf[0].view(torch.float16).reshape(N, H, W, Cin).float()
