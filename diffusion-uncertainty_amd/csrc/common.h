@@ -59,3 +59,16 @@ __device__ __forceinline__ void dua_store_f16f8_quad(void* planes, long plane_el
     *(int*)x8 = lo8;
     *(int*)(x8 + 32) = hi8;
 }
+
+// e2m3 (MXFP6) code of v * 2^(127 - sbyte): sign<<5 | eemmm, round to nearest even; magnitudes < 1 use the subnormal grid (step 1/8).
+// sbyte is the E8M0 block exponent (biased exponent of the block maximum minus one: the maximum lands in [2, 4)).
+__device__ __forceinline__ unsigned dua_e2m3_code(float v, int sbyte) {
+    const float u = v * __uint_as_float((unsigned)(254 - sbyte) << 23);
+    const float a = fabsf(u);
+    const float t = a < 1.0f ? a + 1.0f : a;
+    const unsigned b = __float_as_uint(t);
+    const unsigned rb = (b + 0x7FFFFu + ((b >> 20) & 1u)) >> 20;                // RNE to 3 mantissa bits: exponent | mantissa
+    unsigned c = rb - 1016u + (a < 1.0f ? 0u : 8u);
+    c = c > 31u ? 31u : c;
+    return c | ((__float_as_uint(u) >> 31) << 5);
+}

@@ -331,6 +331,39 @@ __device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const f
     if (!p.split) {
         *(float4*)(p.y + off) = make_float4(f[0], f[1], f[2], f[3]);
         *(float4*)(p.y + off + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else if (p.split == 3) {
+        // f16f6 planes: plane 0 fp16; plane 1 per 32-channel block [24 B e2m3(lo) | exp | 7 pad | 24 B e2m3(x) | exp | 7 pad].
+        // The four lanes of a block (8 channels each) agree on the block exponents (two butterfly steps), encode their 8 values
+        // of each term as 48 bits, and pass bits along so that lanes 0-2 each store 8 aligned bytes of the 24-byte stream and
+        // lane 3 the exponent byte.
+        gn_f16x8 h;
+        float l[8], ml = 0.f, mh = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 t = (_Float16)f[j];
+            h[j] = t;
+            l[j] = f[j] - (float)t;
+            ml = fmaxf(ml, fabsf(l[j]));
+            mh = fmaxf(mh, fabsf(f[j]));
+        }
+        *(gn_f16x8*)((_Float16*)p.y + off) = h;
+        ml = fmaxf(ml, __shfl_xor(ml, 1)); ml = fmaxf(ml, __shfl_xor(ml, 2));
+        mh = fmaxf(mh, __shfl_xor(mh, 1)); mh = fmaxf(mh, __shfl_xor(mh, 2));
+        const int ebl = (int)((__float_as_uint(ml) >> 23) & 0xff), ebh = (int)((__float_as_uint(mh) >> 23) & 0xff);
+        const int sbl = ebl > 1 ? ebl - 1 : 0, sbh = ebh > 1 ? ebh - 1 : 0;
+        unsigned long long pl = 0, ph = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pl |= (unsigned long long)dua_e2m3_code(l[j], sbl) << (6 * j);
+            ph |= (unsigned long long)dua_e2m3_code(f[j], sbh) << (6 * j);
+        }
+        const unsigned long long nl = __shfl_down(pl, 1), nh = __shfl_down(ph, 1);
+        const int q = (int)((off >> 3) & 3);                              // this lane's octet inside the 32-channel block
+        const unsigned long long ol = q == 3 ? (unsigned long long)sbl : (pl >> (16 * q)) | (nl << (48 - 16 * q));
+        const unsigned long long oh = q == 3 ? (unsigned long long)sbh : (ph >> (16 * q)) | (nh << (48 - 16 * q));
+        unsigned char* blk = (unsigned char*)((_Float16*)p.y + p.plane) + (off >> 5) * 64 + 8 * q;
+        *(unsigned long long*)blk = ol;
+        *(unsigned long long*)(blk + 32) = oh;
     } else if (p.split == 1) {
         gn_bf16x8 h, l;
 #pragma unroll
@@ -464,6 +497,13 @@ extern "C" int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const fl
     return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 2, stream);
 }
 
+extern "C" int dua_groupnorm_apply_split_f16f6(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                               int resample, const float* dropmask, void* yplanes, void* stream) {
+    DUA_REQUIRE((C1 + C2) % 32 == 0 && C1 % 32 == 0 && (C1 + C2) / 8 <= BLK, "dua_groupnorm_apply_split_f16f6: channel counts must be multiples of 32, at most 2048");
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 3, stream);
+}
+
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                          const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                          int resample, const float* dropmask, float* y, int split, void* stream) {
@@ -488,7 +528,7 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     // fewer, fatter lanes leave part of a workgroup idle
     const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && (split != 2 || (C1 % 16 == 0 && C2 % 16 == 0)) &&
                       (long)Ho * Wo >= 4096 && BLK % (C / 8) == 0;
-    if (wide && gn_apply_wide) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    if ((wide && gn_apply_wide) || split == 3) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= 2 * BLK) hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else hipLaunchKernelGGL(k_gn_apply<3>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);    // SD-1.5 up blocks: 1280 + 1280

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 
     const int lr = lane & 31, kh = lane >> 5;
   if constexpr (FMT == 0) {
+    static_assert(!RS, "the row-shift loop is built for the f16f8 / f16f6 formats");
     // Fragment registers of ONE half step (16 of the 32 K columns of a stage); they are refilled in place while the
     // MFMA group that no longer needs them is executing, so the matrix pipe always has a full group queued when the
     // next one's operands arrive (no extra registers: the accumulators already take 128 of the 256):
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const int sca = kh ? 127 : 115;                                                  // E8M0: 2^0 (a_hi8) / 2^-12 (a_lo8 * 2^12)
     int scbp = 0;                                                                    // the NT column-tile scales, one byte each
     auto load_scales = [&]() {       // called AFTER the prologue DMA has been issued: its latency then runs under that of the DMA
+        if (FMT == 2) return;        // (MXFP6: block exponents travel with the operands)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
             scbp |= ((127 - (int)p.Bscale[n0 + wn * 32 * NT + 32 * j + lr] - (kh ? 12 : 0)) & 0xff) << (8 * j);
@@ -924,7 +926,10 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
         for (int m_ = 0; m_ < NM; ++m_) {
             const int i_ = m_ / NT, j_ = m_ % NT;
-            acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 0, 0, 0, sca_k, 0, scbp >> (8 * j_));
+            if (FMT == 2)     // MXFP6 (e2m3) cross terms: the E8M0 block exponent of each lane's 32-k block rides in dword 6 of its operand
+                acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 2, 2, 0, ax[i_][6], 0, bx[j_][6]);
+            else
+                acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 0, 0, 0, sca_k, 0, scbp >> (8 * j_));
             SBAR();
             if (m_ < NDBL) { rd_hi(2 * m_); rd_hi(2 * m_ + 1); }
             else rd_hi(2 * NDBL + (m_ - NDBL));
@@ -1336,6 +1341,9 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
+    } else if (fmt == 2) {                                                        // MXFP6 cross terms: row-shift convolutions only
+        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 2, true>), dim3(grid), 512, 0, st, d);
+        else hipLaunchKernelGGL((k_xconv_dma<2, 2, true>), dim3(grid), 512, 0, st, d);
     } else if (d.ntaps == 9 && 256 % d.W == 0 && dua_dma_conv_enabled != 6) {     // row-shift form (6: A/B switch to the per-tap form)
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 1, true>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 1, true>), dim3(grid), 512, 0, st, d);
@@ -1355,8 +1363,9 @@ static int conv3x3_presplit_impl(const void* xplanes, const void* planes, const 
     size_t plane = dua_bf16x3_plane_elems(Cout, 9 * Cin);
     const size_t a_plane = (size_t)N * H * W * Cin;
     const bool dma_ok = 4 * plane < 0x7FFFFFF0ull && (size_t)(2 * W + 260) * Cin * 2 < 0x7FFFFFF0ull;
-    if (fmt == 1) DUA_REQUIRE(dma_ok, "dua_conv3x3_f16f8_presplit: operand too large for the LDS-DMA kernel");
-    if ((dua_dma_conv_enabled != 0 || fmt == 1) && dma_ok) {
+    if (fmt >= 1) DUA_REQUIRE(dma_ok, "dua_conv3x3_f16f8_presplit: operand too large for the LDS-DMA kernel");
+    if (fmt == 2) DUA_REQUIRE(256 % W == 0, "dua_conv3x3_f16f6_presplit: the image width must divide 256 (got %d)", W);
+    if ((dua_dma_conv_enabled != 0 || fmt >= 1) && dma_ok) {
         DConvP d{};
         d.A = (const __bf16*)xplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = y;
         d.a_plane = (long)a_plane; d.b_plane = (long)plane;
@@ -1380,6 +1389,57 @@ extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* plan
 extern "C" int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,
                                           float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
     return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 1, stream);
+}
+extern "C" int dua_conv3x3_f16f6_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,
+                                          float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
+    return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 2, stream);
+}
+
+// ---- f16f6 weight format: plane 0 = fp16(w) [Npad128][K]; plane 1 per (row, 32-k block) 64 bytes:
+//   [32 x e2m3(w * 2^-Ew) (24 B)][E8M0 byte 127 + Ew][7 B pad][32 x e2m3((w - fp16 w) * 2^-El) (24 B)][127 + El][7 B pad]
+// (activation planes: the same block with the low part first - see dua_hip.h).  Block exponent: biased exponent of the block
+// maximum minus one, i.e. the maximum lands in [2, 4) of the e2m3 range [0, 7.5].
+__global__ void k_split_weight_f16f6(const float* __restrict__ w, _Float16* __restrict__ hi, unsigned char* __restrict__ x6,
+                                     int N, int K, int Npad, int conv_cin) {
+    // one thread per (row, 32-k block)
+    const size_t nblk = (size_t)Npad * (K / 32);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (K / 32)), kb = (int)(i % (K / 32)) * 32;
+        float v[32], l[32], mw = 0.f, ml = 0.f;
+        for (int j = 0; j < 32; ++j) {
+            v[j] = split_weight_src(w, n, kb + j, N, K, conv_cin);
+            const _Float16 h = (_Float16)v[j];
+            hi[(size_t)n * K + kb + j] = h;
+            l[j] = v[j] - (float)h;
+            mw = fmaxf(mw, fabsf(v[j]));
+            ml = fmaxf(ml, fabsf(l[j]));
+        }
+        unsigned char* o = x6 + ((size_t)n * K + kb) * 2;
+        for (int t = 0; t < 2; ++t) {
+            const float* src = t == 0 ? v : l;
+            const int eb = (int)((__float_as_uint(t == 0 ? mw : ml) >> 23) & 0xff);
+            const int sb = eb > 1 ? eb - 1 : 0;
+            unsigned long long bits[3] = {0, 0, 0};                               // 192-bit stream, element j at bits [6j, 6j + 6)
+            for (int j = 0; j < 32; ++j) {
+                const unsigned long long c = dua_e2m3_code(src[j], sb);
+                const int bp = 6 * j;
+                bits[bp >> 6] |= c << (bp & 63);
+                if ((bp & 63) > 58) bits[(bp >> 6) + 1] |= c >> (64 - (bp & 63));
+            }
+            for (int q = 0; q < 3; ++q) *(unsigned long long*)(o + 32 * t + 8 * q) = bits[q];
+            *(unsigned long long*)(o + 32 * t + 24) = (unsigned long long)sb;
+        }
+    }
+}
+extern "C" int dua_pack_weight_f16f6(const float* w, void* packed, int N, int K, int conv_cin, void* stream) {
+    DUA_REQUIRE(w && packed && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_f16f6: K must be a positive multiple of 32 (got %d)", K);
+    DUA_REQUIRE(conv_cin == 0 || (K == 9 * conv_cin && conv_cin % BK == 0), "dua_pack_weight_f16f6: conv K must be 9*Cin, Cin %% 32 == 0");
+    int Npad = round_up(N, BN);
+    size_t plane = (size_t)Npad * K;
+    _Float16* hi = (_Float16*)packed;
+    hipLaunchKernelGGL(k_split_weight_f16f6, stream_grid((size_t)Npad * (K / 32), 64), 64, 0, as_stream(stream), w, hi,
+                       (unsigned char*)(hi + plane), N, K, Npad, conv_cin);
+    return dua_check_launch("dua_pack_weight_f16f6");
 }
 
 // C[M][N] = A * W^T (+ bias) (+ residual) with A given as split planes (written by dua_groupnorm_apply_split / _f16f8) and W

@@ -277,11 +277,12 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
     if split:
-        fmt = "f16f8" if split == "f16f8" else "bf16x3"
+        fmt = split if split in ("f16f8", "f16f6") else "bf16x3"
         buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
-        fn = _lib.lib().dua_groupnorm_apply_split_f16f8 if fmt == "f16f8" else _lib.lib().dua_groupnorm_apply_split
+        fn = {"f16f8": _lib.lib().dua_groupnorm_apply_split_f16f8, "f16f6": _lib.lib().dua_groupnorm_apply_split_f16f6}.get(
+            fmt, _lib.lib().dua_groupnorm_apply_split)
         check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film), _film_ld(film, N, C1 + C2),
                  int(act), int(resample), _p(dropmask), _p(buf), _stream()), "dua_groupnorm_apply_split")
         return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt)
@@ -445,6 +446,52 @@ def pack_weight_f16f8(w):
     return packed
 
 
+def pack_weight_f16f6(w):
+    """As pack_weight_f16f8 with the cross plane in MXFP6 (e2m3 + E8M0 exponent per 32-k block); same buffer size."""
+    _req(w, name="w")
+    L = _lib.lib()
+    if w.ndim == 4 and w.shape[2] == 3:
+        N, cin = w.shape[0], w.shape[1]
+        K = 9 * cin
+    else:
+        N, cin = w.shape[0], 0
+        K = w.numel() // N
+    packed = torch.empty(L.dua_f16f8_weight_bytes(N, K), device=w.device, dtype=torch.uint8)
+    check(L.dua_pack_weight_f16f6(_p(w), _p(packed), N, K, cin, _stream()), "dua_pack_weight_f16f6")
+    return packed
+
+
+def planes_f16f6_reference(x):
+    """f16f6 activation planes of an NHWC fp32 tensor built with plain torch ops (tests / micro-benchmarks: the product writer is
+    dua_groupnorm_apply_split_f16f6).  Plane 0 fp16(x); plane 1 per 32-channel block [24 B e2m3(lo) | exp | 7 pad | 24 B e2m3(x) | exp | 7 pad]."""
+    N, H, W, C = x.shape
+    hi = x.to(torch.float16)
+    lo = x - hi.float()
+    blocks = []
+    for t in (lo, x):
+        tb = t.reshape(-1, C // 32, 32)
+        m = tb.abs().amax(-1, keepdim=True)
+        eb = (m.view(torch.int32) >> 23) & 0xff
+        sb = (eb - 1).clamp_min(0)
+        mul = ((254 - sb) << 23).view(torch.float32)
+        u = tb * mul
+        a = u.abs()
+        tt = torch.where(a < 1, a + 1, a)
+        b = tt.view(torch.int32)
+        rb = (b + 0x7FFFF + ((b >> 20) & 1)) >> 20
+        c = (rb - 1016 + torch.where(a < 1, 0, 8)).clamp(0, 31) | ((u.view(torch.int32) >> 31) & 1) << 5
+        c = c.to(torch.int64).reshape(-1, C // 32, 4, 8)
+        sh = torch.arange(8, device=x.device, dtype=torch.int64) * 6
+        w48 = (c << sh).sum(-1)                                                       # 8 codes = 48 bits
+        by = torch.stack([(w48 >> (8 * k)) & 0xff for k in range(6)], -1).reshape(-1, C // 32, 24).to(torch.uint8)
+        tail = torch.zeros(by.shape[0], C // 32, 8, dtype=torch.uint8, device=x.device)
+        tail[..., 0] = sb.squeeze(-1).to(torch.uint8)
+        blocks.append(torch.cat([by, tail], -1))
+    x6 = torch.cat(blocks, -1).reshape(-1)                                            # [rows][C/32][64] bytes
+    buf = torch.cat([hi.reshape(-1).view(torch.uint8), x6]).view(torch.int16).reshape(2, N, H, W, C)
+    return SplitPlanes(buf, (N, H, W, C), "f16f6")
+
+
 def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=False):
     """Split-operand 3x3 convolution; a SplitPlanes input selects the kernel by its format (the weight must be packed to match)."""
     pre = isinstance(x, SplitPlanes)
@@ -458,7 +505,8 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if pre:
-        fn = _lib.lib().dua_conv3x3_f16f8_presplit if x.fmt == "f16f8" else _lib.lib().dua_conv3x3_bf16x3_presplit
+        fn = {"f16f8": _lib.lib().dua_conv3x3_f16f8_presplit, "f16f6": _lib.lib().dua_conv3x3_f16f6_presplit}.get(
+            x.fmt, _lib.lib().dua_conv3x3_bf16x3_presplit)
         check(fn(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _p(ws), _stream()),
               "dua_conv3x3 presplit")
     else:

@@ -251,6 +251,17 @@ int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, in
                                     int resample, const float* dropmask, void* yplanes, void* stream);
 int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
+/* "f16f6": the f16f8 scheme with the two cross operands in MXFP6 (e2m3) and an E8M0 exponent per (row, 32-k block) - the
+ * same scaled instruction at twice its fp8 rate (96 instead of 128 matrix-core cycles per 32x32x32 block), 3x3 convolutions
+ * whose image width divides 256.  Plane 1 per 32-channel block (64 B): activations
+ * [32 x e2m3(lo * 2^-El) (24 B) | 127 + El | 7 B pad | 32 x e2m3(x * 2^-Ex) (24 B) | 127 + Ex | 7 B pad], weights with the
+ * full-value part first; packed weight size = dua_f16f8_weight_bytes. */
+int dua_groupnorm_apply_split_f16f6(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                    int resample, const float* dropmask, void* yplanes, void* stream);
+int dua_pack_weight_f16f6(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
+int dua_conv3x3_f16f6_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
+                               int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
 int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
                             void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream);
 /* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */

@@ -332,6 +332,42 @@ def test_conv3x3_f16f8(ops, N, H, W, Cin, Cout):
     assert (c.cpu().double() - ref1).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 16, 32, 6),
+                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (3, 64, 64, 64, 256), (8, 128, 128, 32, 256)])
+def test_conv3x3_f16f6(ops, N, H, W, Cin, Cout):
+    """fp16 hi*hi + MXFP6 (e2m3, E8M0 exponent per 32-k block) cross terms: the GroupNorm-apply writer against the plain-torch
+    construction of the planes (bit-exact), packing and kernel vs fp64."""
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    res = rnd(23, N, Cout, H, W)
+    xd = nhwc(x).to(dev)
+    st = torch.tensor([0.0, 1.0]).repeat(N * 32, 1).contiguous().to(dev)
+    xs = ops.groupnorm_apply(xd, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16f6")
+    want = ops.planes_f16f6_reference(xd)
+    assert xs.fmt == want.fmt == "f16f6"
+    np.testing.assert_array_equal(xs.buf.cpu().numpy(), want.buf.cpu().numpy())
+    # the planes decode back to x: fp16 hi + e2m3(lo) * 2^El
+    if N * H * W <= 70000:
+        buf = xs.buf.view(torch.uint8).reshape(2, -1).cpu()
+        blk = buf[1].reshape(-1, 64).numpy()
+        def dec(term):
+            bits = np.unpackbits(blk[:, 32 * term:32 * term + 24], axis=1, bitorder="little").reshape(-1, 32, 6).astype(np.int64)
+            v = torch.from_numpy((bits << np.arange(6)).sum(-1))
+            sb = torch.from_numpy(blk[:, 32 * term + 24].astype(np.int64))[:, None]
+            c, sgn = v & 31, 1 - 2 * (v >> 5)
+            mag = torch.where(c < 8, c / 8.0, (1 + (c & 7) / 8.0) * torch.pow(2.0, ((c >> 3) - 1).double()))
+            return (sgn * mag * torch.pow(2.0, (sb - 127).double())).reshape(N, H, W, Cin)
+        hi = buf[0].view(torch.float16).reshape(N, H, W, Cin).double()
+        lo, xv = dec(0), dec(1)
+        assert (hi + lo - nhwc(x).double()).abs().max().item() < 2e-4
+        assert (xv - nhwc(x).double()).abs().max().item() <= 0.13 * nhwc(x).abs().max().item()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    packed = ops.pack_weight_f16f6(w.to(dev))
+    y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=(Cout % 4 == 0))
+    assert (nchw(y.cpu()).double() - (ref + res)).abs().max().item() < 3e-4
+    y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, nchw_out=True)
+    assert (y.cpu().double() - ref).abs().max().item() < 3e-4
+
+
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0)])
 def test_gemm_bf16x3(ops, M, N, K1, K2):
     a1, a2 = rnd(30, M, K1), (rnd(31, M, K2) if K2 else None)
