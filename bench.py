@@ -47,6 +47,8 @@ class ConvProfile:
     # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
     PMC_TRAFFIC_BF16X3 = 2.145e9
     PMC_TRAFFIC_F16F8 = 1.999e9       # profiles/r01j_pmc_traffic_conv.json (mean over the conv and 1-tap GEMM launches of the kernel)
+    PMC_TRAFFIC_F16F6 = None
+    PMC_TRAFFIC_F16F6_SOURCE = None
 
     def summary(self):
         if not self.items:
@@ -76,6 +78,19 @@ class ConvProfile:
                         executed_mfma_tflops=round(2 * cs["tflops"], 1), executed_frac=round(2 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
                         note="achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of 2 bf16-rate products (one fp16 "
                              "product + two fp8 products at twice the rate), so frac <= 1/2 against the 2.5 PF bf16/fp16 peak by construction")
+        if precision == "f16f6":
+            return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_F16F6,
+                        traffic_source=self.PMC_TRAFFIC_F16F6_SOURCE,
+                        kernel="k_xconv_dma<NT, 2, true> (LDS-DMA row-shift implicit-GEMM conv3x3, fp16 hi*hi on v_mfma_f32_32x32x16_f16 + "
+                               "both cross terms on one MXFP6 (e2m3, E8M0 exponent per 32-k block) v_mfma_scale_f32_32x32x64_f8f6f4 per "
+                               "32-deep K block)",
+                        launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
+                        executed_mfma_tflops=round(1.5 * cs["tflops"], 1),
+                        executed_frac=round(1.5 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
+                        note="achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of 1.5 bf16-rate products (one "
+                             "fp16 product + two fp6 products at four times the rate), so frac <= 2/3 against the 2.5 PF bf16/fp16 peak "
+                             "by construction")
         return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_BF16X3,
                     traffic_source="profiles/r01d_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
@@ -146,7 +161,7 @@ def main():
     ap.add_argument("--start-step-uc", type=int, default=40)
     ap.add_argument("--num-steps-uc", type=int, default=10)
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
-    ap.add_argument("--precision", choices=["f16f8", "bf16x3", "fp32"], default="f16f8",
+    ap.add_argument("--precision", choices=["f16f6", "f16f8", "bf16x3", "fp32"], default="f16f8",
                     help="f16f8: 3x3 convs / qkv on fp16 + block-scaled fp8 matrix-core products (parity ~5e-5); bf16x3: convs / weight "
                          "GEMMs on the bf16 matrix cores with split fp32 operands (parity ~3e-5); fp32: exact fp32 MFMA (parity ~7e-6)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-step run of the other precision mode")
@@ -223,7 +238,10 @@ def main():
             "metric": "images/sec @ ADM ImageNet-128, 50 steps, M=5, bs=128; 1/2/4/8 GPU",
             "value": round(images / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f16f8": "f16f8 (fp32 operands split a = fp16 hi + lo; hi*hi on fp16 MFMA, both cross terms on one block-scaled fp8 "
+            "dtype": {"f16f6": "f16f6 (fp32 operands split a = fp16 hi + lo; 3x3 convs: hi*hi on fp16 MFMA, both cross terms on one MXFP6 "
+                               "(e2m3 + E8M0 exponent per 32 channels) scaled MFMA, fp32 accumulate; qkv / proj_out f16f8; 1x1 / attention "
+                               "products split-bf16; norms/softmax/sampler fp32)",
+                      "f16f8": "f16f8 (fp32 operands split a = fp16 hi + lo; hi*hi on fp16 MFMA, both cross terms on one block-scaled fp8 "
                                "MFMA, fp32 accumulate: ~2^-15 per product; 1x1 / attention products split-bf16; norms/softmax/sampler fp32)",
                       "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 terms, 3 bf16 MFMA products, fp32 accumulate; norms/softmax/"
                                 "attention products/sampler in fp32)", "fp32": "f32"}[a.precision], "data": "synthetic",

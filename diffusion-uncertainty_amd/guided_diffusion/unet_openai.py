@@ -91,7 +91,8 @@ class ResBlock(TimestepBlock):
         gn2, drop, conv2 = self.out_layers[0], self.out_layers[2], self.out_layers[3]
         N, H, W, _ = x.shape
         st = ops.groupnorm_stats(x, skip)
-        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample, split=ctx.split_acts)
+        Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
+        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample, split=ctx.conv_split(Wc))
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
         h = ctx.conv3x3(h, conv1, self.out_channels, colsum=True)      # epilogue leaves GroupNorm statistics for out_layers[0]
@@ -100,7 +101,7 @@ class ResBlock(TimestepBlock):
         mask = None
         if drop.training and drop.p > 0:
             mask = ctx.dropout_mask(h.shape, drop.p)
-        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask, split=ctx.split_acts)  # :249-253
+        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask, split=ctx.conv_split(Wc))  # :249-253
         if isinstance(self.skip_connection, nn.Identity):
             assert skip is None
             res = x
@@ -152,10 +153,10 @@ class AttentionBlock(nn.Module):
         # bf16x3 mode: the normalised tokens go straight out as split bf16 planes and the qkv projection runs on the
         # LDS-DMA kernel (one tap)
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0,
-                                 split=ctx.split_acts if (ctx.model.presplit_qkv and C % 32 == 0) else False)
+                                 split=ctx.gemm_split if (ctx.model.presplit_qkv and C % 32 == 0) else False)
         qkv = ctx.qkv(xn if isinstance(xn, ops.SplitPlanes) else xn.view(N * T, C), self)
         a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision="fp32" if ctx.model.precision == "fp32" else "bf16x3",
-                              planes_out=(ctx.model.precision == "f16f8"))
+                              planes_out=(ctx.gemm_split == "f16f8"))
         if isinstance(a, ops.SplitPlanes):        # attention output already in the operand format: proj_out on the LDS-DMA kernel
             key = (id(self.proj_out), "w1f")
             if key not in ctx.model._packed:
@@ -180,10 +181,17 @@ class _Ctx:
         self.emb = None
         self.film_all = None
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
-        # (False | True = bf16x3 planes | "f16f8" planes)
-        assert model.precision in ("fp32", "bf16x3", "f16f8"), model.precision
+        # (False | True = bf16x3 planes | "f16f8" planes | "f16f6" planes: 3x3 convs whose width divides 256 only)
+        assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6"), model.precision
         self.split_mode = model.precision != "fp32"
-        self.split_acts = "f16f8" if model.precision == "f16f8" else model.precision == "bf16x3"
+        self.split_acts = model.precision if model.precision in ("f16f8", "f16f6") else model.precision == "bf16x3"
+        self.gemm_split = "f16f8" if self.split_acts == "f16f6" else self.split_acts       # one-tap GEMMs (qkv, proj_out)
+
+    def conv_split(self, width):
+        """Operand format the GroupNorm in front of a 3x3 conv of this output width writes."""
+        if self.split_acts == "f16f6" and 256 % width != 0:
+            return "f16f8"
+        return self.split_acts
 
     def packed(self, mod, kind):
         cache = self.model._packed
@@ -198,6 +206,8 @@ class _Ctx:
                 cache[key] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
             elif kind == "w3f":
                 cache[key] = ops.pack_weight_f16f8(mod.weight.detach().contiguous())
+            elif kind == "w3s":
+                cache[key] = ops.pack_weight_f16f6(mod.weight.detach().contiguous())
             elif kind == "qkvf":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16f8(wq), bq)
@@ -245,7 +255,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = "w3f" if isinstance(h, ops.SplitPlanes) and h.fmt == "f16f8" else "w3x"
+            kind = {"f16f8": "w3f", "f16f6": "w3s"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -330,6 +340,8 @@ class UNetModel(nn.Module):
         # with split fp32 operands (csrc/mfma_bf16x3.hip); attention products, embeddings, norms stay fp32.
         # "f16f8": as bf16x3, with the 3x3 convs and the qkv projections on the fp16 + block-scaled-fp8 form of the same
         # kernel (2/3 of the matrix-core cycles; ~2.4x the bf16x3 error, still ~12x inside the 1e-3 bar).
+        # "f16f6": as f16f8, with the cross terms of the 3x3 convs in MXFP6 (e2m3 with an E8M0 exponent per 32 channels): half
+        # the matrix-core cycles of bf16x3.
         self.precision = "fp32"
         # GroupNorm statistics produced in the epilogue of the conv / GEMM that writes the tensor (no re-read); set False to
         # use the stand-alone statistics kernel everywhere.
@@ -397,7 +409,7 @@ class UNetModel(nn.Module):
             h = module.run(ctx, h, hs.pop(), name=f"output_blocks.{i}")
         gn, conv = self.out[0], self.out[2]
         st = ops.groupnorm_stats(h)
-        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split=ctx.split_acts)
+        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split=ctx.conv_split(h.shape[2]))
         keep = self.out_channels if out_channels_keep is None else out_channels_keep
         return ctx.conv3x3(h, conv, keep, nchw_out=True)
 

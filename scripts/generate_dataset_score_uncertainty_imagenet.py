@@ -71,7 +71,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         ae = load_autoencoder_uvit(device="cpu", load_checkpoint=ckpt)
         if not ckpt:
             randomize_parameters_(ae, seed=9)
-        uvit.precision = args.precision
+        uvit.precision = "f16f8" if args.precision == "f16f6" else args.precision            # f16f6 is a 3x3-conv format: ADM only
         ae.precision = "fp32" if args.precision == "fp32" else "bf16x3"       # the VAE decoder has no f16f8 path (one call per batch)
         model = UViTAE(uvit, ae).to(device)
         scheduler = load_uvit_scheduler()
@@ -127,7 +127,7 @@ def parse_args(argv=None):
     p.add_argument("--uncertainty-distance", type=int, default=20, dest="uncertainty_distance")
     p.add_argument("--num-zigzag", "--num-zigzags", "--num-zig-zag", "--num-zig-zags", type=int, default=3, dest="num_zigzag")
     # engine options (not in the reference)
-    p.add_argument("--precision", choices=["f16f8", "bf16x3", "fp32"], default="bf16x3")
+    p.add_argument("--precision", choices=["f16f6", "f16f8", "bf16x3", "fp32"], default="bf16x3")
     p.add_argument("--noise", choices=["host", "device"], default="host", help="host: CPU-generator noise tape in the reference's draw order")
     p.add_argument("--synthetic", action="store_true", help="generate X_T / y like scripts/generate_diffusion_starting_data.py")
     p.add_argument("--random-weights", action="store_true", help="seeded random weights instead of checkpoints")

@@ -243,11 +243,12 @@ def test_device_noise_mode():
 
 
 # ---------------------------------------------------------------- split-bf16 (bf16x3) precision mode
-@pytest.mark.parametrize("precision", ["bf16x3", "f16f8"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16f8", "f16f6"])
 @pytest.mark.parametrize("name", ["tiny", "adm64", "adm128"])
 def test_bf16x3_mode_adm(golden, name, precision):
     """Convs / weight GEMMs on the bf16 matrix cores with split fp32 operands (bf16x3), or on the fp16 + block-scaled fp8
-    form of the same kernel (f16f8): still within the 1e-3 bar against the reference's fp32 CPU output."""
+    form of the same kernel (f16f8; f16f6 = cross terms of the 3x3 convs in MXFP6): still within the 1e-3 bar against the
+    reference's fp32 CPU output."""
     from oracle import adm
     if name == "tiny":
         g = golden("g5_adm_blocks")
@@ -342,7 +343,7 @@ def test_uvit_driver_with_vae():
     assert d.max() <= 1 and (d > 0).mean() < 2e-2
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8", "f16f6"])
 def test_fused_groupnorm_stats_equivalent(precision):
     """fuse_gn_stats (statistics from producer epilogues) vs the stand-alone statistics kernel: same model output."""
     m, _ = build_adm(TINY_ADM, 5)
