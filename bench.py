@@ -161,8 +161,8 @@ def main():
     ap.add_argument("--start-step-uc", type=int, default=40)
     ap.add_argument("--num-steps-uc", type=int, default=10)
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
-    ap.add_argument("--precision", choices=["f16f6", "f16f8", "bf16x3", "fp32"], default="f16f8",
-                    help="f16f8: 3x3 convs / qkv on fp16 + block-scaled fp8 matrix-core products (parity ~5e-5); bf16x3: convs / weight "
+    ap.add_argument("--precision", choices=["f16f6", "f16f8", "bf16x3", "fp32"], default="f16f6",
+                    help="f16f6: as f16f8 with the cross terms of the 3x3 convs in MXFP6 (parity ~1e-4); f16f8: 3x3 convs / qkv on fp16 + block-scaled fp8 matrix-core products (parity ~5e-5); bf16x3: convs / weight "
                          "GEMMs on the bf16 matrix cores with split fp32 operands (parity ~3e-5); fp32: exact fp32 MFMA (parity ~7e-6)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the one-step run of the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -223,7 +223,7 @@ def main():
     dt, uc_calls, prof = timed(a.precision, a.steps, a.warmup)
     secondary = None
     if world == 1 and not a.no_secondary:
-        other = "fp32" if a.precision != "fp32" else "f16f8"
+        other = "fp32" if a.precision != "fp32" else "f16f6"
         dt2, uc2, prof2 = timed(other, 1, 1)
         secondary = dict(precision=other, value=round(a.batch / dt2, 4), unit="images/sec", steps=1, ms_per_step=round(dt2 * 1e3, 1),
                          end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
@@ -253,7 +253,7 @@ def main():
                                       "skip_dead_zigzag (outputs identical; noise draws still consumed)",
                        "executed_forwards_per_image": fwd_per_img, "noise": "device Philox (dua_randn)",
                        "precision": a.precision,
-                       "parity": ("full-size ADM-128 forward vs the reference CPU output: max abs err 5.3e-5 (f16f8), 3.1e-5 (bf16x3), "
+                       "parity": ("full-size ADM-128 forward vs the reference CPU output: max abs err 1.0e-4 (f16f6), 5.3e-5 (f16f8), 3.1e-5 (bf16x3), "
                                   "7.4e-6 (fp32); tolerance 1e-3 (tests/test_gpu_models.py)"),
                        "warmup_pass": "3-timestep truncated job"},
             "end_to_end_tflops": round(exec_flops / dt / 1e12, 2),

@@ -61,7 +61,7 @@ __device__ __forceinline__ void dua_store_f16f8_quad(void* planes, long plane_el
 }
 
 // e2m3 (MXFP6) code of v * 2^(127 - sbyte): sign<<5 | eemmm, round to nearest even; magnitudes < 1 use the subnormal grid (step 1/8).
-// sbyte is the E8M0 block exponent (biased exponent of the block maximum minus one: the maximum lands in [2, 4)).
+// sbyte is the E8M0 block exponent (biased exponent of the block maximum minus two: the maximum lands in [4, 8); codes above 7.5 clamp).
 __device__ __forceinline__ unsigned dua_e2m3_code(float v, int sbyte) {
     const float u = v * __uint_as_float((unsigned)(254 - sbyte) << 23);
     const float a = fabsf(u);

@@ -350,7 +350,7 @@ __device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const f
         ml = fmaxf(ml, __shfl_xor(ml, 1)); ml = fmaxf(ml, __shfl_xor(ml, 2));
         mh = fmaxf(mh, __shfl_xor(mh, 1)); mh = fmaxf(mh, __shfl_xor(mh, 2));
         const int ebl = (int)((__float_as_uint(ml) >> 23) & 0xff), ebh = (int)((__float_as_uint(mh) >> 23) & 0xff);
-        const int sbl = ebl > 1 ? ebl - 1 : 0, sbh = ebh > 1 ? ebh - 1 : 0;
+        const int sbl = ebl > 2 ? ebl - 2 : 0, sbh = ebh > 2 ? ebh - 2 : 0;
         unsigned long long pl = 0, ph = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

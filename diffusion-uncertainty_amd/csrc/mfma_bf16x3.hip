@@ -1398,7 +1398,7 @@ extern "C" int dua_conv3x3_f16f6_presplit(const void* xplanes, const void* packe
 // ---- f16f6 weight format: plane 0 = fp16(w) [Npad128][K]; plane 1 per (row, 32-k block) 64 bytes:
 //   [32 x e2m3(w * 2^-Ew) (24 B)][E8M0 byte 127 + Ew][7 B pad][32 x e2m3((w - fp16 w) * 2^-El) (24 B)][127 + El][7 B pad]
 // (activation planes: the same block with the low part first - see dua_hip.h).  Block exponent: biased exponent of the block
-// maximum minus one, i.e. the maximum lands in [2, 4) of the e2m3 range [0, 7.5].
+// maximum minus two, i.e. the maximum lands in [4, 8) of the e2m3 range [0, 7.5] (a maximum above 7.75 rounds to the 7.5 clamp).
 __global__ void k_split_weight_f16f6(const float* __restrict__ w, _Float16* __restrict__ hi, unsigned char* __restrict__ x6,
                                      int N, int K, int Npad, int conv_cin) {
     // one thread per (row, 32-k block)
@@ -1418,7 +1418,7 @@ __global__ void k_split_weight_f16f6(const float* __restrict__ w, _Float16* __re
         for (int t = 0; t < 2; ++t) {
             const float* src = t == 0 ? v : l;
             const int eb = (int)((__float_as_uint(t == 0 ? mw : ml) >> 23) & 0xff);
-            const int sb = eb > 1 ? eb - 1 : 0;
+            const int sb = eb > 2 ? eb - 2 : 0;
             unsigned long long bits[3] = {0, 0, 0};                               // 192-bit stream, element j at bits [6j, 6j + 6)
             for (int j = 0; j < 32; ++j) {
                 const unsigned long long c = dua_e2m3_code(src[j], sb);

@@ -472,7 +472,7 @@ def planes_f16f6_reference(x):
         tb = t.reshape(-1, C // 32, 32)
         m = tb.abs().amax(-1, keepdim=True)
         eb = (m.view(torch.int32) >> 23) & 0xff
-        sb = (eb - 1).clamp_min(0)
+        sb = (eb - 2).clamp_min(0)
         mul = ((254 - sb) << 23).view(torch.float32)
         u = tb * mul
         a = u.abs()
