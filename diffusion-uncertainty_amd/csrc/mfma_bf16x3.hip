@@ -430,6 +430,11 @@ struct DConvP {
 // floats: the two half-waves write rows 4 apart and must land on different banks), then moves whole rows, 16 B per lane.
 // All residual rows of the half are requested BEFORE the transposition so that their latency runs under it (read one by
 // one they cost a full memory round trip per row group: 55k of the 87k epilogue cycles of a 256x256 tile).
+#ifndef DUA_A_PREFETCH
+#define DUA_A_PREFETCH 1
+#endif
+// pitch of the epilogue patch rows: 256-wide tiles use the bare 128 floats (8 patches = 128 KB: activation stage 1 stays free)
+#define DUA_PATCH_PAD (NT == 4 ? 0 : 8)
 template <int ACT, bool RES, bool SPLIT, int FMT = 0>
 __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const float4 q, const float4 bq, long o, float4& cs, float4& cq) {
     w.x += bq.x; w.y += bq.y; w.z += bq.z; w.w += bq.w;
@@ -454,7 +459,7 @@ __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const f
 template <int NT, bool RES, int ACT, bool SPLIT, int FMT = 0>
 __device__ __forceinline__ void dconv_rows_full(const DConvP& p, f32x16 (&acc)[2][NT], float* patch, int lane, int row0, int colq,
                                                 float4 bq, float4& cs, float4& cq) {
-    constexpr int WC = 32 * NT, WCP = WC + 8, RPI = 64 / (WC / 4), NIT = 32 / RPI;
+    constexpr int WC = 32 * NT, WCP = WC + DUA_PATCH_PAD, RPI = 64 / (WC / 4), NIT = 32 / RPI;
     const int c4 = lane % (WC / 4), rr = lane / (WC / 4), lr = lane & 31, kh = lane >> 5;
     const long rstep = (long)RPI * p.N;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -546,24 +551,43 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         const int ph = slot % p.stagger_phases;
         for (int i = 0; i < ph * p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     }
-  for (int ti = slot; ti < chunk_n; ti += nslot) {
-    const int lid = chunk0 + ti;
-    const int tn = lid % p.ntn, tm = lid / p.ntn;
-    const int m0 = tm * DBM, n0 = tn * DBN;
-    DUA_STAMP(0)
-
-    // ---- DMA geometry.  One wave instruction = 16 rows x 4 chunks of 16 B.  Wave w stages A row groups 2w, 2w+1
-    // (both planes) and B row groups (NT/2)*w .. (both planes).
-    const int lrow = lane >> 2;
-    const int csrc = (lane & 3) ^ ((lane >> 4) & 3);                     // source chunk for this lane's LDS slot
-    const unsigned OOB = 0xFFFFFFF0u;
-    // The buffer descriptors are rebased per workgroup at the first pixel its taps can touch (tile start minus one
-    // image row and one pixel), so the 32-bit buffer offsets stay tiny whatever the size of the activation planes.
-    const int mbase = p.ntaps == 9 ? max(0, m0 - (p.W + 1)) : m0;
-    unsigned abase[2], abits[2], rsy = 0;
+  // ---- activation-side DMA geometry of a tile (its state lives across tiles: the row-shift loop requests the first
+  // activation stage of the NEXT tile before the epilogue of the current one).  One wave instruction = 16 rows x 4 chunks
+  // of 16 B; wave w stages A row groups 2w, 2w+1 (both planes) and B row groups (NT/2)*w .. (both planes).
+  // The buffer descriptors are rebased per tile at the first pixel its taps can touch (tile start minus one image row and
+  // one pixel), so the 32-bit buffer offsets stay tiny whatever the size of the activation planes.
+  const unsigned OOB = 0xFFFFFFF0u;
+  unsigned abase[2] = {0, 0}, abits[2] = {0, 0}, rsy = 0;
+  auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  auto ral = ra;
+  int tap = 0, cb = 0;
+  bool a_prefetched = false;
+  auto a_geom = [&](int m0_) {
+    int lane_g = lane;
+    asm volatile("" : "+v"(lane_g));
+    const int lrow = lane_g >> 2;
+    const int csrc = (lane_g & 3) ^ ((lane_g >> 4) & 3);                 // source chunk for this lane's LDS slot
+    const int mbase = p.ntaps == 9 ? max(0, m0_ - (p.W + 1)) : m0_;
+    rsy = 0;
+    const int lw = __builtin_ctz(p.W);
+    if (RS && ((p.M >> lw) >> 21) == 0) {
+        // row-shift tiles: W is a power of two (it divides 256) and only the y-edge flags are needed: shifts, 24-bit
+        // multiplies and one float quotient (exact for image-row indices below 2^21) instead of four 32-bit integer
+        // divisions (~3k cycles per tile)
+        const float rh = 1.0f / (float)p.H;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = min(m0_ + 16 * (2 * wave + j) + lrow, p.M - 1);
+            abase[j] = (__umul24((unsigned)(m - mbase), (unsigned)p.Cin) + 8u * csrc) * 2u;
+            const int rowq = m >> lw;                                            // image * H + y  (< 2^22: exact in float)
+            const int y = rowq - (int)__umul24((unsigned)(int)(((float)rowq + 0.5f) * rh), (unsigned)p.H);
+            abits[j] = 0;
+            rsy |= (y == 0 ? 1u : 0u) << j | (y == p.H - 1 ? 1u : 0u) << (2 + j);
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int m = min(m0 + 16 * (2 * wave + j) + lrow, p.M - 1);
+        const int m = min(m0_ + 16 * (2 * wave + j) + lrow, p.M - 1);
         abase[j] = (unsigned)(((long)(m - mbase) * p.Cin + 8 * csrc) * 2);
         unsigned bits = 1;
         if (p.ntaps == 9) {
@@ -579,6 +603,21 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         abits[j] = bits;
         if (RS) rsy |= ((bits >> 1) & 1u ? 0u : 1u) << j | ((bits >> 7) & 1u ? 0u : 1u) << (2 + j);   // taps (-1, 0) / (+1, 0) outside
     }
+    const long arem = ((long)p.M - mbase) * p.Cin * 2;                       // bytes from the rebased origin to the plane's end
+    const int arec = (p.dbg_norec & 1) ? 0 : (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)mbase * p.Cin), 0, arec, 0x00020000);
+    ral = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + p.a_plane + (long)mbase * p.Cin), 0, arec, 0x00020000);
+    tap = 0;
+    cb = 0;
+  };
+  for (int ti = slot; ti < chunk_n; ti += nslot) {
+    const int lid = chunk0 + ti;
+    const int tn = lid % p.ntn, tm = lid / p.ntn;
+    const int m0 = tm * DBM, n0 = tn * DBN;
+    DUA_STAMP(0)
+    const int lrow = lane >> 2;
+    const int csrc = (lane & 3) ^ ((lane >> 4) & 3);
+    if (!a_prefetched) a_geom(m0);
     unsigned boff[NT / 2];
     // Every workgroup of the chip streams the SAME weight tile at about the same time: rotate which 16-row group a wave
     // fetches by the workgroup's slot, so that at a given moment the workgroups of an XCD ask different L2 channels.
@@ -592,13 +631,8 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         bgrp[j] = ((NT / 2) * wave + j + brot) % (4 * NT);
         boff[j] = (unsigned)(((long)(n0 + 16 * bgrp[j] + lrow) * p.K + 8 * csrc) * 2);
     }
-    const long arem = ((long)p.M - mbase) * p.Cin * 2;                       // bytes from the rebased origin to the plane's end
-    const int arec = (p.dbg_norec & 1) ? 0 : (int)(arem < 0x7FFFFFF0L ? arem : 0x7FFFFFF0L);
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)mbase * p.Cin), 0, arec, 0x00020000);
-    const auto ral = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + p.a_plane + (long)mbase * p.Cin), 0, arec, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (p.dbg_norec & 2) ? 0 : (int)(2 * p.b_plane * 2), 0x00020000);
     const int b_lo = (int)(p.b_plane * 2);                                   // byte distance hi -> lo weight plane
-    int tap = 0, cb = 0;
     // The DMA pieces of a tile are issued one at a time so that the caller can spread them between MFMA groups
     // (an LDS-DMA issue holds the wave for ~60-180 cycles).
     unsigned vo0 = 0, vo1 = 0;
@@ -808,7 +842,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // (kept in bits 4..7 of the lane word that already holds the y-edge bits of the DMA rows)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int x_ = (m0 + wm * 64 + 32 * i + lr) % p.W;
+        const int x_ = (m0 + wm * 64 + 32 * i + lr) & (p.W - 1);          // W divides 256: a power of two
         rsy |= (x_ == 0 ? 1u : 0u) << (4 + i);
         rsy |= (x_ == p.W - 1 ? 1u : 0u) << (6 + i);
     }
@@ -825,17 +859,21 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const int ngroups = nk / 3;
-    // prologue: stage of group 0, weight tiles 0 and 1
-    dma_setup();
+    // prologue: stage of group 0 (already requested by the previous tile's epilogue unless this is the first tile), weight
+    // tiles 0 and 1.  Every tile starts on activation stage 1: the epilogue patches cover the weight ring and stage 0 only.
+    if (!a_prefetched) {
+        dma_setup();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_a(0, i);
+        for (int i = 0; i < 4; ++i) dma_a(1, i);
+    }
+    a_prefetched = false;
     issue_b(0);
     if (nk > 1) issue_b(1);
     load_scales();
     wait_vm(nk > 1 ? NT : 0);
     __builtin_amdgcn_s_barrier();
     DUA_STAMP(1)
-    int sa = 0, sb = 0, dxi = 0, grp = 0;
+    int sa = 1, sb = 0, dxi = 0, grp = 0;
     bool a_inflight = false;
     {
         const int oh0 = loff(lr, -1, kh);
@@ -843,7 +881,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
 #pragma unroll
-            for (int i_ = 0; i_ < 2; ++i_) ah[s_][i_] = *(const f16x8*)(ldsb + (a_stage0 + 32 * i_ * LDH * 2) + (s_ ? oha[i_] ^ 32 : oha[i_]));
+            for (int i_ = 0; i_ < 2; ++i_) ah[s_][i_] = *(const f16x8*)(ldsb + (a_stage0 + 2 * SA * 2 + 32 * i_ * LDH * 2) + (s_ ? oha[i_] ^ 32 : oha[i_]));
 #pragma unroll
             for (int j_ = 0; j_ < NT; ++j_) rd_bh(0, s_, j_);
         }
@@ -1073,6 +1111,18 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #undef SBAR
   }
     DUA_STAMP(2)
+    // The K loop's last barrier has retired every read of the stages: the row-shift loop requests the first activation stage
+    // of this workgroup's NEXT tile now, into stage 1 (outside the epilogue patches), so that its HBM latency runs under the
+    // epilogue.  (Issued between the two halves of the epilogue instead: K loop and epilogue both slower, 208k -> 224k per tile.)
+    if constexpr (RS) {
+        if (DUA_A_PREFETCH && ti + nslot < chunk_n) {
+            a_geom(((chunk0 + ti + nslot) / p.ntn) * DBM);
+            dma_setup();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_a(1, i);
+            a_prefetched = true;
+        }
+    }
     // The epilogue's lane-derived addresses must not be hoisted above the K loop (the loop owns every VGPR: hoisted
     // values end up in scratch, and their reload waits on vmcnt(0), i.e. on the whole DMA pipeline).
     int lane_e = lane;
@@ -1080,7 +1130,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     const int lr_e = lane_e & 31, kh_e = lane_e >> 5;
     const bool full_tile = m0 + DBM <= p.M && n0 + DBN <= p.N && !p.nchw_out && !(p.res && (p.act_out == 2 || p.Csplit));
     if (full_tile) {
-        constexpr int WC = 32 * NT, WCP = WC + 8;
+        constexpr int WC = 32 * NT, WCP = WC + DUA_PATCH_PAD;
         float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WCP);
         const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);
         const int colq = n0 + wn * WC + 4 * c4;
