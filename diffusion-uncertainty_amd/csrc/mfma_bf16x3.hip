@@ -1114,15 +1114,17 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // The K loop's last barrier has retired every read of the stages: the row-shift loop requests the first activation stage
     // of this workgroup's NEXT tile now, into stage 1 (outside the epilogue patches), so that its HBM latency runs under the
     // epilogue.  (Issued between the two halves of the epilogue instead: K loop and epilogue both slower, 208k -> 224k per tile.)
-    if constexpr (RS) {
-        if (DUA_A_PREFETCH && ti + nslot < chunk_n) {
-            a_geom(((chunk0 + ti + nslot) / p.ntn) * DBM);
-            dma_setup();
+    auto prefetch_next = [&]() {
+        if constexpr (RS) {
+            if (DUA_A_PREFETCH && ti + nslot < chunk_n) {
+                a_geom(((chunk0 + ti + nslot) / p.ntn) * DBM);
+                dma_setup();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dma_a(1, i);
-            a_prefetched = true;
+                for (int i = 0; i < 4; ++i) dma_a(1, i);
+                a_prefetched = true;
+            }
         }
-    }
+    };
     // The epilogue's lane-derived addresses must not be hoisted above the K loop (the loop owns every VGPR: hoisted
     // values end up in scratch, and their reload waits on vmcnt(0), i.e. on the whole DMA pipeline).
     int lane_e = lane;
@@ -1136,6 +1138,10 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         const int colq = n0 + wn * WC + 4 * c4;
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) bq = *(const float4*)(p.bias + colq);
+        if constexpr (RS) {        // the bias must not queue behind the prefetch in the in-order vmcnt counter
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            prefetch_next();
+        }
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
         const int row0 = m0 + wm * 64;
         if (p.Csplit) {
@@ -1162,6 +1168,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             }
         }
     } else if (!p.nchw_out && (p.N & 3) == 0) {
+        prefetch_next();
         // ---- edge tiles: same scheme with per-row / per-column predicates.  Epilogue through LDS: each wave re-lays its 32 x (32*NT) half tile as rows in a private LDS patch
         // (the K loop's last barrier has retired every read of the stages), then moves whole rows: 16 B per lane,
         // 128*NT contiguous bytes per row for the residual read and the output store (the accumulator layout itself
@@ -1226,6 +1233,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             }
         }
     } else {
+        prefetch_next();
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
     #pragma unroll
