@@ -333,7 +333,8 @@ def test_conv3x3_f16f8(ops, N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 16, 32, 6),
-                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (3, 64, 64, 64, 256), (8, 128, 128, 32, 256)])
+                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (3, 64, 64, 64, 256), (8, 128, 128, 32, 256),
+                                             (2, 16, 1, 32, 32), (5, 3, 2, 64, 32)])
 def test_conv3x3_f16f6(ops, N, H, W, Cin, Cout):
     """fp16 hi*hi + MXFP6 (e2m3, E8M0 exponent per 32-k block) cross terms: the GroupNorm-apply writer against the plain-torch
     construction of the planes (bit-exact), packing and kernel vs fp64."""
@@ -366,6 +367,23 @@ def test_conv3x3_f16f6(ops, N, H, W, Cin, Cout):
     assert (nchw(y.cpu()).double() - (ref + res)).abs().max().item() < 3e-4
     y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, nchw_out=True)
     assert (y.cpu().double() - ref).abs().max().item() < 3e-4
+
+
+def test_conv3x3_f16f6_many_rows(ops):
+    """More than 2^21 image rows in one launch: the row-shift kernel's tile geometry leaves its float-quotient fast path for the
+    integer-division one; same bits as the two halves of the batch run separately (fast path), persistent-tile prefetch included."""
+    N, H, W, C = 64, 32768, 1, 32
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, H, W, C, generator=g).to(dev)
+    w, b = rnd(32, 32, C, 3, 3) / math.sqrt(9 * C), rnd(33, 32) * 0.1
+    packed = ops.pack_weight_f16f6(w.to(dev))
+    whole = ops.conv3x3_bf16x3(ops.planes_f16f6_reference(x), packed, b.to(dev), 32)
+    for half in (slice(0, N // 2), slice(N // 2, N)):
+        part = ops.conv3x3_bf16x3(ops.planes_f16f6_reference(x[half].contiguous()), packed, b.to(dev), 32)
+        assert torch.equal(whole[half], part)
+    # spot check against fp64 on a few images
+    ref = F.conv2d(nchw(x[:2].cpu()).double(), w.double(), b.double(), padding=1)
+    assert (nchw(whole[:2].cpu()).double() - ref).abs().max().item() < 3e-4
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0)])
