@@ -47,8 +47,8 @@ class ConvProfile:
     # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
     PMC_TRAFFIC_BF16X3 = 2.145e9
     PMC_TRAFFIC_F16F8 = 1.999e9       # profiles/r01j_pmc_traffic_conv.json (mean over the conv and 1-tap GEMM launches of the kernel)
-    PMC_TRAFFIC_F16F6 = 1.881e9       # profiles/r01k_pmc_traffic_conv.json (same mean)
-    PMC_TRAFFIC_F16F6_SOURCE = "profiles/r01k_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    PMC_TRAFFIC_F16F6 = 2.009e9       # profiles/r01l_pmc_traffic_conv.json (same mean)
+    PMC_TRAFFIC_F16F6_SOURCE = "profiles/r01l_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
     def summary(self):
         if not self.items:
