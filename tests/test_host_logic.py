@@ -190,3 +190,20 @@ def test_oracle_sd_unet_runs_on_cpu():
     b = sd_unet.forward(sd, cfg, x, torch.tensor([10, 900]), enc)
     assert a.shape == (2, 4, 8, 8) and torch.equal(a, b) and torch.isfinite(a).all()
     assert not torch.allclose(a[0], sd_unet.forward(sd, cfg, x, torch.tensor([900, 900]), enc)[0])     # the timestep matters
+
+
+def test_precision_modes_pick_operand_formats():
+    """Which operand format each GroupNorm in front of a matrix-core kernel writes, per precision mode (host logic only: no kernel
+    runs).  f16f6 planes go to the row-shift 3x3 convolutions only (image width divides 256); the one-tap GEMMs stay f16f8."""
+    from diffusion_uncertainty_amd.guided_diffusion.unet_openai import UNetModel, _Ctx
+    m = UNetModel(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1, attention_resolutions=(2,),
+                  channel_mult=(1, 2), num_classes=10, num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)
+    want = {"fp32": (False, False, False), "bf16x3": (True, True, True), "f16f8": ("f16f8", "f16f8", "f16f8"),
+            "f16f6": ("f16f6", "f16f8", "f16f8")}
+    for mode, (w16, w24, gemm) in want.items():
+        m.precision = mode
+        ctx = _Ctx(m)
+        assert (ctx.conv_split(16), ctx.conv_split(24), ctx.gemm_split) == (w16, w24, gemm), mode
+    m.precision = "int8"
+    with pytest.raises(AssertionError):
+        _Ctx(m)
