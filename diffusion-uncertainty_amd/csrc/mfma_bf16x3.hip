@@ -433,6 +433,9 @@ struct DConvP {
 #ifndef DUA_A_PREFETCH
 #define DUA_A_PREFETCH 1
 #endif
+#ifndef DUA_DIAG        // timing diagnostics only (wrong results): 1 = no in-loop barrier, 2 = no in-loop DMA, 4 = no in-loop fragment reads
+#define DUA_DIAG 0
+#endif
 // pitch of the epilogue patch rows: 256-wide tiles use the bare 128 floats (8 patches = 128 KB: activation stage 1 stays free)
 #define DUA_PATCH_PAD (NT == 4 ? 0 : 8)
 template <int ACT, bool RES, bool SPLIT, int FMT = 0>
@@ -895,6 +898,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         const bool issueA = dxi == 0 && grp + 1 < ngroups;
         if (issueA) dma_setup();
         auto dma_piece = [&](int piece) {          // issue order of a step: weight pieces first, then the next activation stage
+            if (DUA_DIAG & 2) return;
             if (piece < NT) { if (preB) dma_b(sbn, piece); }
             else if (piece < NT + 4) { if (issueA) dma_a(sa ^ 1, piece - NT); }
         };
@@ -922,10 +926,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i_], bh[0][j_], acc[i_][j_], 0, 0, 0);
             SBAR();
             if (m_ < 2) {
+                if (!(DUA_DIAG & 4)) {
                 const char* a_ = ldsb + (a_st + SA * 2 + 32 * m_ * LDH * 2);
                 const i32x4 u0_ = *(const i32x4*)(a_ + oxa[m_]), u1_ = *(const i32x4*)(a_ + (oxa[m_] ^ 16));
                 ax[m_] = (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
-            } else if (m_ - 2 < NT) rd_bx_k(sb, m_ - 2);
+                }
+            } else if (m_ - 2 < NT) { if (!(DUA_DIAG & 4)) rd_bx_k(sb, m_ - 2); }
             else dma_piece(m_ - 2 - NT);                                   // NT = 4: gaps 6, 7 -> pieces 0, 1
             SBAR();
         }
@@ -944,7 +950,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         // what may stay in flight: the weight tile two steps ahead, and the next activation stage until its group starts
         if (issueA) a_inflight = true;
         wait_vm((preB ? NT : 0) + ((a_inflight && dxi != 2) ? 4 : 0));
-        __builtin_amdgcn_s_barrier();
+        if (!(DUA_DIAG & 1)) __builtin_amdgcn_s_barrier();
         if (++sb == RB) sb = 0;
         int dxn = dxc + 1;                          // dx of the next step, and the stage it reads
         if (dxi == 2) { sa ^= 1; dxn = -1; dxi = 0; ++grp; a_inflight = false; } else ++dxi;
@@ -955,6 +961,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         SBAR();
         // ---- cross terms of this step (registers); between them the hi fragments of the next step
         auto rd_hi = [&](int r_) {
+            if (DUA_DIAG & 4) return;
             const int s_ = r_ / (2 + NT), q_ = r_ % (2 + NT);
             if (q_ == 0) ah[s_][0] = *(const f16x8*)(ldsb + a_sn + (s_ ? oha[0] ^ 32 : oha[0]));
             else if (q_ <= NT) rd_bh_k(sb, s_, q_ - 1);
