@@ -31,6 +31,11 @@ def build_adm(cfg, seed):
     return m.eval().to(dev), sd
 
 
+# (score abs, uncertainty rel, image LSB) at ~3x the observed end-of-chain deviations: fp32 4.8e-4 / 7e-3 / 1, bf16x3 4.4e-3 / 9e-2 / 1,
+# f16f8 9.4e-3 / 0.18 / 2, f16f6 1.1e-2 / 0.25 / 2 (the random-weight chain amplifies a per-call deviation 50-100x in every mode)
+CHAIN_TOL = {"fp32": (1.5e-3, 2.5e-2, 1), "bf16x3": (1.5e-2, 0.3, 2), "f16f8": (3e-2, 0.6, 3), "f16f6": (3.5e-2, 0.8, 3)}
+
+
 def test_tiny_adm_vs_golden(golden):
     g = golden("g5_adm_blocks")
     m, _ = build_adm(TINY_ADM, 5)
@@ -175,6 +180,28 @@ def test_driver_vs_golden(golden, kind):
     assert d.max() <= 1 and (d > 0).mean() < 2e-2      # +-1 LSB where a pixel sits on a rounding boundary
     with pytest.raises(RuntimeError):
         gen(T(g["X_T"]), T(g["y"]), 3, torch.device("cpu"), m, s)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8", "f16f6"])
+def test_driver_split_modes_vs_golden(golden, precision):
+    """The free-running 10-step guided chain (reference driver output G4) in every precision mode.  The 1e-3 bar is per denoiser
+    call (test_bf16x3_mode_adm); over a 10-step chain of a random-weight model the per-call deviations compound 50-100x (the
+    exact fp32 mode ends at 4.8e-4 from a 7e-6 per-call deviation), so this is a regression guard at ~3x the observed
+    end-of-chain deviation (printed), not the parity bar."""
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    g = golden("g4_driver")
+    m, _ = build_adm(TINY_ADM, 5)
+    m.precision = precision
+    s = _sched("uncertainty_zigzag_centered", m)
+    s.set_timesteps(10)
+    torch.manual_seed(0)
+    r = gen(T(g["X_T"]), T(g["y"]), 3, torch.device(dev), m, s)
+    es = np.abs(r["score"].numpy() - g["zigzag_centered_score"]).max()
+    eu = (np.abs(r["uncertainty"].numpy() - g["zigzag_centered_uncertainty"]) / (np.abs(g["zigzag_centered_uncertainty"]) + 1e-3)).max()
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["zigzag_centered_gen_images"].astype(int))
+    print(f"{precision}: chain score err {es:.2e}, uncertainty rel err {eu:.2e}, image LSB diffs {(d > 0).mean():.2e} (max {d.max()})")
+    assert es < CHAIN_TOL[precision][0] and eu < CHAIN_TOL[precision][1]
+    assert d.max() <= CHAIN_TOL[precision][2]
 
 
 def test_mc_dropout_vs_golden(golden):
