@@ -8,15 +8,15 @@ from diffusion_uncertainty_amd import _lib, ops
 
 dev = "cuda"
 L = _lib.lib()
-for H, C in ((128, 256), (64, 256), (32, 512), (16, 768), (128, 512)):
+for H, C in ((128, 256), (64, 256), (64, 512), (32, 512), (32, 1024), (16, 768), (16, 1536), (8, 1024), (8, 2048), (128, 512)):
     N = 128
-    C1 = C if C != 512 or H != 128 else 256
+    C1 = C if C not in (512, 1024, 1536, 2048) or (H, C) in ((32, 512),) else C // 2
     x = torch.randn(N, H, H, C1, device=dev)
     x2 = torch.randn(N, H, H, C - C1, device=dev) if C1 != C else None
     st = torch.tensor([0.1, 0.9], device=dev).repeat(N * 32, 1).contiguous()
     g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
     film = torch.randn(N, 2 * C, device=dev)
-    for split in (False, True, "f16f8"):
+    for split in (False, True, "f16f8", "f16f6"):
         for wide in (0, 1):
             L.dua_set_gn_apply_wide(wide)
             ops.groupnorm_apply(x, st, g, b, x2=x2, film=film, act=1, split=split)
