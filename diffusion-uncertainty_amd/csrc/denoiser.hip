@@ -193,6 +193,7 @@ struct GnApplyP {
                              // 2: f16f8 planes: fp16 hi | per 32-channel block [32 x fp8(lo * 2^12) | 32 x fp8(x)]
     long plane;              // elements per plane
     long film_ld;            // row stride of film in floats (>= 2*C)
+    float oscale;            // split == 4 (f16x3): planes hold fp16 hi | fp16 lo of y * oscale (a power of two)
 };
 
 typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
@@ -219,6 +220,21 @@ __device__ __forceinline__ void gn_store(const GnApplyP& p, size_t off, float4 v
         hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], hi8, true);
         *(int*)x8 = lo8;
         *(int*)(x8 + 32) = hi8;
+    } else if (p.split == 4) {
+        // f16x3 planes: hi = fp16(s), lo = fp16(s - hi) of s = y * oscale (saturated to the fp16 range): 22 significant bits
+        typedef _Float16 gn_f16x4 __attribute__((ext_vector_type(4)));
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        gn_f16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sv = fminf(fmaxf(f[j] * p.oscale, -65504.f), 65504.f);
+            const _Float16 t = (_Float16)sv;
+            h[j] = t;
+            l[j] = (_Float16)(sv - (float)t);
+        }
+        _Float16* hi = (_Float16*)p.y + off;
+        *(gn_f16x4*)hi = h;
+        *(gn_f16x4*)(hi + p.plane) = l;
     } else {
         __bf16* hi = (__bf16*)p.y + off;
         float f[4] = {v.x, v.y, v.z, v.w};
@@ -364,6 +380,18 @@ __device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const f
         unsigned char* blk = (unsigned char*)((_Float16*)p.y + p.plane) + (off >> 5) * 64 + 8 * q;
         *(unsigned long long*)blk = ol;
         *(unsigned long long*)(blk + 32) = oh;
+    } else if (p.split == 4) {
+        gn_f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sv = fminf(fmaxf(f[j] * p.oscale, -65504.f), 65504.f);
+            const _Float16 t = (_Float16)sv;
+            h[j] = t;
+            l[j] = (_Float16)(sv - (float)t);
+        }
+        _Float16* hi = (_Float16*)p.y + off;
+        *(gn_f16x8*)hi = h;
+        *(gn_f16x8*)(hi + p.plane) = l;
     } else if (p.split == 1) {
         gn_bf16x8 h, l;
 #pragma unroll
@@ -476,7 +504,7 @@ static int gn_apply_wide = 1;          // 0: always the 4-channel-per-lane kerne
 extern "C" int dua_set_gn_apply_wide(int on) { int o = gn_apply_wide; gn_apply_wide = on; return o; }
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                          const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                         int resample, const float* dropmask, float* y, int split, void* stream);
+                         int resample, const float* dropmask, float* y, int split, void* stream, float oscale = 1.0f);
 
 extern "C" int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
@@ -504,16 +532,25 @@ extern "C" int dua_groupnorm_apply_split_f16f6(const float* x1, int C1, const fl
     return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 3, stream);
 }
 
+// "f16x3" planes (fp16 hi | fp16 lo of y * act_scale, act_scale a power of two): operand of dua_conv3x3_f16x3_presplit /
+// dua_gemm_f16x3_presplit, which undo the scale in their epilogue.
+extern "C" int dua_groupnorm_apply_split_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                               int resample, const float* dropmask, float act_scale, void* yplanes, void* stream) {
+    DUA_REQUIRE(act_scale > 0.f && (__builtin_bit_cast(unsigned, act_scale) & 0x7FFFFFu) == 0, "dua_groupnorm_apply_split_f16x3: act_scale must be a power of two");
+    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 4, stream, act_scale);
+}
+
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                          const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                         int resample, const float* dropmask, float* y, int split, void* stream) {
+                         int resample, const float* dropmask, float* y, int split, void* stream, float oscale) {
     int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && y, "dua_groupnorm_apply: null pointer");
     DUA_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0, "dua_groupnorm_apply: unsupported channels");
     DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply: x2/C2 mismatch");
     DUA_REQUIRE(resample >= 0 || (H % 2 == 0 && W % 2 == 0), "dua_groupnorm_apply: pooling needs even H, W");
     DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply: dropout mask with resampling unsupported");
-    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0, film_ld ? film_ld : 2L * (C1 + C2)};
+    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0, film_ld ? film_ld : 2L * (C1 + C2), oscale};
     DUA_REQUIRE(p.film_ld >= 2L * (C1 + C2), "dua_groupnorm_apply: film_ld < 2*C");
     {
         long Hy = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wy = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);

@@ -17,6 +17,12 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// 16-deep 32x32 MFMA on either 2-byte operand type (the split planes are bf16 in the bf16x3 format, fp16 in f16x3)
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(h16x8 a, h16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <bool F16> struct frag8 { typedef bf16x8 type; };
+template <> struct frag8<true> { typedef h16x8 type; };
 
 #define BM 128
 #define BN 128
@@ -418,6 +424,8 @@ struct DConvP {
     const signed char* Bscale;  // FMT 1 (f16f8): per weight row r, w_hi8 = fp8(w * 2^Bscale[r]), w_lo8 = fp8(w_lo * 2^(Bscale[r] + 12))
     int stagger_phases;      // > 1: workgroup start-up stagger (see k_xconv_dma); stagger_sleeps = s_sleep(127) per phase step
     int stagger_sleeps;
+    const float* Cscale;     // FMT 3 (f16x3): per weight row 2^-s (the planes hold w * 2^s), padded to the tile grid
+    float out_scale;         // FMT 3: 1 / activation plane scale; the epilogue multiplies the accumulator by Cscale[col] * out_scale
 };
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
@@ -439,8 +447,9 @@ struct DConvP {
 // pitch of the epilogue patch rows: 256-wide tiles use the bare 128 floats (8 patches = 128 KB: activation stage 1 stays free)
 #define DUA_PATCH_PAD (NT == 4 ? 0 : 8)
 template <int ACT, bool RES, bool SPLIT, int FMT = 0>
-__device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const float4 q, const float4 bq, long o, float4& cs, float4& cq) {
-    w.x += bq.x; w.y += bq.y; w.z += bq.z; w.w += bq.w;
+__device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const float4 q, const float4 bq, const float4 sq, long o, float4& cs, float4& cq) {
+    if (FMT == 3) { w.x = w.x * sq.x + bq.x; w.y = w.y * sq.y + bq.y; w.z = w.z * sq.z + bq.z; w.w = w.w * sq.w + bq.w; }
+    else { w.x += bq.x; w.y += bq.y; w.z += bq.z; w.w += bq.w; }
     if (ACT == 2) { w.x = gelu_x(w.x); w.y = gelu_x(w.y); w.z = gelu_x(w.z); w.w = gelu_x(w.w); }
     if (RES) { w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
     if (SPLIT) {               // the consumer is another split-operand GEMM: hand it the operand format directly
@@ -461,7 +470,7 @@ __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const f
 
 template <int NT, bool RES, int ACT, bool SPLIT, int FMT = 0>
 __device__ __forceinline__ void dconv_rows_full(const DConvP& p, f32x16 (&acc)[2][NT], float* patch, int lane, int row0, int colq,
-                                                float4 bq, float4& cs, float4& cq) {
+                                                float4 bq, float4 sq, float4& cs, float4& cq) {
     constexpr int WC = 32 * NT, WCP = WC + DUA_PATCH_PAD, RPI = 64 / (WC / 4), NIT = 32 / RPI;
     const int c4 = lane % (WC / 4), rr = lane / (WC / 4), lr = lane & 31, kh = lane >> 5;
     const long rstep = (long)RPI * p.N;
@@ -488,7 +497,7 @@ __device__ __forceinline__ void dconv_rows_full(const DConvP& p, f32x16 (&acc)[2
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(rd + (g + u) * RPI * WCP);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dconv_row_out<ACT, RES, SPLIT, FMT>(p, v[u], RES ? q[g + u] : z4, bq, rb + (g + u) * rstep, cs, cq);
+            for (int u = 0; u < 4; ++u) dconv_row_out<ACT, RES, SPLIT, FMT>(p, v[u], RES ? q[g + u] : z4, bq, sq, rb + (g + u) * rstep, cs, cq);
         }
     }
 }
@@ -699,8 +708,9 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
-  if constexpr (FMT == 0) {
+  if constexpr (FMT == 0 || FMT == 3) {
     static_assert(!RS, "the row-shift loop is built for the f16f8 / f16f6 formats");
+    typedef typename frag8<FMT == 3>::type bf16x8;      // FMT 3: the same loop on fp16 planes (v_mfma_f32_32x32x16_f16)
     // Fragment registers of ONE half step (16 of the 32 K columns of a stage); they are refilled in place while the
     // MFMA group that no longer needs them is executing, so the matrix pipe always has a full group queued when the
     // next one's operands arrive (no extra registers: the accumulators already take 128 of the 256):
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #define LD_BL(st, s) { const __bf16* b_ = FR_B(st, s) + SB; _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) bl[j_] = *(const bf16x8*)(b_ + 32 * j_ * LDH); }
 #define MM(AV, BV)                                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)          \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AV[i_], BV[j_], acc[i_][j_], 0, 0, 0);
+        acc[i_][j_] = mfma16(AV[i_], BV[j_], acc[i_][j_]);
     // DMA pieces of the step, a few per MFMA group (an LDS-DMA issue holds the wave ~60-180 cycles), front-loaded:
     // NT = 4: [B0..B3 | A0..A3 | - ...]; NT = 2: [A0 A1 | A2 A3 | B0 B1 | - ...]
 #define DMA_GROUP()                                                                   \
@@ -1143,8 +1153,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WCP);
         const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);
         const int colq = n0 + wn * WC + 4 * c4;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p.bias) bq = *(const float4*)(p.bias + colq);
+        if (FMT == 3) {
+            sq = *(const float4*)(p.Cscale + colq);
+            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+        }
         if constexpr (RS) {        // the bias must not queue behind the prefetch in the in-order vmcnt counter
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             prefetch_next();
@@ -1152,14 +1166,14 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
         const int row0 = m0 + wm * 64;
         if (p.Csplit) {
-            if (p.act_out == 2) dconv_rows_full<NT, false, 2, true, FMT>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
-            else dconv_rows_full<NT, false, 0, true, FMT>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            if (p.act_out == 2) dconv_rows_full<NT, false, 2, true, FMT>(p, acc, patch, lane_e, row0, colq, bq, sq, cs, cq);
+            else dconv_rows_full<NT, false, 0, true, FMT>(p, acc, patch, lane_e, row0, colq, bq, sq, cs, cq);
         } else if (p.res) {
-            dconv_rows_full<NT, true, 0, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            dconv_rows_full<NT, true, 0, false, FMT>(p, acc, patch, lane_e, row0, colq, bq, sq, cs, cq);
         } else if (p.act_out == 2) {
-            dconv_rows_full<NT, false, 2, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            dconv_rows_full<NT, false, 2, false, FMT>(p, acc, patch, lane_e, row0, colq, bq, sq, cs, cq);
         } else {
-            dconv_rows_full<NT, false, 0, false>(p, acc, patch, lane_e, row0, colq, bq, cs, cq);
+            dconv_rows_full<NT, false, 0, false, FMT>(p, acc, patch, lane_e, row0, colq, bq, sq, cs, cq);
         }
         if (p.colsum) {   // GroupNorm statistics of the NEXT layer: fold the row lanes, one float4 store per column quad
             float t[8] = {cs.x, cs.y, cs.z, cs.w, cq.x, cq.y, cq.z, cq.w};
@@ -1185,8 +1199,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
         const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);          // float4 column, row within a group
         constexpr int RPI = 64 / (WC / 4);                // rows per wave instruction (4 for NT=2, 2 for NT=4)
         const int colq = n0 + wn * WC + 4 * c4;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(1.f, 1.f, 1.f, 1.f);
         if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
+        if (FMT == 3) {            // (Cscale is padded to the tile grid: no column predicate needed)
+            sq = *(const float4*)(p.Cscale + colq);
+            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+        }
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;      // this lane's column sums / sums of squares
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -1202,7 +1220,8 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                 const int row = m0 + wm * 64 + mi * 32 + rl;
                 float4 v = *(const float4*)(patch + rl * WC + 4 * c4);
                 if (row < p.M && colq < p.N) {
-                    v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                    if (FMT == 3) { v.x = v.x * sq.x + bq.x; v.y = v.y * sq.y + bq.y; v.z = v.z * sq.z + bq.z; v.w = v.w * sq.w + bq.w; }
+                    else { v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w; }
                     if (p.act_out == 2) { v.x = gelu_x(v.x); v.y = gelu_x(v.y); v.z = gelu_x(v.z); v.w = gelu_x(v.w); }
                     if (p.res) {
                         const float4 q = *(const float4*)(p.res + (long)row * p.N + colq);
@@ -1248,11 +1267,12 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                 const int col = n0 + wn * 32 * NT + ni * 32 + lr_e;
                 if (col >= p.N) continue;
                 const float bv = p.bias ? p.bias[col] : 0.f;
+                const float sv = FMT == 3 ? p.Cscale[col] * p.out_scale : 1.f;
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh_e;
                     if (row >= p.M) continue;
-                    float v = acc[mi][ni][r] + bv;
+                    float v = acc[mi][ni][r] * sv + bv;
                     if (p.res) v += p.res[(long)row * p.N + col];
                     if (p.nchw_out) {
                         int hw = p.H * p.W, n = row / hw, rem = row - n * hw;
@@ -1406,6 +1426,9 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
+    } else if (fmt == 3) {                                                        // f16x3: the bf16x3 loop on fp16 planes
+        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(grid), 512, 0, st, d);
+        else hipLaunchKernelGGL((k_xconv_dma<2, 3>), dim3(grid), 512, 0, st, d);
     } else if (fmt == 2) {                                                        // MXFP6 cross terms: row-shift convolutions only
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 2, true>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 2, true>), dim3(grid), 512, 0, st, d);
@@ -1420,7 +1443,7 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
 }
 
 static int conv3x3_presplit_impl(const void* xplanes, const void* planes, const float* bias, const float* residual, float* y, int N,
-                                 int H, int W, int Cin, int Cout, int nchw_out, float* colsum, int fmt, void* stream) {
+                                 int H, int W, int Cin, int Cout, int nchw_out, float* colsum, int fmt, void* stream, float act_scale = 1.0f) {
     DUA_REQUIRE(!colsum || (!nchw_out && Cout % 4 == 0), "dua_conv3x3 presplit: colsum needs an NHWC output with Cout %% 4 == 0");
     DUA_REQUIRE(xplanes && planes && y, "dua_conv3x3 presplit: null pointer");
     DUA_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && Cin >= BK && Cin % BK == 0, "dua_conv3x3 presplit: Cin must be a multiple of 32 (got %d)", Cin);
@@ -1437,6 +1460,8 @@ static int conv3x3_presplit_impl(const void* xplanes, const void* planes, const 
         d.M = N * H * W; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
         d.ntaps = 9;
         d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
+        d.Cscale = (const float*)((const __bf16*)planes + 2 * plane);
+        d.out_scale = 1.0f / act_scale;
         return launch_dconv(d, fmt, as_stream(stream), "dua_conv3x3 presplit (dma)");
     }
     XTileP p{};
@@ -1507,10 +1532,64 @@ extern "C" int dua_pack_weight_f16f6(const float* w, void* packed, int N, int K,
     return dua_check_launch("dua_pack_weight_f16f6");
 }
 
+// ---- f16x3 weight format (fp32-equivalent split): plane 0 = fp16(w * 2^s) [Npad128][K], plane 1 = fp16(w * 2^s - plane 0), then
+// Npad floats 2^-s.  s per output row such that the row maximum lands in [2^14, 2^15): both planes stay in fp16's normal range
+// for every element within 2^-18 of the row maximum, so hi + lo carries 22 significant bits of w; the product
+// hi*hi + hi*lo + lo*hi (three v_mfma_f32_32x32x16_f16, fp32 accumulate) drops only the lo*lo term (2^-22 relative).
+__global__ void k_weight_row_scale_f16x3(const float* __restrict__ w, float* __restrict__ inv_scale, int N, int K, int Npad) {
+    const int n = blockIdx.x;
+    float m = 0.f;
+    if (n < N)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, fabsf(w[(size_t)n * K + k]));
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (red[0] > 0.f) e = 14 - (int)((__float_as_uint(red[0]) >> 23) & 0xff) + 127;      // 14 - floor(log2 max) (normal floats)
+        e = max(-100, min(100, e));
+        inv_scale[n] = __uint_as_float((unsigned)(127 - e) << 23);                           // 2^-e
+    }
+}
+__global__ void k_split_weight_f16x3(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                     const float* __restrict__ inv_scale, int N, int K, int Npad, int conv_cin) {
+    size_t total = (size_t)Npad * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int n = (int)(i / K), k = (int)(i % K);
+        const float sc = 1.0f / inv_scale[n];                                                // exact: a power of two
+        const float v = split_weight_src(w, n, k, N, K, conv_cin) * sc;
+        const _Float16 h = (_Float16)v;
+        hi[i] = h;
+        lo[i] = (_Float16)(v - (float)h);
+    }
+}
+extern "C" size_t dua_f16x3_weight_bytes(int N, int K) { return 4 * dua_bf16x3_plane_elems(N, K) + 4 * (size_t)round_up(N, 256); }
+extern "C" int dua_pack_weight_f16x3(const float* w, void* packed, int N, int K, int conv_cin, void* stream) {
+    DUA_REQUIRE(w && packed && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_f16x3: K must be a positive multiple of 32 (got %d)", K);
+    DUA_REQUIRE(conv_cin == 0 || (K == 9 * conv_cin && conv_cin % BK == 0), "dua_pack_weight_f16x3: conv K must be 9*Cin, Cin %% 32 == 0");
+    const int Npad = round_up(N, BN), Nsc = round_up(N, 256);
+    size_t plane = (size_t)Npad * K;
+    _Float16* hi = (_Float16*)packed;
+    float* inv_scale = (float*)(hi + 2 * plane);
+    hipLaunchKernelGGL(k_weight_row_scale_f16x3, dim3(Nsc), 256, 0, as_stream(stream), w, inv_scale, N, K, Npad);
+    hipLaunchKernelGGL(k_split_weight_f16x3, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, hi + plane, inv_scale, N, K, Npad, conv_cin);
+    return dua_check_launch("dua_pack_weight_f16x3");
+}
+extern "C" int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,
+                                          float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum,
+                                          float act_scale, void* stream) {
+    DUA_REQUIRE(act_scale > 0.f, "dua_conv3x3_f16x3_presplit: act_scale must be positive");
+    return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 3, stream, act_scale);
+}
+
 // C[M][N] = A * W^T (+ bias) (+ residual) with A given as split planes (written by dua_groupnorm_apply_split / _f16f8) and W
 // packed by dua_pack_weight_bf16x3 / _f16f8: the LDS-DMA kernel with a single tap.
 static int gemm_presplit_impl(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
-                              void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream) {
+                              void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream, float act_scale = 1.0f) {
     DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm presplit: K must be a multiple of 32 (got %d)", K);
     DUA_REQUIRE(N % 4 == 0, "dua_gemm presplit: N must be a multiple of 4");
     DUA_REQUIRE(!Csplit || fmt == 0 || N % 32 == 0, "dua_gemm_f16f8_presplit: a split output needs N %% 32 == 0");
@@ -1522,6 +1601,8 @@ static int gemm_presplit_impl(const void* aplanes, const void* planes, const flo
     d.M = M; d.N = N; d.K = K; d.H = 1; d.W = 1; d.Cin = K; d.nchw_out = 0; d.colsum = colsum; d.ntaps = 1;
     d.act_out = act_out; d.Csplit = (__bf16*)Csplit;
     d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
+    d.Cscale = (const float*)((const __bf16*)planes + 2 * plane);
+    d.out_scale = 1.0f / act_scale;
     return launch_dconv(d, fmt, as_stream(stream), "dua_gemm presplit");
 }
 extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
@@ -1531,6 +1612,12 @@ extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes,
 extern "C" int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
                                        void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
     return gemm_presplit_impl(aplanes, packed, bias, residual, C, Csplit, M, N, K, act_out, colsum, 1, stream);
+}
+
+extern "C" int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
+                                       int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream) {
+    DUA_REQUIRE(act_scale > 0.f, "dua_gemm_f16x3_presplit: act_scale must be positive");
+    return gemm_presplit_impl(aplanes, packed, bias, residual, C, nullptr, M, N, K, act_out, colsum, 3, stream, act_scale);
 }
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,

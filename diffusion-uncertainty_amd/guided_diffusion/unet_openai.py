@@ -155,7 +155,7 @@ class AttentionBlock(nn.Module):
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0,
                                  split=ctx.gemm_split if (ctx.model.presplit_qkv and C % 32 == 0) else False)
         qkv = ctx.qkv(xn if isinstance(xn, ops.SplitPlanes) else xn.view(N * T, C), self)
-        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision="fp32" if ctx.model.precision == "fp32" else "bf16x3",
+        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision="bf16x3" if ctx.split_mode else "fp32",
                               planes_out=(ctx.gemm_split == "f16f8"))
         if isinstance(a, ops.SplitPlanes):        # attention output already in the operand format: proj_out on the LDS-DMA kernel
             key = (id(self.proj_out), "w1f")
@@ -182,9 +182,12 @@ class _Ctx:
         self.film_all = None
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
         # (False | True = bf16x3 planes | "f16f8" planes | "f16f6" planes: 3x3 convs whose width divides 256 only)
-        assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6"), model.precision
-        self.split_mode = model.precision != "fp32"
-        self.split_acts = model.precision if model.precision in ("f16f8", "f16f6") else model.precision == "bf16x3"
+        # "f16x3" (fp32-equivalent): 3x3 convs and qkv on fp16 hi / lo planes; the products that take raw fp32 activations
+        # (1x1 skip, proj_out, attention) stay on the exact fp32 engines
+        assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6", "f16x3"), model.precision
+        self.split_mode = model.precision not in ("fp32", "f16x3")          # on-the-fly bf16 split of raw fp32 operands
+        self.presplit = model.precision != "fp32"
+        self.split_acts = model.precision if model.precision in ("f16f8", "f16f6", "f16x3") else model.precision == "bf16x3"
         self.gemm_split = "f16f8" if self.split_acts == "f16f6" else self.split_acts       # one-tap GEMMs (qkv, proj_out)
 
     def conv_split(self, width):
@@ -208,6 +211,11 @@ class _Ctx:
                 cache[key] = ops.pack_weight_f16f8(mod.weight.detach().contiguous())
             elif kind == "w3s":
                 cache[key] = ops.pack_weight_f16f6(mod.weight.detach().contiguous())
+            elif kind == "w3h":
+                cache[key] = ops.pack_weight_f16x3(mod.weight.detach().contiguous())
+            elif kind == "qkvh":
+                wq, bq = self.packed(mod, "qkv")
+                cache[key] = (ops.pack_weight_f16x3(wq), bq)
             elif kind == "qkvf":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16f8(wq), bq)
@@ -255,7 +263,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16f8": "w3f", "f16f6": "w3s"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16f8": "w3f", "f16f6": "w3s", "f16x3": "w3h"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -270,7 +278,7 @@ class _Ctx:
 
     def qkv(self, xn, blk):
         if isinstance(xn, ops.SplitPlanes):
-            planes, bq = self.packed(blk, "qkvf" if xn.fmt == "f16f8" else "qkvx")
+            planes, bq = self.packed(blk, {"f16f8": "qkvf", "f16x3": "qkvh"}.get(xn.fmt, "qkvx"))
             return ops.gemm_bf16x3_presplit(xn, planes, 3 * blk.channels, bias=bq)
         if self.split_mode and xn.shape[1] % 32 == 0:
             planes, bq = self.packed(blk, "qkvx")

@@ -259,9 +259,10 @@ def groupnorm_stats(x1, x2=None, groups=32, eps=1e-5):
 class SplitPlanes:
     """Activation tensor stored as two bf16 NHWC planes (hi | lo) - the operand format of the bf16x3 conv."""
 
-    def __init__(self, buf, shape, fmt="bf16x3"):
-        # fmt "bf16x3": bf16 hi | bf16 lo;  "f16f8": fp16 hi | per 32-channel block [32 x e4m3(lo * 2^12) | 32 x e4m3(x)]
-        self.buf, self.shape, self.device, self.fmt = buf, tuple(shape), buf.device, fmt
+    def __init__(self, buf, shape, fmt="bf16x3", scale=1.0):
+        # fmt "bf16x3": bf16 hi | bf16 lo;  "f16f8": fp16 hi | per 32-channel block [32 x e4m3(lo * 2^12) | 32 x e4m3(x)];
+        # "f16x3": fp16 hi | fp16 lo of x * scale (the fp32-equivalent split; scale a power of two)
+        self.buf, self.shape, self.device, self.fmt, self.scale = buf, tuple(shape), buf.device, fmt, float(scale)
 
 
 def _film_ld(film, N, C):
@@ -277,10 +278,15 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
     if split:
-        fmt = split if split in ("f16f8", "f16f6") else "bf16x3"
+        fmt = split if split in ("f16f8", "f16f6", "f16x3") else "bf16x3"
         buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
+        if fmt == "f16x3":
+            check(_lib.lib().dua_groupnorm_apply_split_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                                                             _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
+                                                             F16X3_ACT_SCALE, _p(buf), _stream()), "dua_groupnorm_apply_split_f16x3")
+            return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt, F16X3_ACT_SCALE)
         fn = {"f16f8": _lib.lib().dua_groupnorm_apply_split_f16f8, "f16f6": _lib.lib().dua_groupnorm_apply_split_f16f6}.get(
             fmt, _lib.lib().dua_groupnorm_apply_split)
         check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film), _film_ld(film, N, C1 + C2),
@@ -362,6 +368,11 @@ def pack_conv3x3_weight(w):
     wp = torch.empty(L.dua_conv3x3_packed_floats(Cout, Cin), device=w.device, dtype=torch.float32)
     check(L.dua_pack_conv3x3_weight(_p(w), _p(wp), Cout, Cin, _stream()), "dua_pack_conv3x3_weight")
     return wp
+
+
+# Power-of-two scale of the f16x3 activation planes (GroupNorm / SiLU outputs): |x| up to 1023 stays finite in fp16 and
+# every |x| >= 2^-9 keeps its 22 significant bits.
+F16X3_ACT_SCALE = 64.0
 
 
 # Optional per-launch timing hook used by bench.py: an object with .record(kind, flops, start_evt, end_evt).
@@ -446,6 +457,22 @@ def pack_weight_f16f8(w):
     return packed
 
 
+def pack_weight_f16x3(w):
+    """fp32 [N][K] linear / 1x1 weight, or OIHW 3x3 conv weight -> the packed f16x3 weight (fp16 hi plane, fp16 lo plane of the
+    row-scaled weight, per-row 2^-s floats) in one uint8 buffer."""
+    _req(w, name="w")
+    L = _lib.lib()
+    if w.ndim == 4 and w.shape[2] == 3:
+        N, cin = w.shape[0], w.shape[1]
+        K = 9 * cin
+    else:
+        N, cin = w.shape[0], 0
+        K = w.numel() // N
+    packed = torch.empty(L.dua_f16x3_weight_bytes(N, K), device=w.device, dtype=torch.uint8)
+    check(L.dua_pack_weight_f16x3(_p(w), _p(packed), N, K, cin, _stream()), "dua_pack_weight_f16x3")
+    return packed
+
+
 def pack_weight_f16f6(w):
     """As pack_weight_f16f8 with the cross plane in MXFP6 (e2m3 + E8M0 exponent per 32-k block); same buffer size."""
     _req(w, name="w")
@@ -504,7 +531,10 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if pre:
+    if pre and x.fmt == "f16x3":
+        check(_lib.lib().dua_conv3x3_f16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
+                                                    _p(ws), x.scale, _stream()), "dua_conv3x3_f16x3_presplit")
+    elif pre:
         fn = {"f16f8": _lib.lib().dua_conv3x3_f16f8_presplit, "f16f6": _lib.lib().dua_conv3x3_f16f6_presplit}.get(
             x.fmt, _lib.lib().dua_conv3x3_bf16x3_presplit)
         check(fn(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _p(ws), _stream()),
@@ -537,6 +567,15 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
     M = 1
     for d in a.shape[:-1]:
         M *= d
+    if a.fmt == "f16x3":
+        assert not split_out, "f16x3: fp32 output only"
+        c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
+        ws = _colsum_ws(M, n_out, a.device, colsum)
+        if ws is not None:
+            c._dua_colsums_rows = ws
+        check(_lib.lib().dua_gemm_f16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), M, n_out, K, int(act_out), _p(ws),
+                                                 a.scale, _stream()), "dua_gemm_f16x3_presplit")
+        return c
     if a.fmt == "f16f8":
         if split_out:
             buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)

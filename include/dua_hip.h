@@ -264,6 +264,26 @@ int dua_conv3x3_f16f6_presplit(const void* xplanes, const void* packed, const fl
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
 int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
                             void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream);
+/* ---- "f16x3" operand format: the fp32-EQUIVALENT split (22 significant operand bits) ---------------------------------
+ * Same role and call shapes as the bf16x3 / f16f8 entry points (conv / 1x1 / linear products of
+ * guided_diffusion/unet_openai.py:186,212,287,483,616): every fp32 operand is scaled by a power of two into fp16's normal
+ * range and split s = hi + lo with hi = fp16(s), lo = fp16(s - hi) (11 + 11 significant bits); the product is
+ * hi*hi + hi*lo + lo*hi on three v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped lo*lo term is 2^-22 relative),
+ * and the epilogue multiplies the accumulator by 2^-(weight row exponent) / act_scale before bias / residual
+ * (csrc/mfma_bf16x3.hip, FMT 3).  Activation planes ([rows][C], 2 bytes per element): plane 0 fp16(x * act_scale)
+ * (saturating at +-65504), plane 1 fp16(x * act_scale - plane 0); act_scale is a power of two chosen by the caller (the
+ * UNet uses 2^6: GroupNorm+SiLU outputs up to 1023 in magnitude are exact to 22 bits down to 2^-9).  Packed weights
+ * (dua_f16x3_weight_bytes): plane 0 fp16(w * 2^s) [Npad128][K], plane 1 the fp16 remainder, then round_up(N, 256) floats
+ * 2^-s with s per output row such that the row maximum lands in [2^14, 2^15). */
+size_t dua_f16x3_weight_bytes(int N, int K);
+int dua_pack_weight_f16x3(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
+int dua_groupnorm_apply_split_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                    int resample, const float* dropmask, float act_scale, void* yplanes, void* stream);
+int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
+                               int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, float act_scale, void* stream);
+int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
+                            int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream);
 /* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
 int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                               void* stream);

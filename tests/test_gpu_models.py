@@ -33,7 +33,8 @@ def build_adm(cfg, seed):
 
 # (score abs, uncertainty rel, image LSB) at ~3x the observed end-of-chain deviations: fp32 4.8e-4 / 7e-3 / 1, bf16x3 4.4e-3 / 9e-2 / 1,
 # f16f8 9.4e-3 / 0.18 / 2, f16f6 1.1e-2 / 0.25 / 2 (the random-weight chain amplifies a per-call deviation 50-100x in every mode)
-CHAIN_TOL = {"fp32": (1.5e-3, 2.5e-2, 1), "bf16x3": (1.5e-2, 0.3, 2), "f16f8": (3e-2, 0.6, 3), "f16f6": (3.5e-2, 0.8, 3)}
+# "f16x3" (the fp32-equivalent split, the bench headline) is held to the SAME row as exact fp32: no per-mode loosening.
+CHAIN_TOL = {"fp32": (1e-3, 2.5e-2, 1), "f16x3": (1e-3, 2.5e-2, 1), "bf16x3": (1.5e-2, 0.3, 2), "f16f8": (3e-2, 0.6, 3), "f16f6": (3.5e-2, 0.8, 3)}
 
 
 def test_tiny_adm_vs_golden(golden):
@@ -182,7 +183,7 @@ def test_driver_vs_golden(golden, kind):
         gen(T(g["X_T"]), T(g["y"]), 3, torch.device("cpu"), m, s)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8", "f16f6"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3", "f16f8", "f16f6"])
 def test_driver_split_modes_vs_golden(golden, precision):
     """The free-running 10-step guided chain (reference driver output G4) in every precision mode.  The 1e-3 bar is per denoiser
     call (test_bf16x3_mode_adm); over a 10-step chain of a random-weight model the per-call deviations compound 50-100x (the
@@ -270,7 +271,7 @@ def test_device_noise_mode():
 
 
 # ---------------------------------------------------------------- split-bf16 (bf16x3) precision mode
-@pytest.mark.parametrize("precision", ["bf16x3", "f16f8", "f16f6"])
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3", "f16f8", "f16f6"])
 @pytest.mark.parametrize("name", ["tiny", "adm64", "adm128"])
 def test_bf16x3_mode_adm(golden, name, precision):
     """Convs / weight GEMMs on the bf16 matrix cores with split fp32 operands (bf16x3), or on the fp16 + block-scaled fp8
@@ -290,7 +291,8 @@ def test_bf16x3_mode_adm(golden, name, precision):
     err = np.abs(o.cpu().numpy() - ref).max()
     print(f"{precision} {name}: max|hip - reference| = {err:.3e} (|ref|max {np.abs(ref).max():.2f})")
     assert err < TOL
-    assert err < (1e-4 if precision == "bf16x3" else 2.5e-4)          # observed 3e-5 / 8e-5: a regression guard well inside the bar
+    # observed 3e-5 (bf16x3) / 8e-5 (f16f8, f16f6): regression guards well inside the bar; f16x3 is held to 1.5e-5 (exact fp32: 7.4e-6)
+    assert err < {"bf16x3": 1e-4, "f16x3": 1.5e-5}.get(precision, 2.5e-4)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f16f8"])
@@ -370,7 +372,7 @@ def test_uvit_driver_with_vae():
     assert d.max() <= 1 and (d > 0).mean() < 2e-2
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16f8", "f16f6"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3", "f16f8", "f16f6"])
 def test_fused_groupnorm_stats_equivalent(precision):
     """fuse_gn_stats (statistics from producer epilogues) vs the stand-alone statistics kernel: same model output."""
     m, _ = build_adm(TINY_ADM, 5)
@@ -380,7 +382,7 @@ def test_fused_groupnorm_stats_equivalent(precision):
     a = m(x, t, y=y)
     m.fuse_gn_stats = False
     b = m(x, t, y=y)
-    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 if precision == "fp32" else 2e-4)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-5 if precision in ("fp32", "f16x3") else 2e-4)
 
 
 class _StubDenoiser(torch.nn.Module):

@@ -386,6 +386,69 @@ def test_conv3x3_f16f6_many_rows(ops):
     assert (nchw(whole[:2].cpu()).double() - ref).abs().max().item() < 3e-4
 
 
+def _f16x3_planes(ops, x_nhwc):
+    """x in the f16x3 plane format, written by the product kernel itself (identity GroupNorm: mean 0, rstd 1, gamma 1)."""
+    N, C = x_nhwc.shape[0], x_nhwc.shape[3]
+    st = torch.tensor([0.0, 1.0]).repeat(N * 32, 1).contiguous().to(dev)
+    return ops.groupnorm_apply(x_nhwc.to(dev), st, torch.ones(C, device=dev), torch.zeros(C, device=dev), act=0, split="f16x3")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 8, 8, 32, 32), (1, 16, 16, 64, 96), (3, 4, 4, 96, 64), (2, 16, 16, 32, 6),
+                                             (1, 32, 32, 256, 256), (2, 8, 8, 1024, 192), (5, 16, 16, 128, 512),
+                                             (1, 24, 24, 64, 64), (8, 128, 128, 32, 256), (3, 64, 64, 64, 256)])
+def test_conv3x3_f16x3(ops, N, H, W, Cin, Cout):
+    """The fp32-equivalent split (fp16 hi + fp16 lo of the scaled operand, three fp16 MFMAs): plane format, packing and kernel
+    against fp64, held to the error of the exact fp32 MFMA engine on the same problem (within 2x)."""
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    # rows of very different magnitude (per-row weight exponents) and activations over a wide range incl. tiny values
+    w = w * torch.logspace(-3, 1, Cout).reshape(-1, 1, 1, 1)
+    x = x * torch.logspace(-4, 1.5, Cin).reshape(1, -1, 1, 1)
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    scale_out = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)          # per output channel magnitude
+    xs = _f16x3_planes(ops, nhwc(x))
+    assert xs.fmt == "f16x3" and xs.scale == ops.F16X3_ACT_SCALE
+    packed = ops.pack_weight_f16x3(w.to(dev))
+    y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=(Cout % 4 == 0))
+    y32 = ops.conv3x3(nhwc(x).to(dev), ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err = ((nchw(y.cpu()).double() - (ref + res)).abs() / scale_out).max().item()
+    err32 = ((nchw(y32.cpu()).double() - (ref + res)).abs() / scale_out).max().item()
+    print(f"f16x3 rel err {err:.2e}  fp32-MFMA rel err {err32:.2e}")
+    assert err < max(2 * err32, 2e-6), (err, err32)
+    if N * H * W <= 70000:
+        buf = xs.buf.view(torch.uint8).reshape(2, -1).cpu()
+        hi = buf[0].view(torch.float16).reshape(N, H, W, Cin).double()
+        lo = buf[1].view(torch.float16).reshape(N, H, W, Cin).double()
+        s = nhwc(x).double() * xs.scale
+        np.testing.assert_array_equal(hi.numpy(), (nhwc(x) * xs.scale).half().double().numpy())
+        big = s.abs() >= 2.0 ** -3                                   # lo is a normal fp16 there: 22 significant bits
+        assert ((hi + lo - s).abs()[big] / s.abs()[big]).max().item() < 2.0 ** -21
+        assert (hi + lo - s).abs()[~big].max().item() <= 2.0 ** -25 if (~big).any() else True
+        y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, nchw_out=True)
+        assert ((y.cpu().double() - ref).abs() / scale_out).max().item() < max(2 * err32, 2e-6)
+    if Cout % 4:
+        return
+    w1 = rnd(24, Cout, Cin) / math.sqrt(Cin)
+    c = ops.gemm_bf16x3_presplit(xs, ops.pack_weight_f16x3(w1.to(dev)), Cout, bias=b.to(dev))
+    ref1 = nhwc(x).reshape(-1, Cin).double() @ w1.double().t() + b.double()
+    c32 = ops.gemm(nhwc(x).reshape(-1, Cin).to(dev), w1.to(dev), bias=b.to(dev))
+    e1, e32 = (c.cpu().double() - ref1).abs().max().item(), (c32.cpu().double() - ref1).abs().max().item()
+    assert e1 < max(2 * e32, 2e-6 * ref1.abs().max().item()), (e1, e32)
+
+
+def test_f16x3_fp16_subnormal_operands(ops):
+    """The lo plane of small operands is a subnormal fp16: v_mfma_f32_32x32x16_f16 must not flush it (the format's error
+    analysis in include/dua_hip.h assumes at most 2^-25 absolute on the scaled operand)."""
+    N, H, W, Cin, Cout = 1, 8, 8, 32, 32
+    x = rnd(30, N, Cin, H, W) * 1e-3                     # scaled by 2^6: |s| ~ 0.06 -> |lo| <= 2^-15 (subnormal: < 6.1e-5)
+    w = rnd(31, Cout, Cin, 3, 3) / math.sqrt(9 * Cin)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    y = ops.conv3x3_bf16x3(_f16x3_planes(ops, nhwc(x)), ops.pack_weight_f16x3(w.to(dev)), None, Cout)
+    rel = ((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
+    print(f"subnormal-lo operands: rel err {rel:.2e}")
+    assert rel < 5e-6, rel                               # flushed lo planes would leave ~2^-12 = 2.4e-4
+
+
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0)])
 def test_gemm_bf16x3(ops, M, N, K1, K2):
     a1, a2 = rnd(30, M, K1), (rnd(31, M, K2) if K2 else None)
