@@ -3,37 +3,83 @@
 (BASELINE.json configs[1]), `uncertainty_zigzag_centered`, num_zigzag=3, UC window = README window W10
 (--start-step-uc 40 --num-steps-uc 10), eta=0, synthetic X_T/y, seeded random-init weights.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: this process starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete sampling job of one batch of 128 images on each GPU (50 main denoiser forwards +
-the UC-window forwards + all sampler kernels + uint8 conversion, inputs resident in HBM).  A warmup step is
-a truncated job (3 timesteps, one of them in the UC window): untimed, it only pages in code, packs the
-weights and warms the allocator.  Ranks shard independent batches (weak scaling); the only collective is
-one RCCL all_gather of the uint8 images at the end of each step.
+One "step" = FIVE consecutive DDIM timesteps of the sampling job of one batch of 128 images on each GPU (denoiser
+forwards + UC-window forwards + all sampler kernels); ten steps = one complete job (50 timesteps, then the uint8
+conversion and the collation).  Only whole jobs are run: K is rounded up to a multiple of ten (the JSON reports the
+K that was timed) and `value` = images of the timed jobs / wall time.  A warmup step is a five-timestep job whose last
+timestep is in the UC window: untimed, it pages in code, packs the weights and warms the allocator.  Ranks shard
+independent batches (weak scaling, reference scripts/generate_dataset_score_uncertainty_imagenet.py:51,137-144: one
+process per GPU, rank-sliced X_T, no data-path collective); the only collective is one RCCL all_gather of the uint8
+images at the end of each job.
+
+The headline precision is `f16x3`, the fp32-EQUIVALENT split (22 significant operand bits, fp32 accumulation; held by
+tests/test_gpu_models.py to the same end-to-end tolerances as the exact fp32 mode); `--precision fp32` runs the exact
+fp32 MFMA engine.  The narrower split modes (bf16x3 / f16f8 / f16f6) are reported under `other_precision_modes` only.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     - dominant kernel (implicit-GEMM conv3x3 of the selected precision mode): algorithmic FLOPs per launch / mean
                  launch duration, HIP events on the launch stream, over the timed region; peak = 2.5 PFLOP/s (fp16 / bf16 MFMA)
-                 for the split modes, 157.3 TFLOP/s (fp32-input MFMA) for --precision fp32.
-  cpu_baseline - the CPU oracle (port of the reference path, fp32, all host cores) timed on rank 0 at N=1 on a bounded
-                 sample and extrapolated with the reference's exact forward count (200 / image for W10).
+                 for the split modes, 157.3 TFLOP/s (fp32-input MFMA) for --precision fp32; `traffic` = HBM-side bytes per
+                 launch from the rocprofv3 --pmc passes committed under profiles/ (read at run time, null if absent).
+  cpu_baseline - the CPU oracle (port of the reference path, fp32) timed on rank 0 at N=1 on a bounded sample (bs=8, two DDIM
+                 timesteps, one of them a UC step, 3 repeats, median) and extrapolated with the reference's exact forward count.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 ADM128_FLOPS_PER_FWD_IMG = 6.139e11      # BASELINE.md section 3 (2*MAC, hooks on the reference modules)
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table (fp32-input MFMA)
-BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md chip table (dense bf16 MFMA)
+BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md chip table (dense bf16 / fp16 MFMA)
+STEP_TIMESTEPS = 5                       # one bench step = 5 DDIM timesteps
+PRECISIONS = ["f16x3", "fp32", "bf16x3", "f16f8", "f16f6"]
+
+# per precision mode: (kernel description, MFMA products executed per algorithmic product at the bf16 rate, dtype string)
+MODES = {
+    "f16x3": ("k_xconv_dma<NT, 3> (LDS-DMA implicit-GEMM conv3x3 on fp16 hi / lo planes of the scaled fp32 operands, "
+              "hi*hi + hi*lo + lo*hi = 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)", 3.0,
+              "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
+              "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 1x1 / proj_out / attention products exact fp32 MFMA; "
+              "norms / softmax / sampler fp32)"),
+    "fp32": ("k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)", None, "f32"),
+    "bf16x3": ("k_xconv_dma<NT, 0> (LDS-DMA split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)", 3.0,
+               "bf16x3 (fp32 operands split into 2 bf16 terms = 16 significant bits, 3 bf16 MFMA products, fp32 accumulate)"),
+    "f16f8": ("k_xconv_dma<NT, 1> (fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms on one block-scaled "
+              "v_mfma_scale_f32_32x32x64_f8f6f4 per 32-deep K block)", 2.0,
+              "f16f8 (fp16 hi + fp8 cross terms: ~15 significant bits)"),
+    "f16f6": ("k_xconv_dma<NT, 2, true> (row-shift loop, fp16 hi*hi + both cross terms on one MXFP6 scaled MFMA per 32-deep K block)", 1.5,
+              "f16f6 (fp16 hi + MXFP6 cross terms: ~14-15 significant bits)"),
+}
+PARITY_NOTE = ("full-size ADM-128 forward vs the reference CPU output (tests/test_gpu_models.py, tolerance 1e-3): max abs err "
+               "f16x3 see test_bf16x3_mode_adm[adm128-f16x3] (bound 1.5e-5), fp32 7.4e-6, bf16x3 3.1e-5, f16f8 5.3e-5, f16f6 6.8e-5")
+
+
+def pmc_traffic(precision):
+    """HBM-side bytes per conv launch measured with rocprofv3 --pmc (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE,
+    separate passes): the newest profiles/r*_pmc_traffic_conv*.json that names this precision.  None if there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_conv*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("precision", "f16f6" if "r01k" in f or "r01l" in f else None) != precision:
+            continue
+        k = d.get("kernels", {}).get("k_xconv_dma") or d.get("kernels", {}).get("conv")
+        if k and "hbm_side_bytes_per_launch" in k:
+            best = (float(k["hbm_side_bytes_per_launch"]), os.path.relpath(f, ROOT))
+    return best
 
 
 class ConvProfile:
@@ -42,13 +88,6 @@ class ConvProfile:
 
     def record(self, kind, flops, e0, e1):
         self.items.append((flops, e0, e1))
-
-    # HBM-side bytes per conv launch from the PMC passes of profiles/r01d_pmc_traffic_conv.json (FETCH_SIZE doubled per the
-    # gfx950 correction + WRITE_SIZE); collected on a truncated job with the same batch and layer shapes.
-    PMC_TRAFFIC_BF16X3 = 2.145e9
-    PMC_TRAFFIC_F16F8 = 1.999e9       # profiles/r01j_pmc_traffic_conv.json (mean over the conv and 1-tap GEMM launches of the kernel)
-    PMC_TRAFFIC_F16F6 = 2.009e9       # profiles/r01l_pmc_traffic_conv.json (same mean)
-    PMC_TRAFFIC_F16F6_SOURCE = "profiles/r01l_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
     def summary(self):
         if not self.items:
@@ -63,42 +102,17 @@ class ConvProfile:
         cs = self.summary()
         if cs is None:
             return None
-        if precision == "fp32":
-            return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(cs["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                        kernel="k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)",
-                        launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
-        if precision == "f16f8":
-            return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_F16F8,
-                        traffic_source="profiles/r01j_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                        kernel="k_xconv_dma<NT, 1> (LDS-DMA implicit-GEMM conv3x3, fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross "
-                               "terms on one block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per 32-deep K block)",
-                        launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
-                        executed_mfma_tflops=round(2 * cs["tflops"], 1), executed_frac=round(2 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
-                        note="achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of 2 bf16-rate products (one fp16 "
-                             "product + two fp8 products at twice the rate), so frac <= 1/2 against the 2.5 PF bf16/fp16 peak by construction")
-        if precision == "f16f6":
-            return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_F16F6,
-                        traffic_source=self.PMC_TRAFFIC_F16F6_SOURCE,
-                        kernel="k_xconv_dma<NT, 2, true> (LDS-DMA row-shift implicit-GEMM conv3x3, fp16 hi*hi on v_mfma_f32_32x32x16_f16 + "
-                               "both cross terms on one MXFP6 (e2m3, E8M0 exponent per 32-k block) v_mfma_scale_f32_32x32x64_f8f6f4 per "
-                               "32-deep K block)",
-                        launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
-                        executed_mfma_tflops=round(1.5 * cs["tflops"], 1),
-                        executed_frac=round(1.5 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
-                        note="achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of 1.5 bf16-rate products (one "
-                             "fp16 product + two fp6 products at four times the rate), so frac <= 2/3 against the 2.5 PF bf16/fp16 peak "
-                             "by construction")
-        return dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), traffic=self.PMC_TRAFFIC_BF16X3,
-                    traffic_source="profiles/r01d_pmc_traffic_conv.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                    kernel="k_xconv_dma<NT> (LDS-DMA split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)",
-                    launches=cs["launches"], flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4),
-                    executed_mfma_tflops=round(3 * cs["tflops"], 1), executed_frac=round(3 * cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
-                    note="achieved counts ALGORITHMIC fp32 FLOPs; each is executed as 3 bf16 MFMA products (hi*hi + hi*lo + lo*hi), "
-                         "so frac <= 1/3 by construction")
+        kernel, mult, _ = MODES[precision]
+        peak = FP32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        tr = pmc_traffic(precision)
+        r = dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(cs["tflops"] / peak, 4),
+                 traffic=(tr[0] if tr else None), traffic_source=(tr[1] if tr else None), kernel=kernel, launches=cs["launches"],
+                 flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
+        if mult:
+            r.update(executed_mfma_tflops=round(mult * cs["tflops"], 1), executed_frac=round(mult * cs["tflops"] / peak, 4),
+                     note=f"achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of {mult:g} bf16-rate products, "
+                          f"so frac <= 1/{mult:g} against the 2.5 PF fp16/bf16 peak by construction")
+        return r
 
 
 def build_model(device, seed=128):
@@ -121,14 +135,45 @@ def make_scheduler(model, base, M, start, num, nz, seed, faithful):
     return s
 
 
-def cpu_baseline(sd, threads):
-    """Oracle (CPU port of the reference path) on a bounded sample: bs=2, two DDIM steps, one of them in the UC window
-    (M=1, num_zigzag=2, every forward executed like the reference) = 4 forwards x 2 images; about 10-30 s of CPU work."""
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    return model, (len(phys) or None), avail
+
+
+def cpu_baseline(sd, M, nz, gen_steps, n_uc):
+    """the oracle (CPU port of the reference path, fp32) on a reduced run - bs=8, two DDIM timesteps of which one is a
+    UC step (M=1, num_zigzag=1: 3 forwards of 8 images, every forward executed like the reference), 3 repeats, median - to get
+    s/forward/image, extrapolated with the reference's exact forward count (it executes every zig-zag forward)."""
+    import torch
     from oracle import adm, driver, schedule
+    cpu_model, phys, avail = cpu_info()
+    # torch's intra-op pool stops scaling (and collapses from oversubscription) well before a 256-thread host is full at
+    # batch 8: use the physical cores this process may run on, at most 64, and report that count
+    threads = max(1, min(avail, phys or avail, 64))
     torch.set_num_threads(threads)
     cfg = dict(adm.ADM128)
     g = torch.Generator().manual_seed(49394)
-    X_T, y = torch.randn(2, 3, 128, 128, generator=g), torch.randint(0, 1000, (2,), generator=g)
+    bs = 8
+    X_T, y = torch.randn(bs, 3, 128, 128, generator=g), torch.randint(0, 1000, (bs,), generator=g)
     nfwd = [0]
 
     def model(x, t, yy, train=False):
@@ -136,57 +181,134 @@ def cpu_baseline(sd, threads):
         return adm.forward(sd, cfg, x, t, yy)
 
     with torch.no_grad():
-        model(X_T, torch.tensor([500, 500]), y)          # untimed: first-touch of the 1.7 GB of weights, thread pool start
-    nfwd[0] = 0
-    torch.manual_seed(0)
-    t0 = time.perf_counter()
-    driver.generate(X_T, y, 2, model, schedule.Tables(), 2, "zigzag_centered", M=1, after_step=1, num_steps_uc=1, num_zigzag=2)
-    dt = time.perf_counter() - t0
-    s_per_img_fwd = dt / (nfwd[0] * 2)
-    ref_forwards = 50 + 10 * 5 * 3                   # the reference executes every zig-zag forward (W10: 200 / image)
+        model(X_T[:2], torch.tensor([500, 500]), y[:2])      # untimed: first touch of the 1.7 GB of weights, thread pool start
+    reps = []
+    for r in range(3):
+        nfwd[0] = 0
+        torch.manual_seed(r)
+        t0 = time.perf_counter()
+        driver.generate(X_T, y, bs, model, schedule.Tables(), 2, "zigzag_centered", M=1, after_step=1, num_steps_uc=1, num_zigzag=1)
+        reps.append((time.perf_counter() - t0) / (nfwd[0] * bs))
+    reps.sort()
+    s_per_img_fwd = reps[1]
+    ref_forwards = gen_steps + n_uc * M * nz             # the reference executes every zig-zag forward (W10, M=5: 200 / image)
     return dict(value=1.0 / (ref_forwards * s_per_img_fwd), unit="images/sec", cores=threads, kind="port",
-                sample=f"oracle ADM-128 fp32, bs=2, 2 DDIM steps (1 in UC window, M=1, nz=2): {nfwd[0]} forwards in {dt:.1f}s "
-                       f"-> {s_per_img_fwd:.3f} s/forward/image, extrapolated to the reference's {ref_forwards} forwards/image")
+                cpu_model=cpu_model, physical_cores=phys, logical_cpus_available=avail,
+                sample=f"oracle ADM-128 fp32, bs={bs}, 2 DDIM timesteps (1 in the UC window, M=1, nz=1) = {nfwd[0]} forwards x {bs} images, "
+                       f"3 repeats: {', '.join(f'{v:.3f}' for v in reps)} s/forward/image, median {s_per_img_fwd:.3f}; "
+                       f"extrapolated to the reference's {ref_forwards} forwards/image")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="bench steps of 5 DDIM timesteps each; rounded up to whole jobs (10 steps)")
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="SURVEY 8(d) numbering: 2 = headline (BASELINE configs[1], M=5); 4 (alias 3) = BASELINE configs[3], M=10, 128 images per GPU")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--generation-steps", type=int, default=50)
-    ap.add_argument("-M", type=int, default=5)
+    ap.add_argument("-M", type=int, default=None)
     ap.add_argument("--num-zigzag", type=int, default=3)
     ap.add_argument("--start-step-uc", type=int, default=40)
     ap.add_argument("--num-steps-uc", type=int, default=10)
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
-    ap.add_argument("--precision", choices=["f16f6", "f16f8", "bf16x3", "fp32"], default="f16f6",
-                    help="f16f6: as f16f8 with the cross terms of the 3x3 convs in MXFP6 (parity ~7e-5); f16f8: 3x3 convs / qkv on fp16 + block-scaled fp8 matrix-core products (parity ~5e-5); bf16x3: convs / weight "
-                         "GEMMs on the bf16 matrix cores with split fp32 operands (parity ~3e-5); fp32: exact fp32 MFMA (parity ~7e-6)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the one-step run of the other precision mode")
+    ap.add_argument("--precision", choices=PRECISIONS, default="f16x3")
+    ap.add_argument("--secondary", default="fp32,f16f6", help="comma list of precision modes run for ONE job each after the headline (N=1 only)")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    a = ap.parse_args()
+    # launcher / test plumbing
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the launch path (needs --stub-job)")
+    ap.add_argument("--stub-job", action="store_true", help="replace the sampling job by a host-side stub (tests of the launcher)")
+    a = ap.parse_args(argv)
+    if a.M is None:
+        a.M = 10 if a.config in (3, 4) else 5
+    return a
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU, 127.0.0.1 rendezvous) BEFORE this process touches the GPU, relay their output and
+    exit with their status.  Reference: mp.spawn(generate_and_save, nprocs=device_count), script :137-144."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a, argv))
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ          # under torch.distributed.run
-    if world > 1 or launched:
-        dist.init_process_group("nccl", device_id=dev)
+    if world != a.gpus and launched:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.stub_job:
+        dev = torch.device("cpu")
+        if world > 1 or launched:
+            dist.init_process_group(a.backend)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1 or launched:
+            dist.init_process_group("nccl", device_id=dev)
+
+    from diffusion_uncertainty_amd.distributed import gather_images, max_over_ranks, shard_range
+
+    jobs = max(1, -(-a.steps // (a.generation_steps // STEP_TIMESTEPS)))
+    steps_per_job = a.generation_steps // STEP_TIMESTEPS
+    steps_run = jobs * steps_per_job
+
+    def sync():
+        if dist.is_initialized():
+            dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    if a.stub_job:
+        # launcher rehearsal: same sharding, barrier bracket, collation and max-over-ranks as the real job
+        g = torch.Generator().manual_seed(49394)
+        X_all = torch.randn(4 * world, 3, 8, 8, generator=g)
+        lo, hi = shard_range(4 * world, rank, world)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(jobs):
+            imgs = ((X_all[lo:hi] / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)
+            gathered = gather_images(imgs)
+            assert gathered.shape[0] == world
+        sync()
+        dt = max_over_ranks(time.perf_counter() - t0, dev)
+        if rank == 0:
+            print(json.dumps({"metric": "stub", "value": 4 * world * jobs / max(dt, 1e-9), "unit": "images/sec", "n_gpus": world,
+                              "steps": steps_run, "warmup": a.warmup, "ms_per_step": dt / steps_run * 1e3, "backend": a.backend,
+                              "ranks_seen": int(gathered.shape[0])}), flush=True)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from diffusion_uncertainty_amd import ops
-    from diffusion_uncertainty_amd.distributed import gather_images, max_over_ranks, shard_range
     from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
 
     model, base, sd = build_model(dev)
     # synthetic inputs exactly as scripts/generate_diffusion_starting_data.py:27-49, sharded by rank like the script (:51)
-    g = torch.Generator().manual_seed(49394)
+    g = torch.Generator().manual_seed(49394 + 1)         # dataset index k = 1 (imagenet128), SURVEY 8(d)
     X_all = torch.randn(a.batch * world, 3, 128, 128, generator=g)
     y_all = torch.randint(0, 1000, (a.batch * world,), generator=g)
     lo, hi = shard_range(a.batch * world, rank, world)
@@ -199,76 +321,64 @@ def main():
         gather_images(r["gen_images"].to(dev))             # RCCL over xGMI: the only collective of the path
         return s.denoiser_calls
 
-    def sync():
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(precision, steps, warmup):
+    def timed(precision, njobs, warmup):
         model.precision = precision
         for w in range(warmup):
-            job(3, 1, 1, 1000 + w)
+            job(STEP_TIMESTEPS, STEP_TIMESTEPS - 1, 1, 1000 + w)
         prof = None if a.no_profile else ConvProfile()
         ops.PROFILE = prof
         sync()
         t0 = time.perf_counter()
         uc = 0
-        for k in range(steps):
+        for k in range(njobs):
             uc += job(a.generation_steps, a.start_step_uc, a.num_steps_uc, k)
         sync()
         dt = time.perf_counter() - t0
         ops.PROFILE = None
         return max_over_ranks(dt, dev), uc, prof
 
-    dt, uc_calls, prof = timed(a.precision, a.steps, a.warmup)
-    secondary = None
+    dt, uc_calls, prof = timed(a.precision, jobs, a.warmup)
+    fwd_per_img = a.generation_steps + uc_calls / jobs
+    others = []
     if world == 1 and not a.no_secondary:
-        other = "fp32" if a.precision != "fp32" else "f16f6"
-        dt2, uc2, prof2 = timed(other, 1, 1)
-        secondary = dict(precision=other, value=round(a.batch / dt2, 4), unit="images/sec", steps=1, ms_per_step=round(dt2 * 1e3, 1),
-                         end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
-                         roofline=(prof2.roofline(other) if prof2 is not None else None))
+        for other in [m for m in a.secondary.split(",") if m and m != a.precision]:
+            dt2, uc2, prof2 = timed(other, 1, 1)
+            others.append(dict(precision=other, value=round(a.batch / dt2, 4), unit="images/sec", steps=steps_per_job,
+                               ms_per_step=round(dt2 / steps_per_job * 1e3, 1), dtype=MODES[other][2],
+                               end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
+                               roofline=(prof2.roofline(other) if prof2 is not None else None)))
 
     if rank == 0:
-        images = a.batch * world * a.steps
-        fwd_per_img = a.generation_steps + uc_calls / max(a.steps, 1)
+        images = a.batch * world * jobs
         exec_flops = fwd_per_img * ADM128_FLOPS_PER_FWD_IMG * images
-        roof = prof.roofline(a.precision) if prof is not None else None
+        ref_fwd = a.generation_steps + a.num_steps_uc * a.M * a.num_zigzag
         line = {
             "metric": "images/sec @ ADM ImageNet-128, 50 steps, M=5, bs=128; 1/2/4/8 GPU",
-            "value": round(images / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f16f6": "f16f6 (fp32 operands split a = fp16 hi + lo; 3x3 convs: hi*hi on fp16 MFMA, both cross terms on one MXFP6 "
-                               "(e2m3 + E8M0 exponent per 32 channels) scaled MFMA, fp32 accumulate; qkv / proj_out f16f8; 1x1 / attention "
-                               "products split-bf16; norms/softmax/sampler fp32)",
-                      "f16f8": "f16f8 (fp32 operands split a = fp16 hi + lo; hi*hi on fp16 MFMA, both cross terms on one block-scaled fp8 "
-                               "MFMA, fp32 accumulate: ~2^-15 per product; 1x1 / attention products split-bf16; norms/softmax/sampler fp32)",
-                      "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 terms, 3 bf16 MFMA products, fp32 accumulate; norms/softmax/"
-                                "attention products/sampler in fp32)", "fp32": "f32"}[a.precision], "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ADM ImageNet-128, 50 DDIM steps, M=5, uncertainty_zigzag_centered, "
-                                   "num_zigzag=3, UC window W10 (start 40, 10 steps), batch 128 per GPU",
+            "value": round(images / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": steps_run, "warmup": a.warmup,
+            "ms_per_step": round(dt / steps_run * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": MODES[a.precision][2], "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[{1 if a.M == 5 else 3}]: ADM ImageNet-128, {a.generation_steps} DDIM steps, M={a.M}, "
+                                    f"uncertainty_zigzag_centered, num_zigzag={a.num_zigzag}, UC window (start {a.start_step_uc}, "
+                                    f"{a.num_steps_uc} steps), batch {a.batch} per GPU"),
+                       "step": f"{STEP_TIMESTEPS} consecutive DDIM timesteps of the {a.batch}-image job; {steps_per_job} steps = 1 job; "
+                               f"{jobs} whole job(s) timed" + (f" (--steps {a.steps} rounded up)" if steps_run != a.steps else ""),
                        "global_batch": a.batch * world, "parallelism": f"independent batches x{world} (no data-path collective; "
                                                                         "one RCCL all_gather of uint8 images per job)",
                        "zigzag_mode": "faithful (all forwards executed)" if a.faithful_zigzag else
                                       "skip_dead_zigzag (outputs identical; noise draws still consumed)",
-                       "executed_forwards_per_image": fwd_per_img, "noise": "device Philox (dua_randn)",
-                       "precision": a.precision,
-                       "parity": ("full-size ADM-128 forward vs the reference CPU output: max abs err 6.8e-5 (f16f6), 5.3e-5 (f16f8), 3.1e-5 (bf16x3), "
-                                  "7.4e-6 (fp32); tolerance 1e-3 (tests/test_gpu_models.py)"),
-                       "warmup_pass": "3-timestep truncated job"},
+                       "executed_forwards_per_image": fwd_per_img, "reference_forwards_per_image": ref_fwd,
+                       "noise": "device Philox (dua_randn)", "precision": a.precision, "parity": PARITY_NOTE,
+                       "warmup_pass": f"{STEP_TIMESTEPS}-timestep job, last timestep in the UC window"},
             "end_to_end_tflops": round(exec_flops / dt / 1e12, 2),
-            "roofline": roof,
+            "value_at_reference_forward_count": round(images / dt * fwd_per_img / ref_fwd, 4),
+            "roofline": prof.roofline(a.precision) if prof is not None else None,
         }
-        if secondary is not None:
-            line["other_precision_mode"] = secondary
+        if others:
+            line["other_precision_modes"] = others
         if not a.no_cpu_baseline and world == 1:
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except Exception:
-                cores = os.cpu_count() or 1
-            # torch's intra-op pool stops scaling (and collapses from oversubscription) well before a 256-core host is
-            # full at batch 2: use at most 32 threads and report that count.
-            line["cpu_baseline"] = cpu_baseline(sd, min(cores, 32))
+            cb = cpu_baseline(sd, a.M, a.num_zigzag, a.generation_steps, a.num_steps_uc)
+            cb["gpu_over_cpu_same_forward_count"] = round(line["value_at_reference_forward_count"] / cb["value"], 1)
+            line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -61,3 +61,46 @@ def test_single_process_fallbacks():
     assert gather_images(x).shape == (1, 2, 3, 4, 4)
     assert max_over_ranks(1.5, "cpu") == 1.5
     assert shard_range(1024, 3, 8) == (384, 512)
+
+
+def test_bench_launcher_starts_ranks_itself():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must start two ranks itself (--gpus
+    was a no-op) and rank 0 must print ONE JSON line with n_gpus = 2.  CPU rehearsal: gloo backend, stub job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "0",
+                          "--backend", "gloo", "--stub-job"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 20 and r["backend"] == "gloo"
+
+
+def test_bench_launcher_propagates_failure():
+    """A failing rank must make the launcher exit non-zero (no silent single-rank fallback)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # without --stub-job the ranks need a GPU: on this CPU box every rank raises SystemExit("bench.py needs a GPU ...")
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode != 0
+
+
+def test_bench_steps_round_up_to_whole_jobs():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    a = b.parse_args(["--steps", "20", "--warmup", "5"])
+    assert a.precision == "f16x3" and a.M == 5 and a.steps == 20        # driver invocation: 2 whole jobs of the fp32-equivalent mode
+    assert b.parse_args(["--config", "3"]).M == 10                    # BASELINE configs[3]: M = 10, 128 images per GPU
+    assert b.MODES["f16x3"][1] == 3.0 and b.STEP_TIMESTEPS * 10 == 50
