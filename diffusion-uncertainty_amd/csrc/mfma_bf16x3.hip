@@ -1394,13 +1394,26 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
 
 // Engine selector for the pre-split conv: 1 = LDS-DMA kernels (default; 256x256 tile where Cout % 256 == 0),
 // 2 = LDS-DMA 256x128 only, 0 = register-staged kernel (debug / A-B).
+// Process-global A/B switch (set it before any work is queued; not synchronised with running streams).  Modes 3 - 5 build
+// zero-record buffer descriptors - timing-only runs with WRONG results - and exist only in the diagnostic library
+// (-DDUA_CONV_TIMING, scripts/conv_tile_timing.py --build); the product library rejects them.
 static int dua_dma_conv_enabled = 1;
-extern "C" int dua_set_dma_conv(int on) { int o = dua_dma_conv_enabled; dua_dma_conv_enabled = on; return o; }
+extern "C" int dua_set_dma_conv(int on) {
+#ifndef DUA_CONV_TIMING
+    DUA_REQUIRE(on == 0 || on == 1 || on == 2 || on == 6, "dua_set_dma_conv: mode %d exists only in the diagnostic build (wrong results by design)", on);
+#endif
+    int o = dua_dma_conv_enabled;
+    dua_dma_conv_enabled = on;
+    return o;
+}
 
 // Start-up stagger of the persistent LDS-DMA workgroups: `phases` phases per XCD (0 / 1 = off), each `percent` % of 1/phases
 // of the estimated tile period.  Applied only when every workgroup owns at least `min_tiles` tiles.
 static int dua_stagger_phases = 0, dua_stagger_percent = 100, dua_stagger_min_tiles = 6;
 extern "C" int dua_set_conv_stagger(int phases, int percent, int min_tiles) {
+#ifndef DUA_CONV_TIMING
+    DUA_REQUIRE(phases <= 1, "dua_set_conv_stagger: the start-up stagger (measured: -1 .. -4 %%) is compiled into the diagnostic build only");
+#endif
     dua_stagger_phases = phases; dua_stagger_percent = percent; dua_stagger_min_tiles = min_tiles;
     return 0;
 }
@@ -1421,7 +1434,11 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     const bool wide = dua_dma_conv_enabled != 2 && d.N % 256 == 0 && (long)d.ntm * (d.N / 256) >= 512;
     d.ntn = wide ? d.N / 256 : (d.N + BN - 1) / BN;
     const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
+#ifdef DUA_CONV_TIMING
     d.dbg_norec = dua_dma_conv_enabled == 3 ? 3 : (dua_dma_conv_enabled == 4 ? 1 : (dua_dma_conv_enabled == 5 ? 2 : 0));   // 4: A only, 5: B only
+#else
+    d.dbg_norec = 0;
+#endif
     dconv_set_stagger(d, wide, ntiles, grid);
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);

@@ -26,6 +26,7 @@ from .. import ops
 from ..generate_samples import _require_gpu, predict_model
 from ..schedulers_uncertainty.noise import HostNoise
 from ..uvit.uvit_ae import UViTAE
+from . import _core
 
 noise_source = HostNoise()          # torch.randn_like(prev_noisy_sample) :57; swap for DeviceNoise to keep the draws on the GPU
 
@@ -71,6 +72,8 @@ def estimate_score_update_posterior(M: int, model, scheduler, input, y_slice, t_
 
 
 class DiffusionClassConditionalGuidedPosteriorDistribution:
+    """Same constructor / call surface as the reference class (:69-175); the loops are the shared skeleton of ``_core`` and the
+    guided update is the ``revise`` callback of the timestep loop."""
 
     def __init__(self, model, scheduler, threshold, image_size: int, device, batch_size: int, init_seed_rng: int,
                  fid_evaluator: Optional[object] = None, M: int = 5, threshold_type: str = "higher"):
@@ -78,74 +81,40 @@ class DiffusionClassConditionalGuidedPosteriorDistribution:
         if isinstance(threshold, float):
             assert 0 <= threshold <= 1, "Threshold percentile must be between 0 and 1"
         _require_gpu(device)
-        self.model = model
-        self.scheduler = scheduler
-        self.threshold = threshold
-        self.image_size = image_size
-        self.device = device
-        self.fid_evaluator = fid_evaluator
-        self.batch_size = batch_size
+        self.model, self.scheduler, self.threshold, self.device = model, scheduler, threshold, device
+        self.image_size, self.batch_size, self.init_seed_rng = image_size, batch_size, init_seed_rng
+        self.fid_evaluator, self.M, self.threshold_type = fid_evaluator, M, threshold_type
         self.is_uvit = isinstance(model, UViTAE)
-        self.is_cifar10 = False
-        self.init_seed_rng = init_seed_rng
-        self.M = M
         self.lambda_update = 7
-        self.threshold_type = threshold_type
 
     @torch.no_grad()
     def __call__(self, num_samples: Optional[int] = None, num_classes: Optional[int] = None,
                  X_T: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None, start_step: int = 0,
                  num_steps: Optional[int] = None) -> Dict[str, torch.Tensor]:
-        assert num_samples is not None or X_T is not None, "Either num_samples or X_T must be provided"
-        assert num_classes is not None or y is not None, "Either num_classes or y must be provided"
-        num_generated_samples = 0
-        samples_x_t, samples_y, samples_gen_images = [], [], []
+        sched = self.scheduler
+        n_t = sched.timesteps.shape[0]
         if num_steps is None:
-            num_steps = self.scheduler.timesteps.shape[0] - start_step
-        if num_samples is None:
-            num_samples = X_T.shape[0]
+            num_steps = n_t - start_step
         if isinstance(self.threshold, torch.Tensor):
-            assert self.threshold.shape[0] == self.scheduler.timesteps.shape[0], \
-                f"{self.threshold.shape=} {self.scheduler.timesteps.shape=}"
-        self.scheduler.config.after_step = start_step                     # :117-119
-        self.scheduler.config.num_steps_uc = num_steps
-        self.scheduler.set_timesteps(len(self.scheduler.timesteps))
-        generator = torch.Generator(device=self.device)
-        i_batch = 0
-        while num_samples > num_generated_samples:
-            input = self.get_X_T_batch(X_T, num_generated_samples, i_batch, generator).to(self.device)
-            samples_x_t.append(input.cpu().clone())
-            y_slice = self.get_y_batch(num_classes, y, num_generated_samples, i_batch, generator, input).to(self.device)
-            samples_y.append(y_slice)
-            self.scheduler.prompt_embeds = y_slice
-            for i, t in enumerate(self.scheduler.timesteps):
-                t = t.item()
-                t_tensor = torch.full((y_slice.shape[0],), t, device=self.device, dtype=torch.long)
-                noisy_residual = ops._f32c(predict_model(self.model, input, t_tensor, y_slice))
-                output = self.scheduler.step(noisy_residual, t, input)
-                prev_noisy_sample = output.prev_sample
-                alpha_hat_t = self.scheduler.alphas_cumprod[i]            # loop index, as upstream (:146)
-                if (start_step + num_steps) >= i >= start_step:
-                    pixel_wise_uncertainty, posterior_score = self.estimate_score_update(
-                        input, y_slice, i, t_tensor, noisy_residual, prev_noisy_sample, alpha_hat_t)
-                    thresholded_map = calculate_threshold_map(self.threshold, i, pixel_wise_uncertainty, self.threshold_type)
-                    noisy_residual = ops.map_blend(posterior_score, noisy_residual, thresholded_map)     # :152
-                    output = self.scheduler.step(noisy_residual, t, input)
-                    prev_noisy_sample = output.prev_sample
-                input = prev_noisy_sample
-            gen_images = ops.to_uint8(ops._f32c(input))                   # :157-170 (no VAE decode here upstream either)
-            num_generated_samples += gen_images.shape[0]
-            if self.fid_evaluator is not None:
-                self.fid_evaluator.update(gen_images, real=False)
-            samples_gen_images.append(gen_images)
-            i_batch += 1
-        results = {"y": torch.cat(samples_y, dim=0).cpu(),
-                   "x_t": torch.cat(samples_x_t, dim=0).cpu(),
-                   "timestep": self.scheduler.timesteps,
-                   "gen_images": torch.cat(samples_gen_images, dim=0).cpu()}
-        if self.fid_evaluator is not None:
-            results["fid"] = self.fid_evaluator.compute()
-        return results
+            assert self.threshold.shape[0] == n_t, f"{self.threshold.shape=} {sched.timesteps.shape=}"
+        sched.config.after_step, sched.config.num_steps_uc = start_step, num_steps          # :117-119
+        sched.set_timesteps(n_t)
+        yb_now = [None]
+
+        def guided(i, t, t_tensor, x, eps, out):
+            if not (start_step <= i <= start_step + num_steps):                               # inclusive on both ends (:148)
+                return None
+            eps = ops._f32c(eps)
+            u, post = self.estimate_score_update(x, yb_now[0], i, t_tensor, eps, out.prev_sample, sched.alphas_cumprod[i])   # loop index (:146)
+            tmap = calculate_threshold_map(self.threshold, i, u, self.threshold_type)
+            return sched.step(ops.map_blend(post, eps, tmap), t, x)                           # :152-154
+
+        def chain(xb, yb):
+            yb_now[0] = yb
+            x, _, _ = _core.sample_chain(self.model, sched, xb, yb, self.device, revise=guided)
+            return _core.to_images(x), {}                                                     # (no VAE decode here upstream either)
+
+        return _core.run_pipeline(self, X_T, y, num_samples, num_classes, chain)
 
     def calculate_threshold_map(self, i, pixel_wise_uncertainty):
         """:230-238 (always 'higher')."""
@@ -155,19 +124,3 @@ class DiffusionClassConditionalGuidedPosteriorDistribution:
         """:240-267 - the module-level function with M = self.M."""
         return estimate_score_update_posterior(self.M, self.model, self.scheduler, input, y_slice, t_tensor, noisy_residual,
                                                prev_noisy_sample, alpha_hat_t)
-
-    def get_y_batch(self, num_classes, y, num_generated_samples, i_batch, generator, X_t):
-        if y is not None:
-            return y[num_generated_samples:num_generated_samples + self.batch_size]
-        return torch.randint(0, num_classes, (self.batch_size,), device=self.device,
-                             generator=generator.manual_seed(self.init_seed_rng + i_batch))
-
-    def get_X_T_batch(self, X_T, num_generated_samples, i_batch, generator):
-        if X_T is not None:
-            return X_T[num_generated_samples:num_generated_samples + self.batch_size]
-        c = 4 if self.is_uvit else 3
-        return torch.randn(self.batch_size, c, self.image_size, self.image_size, device=self.device, dtype=torch.float32,
-                           generator=generator.manual_seed(self.init_seed_rng + i_batch))
-
-    def predict_score(self, input, y_batch, t_tensor):
-        return predict_model(self.model, input, t_tensor, y_batch)

@@ -41,6 +41,19 @@ def betas_for_alpha_bar(num_diffusion_timesteps, max_beta=0.999, alpha_transform
     return torch.tensor(betas, dtype=torch.float32)
 
 
+def make_betas(owner, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas):
+    """fp32 beta table of a scheduler config (zigzag_centered.py:218-233; the same four branches open every reference scheduler)."""
+    if trained_betas is not None:
+        return torch.tensor(trained_betas, dtype=torch.float32)
+    if beta_schedule == "linear":
+        return torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+    if beta_schedule == "scaled_linear":             # the latent-diffusion schedule: linear in sqrt(beta)
+        return torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    if beta_schedule == "squaredcos_cap_v2":
+        return betas_for_alpha_bar(num_train_timesteps)
+    raise NotImplementedError(f"{beta_schedule} does is not implemented for {owner}")
+
+
 class DDIMUncertaintyCore(SchedulerMixin, ConfigMixin):
     _compatibles = [e.name for e in KarrasDiffusionSchedulers]
     order = 1
@@ -48,16 +61,7 @@ class DDIMUncertaintyCore(SchedulerMixin, ConfigMixin):
     def _init_tables(self, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, clip_sample,
                      set_alpha_to_one, steps_offset, prediction_type, thresholding, dynamic_thresholding_ratio,
                      clip_sample_range, sample_max_value, timestep_spacing, rescale_betas_zero_snr):
-        if trained_betas is not None:
-            self.betas = torch.tensor(trained_betas, dtype=torch.float32)
-        elif beta_schedule == "linear":
-            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
-        elif beta_schedule == "scaled_linear":
-            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
-        elif beta_schedule == "squaredcos_cap_v2":
-            self.betas = betas_for_alpha_bar(num_train_timesteps)
-        else:
-            raise NotImplementedError(f"{beta_schedule} does is not implemented for {self.__class__}")
+        self.betas = make_betas(self.__class__, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
         if rescale_betas_zero_snr:
             raise NotImplementedError("rescale_betas_zero_snr is not on the accelerated path")
         self.alphas = 1.0 - self.betas

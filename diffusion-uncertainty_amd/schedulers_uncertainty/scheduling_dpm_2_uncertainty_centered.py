@@ -23,7 +23,7 @@ import torch
 
 from .. import ops
 from ..configuration import BaseOutput, ConfigMixin, KarrasDiffusionSchedulers, SchedulerMixin, register_to_config
-from ._base import betas_for_alpha_bar
+from ._base import make_betas
 from .noise import HostNoise
 from .traits import PredictorClassConditionedTrait
 
@@ -43,6 +43,25 @@ class SchedulerUncertaintyOutput(BaseOutput):
                          pred_epsilon=pred_epsilon, **kw)
 
 
+def _half_logsnr(sigma):
+    """(alpha, sigma_vp, lambda) of a k-diffusion sigma: alpha = 1/sqrt(sigma^2+1), sigma_vp = sigma*alpha, lambda = log alpha -
+    log sigma_vp (:436-440 and the lambda lines of :609-612 / :700-706), on 0-dim fp32 tensors as upstream."""
+    alpha = 1 / ((sigma ** 2 + 1) ** 0.5)
+    sig = sigma * alpha
+    return alpha, sig, torch.log(alpha) - torch.log(sig)
+
+
+def _solver_grid(spacing, n, last_t, n_train, offset):
+    """Integer timestep grid of set_timesteps (:296-321).  Note the N + 1 points of 'linspace' / 'leading' with the last dropped."""
+    if spacing == "linspace":
+        return np.linspace(0, last_t - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+    if spacing == "leading":
+        return (np.arange(0, n + 1) * (last_t // (n + 1))).round()[::-1][:-1].copy().astype(np.int64) + offset
+    if spacing == "trailing":
+        return np.arange(last_t, 0, -(n_train / n)).round().copy().astype(np.int64) - 1
+    raise ValueError(f"{spacing} is not supported. Please make sure to choose one of 'linspace', 'leading' or 'trailing'.")
+
+
 class KDPM2DiscreteSchedulerUncertainty(SchedulerMixin, ConfigMixin):
     _compatibles = [e.name for e in KarrasDiffusionSchedulers]
     order = 1
@@ -55,40 +74,34 @@ class KDPM2DiscreteSchedulerUncertainty(SchedulerMixin, ConfigMixin):
                  use_lu_lambdas=False, final_sigmas_type="zero", lambda_min_clipped=-float("inf"), variance_type=None,
                  timestep_spacing="linspace", steps_offset=0, M=30, after_step=10, num_steps_uc=10, unet=None,
                  predict_next=False, prompt_embed=None):
-        if trained_betas is not None:
-            self.betas = torch.tensor(trained_betas, dtype=torch.float32)
-        elif beta_schedule == "linear":
-            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
-        elif beta_schedule == "scaled_linear":
-            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
-        elif beta_schedule == "squaredcos_cap_v2":
-            self.betas = betas_for_alpha_bar(num_train_timesteps)
-        else:
-            raise NotImplementedError(f"{beta_schedule} does is not implemented for {self.__class__}")
         if algorithm_type != "dpmsolver++" or solver_type != "midpoint" or solver_order not in (1, 2):
             raise NotImplementedError("the HIP path implements dpmsolver++ / midpoint / order <= 2 (what the factory builds)")
         if prediction_type != "epsilon" or thresholding or use_karras_sigmas or use_lu_lambdas:
             raise NotImplementedError("the HIP path implements prediction_type='epsilon' without thresholding / Karras / Lu sigmas")
         if final_sigmas_type not in ("zero", "sigma_min"):
             raise ValueError(f"`final_sigmas_type` must be one of 'zero', or 'sigma_min', but got {final_sigmas_type}")
+        # VP tables (:184-225)
+        self.betas = make_betas(self.__class__, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
-        self.alpha_t = torch.sqrt(self.alphas_cumprod)
-        self.sigma_t = torch.sqrt(1 - self.alphas_cumprod)
+        self.alpha_t, self.sigma_t = torch.sqrt(self.alphas_cumprod), torch.sqrt(1 - self.alphas_cumprod)
         self.lambda_t = torch.log(self.alpha_t) - torch.log(self.sigma_t)
         self.sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
         self.init_noise_sigma = 1.0
+        self.timesteps = torch.from_numpy(np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy())
         self.num_inference_steps = None
-        timesteps = np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy()
-        self.timesteps = torch.from_numpy(timesteps)
-        self.model_outputs = [None] * solver_order
-        self.lower_order_nums = 0
-        self._step_index = None
+        self._reset_solver(solver_order)
+        # estimator state
         self.M, self.after_step, self.num_steps_uc = M, after_step, num_steps_uc
         self.unet, self.predict_next, self.prompt_embed = unet, predict_next, prompt_embed
         self.prompt_embeds = None
         self.noise_source = HostNoise()
         self.denoiser_calls = 0
+
+    def _reset_solver(self, order):
+        self.model_outputs = [None] * order          # x0 predictions of the last `order` steps, newest last
+        self.lower_order_nums = 0                    # steps taken since the reset, capped at the order
+        self._step_index = None
 
     @property
     def step_index(self):
@@ -96,128 +109,106 @@ class KDPM2DiscreteSchedulerUncertainty(SchedulerMixin, ConfigMixin):
 
     def set_timesteps(self, num_inference_steps=None, device=None):
         """:285-367."""
-        clipped_idx = torch.searchsorted(torch.flip(self.lambda_t, [0]), self.config.lambda_min_clipped)
-        last_timestep = ((self.config.num_train_timesteps - clipped_idx).numpy()).item()
-        if self.config.timestep_spacing == "linspace":
-            timesteps = np.linspace(0, last_timestep - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
-        elif self.config.timestep_spacing == "leading":
-            step_ratio = last_timestep // (num_inference_steps + 1)
-            timesteps = (np.arange(0, num_inference_steps + 1) * step_ratio).round()[::-1][:-1].copy().astype(np.int64)
-            timesteps += self.config.steps_offset
-        elif self.config.timestep_spacing == "trailing":
-            step_ratio = self.config.num_train_timesteps / num_inference_steps
-            timesteps = np.arange(last_timestep, 0, -step_ratio).round().copy().astype(np.int64)
-            timesteps -= 1
-        else:
-            raise ValueError(f"{self.config.timestep_spacing} is not supported. Please make sure to choose one of "
-                             "'linspace', 'leading' or 'trailing'.")
-        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
-        sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)
-        if self.config.final_sigmas_type == "sigma_min":
-            sigma_last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
-        else:
-            sigma_last = 0
-        sigmas = np.concatenate([sigmas, [sigma_last]]).astype(np.float32)
-        self.sigmas = torch.from_numpy(sigmas)
-        self.timesteps = torch.from_numpy(timesteps).to(device=device, dtype=torch.int64)
-        self.num_inference_steps = len(timesteps)
-        self.model_outputs = [None] * self.config.solver_order
-        self.lower_order_nums = 0
-        self._step_index = None
+        cfg = self.config
+        clipped = torch.searchsorted(torch.flip(self.lambda_t, [0]), cfg.lambda_min_clipped)
+        last_t = int((cfg.num_train_timesteps - clipped).item())
+        grid = _solver_grid(cfg.timestep_spacing, num_inference_steps, last_t, cfg.num_train_timesteps, cfg.steps_offset)
+        table = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        tail = float(table[0]) if cfg.final_sigmas_type == "sigma_min" else 0.0
+        sig = np.concatenate([np.interp(grid, np.arange(len(table)), table), [tail]]).astype(np.float32)      # :333-352
+        self.sigmas = torch.from_numpy(sig)
+        self.timesteps = torch.from_numpy(grid).to(device=device, dtype=torch.int64)
+        self.num_inference_steps = len(grid)
+        self._reset_solver(cfg.solver_order)
         # IndexError when the window exceeds the grid, like the reference (:366-367)
-        self.timestep_after_step = int(timesteps[self.config.after_step])
-        self.timestep_end_step = int(timesteps[self.config.after_step + self.config.num_steps_uc - 1])
+        self.timestep_after_step = int(grid[cfg.after_step])
+        self.timestep_end_step = int(grid[cfg.after_step + cfg.num_steps_uc - 1])
 
     def _sigma_to_alpha_sigma_t(self, sigma):
-        """:436-440."""
-        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
-        return alpha_t, sigma * alpha_t
+        a, s, _ = _half_logsnr(sigma)
+        return a, s
+
+    def _locate(self, timestep):
+        """Index of ``timestep`` in the grid (:857-874): the second hit if it occurs twice, the last index if absent."""
+        hits = (self.timesteps == (timestep.to(self.timesteps.device) if isinstance(timestep, torch.Tensor) else timestep)).nonzero()
+        if len(hits) == 0:
+            return len(self.timesteps) - 1
+        return hits[min(1, len(hits) - 1)].item()
 
     def _init_step_index(self, timestep):
-        """:857-874."""
-        if isinstance(timestep, torch.Tensor):
-            timestep = timestep.to(self.timesteps.device)
-        index_candidates = (self.timesteps == timestep).nonzero()
-        if len(index_candidates) == 0:
-            step_index = len(self.timesteps) - 1
-        elif len(index_candidates) > 1:
-            step_index = index_candidates[1].item()
-        else:
-            step_index = index_candidates[0].item()
-        self._step_index = step_index
+        self._step_index = self._locate(timestep)
 
     def convert_model_output(self, model_output, sample=None):
         """:523-528 - data prediction of the epsilon model."""
         if self.config.variance_type in ["learned", "learned_range"]:
             model_output = model_output[:, :3]
-        sigma = self.sigmas[self.step_index]
-        alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(sigma)
+        alpha_t, sigma_t, _ = _half_logsnr(self.sigmas[self.step_index])
         return ops.x0_from_eps(ops._f32c(model_output), ops._f32c(sample), sigma_t, alpha_t)
 
-    def _lambdas(self, *sigmas):
-        out = []
-        for s in sigmas:
-            a, sg = self._sigma_to_alpha_sigma_t(s)
-            out.append((a, sg, torch.log(a) - torch.log(sg)))
-        return out
+    def _update_coefficients(self, second_order):
+        """Scalars of the data-prediction DPM-Solver++ update from step_index to step_index + 1:
+        x_next = c1 * x - c2 * m0 [- c3 * (m0 - m1) / r0], c1 = sigma_t/sigma_s, c2 = alpha_t (e^{-h} - 1), c3 = c2 / 2 (:624-632, :694-727)."""
+        i = self.step_index
+        alpha_t, sigma_t, lam_t = _half_logsnr(self.sigmas[i + 1])
+        _, sigma_s, lam_s = _half_logsnr(self.sigmas[i])
+        h = lam_t - lam_s
+        c1, c2 = sigma_t / sigma_s, alpha_t * (torch.exp(-h) - 1.0)
+        if not second_order:
+            return c1, c2, None, None
+        lam_p = _half_logsnr(self.sigmas[i - 1])[2]
+        return c1, c2, 0.5 * c2, 1.0 / ((lam_s - lam_p) / h)
 
     def dpm_solver_first_order_update(self, model_output, sample=None, noise=None):
-        """:624-632."""
-        (alpha_t, sigma_t, lambda_t), (_, sigma_s, lambda_s) = self._lambdas(self.sigmas[self.step_index + 1],
-                                                                            self.sigmas[self.step_index])
-        h = lambda_t - lambda_s
-        return ops.axpby(ops._f32c(sample), model_output, sigma_t / sigma_s, -(alpha_t * (torch.exp(-h) - 1.0)))
+        c1, c2, _, _ = self._update_coefficients(False)
+        return ops.axpby(ops._f32c(sample), model_output, c1, -c2)
 
     def multistep_dpm_solver_second_order_update(self, model_output_list, sample=None, noise=None):
-        """:694-727 (dpmsolver++, midpoint)."""
-        (alpha_t, sigma_t, lambda_t), (_, sigma_s0, lambda_s0), (_, _, lambda_s1) = self._lambdas(
-            self.sigmas[self.step_index + 1], self.sigmas[self.step_index], self.sigmas[self.step_index - 1])
-        m0, m1 = model_output_list[-1], model_output_list[-2]
-        h, h_0 = lambda_t - lambda_s0, lambda_s0 - lambda_s1
-        r0 = h_0 / h
-        c2 = alpha_t * (torch.exp(-h) - 1.0)
-        return ops.dpmpp_2m_update(ops._f32c(sample), m0, m1, sigma_t / sigma_s0, c2, 0.5 * c2, 1.0 / r0)
+        c1, c2, c3, rinv = self._update_coefficients(True)
+        return ops.dpmpp_2m_update(ops._f32c(sample), model_output_list[-1], model_output_list[-2], c1, c2, c3, rinv)
+
+    def _advance(self, x0_pred, sample):
+        """Push the new data prediction into the history and take the solver step (:924-941)."""
+        n, cfg = len(self.timesteps), self.config
+        last = self.step_index == n - 1
+        first_order_last = last and (cfg.euler_at_final or (cfg.lower_order_final and n < 15) or cfg.final_sigmas_type == "zero")
+        self.model_outputs = self.model_outputs[1:] + [x0_pred]
+        if cfg.solver_order == 1 or self.lower_order_nums < 1 or first_order_last:
+            prev = self.dpm_solver_first_order_update(x0_pred, sample=sample)
+        else:
+            prev = self.multistep_dpm_solver_second_order_update(self.model_outputs, sample=sample)
+        self.lower_order_nums = min(self.lower_order_nums + 1, cfg.solver_order)
+        return prev
+
+    def _centred_uncertainty(self, x0_pred, timestep, sample):
+        """The estimator of :943-968 with its upstream quirk: the 'epsilon' it centres on is the converted x0 prediction."""
+        a = self.alphas_cumprod[int(timestep)]
+        pred_original_sample = ops.x0_from_eps(x0_pred, ops._f32c(sample), (1 - a) ** 0.5, a ** 0.5)           # :946
+        uncertainty = torch.empty_like(x0_pred)
+        for m in range(self.M):
+            noise = self.noise_source.draw(sample.shape, sample.device)
+            if self.predict_next:
+                raise NotImplementedError("predict_next not implemented yet")                                  # :955
+            x_t_hat = self.scale_model_input(ops.axpby(pred_original_sample, noise, torch.sqrt(a), torch.sqrt(1 - a)), timestep)
+            eps_m = self.predict_model(x_t_hat, timestep)
+            self.denoiser_calls += 1
+            ops.mc_centered_accum(ops._f32c(eps_m), x0_pred, uncertainty, m, self.M)
+        return pred_original_sample, uncertainty
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=True):
-        """:876-977."""
+        """:876-977 (``return_dict`` is ignored upstream too)."""
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         if self.step_index is None:
             self._init_step_index(timestep)
-        n = len(self.timesteps)
-        lower_order_final = (self.step_index == n - 1) and (
-            self.config.euler_at_final or (self.config.lower_order_final and n < 15) or self.config.final_sigmas_type == "zero")
-        model_output = self.convert_model_output(model_output, sample=sample)
-        for i in range(self.config.solver_order - 1):
-            self.model_outputs[i] = self.model_outputs[i + 1]
-        self.model_outputs[-1] = model_output
-        if self.config.solver_order == 1 or self.lower_order_nums < 1 or lower_order_final:
-            prev_sample = self.dpm_solver_first_order_update(model_output, sample=sample)
-        else:
-            prev_sample = self.multistep_dpm_solver_second_order_update(self.model_outputs, sample=sample)
-        if self.lower_order_nums < self.config.solver_order:
-            self.lower_order_nums += 1
-
-        is_uncertainty_timestep = self.timestep_end_step <= timestep <= self.timestep_after_step
-        if is_uncertainty_timestep:
-            alpha_prod_t = self.alphas_cumprod[int(timestep)]
-            beta_prod_t = 1 - alpha_prod_t
-            # upstream quirk (:946): model_output is the converted x0 prediction here
-            pred_original_sample = ops.x0_from_eps(model_output, ops._f32c(sample), beta_prod_t ** 0.5, alpha_prod_t ** 0.5)
-            uncertainty = torch.empty_like(model_output)
-            for m in range(self.M):
-                noise = self.noise_source.draw(sample.shape, sample.device)
-                if self.predict_next:
-                    raise NotImplementedError("predict_next not implemented yet")        # :955
-                x_t_hat = ops.axpby(pred_original_sample, noise, torch.sqrt(alpha_prod_t), torch.sqrt(1 - alpha_prod_t))
-                x_t_hat = self.scale_model_input(x_t_hat, timestep)
-                model_output_uc = self.predict_model(x_t_hat, timestep)
-                self.denoiser_calls += 1
-                ops.mc_centered_accum(ops._f32c(model_output_uc), model_output, uncertainty, m, self.M)
+        x0_pred = self.convert_model_output(model_output, sample=sample)
+        prev_sample = self._advance(x0_pred, sample)
+        in_window = self.timestep_end_step <= timestep <= self.timestep_after_step
+        if in_window:
+            pred_original_sample, uncertainty = self._centred_uncertainty(x0_pred, timestep, sample)
         self._step_index += 1
-        if is_uncertainty_timestep:
+        if in_window:
             return SchedulerUncertaintyOutput(prev_sample=prev_sample, uncertainty=uncertainty,
-                                              pred_original_sample=pred_original_sample, pred_epsilon=model_output)
+                                              pred_original_sample=pred_original_sample, pred_epsilon=x0_pred)
         return SchedulerOutput(prev_sample=prev_sample)
 
     def scale_model_input(self, sample, *args, **kwargs):
@@ -229,9 +220,7 @@ class KDPM2DiscreteSchedulerUncertainty(SchedulerMixin, ConfigMixin):
             if timesteps.numel() != 1:
                 raise NotImplementedError("add_noise: per-sample timesteps are not on the accelerated path")
             timesteps = int(timesteps.reshape(-1)[0])
-        cand = (self.timesteps == timesteps).nonzero()
-        idx = len(self.timesteps) - 1 if len(cand) == 0 else (cand[1].item() if len(cand) > 1 else cand[0].item())
-        alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(self.sigmas[idx])
+        alpha_t, sigma_t, _ = _half_logsnr(self.sigmas[self._locate(timesteps)])
         return ops.axpby(ops._f32c(original_samples), ops._f32c(noise), alpha_t, sigma_t)
 
     def __len__(self):

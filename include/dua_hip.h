@@ -287,14 +287,17 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
 /* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
 int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                               void* stream);
-/* Diagnostic engine selector for dua_conv3x3_bf16x3_presplit (returns the previous mode): 1 = LDS-DMA kernels, 256x256
- * tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel; 3 = LDS-DMA with zero-record
- * buffer descriptors (every DMA returns zeros at once: a timing-only run that prices the memory path; wrong results). */
+/* A/B engine selector for the presplit conv / GEMM kernels (returns the previous mode, or DUA_EINVAL): 1 = LDS-DMA kernels,
+ * 256x256 tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel (bf16x3); 6 = per-tap instead of
+ * row-shift f16f8 loop.  Process-global and unsynchronised: set it before queueing work.  The zero-record-descriptor modes
+ * 3 - 5 (timing-only, wrong results) exist only in the diagnostic library built with -DDUA_CONV_TIMING
+ * (scripts/conv_tile_timing.py --build); the product library rejects them. */
 int dua_set_dma_conv(int mode);
 /* A/B switch of the GroupNorm-apply kernels (returns the previous value): 1 = 8 channels per lane with 16-byte stores on
  * every plane where the channel counts allow (default), 0 = always the 4-channel-per-lane kernel. */
 int dua_set_gn_apply_wide(int on);
-/* Start-up stagger of the persistent LDS-DMA workgroups (tuning knob): `phases` phases per XCD (0 / 1 = off), each
+/* (diagnostic build only; the product library accepts phases <= 1 = off)
+ * Start-up stagger of the persistent LDS-DMA workgroups (tuning knob): `phases` phases per XCD (0 / 1 = off), each
  * `percent` % of 1/phases of the estimated tile period; applied when every workgroup owns >= min_tiles tiles.  Spreads
  * the epilogues (output / residual HBM traffic) of the 256 workgroups over the tile period instead of one burst. */
 int dua_set_conv_stagger(int phases, int percent, int min_tiles);

@@ -14,14 +14,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "diffusion-uncertainty_amd")
-TLIB = os.path.join(PKG, "libdua_hip_timing.so")
+DIAG = os.path.join(ROOT, "scripts", "diag", "build")          # diagnostic builds stay out of the product package directory
+TLIB = os.path.join(DIAG, "libdua_hip_timing.so")
 
 
 def build(extra_flags=(), out=TLIB):
     objs = []
+    os.makedirs(DIAG, exist_ok=True)
     for src, extra in (("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []),
                        ("mfma_bf16x3.hip", ["-DDUA_CONV_TIMING"] + list(extra_flags)), ("attention.hip", [])):
-        o = os.path.join(PKG, "csrc", src.replace(".hip", ".o" if "bf16x3" not in src else ".timing.o"))
+        o = os.path.join(PKG, "csrc", src.replace(".hip", ".o")) if "bf16x3" not in src else os.path.join(DIAG, "mfma_bf16x3.timing.o")
         if "bf16x3" in src or not os.path.exists(o):
             subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
                                   + extra + ["-c", os.path.join(PKG, "csrc", src), "-o", o])
