@@ -10,7 +10,9 @@ sqrt(beta_t) z of the SAME prev_sample and a denoiser call each; ``predict_next`
 upstream (:272), so the zig-zag state x_t1 is never read and only the LAST call of a chain reaches
 ``uncertainty = mean_m (eps_m - eps)^2`` (:549).  With ``faithful_zigzag=False`` (default) the dead
 num_zigzag-1 calls per chain are skipped - their noise draws are still consumed, so every output is
-bit-identical to the faithful run; set ``scheduler.faithful_zigzag = True`` to execute them.
+bit-identical to the faithful run; set ``scheduler.faithful_zigzag = True`` to execute them.  ``step`` honours the
+``predict_next`` attribute like upstream (:533-535): set to False after construction, every chain walks the x_t1 zig-zag
+(``add_noise`` of the running x0 estimate, :545-546) and every forward is live - nothing is skipped then.
 """
 import torch
 
@@ -54,16 +56,24 @@ class DDIMSchedulerUncertainty(DDIMUncertaintyCore):
         in_window = self.in_uc_window(timestep)
         if in_window:
             uncertainty = torch.empty_like(pred_epsilon)
+            sb_t, sa_t = self._coefficients(timestep)[:2]
             for m in range(self.M):
+                x_t1 = pred_original_sample                                          # :530
                 for j in range(self.num_zigzag):
+                    last = j == self.num_zigzag - 1
                     noise = self.noise_source.draw(sample.shape, sample.device)      # :532
-                    if j != self.num_zigzag - 1 and not self.faithful_zigzag:
-                        continue                                                     # dead forward (F4)
-                    x_t_hat = self._renoise_next(prev_sample, noise, timestep)       # :538
+                    if self.predict_next:
+                        if not last and not self.faithful_zigzag:
+                            continue                                                 # dead forward (F4): x_t1 is never read
+                        x_t_hat = self._renoise_next(prev_sample, noise, timestep)   # :538
+                    else:
+                        x_t_hat = self.add_noise(x_t1, noise, timestep)              # :535
                     x_t_hat = self.scale_model_input(x_t_hat, timestep)
-                    model_output_uc = self.predict_model(x_t_hat, timestep)          # :541-544
+                    model_output_uc = ops._f32c(self.predict_model(x_t_hat, timestep))   # :541-544
                     self.denoiser_calls += 1
-                ops.mc_centered_accum(ops._f32c(model_output_uc), pred_epsilon, uncertainty, m, self.M)   # :549
+                    if not last and not self.predict_next:                           # :545-546, unclipped x0 of the forward
+                        x_t1 = ops.ddim_step(model_output_uc, x_t_hat, sb_t, sa_t, 0.0, 0.0, clip=False)[1]
+                ops.mc_centered_accum(model_output_uc, pred_epsilon, uncertainty, m, self.M)   # :549
         if not return_dict:
             return (prev_sample,)
         output = DDIMSchedulerUncertaintyOutput(prev_sample=prev_sample, pred_original_sample=pred_original_sample)

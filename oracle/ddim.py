@@ -48,13 +48,15 @@ def add_noise(tab, x0, noise, t):
 
 
 def step_zigzag_centered(tab, denoise, eps, t, x, n_steps, window, M, num_zigzag, eta=0.0,
-                         clip_sample=True, draw=torch.randn_like):
+                         clip_sample=True, draw=torch.randn_like, predict_next=True):
     """zigzag_centered.py:462-559.  window = (timestep_after_step, timestep_end_step).
 
     Returns dict(prev_sample, pred_original_sample[, uncertainty, pred_epsilon]).
     predict_next is hard-coded True in the reference (:272) so every MC chain
     re-noises prev_sample; the x_t1 zig-zag state (:545-546) is dead and only
-    the last of the num_zigzag forwards of each chain is used (:548).
+    the last of the num_zigzag forwards of each chain is used (:548).  With the attribute set to False after
+    construction, step() takes its other branch (:533-535): x_hat = add_noise(x_t1, noise, t) with x_t1 starting at
+    pred_original_sample and replaced by the unclipped x0 of each forward but the last (:545-546) - every forward live.
     """
     prev, x0, c = ddim_update(tab, eps, t, x, n_steps, eta, clip_sample)
     best_noise = draw(x0)                                            # :500, always drawn
@@ -65,10 +67,13 @@ def step_zigzag_centered(tab, denoise, eps, t, x, n_steps, window, M, num_zigzag
     if lo <= t <= hi:
         acc = torch.zeros_like(eps)
         for _ in range(M):
-            last = None
-            for _ in range(num_zigzag):
-                x_hat = renoise_next(tab, prev, draw(x0), t)
+            last, x_t1 = None, x0
+            for j in range(num_zigzag):
+                noise = draw(x0)
+                x_hat = renoise_next(tab, prev, noise, t) if predict_next else add_noise(tab, x_t1, noise, t)
                 last = denoise(x_hat, t)
+                if j != num_zigzag - 1:
+                    x_t1 = (x_hat - c["sqrt_b_t"] * last) / c["sqrt_a_t"]      # :545-546 (read only when not predict_next)
             acc += (last - eps) ** 2
         out["uncertainty"] = acc / M                                 # :549 mean_m (eps_m - eps)^2
         out["pred_epsilon"] = eps

@@ -544,7 +544,127 @@ def g12():
     save("g12_dpm_solver", **out)
 
 
+def g13():
+    """Full-size ADM-128 through the REFERENCE driver (generate_samples.py:127-233) and the reference scheduler
+    (uncertainty_zigzag_centered): B=1, 10 DDIM steps, M=2, num_zigzag=3, UC window (after_step 6, 3 steps), seeded weights.
+    The only additions around the reference code: a recording wrapper around the denoiser (inputs / outputs of the main pass of
+    selected timesteps, for the teacher-forced per-step comparison) and a re-seed of torch's CPU generator before every
+    scheduler.step() (seed 6000 + step index) so that a teacher-forced step consumes the same noise as the free-running chain."""
+    m = build_adm(ADM128, 128)
+    X_T, y = randn(131, 1, 3, 128, 128), torch.tensor([207])
+    rec = {"main": True, "calls": [], "n": 0}
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x, t, y=None):
+            o = self.inner(x, t, y=y)
+            rec["n"] += 1
+            if rec["main"]:
+                rec["calls"].append((x.clone(), int(t[0]), o[:, :3].clone()))
+            return o
+
+    wrapped = Recorder(m)
+    with _quiet:
+        s = RefZigzag.from_config(CONFIGS["adm128"], M=2, after_step=6, num_steps_uc=3, unet=wrapped, num_zigzag=3)
+        s.set_timesteps(10)
+    ref_step, k = s.step, [0]
+
+    def seeded_step(*a, **kw):
+        torch.manual_seed(6000 + k[0])
+        k[0] += 1
+        rec["main"] = False
+        try:
+            return ref_step(*a, **kw)
+        finally:
+            rec["main"] = True
+
+    s.step = seeded_step
+    with _quiet, torch.no_grad():
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, 1, torch.device("cpu"), wrapped, s)
+    assert len(rec["calls"]) == 10 and rec["n"] == 10 + 3 * 2 * 3, (len(rec["calls"]), rec["n"])
+    out = dict(X_T=X_T, y=y, seed=128, timesteps=s.timesteps, gen_images=r["gen_images"], uncertainty=r["uncertainty"], score=r["score"],
+               kept=np.array([0, 4, 6, 7, 8, 9]), window=np.array([6, 3, s.timestep_after_step, s.timestep_end_step]))
+    for i in out["kept"]:
+        x, t, eps = rec["calls"][int(i)]
+        assert t == int(s.timesteps[int(i)])
+        out[f"x{i}"], out[f"eps{i}"] = x, eps
+    u = r["uncertainty"][:, -1]                                     # percentile-0.9 mask of the final map (uncertainty_guidance.py:112)
+    q = torch.quantile(u.flatten(1).float(), 0.9, dim=1)
+    out["final_mask"] = (u > q.reshape(-1, 1, 1, 1)).to(torch.uint8)
+    save("g13_adm128_chain", **out)
+
+
+def g14():
+    """Dataset-level pixel-wise thresholds from the reference script itself: scripts/compute_threshold_pixel_wise.py
+    ``load_uncertainty_datasets`` (:118-165) run on temporary folders of ``uncertainty_*.pth`` / ``gen_images_*.pth`` files."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="dua_g14_")
+    try:
+        refimport.install_script_standins(os.path.join(tmp, "root"))
+        with _quiet:
+            script = refimport.load_reference_script("compute_threshold_pixel_wise")
+        out, case = {}, 0
+        for N, S, H, perc, kind in ((100, 2, 5, 0.15, "normal"), (257, 3, 4, 0.5, "ties"), (120, 1, 8, 0.9, "fp16ties"),
+                                     (1000, 1, 6, 0.15, "positive"), (101, 2, 3, 0.0, "min"), (99, 1, 3, 0.15, "skipped")):
+            g = torch.Generator().manual_seed(1400 + case)
+            u = torch.randn(N, S, 3, H, H, generator=g)
+            if kind == "ties":
+                u = (u * 2).round() / 2                             # many exact ties, negatives included
+            elif kind == "fp16ties":
+                u = 1000.0 + u * 0.3                                # distinct in fp32, tied after the .half() cast (ulp 0.5)
+            elif kind == "positive":
+                u = u.square() * 1e-3                               # what real uncertainty maps look like
+            folder = os.path.join(tmp, f"case{case}")
+            os.makedirs(folder)
+            torch.save(u, os.path.join(folder, "uncertainty_x_0.pth"))
+            torch.save(torch.zeros(1, dtype=torch.uint8), os.path.join(folder, "gen_images_0.pth"))
+            with _quiet:
+                res = script.load_uncertainty_datasets([folder], perc)
+            out[f"c{case}_u"], out[f"c{case}_meta"] = u, np.array([N, S, H, perc])
+            if kind == "skipped":
+                assert res == []                                    # files with fewer than 100 samples are skipped (:139-140)
+                out[f"c{case}_thr"] = np.zeros(0, dtype=np.float16)
+            else:
+                assert len(res) == 1 and tuple(res[0].shape) == (1, S, 3, H, H) and res[0].dtype == torch.float16
+                out[f"c{case}_thr"] = res[0][0]
+            case += 1
+        out["n_cases"] = case
+        save("g14_thresholds", **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def g15():
+    """zigzag_centered with ``predict_next = False`` (the attribute is hard-coded True in __init__ :272 but step() honours it
+    :533-535,545-546): the x_t1 zig-zag through add_noise, every forward live."""
+    out = {}
+    x, y = randn(3, 2, 3, 16, 16), torch.tensor([3, 7])
+    out["x"], out["y"] = x, y
+    tiny = build_adm(TINY_ADM, seed=5)
+    case = 0
+    for M, nz in ((2, 1), (2, 3), (3, 2)):
+        for t in (500, 400):
+            with _quiet:
+                s = RefZigzag.from_config(CONFIGS["adm128"], M=M, after_step=4, num_steps_uc=3, unet=tiny, num_zigzag=nz)
+                s.predict_next = False
+                s.set_timesteps(10)
+                s.prompt_embeds = y
+                with torch.no_grad():
+                    eps = tiny(x, torch.full((2,), t, dtype=torch.long), y=y)[:, :3]
+                    torch.manual_seed(1500 + case)
+                    o = s.step(eps, t, x)
+            out[f"c{case}_meta"] = np.array([M, nz, t, 1500 + case])
+            out[f"c{case}_eps"], out[f"c{case}_prev"], out[f"c{case}_unc"] = eps, o.prev_sample, o.uncertainty
+            case += 1
+    out["n_cases"] = case
+    save("g15_zigzag_x0", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

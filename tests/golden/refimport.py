@@ -12,7 +12,9 @@ in ``sys.modules``.  All arithmetic of ``step()`` lives in the reference's own
 files - the stand-in contributes only config plumbing.
 """
 import enum
+import glob
 import inspect
+import os
 import sys
 import types
 from collections import OrderedDict
@@ -128,6 +130,54 @@ def install():
     _mod("diffusers.models.resnet", ResnetBlock2D=ResnetBlock2D)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+class _PathStandIn(str):
+    """The handful of ``path.Path`` methods scripts/compute_threshold_pixel_wise.py touches (``path`` is not installed)."""
+
+    def __truediv__(self, other):
+        return _PathStandIn(os.path.join(self, str(other)))
+
+    def joinpath(self, *parts):
+        return _PathStandIn(os.path.join(self, *[str(q) for q in parts]))
+
+    def exists(self):
+        return os.path.exists(self)
+
+    def absolute(self):
+        return _PathStandIn(os.path.abspath(self))
+
+    @property
+    def parent(self):
+        return _PathStandIn(os.path.dirname(self))
+
+    def files(self, pattern="*"):
+        return [_PathStandIn(f) for f in sorted(glob.glob(os.path.join(self, pattern))) if os.path.isfile(f)]
+
+    def mkdir(self):
+        os.makedirs(self, exist_ok=True)
+
+
+def install_script_standins(scratch_dir):
+    """Stand-ins that let ``scripts/compute_threshold_pixel_wise.py`` be imported from /root/reference (read-only) without
+    touching it: ``path`` (not installed), ``diffusion_uncertainty.utils`` (imports omegaconf, not installed; only ``load_config``
+    is imported, never called by ``load_uncertainty_datasets``) and ``diffusion_uncertainty.paths`` (the real module creates
+    directories under the reference root at import: replaced by constants under ``scratch_dir``)."""
+    install()
+    _mod("path", Path=_PathStandIn)
+    import diffusion_uncertainty  # noqa: F401  (namespace of the reference package; the two submodules below are stand-ins)
+    root = _PathStandIn(scratch_dir)
+    _mod("diffusion_uncertainty.utils", load_config=lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stand-in")))
+    _mod("diffusion_uncertainty.paths", ROOT=root, CONFIG=root / "config", FID=root / "results" / "fid", RESULTS=root / "results")
+
+
+def load_reference_script(name):
+    """Import /root/reference/scripts/<name>.py as a module (its ``main`` is guarded by ``__name__``)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_script_" + name, os.path.join(REFERENCE_ROOT, "scripts", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def ddpm_base_config(**over):

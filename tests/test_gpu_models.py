@@ -590,3 +590,103 @@ def test_dpm_solver_vs_golden(golden):
     with pytest.raises(NotImplementedError):                         # :955
         for t in s2.timesteps.tolist():
             cur = s2.step(torch.zeros_like(cur), t, cur).prev_sample
+
+
+# ---------------------------------------------------------------- full-size chain (G13) and the round-2 fixtures
+# per precision: (teacher-forced eps abs, free-running score abs, free-running uncertainty rel, image LSB, min mask agreement)
+FULL_CHAIN_TOL = {"fp32": (1e-3, 1e-3, 2.5e-2, 1, 0.99), "f16x3": (1e-3, 1e-3, 2.5e-2, 1, 0.99),
+                  "bf16x3": (1e-3, 5e-3, 0.3, 2, 0.97), "f16f8": (1e-3, 1e-2, 0.6, 3, 0.95), "f16f6": (1e-3, 1e-2, 0.8, 3, 0.95)}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3", "f16f8", "f16f6"])
+def test_full_size_chain_vs_golden(golden, precision):
+    """Full-size ADM-128 through the driver, 10 DDIM steps, M=2, num_zigzag=3, window (6, 3), against the reference driver's own
+    run (G13): teacher-forced per step (the fixture's x_t in, eps compared; scheduler.step on the fixture's eps with the same
+    noise tape), free-running end to end, and the agreement of the percentile-0.9 mask of the final uncertainty map
+    (uncertainty_guidance.py:112).  The fp32-equivalent modes (fp32, f16x3) are held to the north star's 1e-3 END TO END."""
+    from oracle import adm
+    from diffusion_uncertainty_amd import ops
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    g = golden("g13_adm128_chain")
+    m, _ = build_adm(dict(adm.ADM128), int(g["seed"]))
+    m.precision = precision
+    tol_tf, tol_s, tol_u, tol_lsb, tol_mask = FULL_CHAIN_TOL[precision]
+    after, num = int(g["window"][0]), int(g["window"][1])
+    a = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=2, start_step_uc=after, num_steps_uc=num, predict_next=True,
+                           eta=0.0, num_zigzag=3, uncertainty_distance=1)
+    s = get_uncertainty_scheduler(a, None, m, init_scheduler_imagenet128())
+    s.set_timesteps(10)
+    y = T(g["y"]).to(dev)
+    s.prompt_embeds = y
+    ts = [int(t) for t in g["timesteps"]]
+    assert s.timesteps.tolist() == ts and (s.timestep_after_step, s.timestep_end_step) == (int(g["window"][2]), int(g["window"][3]))
+    # ---- teacher-forced: every kept step from the reference's own x_t
+    worst = 0.0
+    for i in [int(v) for v in g["kept"]]:
+        x = T(g[f"x{i}"]).to(dev)
+        eps = m(x, torch.full((1,), ts[i], dtype=torch.long, device=dev), y=y, out_channels_keep=3)
+        worst = max(worst, np.abs(eps.cpu().numpy() - g[f"eps{i}"]).max())
+        if after <= i < after + num:
+            torch.manual_seed(6000 + i)
+            o = s.step(T(g[f"eps{i}"]).to(dev), ts[i], x)
+            ref_u = g["uncertainty"][:, i - after]
+            eu = np.abs(o.uncertainty.cpu().numpy() - ref_u).max() / np.abs(ref_u).max()
+            assert eu < tol_u, (precision, i, eu)
+            np.testing.assert_allclose(o.pred_epsilon.cpu().numpy(), g["score"][:, i - after], rtol=0, atol=1e-6)
+    print(f"{precision}: teacher-forced max |eps - reference| over {len(g['kept'])} steps = {worst:.2e}")
+    assert worst < tol_tf
+    # ---- free-running end to end, same noise tape (the fixture re-seeds the CPU generator before every scheduler.step)
+    s = get_uncertainty_scheduler(a, None, m, init_scheduler_imagenet128())
+    s.set_timesteps(10)
+    inner, k = s.step, [0]
+
+    def seeded_step(*aa, **kw):
+        torch.manual_seed(6000 + k[0])
+        k[0] += 1
+        return inner(*aa, **kw)
+
+    s.step = seeded_step
+    r = gen(T(g["X_T"]), T(g["y"]), 1, torch.device(dev), m, s)
+    es = np.abs(r["score"].numpy() - g["score"]).max()
+    eu = (np.abs(r["uncertainty"].numpy() - g["uncertainty"]) / (np.abs(g["uncertainty"]) + 1e-3 * np.abs(g["uncertainty"]).max())).max()
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["gen_images"].astype(int))
+    mask, _q = ops.quantile_mask(r["uncertainty"][:, -1].contiguous().to(dev), 0.9)
+    agree = (mask.cpu().numpy() == g["final_mask"]).mean()
+    print(f"{precision}: end-to-end score err {es:.2e}, uncertainty rel err {eu:.2e}, image LSB diffs {(d > 0).mean():.2e} (max {d.max()}), "
+          f"percentile-0.9 mask agreement {100 * agree:.3f} %")
+    assert es < tol_s and eu < tol_u and d.max() <= tol_lsb and agree >= tol_mask
+
+
+def test_thresholds_vs_reference_script(golden):
+    """a15: dua_pixelwise_order_statistic against the reference script's own load_uncertainty_datasets outputs (G14), bit for bit."""
+    from diffusion_uncertainty_amd.thresholds import compute_threshold_pixel_wise
+    g = golden("g14_thresholds")
+    n = 0
+    for c in range(int(g["n_cases"])):
+        if g[f"c{c}_thr"].size == 0:
+            continue
+        thr = compute_threshold_pixel_wise(T(g[f"c{c}_u"]).to(dev), float(g[f"c{c}_meta"][3]))
+        assert thr.dtype == torch.float16
+        np.testing.assert_array_equal(thr.cpu().numpy().view(np.uint16), g[f"c{c}_thr"].view(np.uint16))
+        n += 1
+    assert n >= 5
+
+
+def test_zigzag_x0_branch_vs_golden(golden):
+    """zigzag_centered with predict_next = False (set after construction, as upstream allows): x_t1 zig-zag, every forward live."""
+    g = golden("g15_zigzag_x0")
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    m, _ = build_adm(TINY_ADM, 5)
+    for c in range(int(g["n_cases"])):
+        M, nz, t, seed = [int(v) for v in g[f"c{c}_meta"]]
+        s = _sched("uncertainty_zigzag_centered", m, M=M, num_zigzag=nz)
+        s.predict_next = False
+        s.set_timesteps(10)
+        s.prompt_embeds = y
+        torch.manual_seed(seed)
+        o = s.step(T(g[f"c{c}_eps"]).to(dev), t, x)
+        np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"c{c}_prev"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o.uncertainty.cpu().numpy(), g[f"c{c}_unc"], rtol=1e-2, atol=1e-6)
+        assert s.denoiser_calls == M * nz                  # nothing skipped on this branch

@@ -399,3 +399,37 @@ def test_g12_dpm_solver(golden):
     np.testing.assert_allclose(r["uncertainty"].numpy(), g["drv_uncertainty"], rtol=5e-3, atol=1e-6)
     d = np.abs(r["gen_images"].numpy().astype(int) - g["drv_gen_images"].astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+def test_g14_thresholds_vs_reference_script(golden):
+    """a15: the oracle restatement against outputs of the reference script's own load_uncertainty_datasets (bit-exact fp16)."""
+    from oracle import thresholds
+    g = golden("g14_thresholds")
+    for c in range(int(g["n_cases"])):
+        N, S, H, perc = g[f"c{c}_meta"]
+        thr = thresholds.compute_threshold_pixel_wise(T(g[f"c{c}_u"]), float(perc), min_samples=100)
+        if g[f"c{c}_thr"].size == 0:
+            assert thr is None and N < 100
+            continue
+        assert thr.dtype == torch.float16 and tuple(thr.shape) == (int(S), 3, int(H), int(H))
+        np.testing.assert_array_equal(thr.numpy().view(np.uint16), g[f"c{c}_thr"].view(np.uint16))
+
+
+def test_g15_zigzag_x0_branch(golden):
+    """zigzag_centered with predict_next = False (x_t1 zig-zag through add_noise): oracle vs the reference's step()."""
+    g = golden("g15_zigzag_x0")
+    x, y = T(g["x"]), T(g["y"])
+    sd = tiny_adm()
+    tab = TABLES["adm128"]()
+    ts = schedule.leading_timesteps(1000, 10)
+    window = schedule.uc_window(ts, 4, 3)
+
+    def den(xx, t, train=False):
+        return adm.forward(sd, TINY_ADM, xx, torch.full((xx.shape[0],), int(t), dtype=torch.long), y)[:, :3]
+
+    for c in range(int(g["n_cases"])):
+        M, nz, t, seed = [int(v) for v in g[f"c{c}_meta"]]
+        torch.manual_seed(seed)
+        o = ddim.step_zigzag_centered(tab, den, T(g[f"c{c}_eps"]), t, x, 10, window, M, nz, predict_next=False)
+        np.testing.assert_array_equal(o["prev_sample"].numpy(), g[f"c{c}_prev"])
+        np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"c{c}_unc"], rtol=1e-4, atol=1e-6)
