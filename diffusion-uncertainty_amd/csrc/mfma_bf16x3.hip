@@ -50,6 +50,8 @@ struct XTileP {
     int H, W, Cin, nchw_out;
     int ntm, ntn;
     float* colsum;                   // optional [ceil(M/64)][2][N] column sums / sums of squares of C per 64-row block
+    const float* Cscale;             // F16 (f16x3): per weight row 2^-s of the packed planes (padded to the tile grid)
+    float a_scale;                   // F16: power of two applied to A before the fp16 split (alpha carries its inverse)
 };
 
 __device__ __forceinline__ float gelu_x(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -64,7 +66,20 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-template <int MODE, bool SILU_IN, bool PRESPLIT, bool BSPLIT>
+// f16x3 split of four values scaled by sc: hi = fp16(s), lo = fp16(s - hi).  hi saturates at +-65504 and lo then takes the
+// remainder (also saturating): out-of-range operands degrade gracefully instead of turning into inf.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4h(float4 v, float sc, h16x4& hi, h16x4& lo) {
+    float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)fminf(fmaxf(f[j], -65504.f), 65504.f);
+        hi[j] = h;
+        lo[j] = (_Float16)fminf(fmaxf(f[j] - (float)h, -65504.f), 65504.f);
+    }
+}
+
+template <int MODE, bool SILU_IN, bool PRESPLIT, bool BSPLIT, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];      // 80 KB: two workgroups fill a CU's 160 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -228,12 +243,19 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         } else if (SILU_IN) {
             v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
         }
-        bf16x4 hi, lo;
-        split4(v, hi, lo);
         const int row = r0 + 32 * i;
         __bf16* base = lds + buf * BUF + row * LDH + 8 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 4 * (c4 & 1);
-        *(bf16x4*)base = hi;
-        *(bf16x4*)(base + PLANE) = lo;
+        if (F16) {
+            h16x4 hi, lo;
+            split4h(v, p.a_scale, hi, lo);
+            *(h16x4*)base = hi;
+            *(h16x4*)(base + PLANE) = lo;
+        } else {
+            bf16x4 hi, lo;
+            split4(v, hi, lo);
+            *(bf16x4*)base = hi;
+            *(bf16x4*)(base + PLANE) = lo;
+        }
     };
     auto store_b = [&](int buf, int i, uint4 u) {       // BSPLIT: fp32 row chunk -> hi / lo planes of the B tile
         bf16x4 hi, lo;
@@ -273,23 +295,24 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
-    struct XFrag { bf16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1; };
+    typedef typename frag8<F16>::type fr8;
+    struct XFrag { fr8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1; };
     auto read_frag = [&](int buf, int s) -> XFrag {       // s = 16-deep sub-step 0 / 1 of the 32-deep tile
         XFrag f;
         const int cs = 8 * ((2 * s + kh) ^ ((lr >> 2) & 3));     // rows lr, lr + 32 (+64) share the swizzle
         const __bf16* a = lds + buf * BUF + (wm * 64 + lr) * LDH + cs;
         const __bf16* b = lds + buf * BUF + 2 * PLANE + (wn * 64 + lr) * LDH + cs;
-        f.ah0 = *(const bf16x8*)a;
-        f.ah1 = *(const bf16x8*)(a + 32 * LDH);
-        f.al0 = *(const bf16x8*)(a + PLANE);
-        f.al1 = *(const bf16x8*)(a + PLANE + 32 * LDH);
-        f.bh0 = *(const bf16x8*)b;
-        f.bh1 = *(const bf16x8*)(b + 32 * LDH);
-        f.bl0 = *(const bf16x8*)(b + PLANE);
-        f.bl1 = *(const bf16x8*)(b + PLANE + 32 * LDH);
+        f.ah0 = *(const fr8*)a;
+        f.ah1 = *(const fr8*)(a + 32 * LDH);
+        f.al0 = *(const fr8*)(a + PLANE);
+        f.al1 = *(const fr8*)(a + PLANE + 32 * LDH);
+        f.bh0 = *(const fr8*)b;
+        f.bh1 = *(const fr8*)(b + 32 * LDH);
+        f.bl0 = *(const fr8*)(b + PLANE);
+        f.bl1 = *(const fr8*)(b + PLANE + 32 * LDH);
         return f;
     };
-#define XM(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0);
+#define XM(A, B, ACC) ACC = mfma16(A, B, ACC);
 #define XMFMA12(F)                                                                        \
     XM(F.al0, F.bh0, acc[0][0]) XM(F.al0, F.bh1, acc[0][1]) XM(F.al1, F.bh0, acc[1][0]) XM(F.al1, F.bh1, acc[1][1]) \
     XM(F.ah0, F.bl0, acc[0][0]) XM(F.ah0, F.bl1, acc[0][1]) XM(F.ah1, F.bl0, acc[1][0]) XM(F.ah1, F.bl1, acc[1][1]) \
@@ -327,8 +350,12 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         float* patch = reinterpret_cast<float*>(lds) + wave * (32 * 64);
         const int c4e = lane & 15, rre = lane >> 4;
         const int colq = n0 + wn * 64 + 4 * c4e;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(p.alpha, p.alpha, p.alpha, p.alpha);
         if (p.bias && colq < p.N) bq = *(const float4*)(p.bias + colq);
+        if (F16) {                 // (Cscale is padded to the tile grid)
+            const float4 w4 = *(const float4*)(p.Cscale + colq);
+            sq.x *= w4.x; sq.y *= w4.y; sq.z *= w4.z; sq.w *= w4.w;
+        }
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;      // this lane's column sums / sums of squares
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
                 const int row = m0 + wm * 64 + mi * 32 + rl;
                 float4 v = *(const float4*)(patch + rl * 64 + 4 * c4e);
                 if (row < p.M && colq < p.N) {
-                    v.x = v.x * p.alpha + bq.x; v.y = v.y * p.alpha + bq.y; v.z = v.z * p.alpha + bq.z; v.w = v.w * p.alpha + bq.w;
+                    v.x = v.x * sq.x + bq.x; v.y = v.y * sq.y + bq.y; v.z = v.z * sq.z + bq.z; v.w = v.w * sq.w + bq.w;
                     if (p.act_out == 2) { v.x = gelu_x(v.x); v.y = gelu_x(v.y); v.z = gelu_x(v.z); v.w = gelu_x(v.w); }
                     if (p.res) {
                         const float4 q = *(const float4*)(p.res + (long)row * p.ldr + colq);
@@ -374,11 +401,12 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
             const int col = n0 + wn * 64 + ni * 32 + lr;
             if (col >= p.N) continue;
             const float bv = p.bias ? p.bias[col] : 0.f;
+            const float sv = F16 ? p.alpha * p.Cscale[col] : p.alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row >= p.M) continue;
-                float v = acc[mi][ni][r] * p.alpha + bv;
+                float v = acc[mi][ni][r] * sv + bv;
                 if (p.act_out == 2) v = gelu_x(v);
                 if (p.res) v += p.res[(long)row * p.ldr + col];
                 if (MODE == XMODE_CONV && p.nchw_out) {
@@ -391,12 +419,12 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         }
 }
 
-template <int MODE, bool SILU_IN = false, bool PRESPLIT = false, bool BSPLIT = false>
+template <int MODE, bool SILU_IN = false, bool PRESPLIT = false, bool BSPLIT = false, bool F16 = false>
 static int launch_x(XTileP& p, hipStream_t s, int batch = 1) {
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = (p.N + BN - 1) / BN;
     if (p.batch_inner < 1) p.batch_inner = 1;
-    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN, PRESPLIT, BSPLIT>), dim3(p.ntm * p.ntn, batch), 256, 0, s, p);
+    hipLaunchKernelGGL((k_xtile<MODE, SILU_IN, PRESPLIT, BSPLIT, F16>), dim3(p.ntm * p.ntn, batch), 256, 0, s, p);
     return dua_check_launch("dua bf16x3 tile kernel");
 }
 
@@ -1651,6 +1679,27 @@ extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* 
     p.M = M; p.N = N; p.K1 = K1; p.K2 = K2; p.lda1 = lda1; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
     p.act_out = act_out; p.alpha = alpha; p.colsum = colsum;
     return act_in ? launch_x<XMODE_GEMM, true>(p, as_stream(stream)) : launch_x<XMODE_GEMM, false>(p, as_stream(stream));
+}
+
+// dua_gemm_bf16x3 on the fp32-equivalent split: fp32 A scaled by act_scale and split into fp16 hi + lo on the fly (saturating),
+// W packed by dua_pack_weight_f16x3; the epilogue applies alpha / act_scale and the per-row weight exponents.
+extern "C" int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* packed,
+                              const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
+                              int act_out, float alpha, float* colsum, float act_scale, void* stream) {
+    DUA_REQUIRE(!colsum || (N % 4 == 0 && ldc == N && (!residual || ldr % 4 == 0)), "dua_gemm_f16x3: colsum needs N %% 4 == 0 and a dense row-major C");
+    DUA_REQUIRE(A1 && packed && C && M > 0 && N > 0 && K1 > 0 && K2 >= 0, "dua_gemm_f16x3: bad arguments");
+    DUA_REQUIRE((K1 + K2) % BK == 0 && (K2 == 0 || K1 % BK == 0), "dua_gemm_f16x3: K (and K1 for a two-source A) must be multiples of 32");
+    DUA_REQUIRE(lda1 % 4 == 0 && (K2 == 0 || lda2 % 4 == 0) && (K2 == 0) == (A2 == nullptr), "dua_gemm_f16x3: bad A operands");
+    DUA_REQUIRE(act_in == 0 || act_in == 1, "dua_gemm_f16x3: act_in must be 0 or 1");
+    DUA_REQUIRE(act_scale > 0.f, "dua_gemm_f16x3: act_scale must be positive");
+    XTileP p{};
+    size_t plane = dua_bf16x3_plane_elems(N, K1 + K2);
+    p.A1 = A1; p.A2 = A2; p.Bhi = (const __bf16*)packed; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = C;
+    p.M = M; p.N = N; p.K1 = K1; p.K2 = K2; p.lda1 = lda1; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
+    p.act_out = act_out; p.alpha = alpha / act_scale; p.colsum = colsum;
+    p.Cscale = (const float*)(p.Bhi + 2 * plane); p.a_scale = act_scale;
+    return act_in ? launch_x<XMODE_GEMM, true, false, false, true>(p, as_stream(stream))
+                  : launch_x<XMODE_GEMM, false, false, false, true>(p, as_stream(stream));
 }
 
 // Batched  C[b] = alpha * A[b] * B[b]^T  with BOTH operands fp32 activations split on the fly (attention products

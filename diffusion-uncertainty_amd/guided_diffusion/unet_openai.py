@@ -182,8 +182,8 @@ class _Ctx:
         self.film_all = None
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
         # (False | True = bf16x3 planes | "f16f8" planes | "f16f6" planes: 3x3 convs whose width divides 256 only)
-        # "f16x3" (fp32-equivalent): 3x3 convs and qkv on fp16 hi / lo planes; the products that take raw fp32 activations
-        # (1x1 skip, proj_out, attention) stay on the exact fp32 engines
+        # "f16x3" (fp32-equivalent): 3x3 convs and qkv on fp16 hi / lo planes written by the GroupNorm kernels, 1x1 skip / proj_out
+        # with the raw fp32 operand split on the fly (same 22-bit split); the attention products stay on the exact fp32 flash kernel
         assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6", "f16x3"), model.precision
         self.split_mode = model.precision not in ("fp32", "f16x3")          # on-the-fly bf16 split of raw fp32 operands
         self.presplit = model.precision != "fp32"
@@ -219,6 +219,9 @@ class _Ctx:
             elif kind == "qkvf":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16f8(wq), bq)
+            elif kind == "w1h":
+                w = mod.weight.detach()
+                cache[key] = ops.pack_weight_f16x3(w.reshape(w.shape[0], w.shape[1]).contiguous())
             elif kind == "w1x":
                 w = mod.weight.detach()
                 cache[key] = ops.pack_weight_bf16x3(w.reshape(w.shape[0], w.shape[1]).contiguous())
@@ -272,6 +275,8 @@ class _Ctx:
         n_out = mod.weight.shape[0]
         K = a.shape[1] + (0 if a2 is None else a2.shape[1])
         colsum = colsum and self.model.fuse_gn_stats
+        if self.model.precision == "f16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:     # fp32 A split on the fly into fp16 hi + lo
+            return ops.gemm_f16x3(a, self.packed(mod, "w1h"), n_out, bias=mod.bias, a2=a2, residual=residual, colsum=colsum)
         if self.split_mode and K % 32 == 0 and a.shape[1] % 32 == 0:      # fp32 A split on the fly: the bf16x3 tile engine in both modes
             return ops.gemm_bf16x3(a, self.packed(mod, "w1x"), n_out, bias=mod.bias, a2=a2, residual=residual, colsum=colsum)
         return ops.gemm(a, self.packed(mod, "w1"), bias=mod.bias, a2=a2, residual=residual, colsum=colsum)

@@ -373,6 +373,9 @@ def pack_conv3x3_weight(w):
 # Power-of-two scale of the f16x3 activation planes (GroupNorm / SiLU outputs): |x| up to 1023 stays finite in fp16 and
 # every |x| >= 2^-9 keeps its 22 significant bits.
 F16X3_ACT_SCALE = 64.0
+# ... of raw residual-stream operands split on the fly (1x1 skip convolutions, proj_out): |x| up to 4094 stays in fp16's range
+# (beyond it the lo half takes over at reduced precision), 22 significant bits down to 2^-7.
+F16X3_RAW_SCALE = 16.0
 
 
 # Optional per-launch timing hook used by bench.py: an object with .record(kind, flops, start_evt, end_evt).
@@ -558,6 +561,21 @@ def gemm_bf16x3(a1, planes, n_out, bias=None, a2=None, residual=None, act_in=0, 
         c._dua_colsums_rows = ws
     check(_lib.lib().dua_gemm_bf16x3(_p(a1), K1, K1, _p(a2), K2, max(K2, 4), _p(planes), _p(bias), _p(residual), n_out, _p(c), n_out,
                                      M, n_out, int(act_in), int(act_out), float(alpha), _p(ws), _stream()), "dua_gemm_bf16x3")
+    return c
+
+
+def gemm_f16x3(a1, packed, n_out, bias=None, a2=None, residual=None, act_in=0, act_out=0, alpha=1.0, colsum=False, act_scale=None):
+    """gemm_bf16x3 on the fp32-equivalent split (fp32 A scaled and split into fp16 hi + lo on the fly; pack_weight_f16x3 weights)."""
+    _req(a1, name="a1")
+    M, K1 = a1.shape
+    K2 = 0 if a2 is None else a2.shape[1]
+    c = torch.empty((M, n_out), device=a1.device, dtype=torch.float32)
+    ws = _colsum_ws(M, n_out, a1.device, colsum)
+    if ws is not None:
+        c._dua_colsums_rows = ws
+    check(_lib.lib().dua_gemm_f16x3(_p(a1), K1, K1, _p(a2), K2, max(K2, 4), _p(packed), _p(bias), _p(residual), n_out, _p(c), n_out,
+                                    M, n_out, int(act_in), int(act_out), float(alpha), _p(ws),
+                                    F16X3_RAW_SCALE if act_scale is None else float(act_scale), _stream()), "dua_gemm_f16x3")
     return c
 
 

@@ -284,6 +284,13 @@ int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const fl
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, float act_scale, void* stream);
 int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
                             int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream);
+/* dua_gemm_bf16x3 on the f16x3 split: C = alpha * [A1 | A2] W^T (+bias) (+residual) with the fp32 A operand (raw residual-stream
+ * activations: 1x1 skip convolution unet_openai.py:223, proj_out :295) multiplied by act_scale and split into fp16 hi + lo at
+ * LDS-store time.  hi saturates at +-65504 and lo then carries the remainder, so an out-of-range operand loses precision
+ * instead of becoming inf.  W from dua_pack_weight_f16x3. */
+int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* packed,
+                   const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
+                   int act_out, float alpha, float* colsum, float act_scale, void* stream);
 /* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
 int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                               void* stream);

@@ -669,7 +669,12 @@ def test_thresholds_vs_reference_script(golden):
             continue
         thr = compute_threshold_pixel_wise(T(g[f"c{c}_u"]).to(dev), float(g[f"c{c}_meta"][3]))
         assert thr.dtype == torch.float16
-        np.testing.assert_array_equal(thr.cpu().numpy().view(np.uint16), g[f"c{c}_thr"].view(np.uint16))
+        got, ref = thr.cpu().numpy(), g[f"c{c}_thr"]
+        np.testing.assert_array_equal(got, ref)                      # the selected VALUE, exactly
+        # bit for bit too, except where the k-th value is a zero tied between +0 and -0 samples (which of the tied samples an
+        # unstable argsort returns is not defined; uncertainty maps are sums of squares and never hold -0)
+        nz = ref != 0
+        np.testing.assert_array_equal(got.view(np.uint16)[nz], ref.view(np.uint16)[nz])
         n += 1
     assert n >= 5
 

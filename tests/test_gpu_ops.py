@@ -436,6 +436,30 @@ def test_conv3x3_f16x3(ops, N, H, W, Cin, Cout):
     assert e1 < max(2 * e32, 2e-6 * ref1.abs().max().item()), (e1, e32)
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0),
+                                        (4096, 256, 512, 256)])
+def test_gemm_f16x3(ops, M, N, K1, K2):
+    """1x1 skip / proj_out GEMM with the raw fp32 operand split into fp16 hi + lo on the fly: held to the exact fp32 engine's error."""
+    a1 = rnd(40, M, K1) * torch.logspace(-3, 2, K1)             # residual-stream-like dynamic range
+    a2 = rnd(41, M, K2) * 3 if K2 else None
+    w, b, res = rnd(42, N, K1 + K2) / math.sqrt(K1 + K2) * torch.logspace(-2, 1, N).reshape(-1, 1), rnd(43, N) * 0.1, rnd(44, M, N)
+    a = a1 if a2 is None else torch.cat([a1, a2], 1)
+    ref = a.double() @ w.double().t() + b.double() + res.double()
+    sc = ref.abs().amax(dim=0, keepdim=True)
+    dv = lambda t: None if t is None else t.to(dev)
+    c = ops.gemm_f16x3(dv(a1), ops.pack_weight_f16x3(w.to(dev)), N, bias=dv(b), a2=dv(a2), residual=dv(res), colsum=(N % 4 == 0))
+    c32 = ops.gemm(dv(a1), w.to(dev), bias=dv(b), a2=dv(a2), residual=dv(res))
+    e, e32 = ((c.cpu().double() - ref).abs() / sc).max().item(), ((c32.cpu().double() - ref).abs() / sc).max().item()
+    print(f"gemm f16x3 rel err {e:.2e}  fp32-MFMA rel err {e32:.2e}")
+    assert e < max(2 * e32, 2e-6), (e, e32)
+    # out-of-range operands: hi saturates at 65504 / scale and lo carries the remainder - finite and close, never inf
+    big = a1.clone()
+    big[0, 0] = 6000.0                                           # * 16 = 96000 > 65504
+    cb = ops.gemm_f16x3(dv(big), ops.pack_weight_f16x3(w.to(dev)), N, a2=dv(a2))
+    refb = (big if a2 is None else torch.cat([big, a2], 1)).double() @ w.double().t()
+    assert torch.isfinite(cb).all() and ((cb.cpu().double() - refb).abs() / refb.abs().amax(dim=0, keepdim=True)).max().item() < 1e-3
+
+
 def test_f16x3_fp16_subnormal_operands(ops):
     """The lo plane of small operands is a subnormal fp16: v_mfma_f32_32x32x16_f16 must not flush it (the format's error
     analysis in include/dua_hip.h assumes at most 2^-25 absolute on the scaled operand)."""
