@@ -83,6 +83,7 @@ SIGNATURES = {
     "dua_conv3x3_f16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _P]),
     "dua_gemm_f16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "dua_gemm_f16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _F, _P]),
+    "dua_attention_f16x3": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _F, _P]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),

@@ -25,6 +25,7 @@ struct AttnP {
     float scale;
     void* out_planes;        // split kernel only: write the result as f16f8 planes [B*T][C] (operand of the presplit proj GEMM)
     long plane_elems;
+    float planes_scale;      // f16x3 kernel: out_planes holds fp16 hi | fp16 lo of out * planes_scale
 };
 
 template <int CT /* 32-channel tiles: ceil(ch/32) */, int QW /* waves (32 queries each) per workgroup */>
@@ -184,12 +185,34 @@ __device__ __forceinline__ void asplit(float v, __bf16& h, __bf16& l) {
     l = (__bf16)(v - (float)h);
 }
 
-template <int CT16 /* 16-channel steps: ceil(ch/16) */, int QW>
+// fp16 split of the f16x3 format: hi = fp16(v) saturating at +-65504, lo = fp16(v - hi) (saturating): 22 significant bits
+__device__ __forceinline__ void asplit(float v, _Float16& h, _Float16& l) {
+    h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+    l = (_Float16)fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+}
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 amfma(abf16x8 a, abf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 amfma(af16x8 a, af16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <bool F16> struct AT { typedef __bf16 e; typedef abf16x8 v8; typedef abf16x4 v4; };
+template <> struct AT<true> { typedef _Float16 e; typedef af16x8 v8; typedef af16x4 v4; };
+// F16 (the f16x3 mode): the same kernel on fp16 hi / lo halves with power-of-two operand scales that keep the lo halves in
+// fp16's normal range - q * 2^8 (after the ch^-1/2 scale), k * 2^4 (logits rescaled by 2^-12 before the softmax), P * 2^12
+// (P in (0, 1]), v * 2^4 (the 2^-16 is folded into the final 1/l).  Every product is hi*hi + hi*lo + lo*hi: 2^-22 relative.
+#define DUA_AX_SQ 256.0f
+#define DUA_AX_SK 16.0f
+#define DUA_AX_SP 4096.0f
+#define DUA_AX_SV 16.0f
+
+template <int CT16 /* 16-channel steps: ceil(ch/16) */, int QW, bool F16 = false>
 __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
+    typedef typename AT<F16>::e el;
+    typedef typename AT<F16>::v8 abf16x8;
+    typedef typename AT<F16>::v4 abf16x4;
     constexpr int CHP = CT16 * 16, CT32 = (CHP + 31) / 32;
     constexpr int KP = CHP + 8;          // K tile row pitch (bf16): 16-byte reads of 16 consecutive rows hit distinct banks
     constexpr int VP = 40;               // V^T row pitch (32 keys + 8)
-    __shared__ __attribute__((aligned(16))) __bf16 Kh[32 * KP], Kl[32 * KP], Vh[CT32 * 32 * VP], Vl[CT32 * 32 * VP];
+    __shared__ __attribute__((aligned(16))) el Kh[32 * KP], Kl[32 * KP], Vh[CT32 * 32 * VP], Vl[CT32 * 32 * VP];
     const int ch = p.ch, C = p.heads * ch, T = p.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, kh = lane >> 5;
@@ -210,15 +233,16 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
             for (int j = 0; j < 8; j += 4) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c0 + j < ch) t = *(const float4*)(qrow + c0 + j);       // ch % 4 == 0: a float4 is all in or all out
-                v[j] = t.x * p.scale; v[j + 1] = t.y * p.scale; v[j + 2] = t.z * p.scale; v[j + 3] = t.w * p.scale;
+                const float qs = F16 ? p.scale * DUA_AX_SQ : p.scale;
+                v[j] = t.x * qs; v[j + 1] = t.y * qs; v[j + 2] = t.z * qs; v[j + 3] = t.w * qs;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { __bf16 a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; ql[c][j] = b_; }
+            for (int j = 0; j < 8; ++j) { el a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; ql[c][j] = b_; }
         }
     }
     // ---- zero the padded channel columns of the K tile (they meet zero Q channels: must not be NaN patterns) and all of V^T
-    for (int i = tid; i < 32 * KP; i += nthr) { Kh[i] = (__bf16)0.f; Kl[i] = (__bf16)0.f; }
-    for (int i = tid; i < CT32 * 32 * VP; i += nthr) { Vh[i] = (__bf16)0.f; Vl[i] = (__bf16)0.f; }
+    for (int i = tid; i < 32 * KP; i += nthr) { Kh[i] = (el)0.f; Kl[i] = (el)0.f; }
+    for (int i = tid; i < CT32 * 32 * VP; i += nthr) { Vh[i] = (el)0.f; Vl[i] = (el)0.f; }
 
     f32x16 o[CT32];
 #pragma unroll
@@ -266,15 +290,15 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
                 const float kf[4] = {kr[j].x, kr[j].y, kr[j].z, kr[j].w}, vf[4] = {vr[j].x, vr[j].y, vr[j].z, vr[j].w};
                 abf16x4 a_, b_;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { __bf16 x_, y_; asplit(kf[u], x_, y_); a_[u] = x_; b_[u] = y_; }
+                for (int u = 0; u < 4; ++u) { el x_, y_; asplit(F16 ? kf[u] * DUA_AX_SK : kf[u], x_, y_); a_[u] = x_; b_[u] = y_; }
                 *(abf16x4*)(Kh + r * KP + c) = a_;
                 *(abf16x4*)(Kl + r * KP + c) = b_;
                 // V^T with the key order of the accumulator rows: key = 16s + 8(j>>2) + 4h + (j&3)  <->  position 16s + 8h + j
                 const int kk = r & 15, pos = (r & 16) + 8 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    __bf16 x_, y_;
-                    asplit(vf[u], x_, y_);
+                    el x_, y_;
+                    asplit(F16 ? vf[u] * DUA_AX_SV : vf[u], x_, y_);
                     Vh[(c + u) * VP + pos] = x_;
                     Vl[(c + u) * VP + pos] = y_;
                 }
@@ -289,16 +313,16 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
 #pragma unroll
         for (int c = 0; c < CT16; ++c) {
             const abf16x8 ah = *(const abf16x8*)(Kh + lr * KP + 16 * c + 8 * kh), al = *(const abf16x8*)(Kl + lr * KP + 16 * c + 8 * kh);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[c], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[c], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[c], s, 0, 0, 0);
+            s = amfma(al, qh[c], s);
+            s = amfma(ah, ql[c], s);
+            s = amfma(ah, qh[c], s);
         }
         // ---- online softmax (query = lane; this lane holds keys (r&3) + 8(r>>2) + 4kh of the tile)
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            s[r] = key < T ? s[r] : -INFINITY;
+            s[r] = key < T ? (F16 ? s[r] * (1.0f / (DUA_AX_SQ * DUA_AX_SK)) : s[r]) : -INFINITY;
             mloc = fmaxf(mloc, s[r]);
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
@@ -310,8 +334,8 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
         for (int r = 0; r < 16; ++r) {
             const float e = __expf(s[r] - m_new);
             psum += e;
-            __bf16 x_, y_;
-            asplit(e, x_, y_);
+            el x_, y_;
+            asplit(F16 ? e * DUA_AX_SP : e, x_, y_);
             ph[r >> 3][r & 7] = x_;
             pl[r >> 3][r & 7] = y_;
         }
@@ -328,14 +352,14 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const abf16x8 vh = *(const abf16x8*)(Vh + (32 * t + lr) * VP + 16 * s2 + 8 * kh),
                               vl = *(const abf16x8*)(Vl + (32 * t + lr) * VP + 16 * s2 + 8 * kh);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], o[t], 0, 0, 0);
+                o[t] = amfma(vl, ph[s2], o[t]);
+                o[t] = amfma(vh, pl[s2], o[t]);
+                o[t] = amfma(vh, ph[s2], o[t]);
             }
     }
 #undef DUA_ATTNX_FETCH
     const float l_full = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_full;
+    const float inv = (F16 ? 1.0f / (DUA_AX_SP * DUA_AX_SV) : 1.0f) / l_full;
     const int q = q0 + wave * 32 + lr;
     if (q < T) {
         const long ro = ((long)b * T + q) * C + h * ch;
@@ -346,21 +370,40 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
                 const int c = 32 * t + 8 * g + 4 * kh;
                 if (c < ch) {
                     const float4 w = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
-                    if (p.out_planes) dua_store_f16f8_quad(p.out_planes, p.plane_elems, ro + c, w);
+                    if (p.out_planes && F16) {           // f16x3 planes: fp16 hi | fp16 lo of out * planes_scale
+                        const float f[4] = {w.x * p.planes_scale, w.y * p.planes_scale, w.z * p.planes_scale, w.w * p.planes_scale};
+                        af16x4 hh, ll;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { _Float16 x_, y_; asplit(f[u], x_, y_); hh[u] = x_; ll[u] = y_; }
+                        *(af16x4*)((_Float16*)p.out_planes + ro + c) = hh;
+                        *(af16x4*)((_Float16*)p.out_planes + p.plane_elems + ro + c) = ll;
+                    } else if (p.out_planes) dua_store_f16f8_quad(p.out_planes, p.plane_elems, ro + c, w);
                     else *(float4*)(p.out + ro + c) = w;
                 }
             }
     }
 }
 
-template <int CT16, int QW>
+template <int CT16, int QW, bool F16 = false>
 static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
     dim3 grid((p.T + QW * 32 - 1) / (QW * 32), B * p.heads);
-    hipLaunchKernelGGL((k_flash_attn_x<CT16, QW>), grid, 64 * QW, 0, s, p);
+    hipLaunchKernelGGL((k_flash_attn_x<CT16, QW, F16>), grid, 64 * QW, 0, s, p);
     return dua_check_launch("dua_attention_bf16x3");
 }
 
-static int attention_x_launch(const AttnP& p, int B, void* stream);
+static int attention_x_launch(const AttnP& p, int B, void* stream, bool f16 = false);
+
+/* The fused attention on the fp32-equivalent split (f16x3): fp32 output, or f16x3 planes of out * planes_scale (operand of
+ * dua_gemm_f16x3_presplit: proj_out) when out_planes != NULL. */
+extern "C" int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float planes_scale, int B, int T, int heads, int ch,
+                                   float scale, void* stream) {
+    DUA_REQUIRE(qkv && (out || out_planes) && B > 0 && T > 0 && heads > 0, "dua_attention_f16x3: bad arguments");
+    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_attention_f16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
+    DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_f16x3: B*heads must be <= 65535");
+    DUA_REQUIRE(!out_planes || planes_scale > 0.f, "dua_attention_f16x3: planes_scale must be positive");
+    AttnP p{qkv, out, T, heads, ch, scale, out_planes, (long)B * T * heads * ch, planes_scale};
+    return attention_x_launch(p, B, stream, true);
+}
 
 extern "C" int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream) {
     DUA_REQUIRE(qkv && out && B > 0 && T > 0 && heads > 0, "dua_attention_bf16x3: bad arguments");
@@ -380,12 +423,13 @@ extern "C" int dua_attention_bf16x3_planes(const float* qkv, void* out_planes, i
     return attention_x_launch(p, B, stream);
 }
 
-static int attention_x_launch(const AttnP& p, int B, void* stream) {
+static int attention_x_launch(const AttnP& p, int B, void* stream, bool f16) {
     const int T = p.T, ch = p.ch;
     hipStream_t s = as_stream(stream);
     const bool small = T <= 512;
 #define ATTNX_CASE(CTV) \
-    case CTV: return small ? launch_attn_x<CTV, 2>(p, B, s) : launch_attn_x<CTV, 4>(p, B, s);
+    case CTV: return f16 ? (small ? launch_attn_x<CTV, 2, true>(p, B, s) : launch_attn_x<CTV, 4, true>(p, B, s)) \
+                         : (small ? launch_attn_x<CTV, 2>(p, B, s) : launch_attn_x<CTV, 4>(p, B, s));
     switch ((ch + 15) / 16) {
         ATTNX_CASE(1) ATTNX_CASE(2) ATTNX_CASE(3) ATTNX_CASE(4) ATTNX_CASE(5) ATTNX_CASE(6) ATTNX_CASE(7) ATTNX_CASE(8)
     }

@@ -155,13 +155,15 @@ class AttentionBlock(nn.Module):
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0,
                                  split=ctx.gemm_split if (ctx.model.presplit_qkv and C % 32 == 0) else False)
         qkv = ctx.qkv(xn if isinstance(xn, ops.SplitPlanes) else xn.view(N * T, C), self)
-        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads, precision="bf16x3" if ctx.split_mode else "fp32",
-                              planes_out=(ctx.gemm_split == "f16f8"))
+        a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads,
+                              precision="f16x3" if ctx.model.precision == "f16x3" else ("bf16x3" if ctx.split_mode else "fp32"),
+                              planes_out=(ctx.gemm_split in ("f16f8", "f16x3")))
         if isinstance(a, ops.SplitPlanes):        # attention output already in the operand format: proj_out on the LDS-DMA kernel
-            key = (id(self.proj_out), "w1f")
+            key = (id(self.proj_out), "w1f" if a.fmt == "f16f8" else "w1hp")
             if key not in ctx.model._packed:
                 w = self.proj_out.weight.detach()
-                ctx.model._packed[key] = ops.pack_weight_f16f8(w.reshape(w.shape[0], w.shape[1]).contiguous())
+                pack = ops.pack_weight_f16f8 if a.fmt == "f16f8" else ops.pack_weight_f16x3
+                ctx.model._packed[key] = pack(w.reshape(w.shape[0], w.shape[1]).contiguous())
             out2d = ops.gemm_bf16x3_presplit(a, ctx.model._packed[key], C, bias=self.proj_out.bias, residual=x.view(N * T, C),
                                              colsum=ctx.model.fuse_gn_stats)
         else:
@@ -183,7 +185,7 @@ class _Ctx:
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
         # (False | True = bf16x3 planes | "f16f8" planes | "f16f6" planes: 3x3 convs whose width divides 256 only)
         # "f16x3" (fp32-equivalent): 3x3 convs and qkv on fp16 hi / lo planes written by the GroupNorm kernels, 1x1 skip / proj_out
-        # with the raw fp32 operand split on the fly (same 22-bit split); the attention products stay on the exact fp32 flash kernel
+        # with the raw fp32 operand split on the fly (same 22-bit split), attention (head dims <= 128) on the split flash kernel in the same format
         assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6", "f16x3"), model.precision
         self.split_mode = model.precision not in ("fp32", "f16x3")          # on-the-fly bf16 split of raw fp32 operands
         self.presplit = model.precision != "fp32"

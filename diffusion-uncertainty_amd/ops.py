@@ -667,6 +667,18 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32", planes_out=False):
     C = heads * ch
     assert qkv.shape == (B * T, 3 * C)
     assert B * heads <= 65535
+    if precision == "f16x3":
+        if ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):      # the split flash kernel on fp16 hi / lo halves
+            if planes_out and C % 32 == 0:
+                buf = torch.empty((2, B * T, C), device=qkv.device, dtype=torch.int16)
+                check(_lib.lib().dua_attention_f16x3(_p(qkv), None, _p(buf), F16X3_RAW_SCALE, B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()),
+                      "dua_attention_f16x3")
+                return SplitPlanes(buf, (B * T, C), "f16x3", F16X3_RAW_SCALE)
+            out = torch.empty((B * T, C), device=qkv.device, dtype=torch.float32)
+            check(_lib.lib().dua_attention_f16x3(_p(qkv), _p(out), None, 0.0, B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()),
+                  "dua_attention_f16x3")
+            return out
+        precision = "fp32"                       # wide heads (ADM-128's 16^2 / 8^2 levels): the exact fp32 paths
     if precision == "bf16x3" and ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
         if planes_out and C % 32 == 0:       # result straight in the operand format of the presplit proj GEMM
             buf = torch.empty((2, B * T, C), device=qkv.device, dtype=torch.int16)

@@ -291,6 +291,12 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
 int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* packed,
                    const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                    int act_out, float alpha, float* colsum, float act_scale, void* stream);
+/* Fused attention (dua_attention) with both products on the f16x3 split: q, k, P and v scaled by powers of two and split
+ * into fp16 hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2^-22 per product), softmax in fp32.  Head dims <= 128.
+ * out_planes != NULL: the result is written as f16x3 planes of out * planes_scale ([B*T][heads*ch] hi | lo), the operand of
+ * dua_gemm_f16x3_presplit (proj_out, unet_openai.py:295); otherwise fp32 `out`. */
+int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float planes_scale, int B, int T, int heads, int ch,
+                        float scale, void* stream);
 /* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
 int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                               void* stream);

@@ -249,6 +249,28 @@ def test_qkv_attention(ops, B, T_, heads, ch):
         O.ATTENTION_MODE = "auto"
 
 
+@pytest.mark.parametrize("B,T_,heads,ch", [(2, 64, 4, 32), (1, 16, 2, 64), (2, 256, 4, 96), (1, 1024, 4, 128), (2, 258, 16, 72), (1, 1, 2, 8),
+                                            (2, 77, 3, 40), (3, 64, 4, 256)])
+def test_qkv_attention_f16x3(ops, B, T_, heads, ch):
+    """The split flash kernel on fp16 hi / lo halves (f16x3): held to the error of the exact fp32 flash kernel against fp64
+    (within 2x), on O(1) and on large-magnitude q / k / v; the planes output decodes to the fp32 output."""
+    C = heads * ch
+    for mag in (1.0, 8.0):
+        qkv = (rnd(45, B * T_, 3 * C) * mag).to(dev)
+        q, k, v = [t.reshape(B, T_, heads, ch).permute(0, 2, 1, 3).double().cpu() for t in qkv.split(C, dim=1)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(ch), -1) @ v).permute(0, 2, 1, 3).reshape(B * T_, C)
+        out = ops.qkv_attention(qkv, B, T_, heads, ch, precision="f16x3")
+        o32 = ops.qkv_attention(qkv, B, T_, heads, ch, precision="fp32")
+        e, e32 = (out.cpu().double() - ref).abs().max().item(), (o32.cpu().double() - ref).abs().max().item()
+        print(f"attention f16x3 mag {mag}: err {e:.2e}  fp32 err {e32:.2e}")
+        assert e < max(2 * e32, 3e-6 * mag), (e, e32)
+        if ch <= 128 and C % 32 == 0:
+            pl = ops.qkv_attention(qkv, B, T_, heads, ch, precision="f16x3", planes_out=True)
+            assert pl.fmt == "f16x3"
+            h = pl.buf.view(torch.float16).reshape(2, B * T_, C).float().cpu()
+            np.testing.assert_allclose(((h[0] + h[1]) / pl.scale).numpy(), out.cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
 def test_softmax_layernorm_embeddings(ops):
     from oracle import adm
     for cols in (1, 64, 100, 258, 1024, 2048):
