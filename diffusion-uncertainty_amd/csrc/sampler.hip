@@ -198,6 +198,7 @@ extern "C" int dua_mc_reduce_var(const float* stack, float* u, size_t n, int M, 
 }
 
 // ---- exact per-sample quantile + strict mask ---------------------------------------------------
+// Streaming form (n > 65536 per sample; also the A/B reference of the register-resident kernel below):
 // One 1024-thread workgroup per sample.  Four 8-bit radix-select passes over the order-preserving
 // integer image of the fp32 values find s[lo] exactly; one more pass finds s[lo+1]; the threshold is
 // interpolated with torch's lerp formula (no FMA) and the mask written in a last pass.
@@ -270,11 +271,214 @@ __global__ __launch_bounds__(QT) void k_quantile_mask(const float* __restrict__ 
     for (int i = tid; i < n; i += QT) mb[i] = ub[i] > thr ? 1 : 0;
 }
 
+// ---- register-resident form (n <= 65536 per sample: every map the reference thresholds) -------------------------------
+// One 1024-thread workgroup per sample keeps the WHOLE sample in registers as order-preserving integer keys (4*V4 per
+// thread), so HBM sees the algorithmic minimum: u once in, the mask once out.  Selection of s[lo] (exact):
+//   1. min / max of the keys (wavefront shuffles + 16 partials in LDS);
+//   2. an LDS histogram of 2048 bins over [min, max] (bin = (key - min) >> shift: monotone in the key, and spread over
+//      the sample's own range - uncertainty maps span a few binades, their top key bits are all equal); a wavefront whose
+//      lanes all fall into one bin adds 64 with a single atomic (constant / clipped regions);
+//   3. a workgroup-wide prefix scan (wavefront shuffles + 16 partials) locates the bin holding rank lo; while that bin holds
+//      more than 512 keys and is wider than one key, 2. - 3. repeat inside it;
+//   4. the bin's keys are compacted into LDS and ranked by counting (key < mine, key == mine): s[lo] and the length of its
+//      run of equal keys.  s[lo+1] is s[lo] if the run extends past lo, else the smallest larger key (register scan).
+// q and the mask follow as in the streaming kernel, the mask straight from the registers.
+#define QBINS 2048
+#define QCAP 512
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+
+template <int V4, int NTH, bool VEC>
+__global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restrict__ u, int n, int lo, int hi, float w,
+                                                           uint8_t* __restrict__ mask, float* __restrict__ q) {
+    constexpr int NW = NTH / 64, BPT = QBINS / NTH;          // waves, histogram bins owned by a thread in the scan
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    __shared__ uint32_t hist[QBINS + 1];                     // + one slot that absorbs the adds of non-candidates
+    __shared__ uint32_t cand[QCAP];
+    __shared__ uint32_t part[2][NW];
+    __shared__ uint32_t s_bin, s_rank, s_cnt, s_klo, s_cnt_eq, s_rank_eq, s_next, s_ncand;
+    __shared__ float s_q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* ub = u + (size_t)blockIdx.x * n;
+    uint8_t* mb = mask + (size_t)blockIdx.x * n;
+
+    // ---- the sample -> registers (element (j*NTH + tid)*4 + e), branch-free: loads past the end are clamped and their keys
+    // replaced by NONE = 0xFFFFFFFF, which no ordered float maps to (it is the image of a NaN payload) and every step skips.
+    uint32_t key[4 * V4];
+    uint32_t kmin = NONE, kmax = 0;
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const int idx = (j * NTH + tid) * 4;
+        float f[4];
+        if (VEC) {                                           // n % 4 == 0, 16-byte aligned rows
+            const float4 v = *(const float4*)(ub + min(idx, n - 4));
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = ub[min(idx + e, n - 1)];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = idx + e < n ? f2key(f[e]) : NONE;
+            key[4 * j + e] = k;
+            kmin = min(kmin, k);
+            kmax = k != NONE ? max(kmax, k) : kmax;
+        }
+    }
+    kmin = wave_min_u32(kmin);
+    kmax = wave_max_u32(kmax);
+    if (lane == 0) { part[0][wave] = kmin; part[1][wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { kmin = min(kmin, part[0][i]); kmax = max(kmax, part[1][i]); }
+
+    // ---- histogram levels: candidates are the keys with key - base <= span (NONE never is: base + span <= kmax < NONE);
+    // `rank` counts inside the candidates
+    uint32_t base = kmin, span = kmax - kmin, rank = (uint32_t)lo, shift, bsel, csel;
+    for (;;) {
+        shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) hist[tid + i * NTH] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4 * V4; ++i) {
+            const uint32_t d = key[i] - base;
+            const uint32_t bin = (key[i] >= base && d <= span) ? d >> shift : (uint32_t)QBINS;
+            // a wavefront whose lanes all hit one bin adds 64 once (64 same-address LDS atomics would serialise)
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
+            const bool uni = __all(bin == first);
+            if (!uni || lane == 0) atomicAdd(&hist[bin], uni ? 64u : 1u);
+        }
+        __syncthreads();
+        // thread t owns bins BPT*t .. BPT*t + BPT-1: inclusive scan of their sums over the workgroup
+        uint32_t cb[BPT], own = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) { cb[i] = hist[BPT * tid + i]; own += cb[i]; }
+        uint32_t incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) part[0][wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) off += i < wave ? part[0][i] : 0u;
+        uint32_t excl = incl - own + off;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            if (rank >= excl && rank < excl + cb[i]) { s_bin = BPT * tid + i; s_rank = rank - excl; s_cnt = cb[i]; }
+            excl += cb[i];
+        }
+        __syncthreads();
+        bsel = s_bin;
+        rank = s_rank;
+        csel = s_cnt;
+        if (csel <= QCAP || shift == 0) break;
+        base += bsel << shift;
+        span = (1u << shift) - 1u;
+    }
+    if (shift == 0) {                      // the bin is one key wide: a run of csel equal keys
+        if (tid == 0) { s_klo = base + bsel; s_cnt_eq = csel; s_rank_eq = rank; }
+    } else {
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+        const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < 4 * V4; ++i) {
+            const uint32_t d = key[i] - base;
+            const bool hit = key[i] >= base && d <= span && (d >> shift) == bsel;
+            const uint64_t m = __ballot(hit);
+            if (m) {                       // (uniform) few wavefronts hold any of the <= 512 candidates
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                if (hit) cand[at + (uint32_t)__popcll(m & lt)] = key[i];
+            }
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < csel; t += NTH) {
+            const uint32_t k = cand[t];
+            uint32_t less = 0, eq = 0;
+            for (uint32_t j2 = 0; j2 < csel; ++j2) {
+                const uint32_t kj = cand[j2];
+                less += kj < k ? 1u : 0u;
+                eq += kj == k ? 1u : 0u;
+            }
+            if (less <= rank && rank < less + eq) { s_klo = k; s_cnt_eq = eq; s_rank_eq = rank - less; }   // (equal keys write equal values)
+        }
+    }
+    if (tid == 0) s_next = NONE;
+    __syncthreads();
+    const uint32_t klo = s_klo;
+    const bool need_next = hi != lo && s_rank_eq + 1 >= s_cnt_eq;
+    if (need_next) {                       // (uniform)
+        uint32_t best = NONE;
+#pragma unroll
+        for (int i = 0; i < 4 * V4; ++i) best = key[i] > klo ? min(best, key[i]) : best;       // NONE can only "win" as NONE
+        best = wave_min_u32(best);
+        if (lane == 0) atomicMin(&s_next, best);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float a = key2f(klo);
+        const float b = need_next ? key2f(s_next) : a;
+        const float d = __fsub_rn(b, a);
+        const float r = (w < 0.5f) ? __fadd_rn(a, __fmul_rn(w, d)) : __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.0f, w)));
+        s_q = r;
+        q[blockIdx.x] = r;
+    }
+    __syncthreads();
+    const float thr = s_q;
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const int idx = (j * NTH + tid) * 4;
+        uint32_t m4 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m4 |= (key2f(key[4 * j + e]) > thr ? 1u : 0u) << (8 * e);
+        if (VEC) {
+            if (idx < n) *(uint32_t*)(mb + idx) = m4;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (idx + e < n) mb[idx + e] = (uint8_t)((m4 >> (8 * e)) & 1u);
+        }
+    }
+}
+
+static int quantile_force_stream = 0;      // A/B switch for tests: 1 = always the streaming (multi-pass) kernel
+extern "C" int dua_set_quantile_stream(int on) { int o = quantile_force_stream; quantile_force_stream = on; return o; }
+
 extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uint8_t* mask, float* q, void* stream) {
     DUA_REQUIRE(u && mask && q, "dua_quantile_mask: null pointer");
     DUA_REQUIRE(B >= 0 && n >= 1 && lo >= 0 && hi >= lo && hi <= lo + 1 && hi < n, "dua_quantile_mask: bad rank split (n=%d lo=%d hi=%d)", n, lo, hi);
     if (B == 0) return DUA_OK;
-    hipLaunchKernelGGL(k_quantile_mask, B, QT, 0, as_stream(stream), u, n, lo, hi, w, mask, q);
+    hipStream_t st = as_stream(stream);
+    // small samples: 1024 threads x <= 16 keys (128-register budget); up to 65536 elements: 512 threads x <= 128 keys (two
+    // waves per SIMD, 256-register budget); beyond that the streaming kernel
+    const bool vec = n % 4 == 0 && (((uintptr_t)u | (uintptr_t)mask) & 15) == 0;
+#define QREG(V, TH)                                                                                            \
+    {                                                                                                          \
+        if (vec) hipLaunchKernelGGL((k_quantile_mask_reg<V, TH, true>), B, TH, 0, st, u, n, lo, hi, w, mask, q); \
+        else hipLaunchKernelGGL((k_quantile_mask_reg<V, TH, false>), B, TH, 0, st, u, n, lo, hi, w, mask, q);   \
+    }
+    if (quantile_force_stream || n > 65536 || n < 4) hipLaunchKernelGGL(k_quantile_mask, B, QT, 0, st, u, n, lo, hi, w, mask, q);
+    else if (n <= 4096) QREG(1, 1024)
+    else if (n <= 8192) QREG(2, 1024)
+    else if (n <= 16384) QREG(4, 1024)
+    else if (n <= 32768) QREG(16, 512)
+    else if (n <= 49152) QREG(24, 512)
+    else QREG(32, 512)
+#undef QREG
     return dua_check_launch("dua_quantile_mask");
 }
 
