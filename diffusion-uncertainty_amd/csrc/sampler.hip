@@ -327,11 +327,14 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t k = idx + e < n ? f2key(f[e]) : NONE;
+            // (OR with an all-ones word instead of a select: the compiler turns a select on the loaded value into a branch per element)
+            uint32_t k = f2key(f[e]) | ((VEC ? idx : idx + e) < n ? 0u : NONE);
+            asm volatile("" : "+v"(k));                      // opaque: only the key lives on, not the float it came from
             key[4 * j + e] = k;
             kmin = min(kmin, k);
             kmax = k != NONE ? max(kmax, k) : kmax;
         }
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // eight 16-byte loads in flight per lane, converted in place
     }
     kmin = wave_min_u32(kmin);
     kmax = wave_max_u32(kmax);
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
             const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
             const bool uni = __all(bin == first);
             if (!uni || lane == 0) atomicAdd(&hist[bin], uni ? 64u : 1u);
+            __builtin_amdgcn_sched_barrier(0);          // key by key: the unrolled loop must not pre-compute every bin (registers)
         }
         __syncthreads();
         // thread t owns bins BPT*t .. BPT*t + BPT-1: inclusive scan of their sums over the workgroup
@@ -393,10 +397,14 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
         if (tid == 0) s_ncand = 0;
         __syncthreads();
         const uint64_t lt = (1ull << lane) - 1ull;
+        // opaque copies: otherwise the compiler keeps key - base and its shifted bin of EVERY key alive from the histogram
+        // loop above to reuse them here (three registers per key instead of one)
+        uint32_t base_c = base, shift_c = shift;
+        asm volatile("" : "+v"(base_c), "+v"(shift_c));
 #pragma unroll
         for (int i = 0; i < 4 * V4; ++i) {
-            const uint32_t d = key[i] - base;
-            const bool hit = key[i] >= base && d <= span && (d >> shift) == bsel;
+            const uint32_t d = key[i] - base_c;
+            const bool hit = key[i] >= base_c && d <= span && (d >> shift_c) == bsel;
             const uint64_t m = __ballot(hit);
             if (m) {                       // (uniform) few wavefronts hold any of the <= 512 candidates
                 uint32_t at = 0;
@@ -404,6 +412,7 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
                 at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
                 if (hit) cand[at + (uint32_t)__popcll(m & lt)] = key[i];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         for (uint32_t t = tid; t < csel; t += NTH) {
@@ -438,13 +447,17 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
         q[blockIdx.x] = r;
     }
     __syncthreads();
+    // u > thr on the integer keys (order-preserving); the one place where key order and float order differ is +-0, so a zero
+    // threshold is compared as +0: keys above 0x80000000 are exactly the floats above zero.  (Comparing key2f(key) instead
+    // makes the compiler keep every loaded float alive next to its key: twice the registers.)
     const float thr = s_q;
+    const uint32_t tkey = f2key(thr == 0.0f ? 0.0f : thr);
 #pragma unroll
     for (int j = 0; j < V4; ++j) {
         const int idx = (j * NTH + tid) * 4;
         uint32_t m4 = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m4 |= (key2f(key[4 * j + e]) > thr ? 1u : 0u) << (8 * e);
+        for (int e = 0; e < 4; ++e) m4 |= (key[4 * j + e] > tkey && key[4 * j + e] != NONE ? 1u : 0u) << (8 * e);
         if (VEC) {
             if (idx < n) *(uint32_t*)(mb + idx) = m4;
         } else {

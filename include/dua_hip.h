@@ -75,6 +75,9 @@ int dua_mc_reduce_var(const float* stack, float* u, size_t n, int M, void* strea
  * split computed in fp32 on the host: lo = floor(p32*(n-1)), hi = ceil(..), w = rank - lo.
  * u: [B][n]; mask: [B][n] uint8 (0/1); q: [B]. */
 int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uint8_t* mask, float* q, void* stream);
+/* A/B switch (returns the previous value): 1 = always the streaming multi-pass kernel (six passes over u), 0 = default: samples of up
+ * to 65536 elements are held in registers by one workgroup (u read once; min/max-ranged LDS histogram + wavefront-shuffle scans). */
+int dua_set_quantile_stream(int on);
 
 /* Posterior blend, uncertainty_guidance.py:115-120.  eps,u: [B][n]; mask: [B][n] uint8. */
 int dua_posterior_blend(const float* eps, const float* u, const uint8_t* mask, float* out, int B, int n, int M,
