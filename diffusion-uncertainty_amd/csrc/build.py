@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libdua_hip.so")
-SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []), ("mfma_bf16x3.hip", []), ("attention.hip", [])]
+SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []), ("mfma_bf16x3.hip", []), ("conv_f16x3.hip", []), ("attention.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
@@ -19,7 +19,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "dua_hip.h")]
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "dconv.h"), os.path.join(os.path.dirname(PKG), "include", "dua_hip.h")]
     objs = []
     for src, extra in SOURCES:
         s = os.path.join(HERE, src)

@@ -13,6 +13,7 @@
 // chunk c of row r is stored at chunk position c ^ ((r >> 2) & 3): the 16-lane groups of ds_read_b128 (16 rows, one
 // chunk column) then land on 16 distinct 16-byte slots and the 8-lane groups of ds_write_b128 (2 rows x 4 chunks) on 8.
 #include "common.h"
+#include "dconv.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -437,24 +438,7 @@ static int launch_x(XTileP& p, hipStream_t s, int batch = 1) {
 // `s_waitcnt vmcnt(6)` + one raw s_barrier per step publishes tile kt+1.
 #define DBM 256
 
-struct DConvP {
-    const __bf16* A;         // hi plane; lo plane follows at +a_plane elements
-    const __bf16* B;         // pre-split weights, hi plane then lo plane (+b_plane elements)
-    const float *bias, *res;
-    float* C;
-    long a_plane, b_plane;
-    int M, N, K, H, W, Cin, nchw_out, ntm, ntn;
-    float* colsum;           // optional [ceil(M/64)][2][N] column sums / sums of squares per 64-row block
-    int dbg_norec;           // diagnostic: zero-record descriptors (every DMA returns zeros at once) - prices the memory path
-    int ntaps;               // 9 = 3x3 convolution, 1 = plain GEMM over rows (1x1 convolution / linear layer)
-    int act_out;             // 2 = GELU on the output (U-ViT fc1)
-    __bf16* Csplit;          // optional: write the output as split bf16 planes (hi | lo, [M][N] each) instead of fp32 C
-    const signed char* Bscale;  // FMT 1 (f16f8): per weight row r, w_hi8 = fp8(w * 2^Bscale[r]), w_lo8 = fp8(w_lo * 2^(Bscale[r] + 12))
-    int stagger_phases;      // > 1: workgroup start-up stagger (see k_xconv_dma); stagger_sleeps = s_sleep(127) per phase step
-    int stagger_sleeps;
-    const float* Cscale;     // FMT 3 (f16x3): per weight row 2^-s (the planes hold w * 2^s), padded to the tile grid
-    float out_scale;         // FMT 3: 1 / activation plane scale; the epilogue multiplies the accumulator by Cscale[col] * out_scale
-};
+// (DConvP: dconv.h)
 
 // NT = 32-column MFMA tiles per wave: block tile 256 x (64*NT), waves 4(M) x 2(N), wave tile 64 x (32*NT).
 //   NT = 2: 256 x 128; activation ring 3 x 32 KB + weight ring 3 x 16 KB (tile kt+2 of both in flight during step kt);
@@ -1471,7 +1455,9 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
-    } else if (fmt == 3) {                                                        // f16x3: the bf16x3 loop on fp16 planes
+    } else if (fmt == 3 && dua_dma_conv_enabled != 6) {                          // f16x3: the 16x16x32 kernel of conv_f16x3.hip
+        return dua_launch_hconv(d, st, what);
+    } else if (fmt == 3) {                                                        // (mode 6, A/B: the bf16x3 loop on fp16 planes, 32x32x16 shape)
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 3>), dim3(grid), 512, 0, st, d);
     } else if (fmt == 2) {                                                        // MXFP6 cross terms: row-shift convolutions only
