@@ -334,46 +334,64 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
         const int row0 = m0 + wm * 64, c0 = n0 + wn * 32 * NT + 4 * lc_e;
         const bool vec = !p.nchw_out && (p.N & 3) == 0;
         if (vec) {
+            // Channel-block pairs (32 channels) of one 16-pixel block go through a 16 x 144-byte LDS patch of the wave (the
+            // activation ring's last slot: the next tile's prologue DMA targets the other slots) so that the residual read and
+            // the output store move whole 128-byte rows, 8 pixels per instruction; straight from the accumulator layout they
+            // would be 64-byte runs on 16 different rows per instruction.
+            char* pw = reinterpret_cast<char*>(lds) + (AOFF + (RA - 1) * 2 * SA) * 2 + wave * (16 * 144);
+            const int pr_e = lane_e >> 3, pc_e = lane_e & 7;                 // row-major side: pixel of the half block, 16-B chunk of the row
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int c = c0 + 16 * j;
+            for (int jp = 0; jp < NB / 2; ++jp) {
+                const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
                 const bool cok = c < p.N;
-                float4 sq = *(const float4*)(p.Cscale + c);          // (padded to the tile grid)
+                float4 sq = *(const float4*)(p.Cscale + c);                  // (padded to the tile grid)
                 sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
                 float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.bias && cok) bq = *(const float4*)(p.bias + c);
-                float4 rq[4];
+                // residual rows are requested one pixel block ahead of their use
+                float4 rq[2], rn[2];
+                auto res_ld = [&](int i, float4 (&dst)[2]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = row0 + 16 * i + lr_e;
-                    rq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.res && cok && row < p.M) rq[i] = *(const float4*)(p.res + (long)row * p.N + c);
-                }
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = row0 + 16 * i + 8 * h + pr_e;
+                        dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.res && cok && row < p.M) dst[h] = *(const float4*)(p.res + (long)row * p.N + c);
+                    }
+                };
+                res_ld(0, rn);
                 float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int row = row0 + 16 * i + lr_e;
-                    float4 v;
-                    v.x = acc[j][i][0] * sq.x + bq.x + rq[i].x;
-                    v.y = acc[j][i][1] * sq.y + bq.y + rq[i].y;
-                    v.z = acc[j][i][2] * sq.z + bq.z + rq[i].z;
-                    v.w = acc[j][i][3] * sq.w + bq.w + rq[i].w;
-                    if (cok && row < p.M) {
-                        *(float4*)(p.C + (long)row * p.N + c) = v;
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+                    rq[0] = rn[0]; rq[1] = rn[1];
+                    if (i < 3) res_ld(i + 1, rn);
+                    *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc[2 * jp][i];
+                    *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc[2 * jp + 1][i];
+                    // (same-wave LDS write -> read: in-order LDS queue, no barrier)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
+                        const int row = row0 + 16 * i + 8 * h + pr_e;
+                        float4 v;
+                        v.x = a[0] * sq.x + bq.x + rq[h].x;
+                        v.y = a[1] * sq.y + bq.y + rq[h].y;
+                        v.z = a[2] * sq.z + bq.z + rq[h].z;
+                        v.w = a[3] * sq.w + bq.w + rq[h].w;
+                        if (cok && row < p.M) {
+                            *(float4*)(p.C + (long)row * p.N + c) = v;
+                            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                            cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+                        }
                     }
                 }
-                if (p.colsum) {      // GroupNorm statistics of the next layer: fold the 16 pixel lanes that share these channels
+                if (p.colsum) {      // GroupNorm statistics of the next layer: fold the 8 pixel lanes that share these channels
                     float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        t[u] += __shfl_xor(t[u], 1);
-                        t[u] += __shfl_xor(t[u], 2);
-                        t[u] += __shfl_xor(t[u], 4);
                         t[u] += __shfl_xor(t[u], 8);
+                        t[u] += __shfl_xor(t[u], 16);
+                        t[u] += __shfl_xor(t[u], 32);
                     }
-                    if (lr_e == 0 && cok && row0 < p.M) {
+                    if (pr_e == 0 && cok && row0 < p.M) {
                         float* o = p.colsum + (long)(row0 >> 6) * 2 * p.N + c;
                         *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
                         *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);

@@ -1412,7 +1412,7 @@ extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const floa
 static int dua_dma_conv_enabled = 1;
 extern "C" int dua_set_dma_conv(int on) {
 #ifndef DUA_CONV_TIMING
-    DUA_REQUIRE(on == 0 || on == 1 || on == 2 || on == 6, "dua_set_dma_conv: mode %d exists only in the diagnostic build (wrong results by design)", on);
+    DUA_REQUIRE(on == 0 || on == 1 || on == 2 || on == 6 || on == 7, "dua_set_dma_conv: mode %d exists only in the diagnostic build (wrong results by design)", on);
 #endif
     int o = dua_dma_conv_enabled;
     dua_dma_conv_enabled = on;
@@ -1455,7 +1455,10 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
-    } else if (fmt == 3 && dua_dma_conv_enabled != 6) {                          // f16x3: the 16x16x32 kernel of conv_f16x3.hip
+    } else if (fmt == 3 && dua_dma_conv_enabled != 6 && ((wide && (long)d.H * d.W <= 4096) || dua_dma_conv_enabled == 7)) {
+        // f16x3, 256-channel tiles on maps up to 64^2: the 16x16x32 kernel of conv_f16x3.hip (+2..5 % there; the 128^2 layers and
+        // the 128-channel tiles of the 16^2 / 8^2 levels run 2 - 15 % faster on the 32x32x16 loop below: measured per layer with
+        // scripts/bench_conv_mix.py --fmt f16x3 --engine 7 / 6).  Mode 7 forces the new kernel, 6 the old one.
         return dua_launch_hconv(d, st, what);
     } else if (fmt == 3) {                                                        // (mode 6, A/B: the bf16x3 loop on fp16 planes, 32x32x16 shape)
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(grid), 512, 0, st, d);

@@ -305,7 +305,7 @@ int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* b
                               void* stream);
 /* A/B engine selector for the presplit conv / GEMM kernels (returns the previous mode, or DUA_EINVAL): 1 = LDS-DMA kernels,
  * 256x256 tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel (bf16x3); 6 = per-tap instead of
- * row-shift f16f8 loop.  Process-global and unsynchronised: set it before queueing work.  The zero-record-descriptor modes
+ * row-shift f16f8 loop / the 32x32x16 loop for every f16x3 tile; 7 = the 16x16x32 kernel (conv_f16x3.hip) for every f16x3 tile.  Process-global and unsynchronised: set it before queueing work.  The zero-record-descriptor modes
  * 3 - 5 (timing-only, wrong results) exist only in the diagnostic library built with -DDUA_CONV_TIMING
  * (scripts/conv_tile_timing.py --build); the product library rejects them. */
 int dua_set_dma_conv(int mode);

@@ -22,17 +22,18 @@ def stats(db):
         print(f'"{name}",{n},{tot},{avg:.1f},{100.0 * tot / total:.4f},{mn},{mx}')
 
 
-def pmc(out, tag):
+def pmc(out, tag, precision="f16x3"):
     res = defaultdict(dict)
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         acc, cnt = defaultdict(float), defaultdict(int)
         for db in glob.glob(f"{out}/{tag}_pmc_{counter}/**/*.db", recursive=True):
             c = sqlite3.connect(db)
             for name, value in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
-                if "k_xconv_dma" not in name:
+                if "k_xconv_dma" not in name and "k_hconv" not in name:
                     continue
-                key = "k_xconv_dma<4>" if ("<4>" in name or "<4," in name) else "k_xconv_dma<2>"
-                for k in (key, "k_xconv_dma"):
+                fam = "k_hconv" if "k_hconv" in name else "k_xconv_dma"
+                key = fam + ("<4>" if ("<4>" in name or "<4," in name) else "<2>")
+                for k in (key, "conv"):              # "conv": every launch of the LDS-DMA conv / one-tap GEMM kernels
                     acc[k] += float(value)
                     cnt[k] += 1
         for k in acc:
@@ -41,12 +42,13 @@ def pmc(out, tag):
     for d in res.values():
         if "FETCH_SIZE_KB_per_launch" in d and "WRITE_SIZE_KB_per_launch" in d:
             d["hbm_side_bytes_per_launch"] = (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
-    print(json.dumps({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python3 bench.py --generation-steps 2 "
-                                 "--start-step-uc 1 --num-steps-uc 1 -M 1 --num-zigzag 1 --warmup 0 --no-cpu-baseline --no-profile "
-                                 "--no-secondary",
-                      "note": "truncated job (3 denoiser forwards, same batch 128 and layer shapes as the headline job); separate "
-                              "passes per counter; FETCH_SIZE doubled per MI355X_MICROARCH.md; k_xconv_dma also serves the 1-tap "
-                              "GEMMs (qkv), so the per-launch mean is over convs and those GEMMs",
+    print(json.dumps({"precision": precision,
+                      "command": f"rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python3 bench.py --precision {precision} "
+                                 "--generation-steps 5 --steps 1 --start-step-uc 4 --num-steps-uc 1 -M 1 --num-zigzag 1 --warmup 0 "
+                                 "--no-cpu-baseline --no-profile --no-secondary",
+                      "note": "truncated job (6 denoiser forwards, same batch 128 and layer shapes as the headline job); separate "
+                              "passes per counter; FETCH_SIZE doubled per MI355X_MICROARCH.md; the kernels also serve the 1-tap "
+                              "GEMMs (qkv, proj_out), so the per-launch mean 'conv' is over convs and those GEMMs",
                       "kernels": res}, indent=1))
 
 
@@ -54,4 +56,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     else:
-        pmc(sys.argv[2], sys.argv[3])
+        pmc(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))
