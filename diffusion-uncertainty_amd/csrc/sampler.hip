@@ -272,23 +272,19 @@ __global__ __launch_bounds__(QT) void k_quantile_mask(const float* __restrict__ 
 }
 
 // ---- register-resident form (n <= 65536 per sample: every map the reference thresholds) -------------------------------
-// One workgroup per sample keeps the WHOLE sample in registers as order-preserving integer keys (4*V4 per thread), so HBM
-// sees the algorithmic minimum: u once in, the mask once out.  Selection of s[lo] (exact):
-//   1. BRACKET: 256 keys spread over the sample are ranked among themselves by counting (LDS broadcast reads); the two whose
-//      sample ranks sit 5 sigma (binomial) either side of the target quantile become pivots [p_lo, p_hi];
-//   2. ONE register pass counts the keys below p_lo (per-lane counters, wavefront shuffles) and packs the keys inside the
-//      bracket into per-wavefront LDS segments (ballot + popcount positions: no atomics).  The target's rank inside the bracket
-//      is lo - below; a target outside the bracket (about 1e-6 of calls) or an overflowing segment falls back to 3. on ALL keys;
-//   3. LEVELS on the candidates: an LDS histogram of 2048 bins over the candidates' key range (bin = (key - base) >> shift:
-//      monotone in the key; inside a narrow quantile bracket the keys are spread evenly, so the LDS atomics rarely collide; a
-//      wavefront whose lanes all hit one bin adds 64 once), a workgroup prefix scan (wavefront shuffles + per-wave partials)
-//      locates the bin holding the rank; while that bin holds more than 512 keys and is wider than one key, repeat inside it;
-//   4. the bin's keys are packed into LDS and ranked by counting (key < mine, key == mine): s[lo] and the length of its run of
-//      equal keys.  s[lo+1] is s[lo] if the run extends past lo, else the smallest larger key (register scan).
+// One 1024-thread workgroup per sample keeps the WHOLE sample in registers as order-preserving integer keys (4*V4 per
+// thread), so HBM sees the algorithmic minimum: u once in, the mask once out.  Selection of s[lo] (exact):
+//   1. min / max of the keys (wavefront shuffles + 16 partials in LDS);
+//   2. an LDS histogram of 2048 bins over [min, max] (bin = (key - min) >> shift: monotone in the key, and spread over
+//      the sample's own range - uncertainty maps span a few binades, their top key bits are all equal); a wavefront whose
+//      lanes all fall into one bin adds 64 with a single atomic (constant / clipped regions);
+//   3. a workgroup-wide prefix scan (wavefront shuffles + 16 partials) locates the bin holding rank lo; while that bin holds
+//      more than 512 keys and is wider than one key, 2. - 3. repeat inside it;
+//   4. the bin's keys are compacted into LDS and ranked by counting (key < mine, key == mine): s[lo] and the length of its
+//      run of equal keys.  s[lo+1] is s[lo] if the run extends past lo, else the smallest larger key (register scan).
 // q and the mask follow as in the streaming kernel, the mask straight from the registers.
 #define QBINS 2048
 #define QCAP 512
-#define QSAMP 256
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
@@ -299,33 +295,25 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
     return v;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
-}
 
 template <int V4, int NTH, bool VEC>
 __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restrict__ u, int n, int lo, int hi, float w,
                                                            uint8_t* __restrict__ mask, float* __restrict__ q) {
     constexpr int NW = NTH / 64, BPT = QBINS / NTH;          // waves, histogram bins owned by a thread in the scan
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    constexpr int SEGW = NTH == 1024 ? 1024 : 3072;          // bracket candidates per wavefront segment (64 / 96 KB of LDS in all)
     __shared__ uint32_t hist[QBINS + 1];                     // + one slot that absorbs the adds of non-candidates
     __shared__ uint32_t cand[QCAP];
-    __shared__ uint32_t samp[QSAMP];
-    __shared__ uint32_t seg[NW * SEGW];
-    __shared__ uint32_t part[2][NW], segn[NW];
-    __shared__ uint32_t s_bin, s_rank, s_cnt, s_klo, s_cnt_eq, s_rank_eq, s_next, s_ncand, s_plo, s_phi;
+    __shared__ uint32_t part[2][NW];
+    __shared__ uint32_t s_bin, s_rank, s_cnt, s_klo, s_cnt_eq, s_rank_eq, s_next, s_ncand;
     __shared__ float s_q;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* ub = u + (size_t)blockIdx.x * n;
     uint8_t* mb = mask + (size_t)blockIdx.x * n;
-    const uint64_t lt = (1ull << lane) - 1ull;
 
     // ---- the sample -> registers (element (j*NTH + tid)*4 + e), branch-free: loads past the end are clamped and their keys
     // replaced by NONE = 0xFFFFFFFF, which no ordered float maps to (it is the image of a NaN payload) and every step skips.
     uint32_t key[4 * V4];
+    uint32_t kmin = NONE, kmax = 0;
 #pragma unroll
     for (int j = 0; j < V4; ++j) {
         const int idx = (j * NTH + tid) * 4;
@@ -343,199 +331,104 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
             uint32_t k = f2key(f[e]) | ((VEC ? idx : idx + e) < n ? 0u : NONE);
             asm volatile("" : "+v"(k));                      // opaque: only the key lives on, not the float it came from
             key[4 * j + e] = k;
+            kmin = min(kmin, k);
+            kmax = k != NONE ? max(kmax, k) : kmax;
         }
         if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // eight 16-byte loads in flight per lane, converted in place
     }
+    kmin = wave_min_u32(kmin);
+    kmax = wave_max_u32(kmax);
+    if (lane == 0) { part[0][wave] = kmin; part[1][wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { kmin = min(kmin, part[0][i]); kmax = max(kmax, part[1][i]); }
 
-    // generic pieces, parameterised by the key source (`each(f)` calls f(key) for every key of the set, NONE for padding;
-    // every lane of the workgroup makes the same number of calls)
-    auto levels = [&](auto each, uint32_t base, uint32_t span, uint32_t rank, uint32_t& klo_out) {
-        uint32_t shift, bsel, csel;
-        for (;;) {
-            shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
+    // ---- histogram levels: candidates are the keys with key - base <= span (NONE never is: base + span <= kmax < NONE);
+    // `rank` counts inside the candidates
+    uint32_t base = kmin, span = kmax - kmin, rank = (uint32_t)lo, shift, bsel, csel;
+    for (;;) {
+        shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
 #pragma unroll
-            for (int i = 0; i < BPT; ++i) hist[tid + i * NTH] = 0;
-            __syncthreads();
-            each([&](uint32_t k) {
-                const uint32_t d = k - base;
-                const uint32_t bin = (k != NONE && k >= base && d <= span) ? d >> shift : (uint32_t)QBINS;
-                // a wavefront whose lanes all hit one bin adds 64 once (64 same-address LDS atomics would serialise)
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
-                const bool uni = __all(bin == first);
-                if (!uni || lane == 0) atomicAdd(&hist[bin], uni ? 64u : 1u);
-                __builtin_amdgcn_sched_barrier(0);          // key by key: an unrolled loop must not pre-compute every bin (registers)
-            });
-            __syncthreads();
-            // thread t owns bins BPT*t .. BPT*t + BPT-1: inclusive scan of their sums over the workgroup
-            uint32_t cb[BPT], own = 0;
-#pragma unroll
-            for (int i = 0; i < BPT; ++i) { cb[i] = hist[BPT * tid + i]; own += cb[i]; }
-            uint32_t incl = own;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) part[0][wave] = incl;
-            __syncthreads();
-            uint32_t off = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) off += i < wave ? part[0][i] : 0u;
-            uint32_t excl = incl - own + off;
-#pragma unroll
-            for (int i = 0; i < BPT; ++i) {
-                if (rank >= excl && rank < excl + cb[i]) { s_bin = BPT * tid + i; s_rank = rank - excl; s_cnt = cb[i]; }
-                excl += cb[i];
-            }
-            __syncthreads();
-            bsel = s_bin;
-            rank = s_rank;
-            csel = s_cnt;
-            if (csel <= QCAP || shift == 0) break;
-            base += bsel << shift;
-            span = (1u << shift) - 1u;
-        }
-        if (shift == 0) {                  // the bin is one key wide: a run of csel equal keys
-            if (tid == 0) { s_klo = base + bsel; s_cnt_eq = csel; s_rank_eq = rank; }
-        } else {
-            if (tid == 0) s_ncand = 0;
-            __syncthreads();
-            // opaque copies: otherwise the compiler keeps key - base and its shifted bin of EVERY key alive from the histogram
-            // loop above to reuse them here (three registers per key instead of one)
-            uint32_t base_c = base, shift_c = shift;
-            asm volatile("" : "+v"(base_c), "+v"(shift_c));
-            each([&](uint32_t k) {
-                const uint32_t d = k - base_c;
-                const bool hit = k != NONE && k >= base_c && d <= span && (d >> shift_c) == bsel;
-                const uint64_t m = __ballot(hit);
-                if (m) {                   // (uniform) few wavefronts hold any of the <= 512 candidates
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
-                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-                    if (hit) cand[at + (uint32_t)__popcll(m & lt)] = k;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            __syncthreads();
-            for (uint32_t t = tid; t < csel; t += NTH) {
-                const uint32_t k = cand[t];
-                uint32_t less = 0, eq = 0;
-                for (uint32_t j2 = 0; j2 < csel; ++j2) {
-                    const uint32_t kj = cand[j2];
-                    less += kj < k ? 1u : 0u;
-                    eq += kj == k ? 1u : 0u;
-                }
-                if (less <= rank && rank < less + eq) { s_klo = k; s_cnt_eq = eq; s_rank_eq = rank - less; }   // (equal keys write equal values)
-            }
-        }
+        for (int i = 0; i < BPT; ++i) hist[tid + i * NTH] = 0;
         __syncthreads();
-        klo_out = s_klo;
-    };
-    auto each_reg = [&](auto f) {
-#pragma unroll
-        for (int i = 0; i < 4 * V4; ++i) f(key[i]);
-    };
-
-    // ---- 1. bracket: QSAMP keys spread over the whole sample (every (NTH / QSAMP)-th thread gives one of its keys, the
-    // key index cycling with the sample slot: element ((slot mod V4) * NTH + tid) * 4 + (slot / V4) mod 4)
-    {
-        constexpr int STRIDE = NTH / QSAMP;
-        const int sslot = tid / STRIDE, jstar = sslot % V4, estar = (sslot / V4) & 3;
-        uint32_t pick = NONE;
-#pragma unroll
-        for (int j = 0; j < V4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pick = (j == jstar && e == estar) ? key[4 * j + e] : pick;
-        if (tid % STRIDE == 0) samp[sslot] = pick;
-    }
-    if (tid == 0) { s_plo = 0u; s_phi = NONE - 1u; }
-    __syncthreads();
-    if (tid < QSAMP) {
-        const uint32_t mine = samp[tid];
-        uint32_t r = 0, nvalid = 0;        // rank of my key in the strict order (key, index); NONE keys (tails) rank last
-        for (int j = 0; j < QSAMP; j += 4) {
-            const uint4 v = *(const uint4*)(samp + j);
-            const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                r += (kk[e] < mine || (kk[e] == mine && j + e < tid)) ? 1u : 0u;
-                nvalid += kk[e] != NONE ? 1u : 0u;
-            }
-        }
-        // target position in the valid part of the sample and its 5-sigma binomial margin
-        const float pf = (float)lo / (float)max(n - 1, 1), sv = (float)nvalid;
-        const float mg = 5.0f * sqrtf(sv * pf * (1.0f - pf)) + 3.0f;
-        const int a = (int)floorf(pf * sv - mg), b = (int)ceilf(pf * sv + mg);
-        if (a >= 0 && (int)r == a) s_plo = mine;                     // (a < 0: bracket open below)
-        if (b < (int)nvalid && (int)r == b) s_phi = mine;            // (b >= nvalid: open above)
-    }
-    __syncthreads();
-    const uint32_t plo = s_plo, phi = s_phi;
-
-    // ---- 2. one register pass: count the keys below the bracket, pack the keys inside it into this wavefront's LDS segment
-    uint32_t below = 0, wfill = 0;
-    {
-        uint32_t* myseg = seg + wave * SEGW;
 #pragma unroll
         for (int i = 0; i < 4 * V4; ++i) {
-            const uint32_t k = key[i];
-            below += k < plo ? 1u : 0u;
-            const bool hit = k >= plo && k <= phi;                   // (NONE > phi always)
+            const uint32_t d = key[i] - base;
+            const uint32_t bin = (key[i] >= base && d <= span) ? d >> shift : (uint32_t)QBINS;
+            // a wavefront whose lanes all hit one bin adds 64 once (64 same-address LDS atomics would serialise)
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
+            const bool uni = __all(bin == first);
+            if (!uni || lane == 0) atomicAdd(&hist[bin], uni ? 64u : 1u);
+            __builtin_amdgcn_sched_barrier(0);          // key by key: the unrolled loop must not pre-compute every bin (registers)
+        }
+        __syncthreads();
+        // thread t owns bins BPT*t .. BPT*t + BPT-1: inclusive scan of their sums over the workgroup
+        uint32_t cb[BPT], own = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) { cb[i] = hist[BPT * tid + i]; own += cb[i]; }
+        uint32_t incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) part[0][wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) off += i < wave ? part[0][i] : 0u;
+        uint32_t excl = incl - own + off;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            if (rank >= excl && rank < excl + cb[i]) { s_bin = BPT * tid + i; s_rank = rank - excl; s_cnt = cb[i]; }
+            excl += cb[i];
+        }
+        __syncthreads();
+        bsel = s_bin;
+        rank = s_rank;
+        csel = s_cnt;
+        if (csel <= QCAP || shift == 0) break;
+        base += bsel << shift;
+        span = (1u << shift) - 1u;
+    }
+    if (shift == 0) {                      // the bin is one key wide: a run of csel equal keys
+        if (tid == 0) { s_klo = base + bsel; s_cnt_eq = csel; s_rank_eq = rank; }
+    } else {
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+        const uint64_t lt = (1ull << lane) - 1ull;
+        // opaque copies: otherwise the compiler keeps key - base and its shifted bin of EVERY key alive from the histogram
+        // loop above to reuse them here (three registers per key instead of one)
+        uint32_t base_c = base, shift_c = shift;
+        asm volatile("" : "+v"(base_c), "+v"(shift_c));
+#pragma unroll
+        for (int i = 0; i < 4 * V4; ++i) {
+            const uint32_t d = key[i] - base_c;
+            const bool hit = key[i] >= base_c && d <= span && (d >> shift_c) == bsel;
             const uint64_t m = __ballot(hit);
-            const uint32_t pos = wfill + (uint32_t)__popcll(m & lt);
-            if (hit && pos < (uint32_t)SEGW) myseg[pos] = k;
-            wfill += (uint32_t)__popcll(m);
+            if (m) {                       // (uniform) few wavefronts hold any of the <= 512 candidates
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                if (hit) cand[at + (uint32_t)__popcll(m & lt)] = key[i];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
-    below = wave_sum_u32(below);
-    if (lane == 0) { part[1][wave] = below; segn[wave] = wfill; }
-    __syncthreads();
-    uint32_t below_all = 0, ncand = 0, segoff[NW + 1];
-    bool overflow = false;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        below_all += part[1][i];
-        segoff[i] = ncand;
-        ncand += segn[i];
-        overflow = overflow || segn[i] > (uint32_t)SEGW;
-    }
-    segoff[NW] = ncand;
-    uint32_t klo;
-    if (!overflow && (uint32_t)lo >= below_all && (uint32_t)lo - below_all < ncand) {
-        // ---- 3./4. on the bracket's candidates (LDS): flat index -> (segment, offset)
-        auto each_seg = [&](auto f) {
-            for (uint32_t f0 = 0; f0 < ncand; f0 += NTH) {
-                const uint32_t fi = f0 + tid;
-                uint32_t k = NONE;
-                if (fi < ncand) {
-                    int sgi = 0;
-#pragma unroll
-                    for (int i = 1; i < NW; ++i) sgi += fi >= segoff[i] ? 1 : 0;
-                    k = seg[sgi * SEGW + (fi - segoff[sgi])];
-                }
-                f(k);
+        __syncthreads();
+        for (uint32_t t = tid; t < csel; t += NTH) {
+            const uint32_t k = cand[t];
+            uint32_t less = 0, eq = 0;
+            for (uint32_t j2 = 0; j2 < csel; ++j2) {
+                const uint32_t kj = cand[j2];
+                less += kj < k ? 1u : 0u;
+                eq += kj == k ? 1u : 0u;
             }
-        };
-        levels(each_seg, plo, phi - plo, (uint32_t)lo - below_all, klo);
-    } else {
-        // ---- fallback: 3./4. on every key, over the sample's own key range
-        uint32_t kmin = NONE, kmax = 0;
-#pragma unroll
-        for (int i = 0; i < 4 * V4; ++i) { kmin = min(kmin, key[i]); kmax = key[i] != NONE ? max(kmax, key[i]) : kmax; }
-        kmin = wave_min_u32(kmin);
-        kmax = wave_max_u32(kmax);
-        __syncthreads();
-        if (lane == 0) { part[0][wave] = kmin; part[1][wave] = kmax; }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NW; ++i) { kmin = min(kmin, part[0][i]); kmax = max(kmax, part[1][i]); }
-        __syncthreads();
-        levels(each_reg, kmin, kmax - kmin, (uint32_t)lo, klo);
+            if (less <= rank && rank < less + eq) { s_klo = k; s_cnt_eq = eq; s_rank_eq = rank - less; }   // (equal keys write equal values)
+        }
     }
-
     if (tid == 0) s_next = NONE;
     __syncthreads();
+    const uint32_t klo = s_klo;
     const bool need_next = hi != lo && s_rank_eq + 1 >= s_cnt_eq;
     if (need_next) {                       // (uniform)
         uint32_t best = NONE;

@@ -179,7 +179,10 @@ def test_quantile_mask_register_kernel_vs_streaming(ops, shape):
         print(f"quantile_mask {shape} {name}: register kernel {times[0]:.1f} us ({alg / times[0] / 1e6:.2f} TB/s algorithmic), "
               f"streaming kernel {times[1]:.1f} us ({alg / times[1] / 1e6:.2f} TB/s)")
     if shape == (128, 3, 128, 128):
-        assert alg / report["chi2"][0] / 1e6 >= 1.0              # regression guard (VERDICT r01 item 8 asks for 2 TB/s: see DESIGN.md)
+        # regression guard at the measured 1.17 TB/s (r01: 0.53).  VERDICT r01 item 8 asked for 2 TB/s: not reached - the floor of this
+        # structure is 3.0 TB/s (constant input, 18.8 us); the LDS-atomic histogram adds 30 us (an LDS atomic wave-instruction
+        # retires about one lane per clock), see DESIGN.md section 6
+        assert alg / report["chi2"][0] / 1e6 >= 0.9
     if shape == (1, 4, 64, 64):
         assert report["chi2"][0] < 20.0
 
