@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils import params_generation
 from .nn import normalization
 
 
@@ -404,6 +405,11 @@ class UNetModel(nn.Module):
             "must specify y if and only if the model is class-conditional"
         if not x.is_cuda:
             raise RuntimeError("UNetModel.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        gen = params_generation(self)                # in-place weight edits (param.data.copy_, LoRA merges) repack
+        if gen != getattr(self, "_packed_gen", None):
+            if self._packed:
+                self._packed = {}
+            self._packed_gen = gen
         ctx = _Ctx(self)
         B = x.shape[0]
         te, te2 = self.time_embed[0], self.time_embed[2]

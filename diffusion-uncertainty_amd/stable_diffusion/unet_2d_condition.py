@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils import params_generation
 
 
 class ResnetBlock2D(nn.Module):
@@ -257,6 +258,12 @@ class UNet2DConditionModel(nn.Module):
         # microseconds each and the host cannot issue them fast enough; a captured graph removes the launch path.
         self._graphs = None
 
+    def invalidate_packed_weights(self):
+        """Drop the packed weights (and the captured graphs that hold them); the next forward repacks."""
+        self._packed = {}
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs = {}
+
     def enable_hip_graph(self, on=True):
         """Capture the forward once per (input shapes, precision) into a HIP graph and replay it afterwards."""
         self._graphs = {} if on else None
@@ -297,10 +304,15 @@ class UNet2DConditionModel(nn.Module):
         t = (t.reshape(1).expand(B) if t.ndim == 0 else t).to(torch.int64).contiguous()
         enc = encoder_hidden_states.to(torch.float32).contiguous()
         sample = sample.float().contiguous()
+        gen = params_generation(self)                                  # in-place weight edits invalidate packed weights and graphs
+        if gen != getattr(self, "_packed_gen", None):
+            if self._packed:
+                self.invalidate_packed_weights()
+            self._packed_gen = gen
         if self._graphs is None:
             out = self._forward_impl(sample, t, enc)
         else:
-            key = (tuple(sample.shape), tuple(enc.shape), self.precision)
+            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE)
             entry = self._graphs.get(key)
             if entry is None:
                 self._forward_impl(sample, t, enc)                     # eager once: packs the weights, warms the allocator

@@ -55,3 +55,12 @@ def starting_points(n, shape, num_classes=1000, dataset_index=0):
     x = torch.randn(n, *shape, generator=g)
     y = torch.randint(0, num_classes, (n,), generator=g)
     return x, y
+
+
+def params_generation(module):
+    """Sum of the in-place version counters of a module's parameters: moves whenever a weight is edited in place through the
+    parameter itself (``with torch.no_grad(): p.copy_(...)`` / ``p.add_(...)``, an optimizer step, a LoRA merge), which the
+    ``_apply`` / ``load_state_dict`` hooks do not see.  The packed-weight caches of the HIP models compare it at every forward
+    and repack when it moved.  Edits through ``p.data`` bypass torch's version counter and cannot be seen: call
+    ``model.invalidate_packed_weights()`` after those."""
+    return sum(p._version for p in module.parameters())

@@ -695,3 +695,29 @@ def test_zigzag_x0_branch_vs_golden(golden):
         np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"c{c}_prev"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(o.uncertainty.cpu().numpy(), g[f"c{c}_unc"], rtol=1e-2, atol=1e-6)
         assert s.denoiser_calls == M * nz                  # nothing skipped on this branch
+
+
+def test_inplace_weight_edit_repacks():
+    """Packed-weight caches follow in-place edits of the parameters: the output after `p.mul_()` equals a freshly
+    loaded model's, in a split mode whose packed planes would otherwise go stale; `.data` edits need invalidate_packed_weights()."""
+    m, sd = build_adm(TINY_ADM, 5)
+    m.precision = "f16x3"
+    x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(3)).to(dev)
+    t, y = torch.tensor([500, 10]).to(dev), torch.tensor([1, 2]).to(dev)
+    a = m(x, t, y=y)
+    name = "input_blocks.1.0.in_layers.2.weight"
+    with torch.no_grad():
+        dict(m.named_parameters())[name].mul_(1.5)
+    b = m(x, t, y=y)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2[name] = sd2[name] * 1.5
+    m2, _ = build_adm(TINY_ADM, 5)
+    m2.load_state_dict(sd2)
+    m2.precision = "f16x3"
+    c = m2(x, t, y=y)
+    assert (a - b).abs().max().item() > 1e-3                      # the edit is visible ...
+    np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=0, atol=1e-6)     # ... and equals a fresh pack
+    dict(m.named_parameters())[name].data.mul_(2.0)                # invisible to the version counter
+    m.invalidate_packed_weights()
+    d = m(x, t, y=y)
+    assert (d - b).abs().max().item() > 1e-3
