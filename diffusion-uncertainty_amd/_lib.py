@@ -36,6 +36,7 @@ SIGNATURES = {
     "dua_mc_reduce_var": (_I, [_P, _P, _Z, _I, _P]),
     "dua_quantile_mask": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dua_set_quantile_stream": (_I, [_I]),
+    "dua_flip_h": (_I, [_P, _P, _Z, _I, _I, _P]),
     "dua_posterior_blend": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "dua_threshold_map": (_I, [_P, _P, _P, _I, _Z, _I, _I, _P]),
     "dua_batch_sum": (_I, [_P, _P, _I, _Z, _P]),

@@ -495,6 +495,25 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
     return dua_check_launch("dua_quantile_mask");
 }
 
+// ---- vertical flip of NCHW images: torch.flip(x, dims=[2]) (schedulers_uncertainty/scheduling_ddim_flip.py:486,491) ----
+__global__ __launch_bounds__(BLK) void k_flip_h(const float* __restrict__ x, float* __restrict__ y, size_t planes, int H, int W) {
+    const size_t total = planes * H * W, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int w_ = (int)(i % W);
+        const size_t r = i / W;
+        const int h_ = (int)(r % H);
+        const size_t pl = r / H;
+        y[i] = x[(pl * H + (H - 1 - h_)) * W + w_];
+    }
+}
+extern "C" int dua_flip_h(const float* x, float* y, size_t planes, int H, int W, void* stream) {
+    DUA_REQUIRE(H >= 0 && W >= 0, "dua_flip_h: bad shape");
+    if (planes * (size_t)H * W == 0) return DUA_OK;
+    DUA_REQUIRE(x && y && x != y, "dua_flip_h: null pointer / in-place call");
+    hipLaunchKernelGGL(k_flip_h, stream_grid(planes * H * W, BLK), BLK, 0, as_stream(stream), x, y, planes, H, W);
+    return dua_check_launch("dua_flip_h");
+}
+
 // ---- posterior blend: uncertainty_guidance.py:115-120 ------------------------------------------
 __global__ __launch_bounds__(BLK) void k_posterior(const float* __restrict__ eps, const float* __restrict__ u,
                                                    const uint8_t* __restrict__ mask, float* __restrict__ out, int B,

@@ -121,6 +121,15 @@ def quantile_mask(u, p):
     return mask, q
 
 
+def flip_h(x):
+    """torch.flip(x, dims=[2]) of an NCHW tensor."""
+    _req(x, name="x")
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().dua_flip_h(_p(x), _p(y), N * C, H, W, _stream()), "dua_flip_h")
+    return y
+
+
 def posterior_blend(eps, u, mask, M, alpha_hat_t):
     _req(eps, name="eps"), _req(u, name="u"), _req(mask, torch.uint8, "mask")
     B = eps.shape[0]

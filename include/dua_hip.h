@@ -79,6 +79,10 @@ int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uin
  * to 65536 elements are held in registers by one workgroup (u read once; min/max-ranged LDS histogram + wavefront-shuffle scans). */
 int dua_set_quantile_stream(int on);
 
+/* y[p][h][w] = x[p][H-1-h][w] over `planes` = N*C image planes: torch.flip(x, dims=[2]) of an NCHW tensor, the input / output
+ * mirroring of the `flip` estimator (schedulers_uncertainty/scheduling_ddim_flip.py:486,491).  Out of place. */
+int dua_flip_h(const float* x, float* y, size_t planes, int H, int W, void* stream);
+
 /* Posterior blend, uncertainty_guidance.py:115-120.  eps,u: [B][n]; mask: [B][n] uint8. */
 int dua_posterior_blend(const float* eps, const float* u, const uint8_t* mask, float* out, int B, int n, int M,
                         float alpha_hat_t, void* stream);

@@ -192,3 +192,19 @@ def step_centered_d(tab, denoise, eps, t, x, n_steps, window, M, timesteps, unce
         out["uncertainty"] = acc / M
         out["pred_epsilon"] = eps
     return out
+
+
+def step_flip(tab, denoise, eps, t, x, n_steps, window, eta=0.0, clip_sample=True, draw=torch.randn_like):
+    """scheduling_ddim_flip.py:395-530: one extra forward on the vertically flipped (clipped) x0 prediction at the same
+    timestep, flipped back; uncertainty = (eps - flipped_output)^2 (:485-492).  One noise draw per step (:484)."""
+    prev, x0, c = ddim_update(tab, eps, t, x, n_steps, eta, clip_sample)
+    noise = draw(x0)
+    if eta > 0:
+        prev = prev + c["sigma"] * noise
+    out = dict(prev_sample=prev, pred_original_sample=x0, score=eps)
+    hi, lo = window
+    if lo <= t <= hi:
+        back = torch.flip(denoise(torch.flip(x0, dims=[2]), t), dims=[2])
+        out["uncertainty"] = (eps - back) ** 2
+        out["pred_epsilon"] = eps
+    return out

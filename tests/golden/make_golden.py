@@ -664,7 +664,42 @@ def g15():
     save("g15_zigzag_x0", **out)
 
 
+def g16():
+    """`flip` estimator: step() of the reference's own unconditional class (scheduling_ddim_flip.py:610-615) on a tiny
+    UNCONDITIONAL ADM (num_classes=None) and on a stub denoiser, inside and outside the window."""
+    from diffusion_uncertainty.schedulers_uncertainty.scheduling_ddim_flip import DDIMSchedulerUncertaintyImagenet as RefFlip
+    out = {}
+    cfg = dict(TINY_ADM, num_classes=None)
+    tiny = build_adm(cfg, seed=16)
+
+    class Stub(torch.nn.Module):
+        def forward(self, x, t, y=None):
+            h = 0.6 * x + 0.2 * torch.roll(x, 1, dims=-2) + (t.float() / 1000.0)[:, None, None, None]     # not flip-symmetric
+            return torch.cat([h, -h], dim=1)
+
+    x = randn(160, 2, 3, 16, 16)
+    out["x"] = x
+    case = 0
+    for name, model in (("stub", Stub()), ("tiny_adm_uncond", tiny)):
+        for t in (500, 400, 900):
+            with _quiet:
+                s = RefFlip.from_config(CONFIGS["adm128"], after_step=4, num_steps_uc=3, unet=model)
+                s.set_timesteps(10)
+                with torch.no_grad():
+                    eps = model(x, torch.full((2,), t, dtype=torch.long))[:, :3]
+                    torch.manual_seed(1600 + case)
+                    o = s.step(eps, t, x)
+            out[f"c{case}_meta"] = np.array([name, str(t), str(1600 + case)])
+            out[f"c{case}_eps"], out[f"c{case}_prev"], out[f"c{case}_x0"], out[f"c{case}_score"] = eps, o.prev_sample, o.pred_original_sample, o.score
+            if getattr(o, "uncertainty", None) is not None:
+                out[f"c{case}_unc"] = o.uncertainty
+                assert torch.equal(o.pred_epsilon, eps)
+            case += 1
+    out["n_cases"] = case
+    save("g16_flip", **out)
+
+
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -721,3 +721,41 @@ def test_inplace_weight_edit_repacks():
     m.invalidate_packed_weights()
     d = m(x, t, y=y)
     assert (d - b).abs().max().item() > 1e-3
+
+
+def test_flip_estimator_vs_golden(golden):
+    """`flip` (mirror-consistency) scheduler: step() on the GPU vs the reference's own unconditional class (G16), and the factory's
+    class-conditioned variant end to end through the driver."""
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128
+    from diffusion_uncertainty_amd.schedulers_uncertainty.scheduling_ddim_flip import DDIMSchedulerUncertaintyImagenet
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    g = golden("g16_flip")
+    x = T(g["x"]).to(dev)
+    m, _ = build_adm(dict(TINY_ADM, num_classes=None), 16)
+    seen = 0
+    for c in range(int(g["n_cases"])):
+        name, t, seed = g[f"c{c}_meta"]
+        if name != "tiny_adm_uncond":
+            continue
+        s = DDIMSchedulerUncertaintyImagenet.from_config(init_scheduler_imagenet128().config, after_step=4, num_steps_uc=3, unet=m)
+        s.set_timesteps(10)
+        eps = m(x, torch.full((2,), int(t), dtype=torch.long, device=dev))[:, :3]
+        np.testing.assert_allclose(eps.cpu().numpy(), g[f"c{c}_eps"], rtol=0, atol=1e-4)
+        torch.manual_seed(int(seed))
+        o = s.step(T(g[f"c{c}_eps"]).to(dev), int(t), x)
+        np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"c{c}_prev"], rtol=1e-6, atol=1e-6)
+        assert not o.pred_original_sample.is_cuda and not o.score.is_cuda            # moved to the CPU inside step(), as upstream
+        np.testing.assert_allclose(o.pred_original_sample.numpy(), g[f"c{c}_x0"], rtol=1e-6, atol=1e-6)
+        assert (o.uncertainty is not None) == (f"c{c}_unc" in g)
+        if o.uncertainty is not None:
+            seen += 1
+            ref = g[f"c{c}_unc"]
+            assert np.abs(o.uncertainty.numpy() - ref).max() <= 2e-3 * ref.max()
+    assert seen == 2
+    mc, _ = build_adm(TINY_ADM, 5)
+    sc = _sched("flip", mc)
+    sc.set_timesteps(10)
+    torch.manual_seed(0)
+    r = gen(torch.randn(3, 3, 16, 16, generator=torch.Generator().manual_seed(1)), torch.tensor([1, 2, 3]), 2, torch.device(dev), mc, sc)
+    assert r["uncertainty"].shape == (3, 3, 3, 16, 16) and r["score"].shape == (3, 3, 3, 16, 16) and sc.denoiser_calls == 6
+    assert bool((r["uncertainty"] >= 0).all())

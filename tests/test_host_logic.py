@@ -48,9 +48,10 @@ def test_factory_semantics():
         assert isinstance(s, SchedulerUncertaintyMixin) and isinstance(s, SchedulerUncertaintyClassConditionedMixin)
     u = load_uvit_scheduler()
     assert "set_alpha_to_one" not in u.config and u.config.steps_offset == 1 and u.config.clip_sample is False
-    for kind in ("flip", "flip_grad"):
-        with pytest.raises(NotImplementedError):
-            get_uncertainty_scheduler(args(kind), y, None, base)
+    with pytest.raises(NotImplementedError):
+        get_uncertainty_scheduler(args("flip_grad"), y, None, base)
+    fl = get_uncertainty_scheduler(args("flip"), y, "UNET", base)                 # (no M; prompt_embeds= is taken)
+    assert fl.prompt_embeds is y and fl.unet == "UNET" and fl.config.after_step == 4 and not hasattr(fl, "M")
     k = get_uncertainty_scheduler(args("dpm_2_uncertainty_centered"), y, "UNET", base)     # y= / eta= are dropped by from_config
     assert (k.M, k.unet, k.prompt_embeds, k.config.solver_order, k.config.timestep_spacing) == (5, "UNET", None, 2, "leading")
     assert k.config.variance_type == "fixed_small" and k.config.final_sigmas_type == "zero"

@@ -433,3 +433,37 @@ def test_g15_zigzag_x0_branch(golden):
         o = ddim.step_zigzag_centered(tab, den, T(g[f"c{c}_eps"]), t, x, 10, window, M, nz, predict_next=False)
         np.testing.assert_array_equal(o["prev_sample"].numpy(), g[f"c{c}_prev"])
         np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"c{c}_unc"], rtol=1e-4, atol=1e-6)
+
+
+def test_g16_flip(golden):
+    """`flip` estimator: oracle vs the reference's own unconditional class (stub denoiser and tiny unconditional ADM)."""
+    from tests_support import adm_state_shapes
+    g = golden("g16_flip")
+    x = T(g["x"])
+    cfg = dict(TINY_ADM, num_classes=None)
+    sd = seeded_state_dict(adm_state_shapes(cfg), 16)
+    tab = TABLES["adm128"]()
+    window = schedule.uc_window(schedule.leading_timesteps(1000, 10), 4, 3)
+
+    def stub(xx, t, train=False):
+        tv = torch.full((xx.shape[0],), int(t), dtype=torch.long)
+        return 0.6 * xx + 0.2 * torch.roll(xx, 1, dims=-2) + (tv.float() / 1000.0)[:, None, None, None]
+
+    def tiny(xx, t, train=False):
+        return adm.forward(sd, cfg, xx, torch.full((xx.shape[0],), int(t), dtype=torch.long), None)[:, :3]
+
+    seen = 0
+    for c in range(int(g["n_cases"])):
+        name, t, seed = g[f"c{c}_meta"]
+        den = stub if name == "stub" else tiny
+        tol = dict(rtol=0, atol=0) if name == "stub" else dict(rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(den(x, int(t)).numpy(), g[f"c{c}_eps"], **tol)
+        torch.manual_seed(int(seed))
+        o = ddim.step_flip(tab, den, T(g[f"c{c}_eps"]), int(t), x, 10, window)
+        np.testing.assert_array_equal(o["prev_sample"].numpy(), g[f"c{c}_prev"])
+        np.testing.assert_array_equal(o["pred_original_sample"].numpy(), g[f"c{c}_x0"])
+        assert ("uncertainty" in o) == (f"c{c}_unc" in g)
+        if "uncertainty" in o:
+            seen += 1
+            np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"c{c}_unc"], rtol=1e-4, atol=1e-7)
+    assert seen == 4
