@@ -46,11 +46,12 @@ PRECISIONS = ["f16x3", "fp32", "bf16x3", "f16f8", "f16f6"]
 
 # per precision mode: (kernel description, MFMA products executed per algorithmic product at the bf16 rate, dtype string)
 MODES = {
-    "f16x3": ("k_xconv_dma<NT, 3> (LDS-DMA implicit-GEMM conv3x3 on fp16 hi / lo planes of the scaled fp32 operands, "
-              "hi*hi + hi*lo + lo*hi = 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)", 3.0,
+    "f16x3": ("k_xconv_dma<NT, 3> (32x32x16 shape) / k_hconv<NT, RS> (16x16x32 shape, 256-channel tiles on maps <= 64^2): LDS-DMA "
+              "implicit-GEMM conv3x3 on fp16 hi / lo planes of the scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs per "
+              "product, fp32 accumulate", 3.0,
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
-              "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 1x1 / proj_out / attention products exact fp32 MFMA; "
-              "norms / softmax / sampler fp32)"),
+              "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
+              "with head dims <= 128 in this format, wider heads / embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
     "fp32": ("k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)", None, "f32"),
     "bf16x3": ("k_xconv_dma<NT, 0> (LDS-DMA split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)", 3.0,
                "bf16x3 (fp32 operands split into 2 bf16 terms = 16 significant bits, 3 bf16 MFMA products, fp32 accumulate)"),
@@ -61,7 +62,8 @@ MODES = {
               "f16f6 (fp16 hi + MXFP6 cross terms: ~14-15 significant bits)"),
 }
 PARITY_NOTE = ("full-size ADM-128 forward vs the reference CPU output (tests/test_gpu_models.py, tolerance 1e-3): max abs err "
-               "f16x3 see test_bf16x3_mode_adm[adm128-f16x3] (bound 1.5e-5), fp32 7.4e-6, bf16x3 3.1e-5, f16f8 5.3e-5, f16f6 6.8e-5")
+               "f16x3 5.7e-6, fp32 7.4e-6, bf16x3 3.1e-5, f16f8 5.3e-5, f16f6 6.8e-5; free-running full-size 10-step guided chain (G13): score err "
+               "f16x3 2.3e-4, fp32 2.4e-4, bf16x3 8.4e-4, f16f8 1.8e-3, f16f6 2.1e-3; percentile-0.9 mask agreement >= 99.99 % in every mode")
 
 
 def pmc_traffic(precision):
@@ -199,6 +201,80 @@ def cpu_baseline(sd, M, nz, gen_steps, n_uc):
                        f"extrapolated to the reference's {ref_forwards} forwards/image")
 
 
+def other_config_uvit(dev, a):
+    """BASELINE configs[2]: U-ViT-H/2 ImageNet-256 latents [64, 4, 32, 32], 50 steps, M=5, num_zigzag=3, W10, + one KL-VAE decode per
+    batch.  One untimed 5-timestep job, then one timed job.  Random-init weights, synthetic inputs."""
+    import torch
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_uvit_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import load_autoencoder_uvit, load_uvit, load_uvit_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise
+    from diffusion_uncertainty_amd.utils import randomize_parameters_, starting_points
+    from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
+    uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
+    ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
+    uvit.precision, ae.precision = "f16f8", "bf16x3"
+    model = UViTAE(uvit, ae).to(dev)
+    X_T, y = starting_points(64, (4, 32, 32))
+
+    def job(n_steps, start, num, seed):
+        args = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=5, start_step_uc=start, num_steps_uc=num,
+                                  predict_next=True, eta=0.0, num_zigzag=3, uncertainty_distance=1)
+        s = get_uncertainty_scheduler(args, y.to(dev), model, load_uvit_scheduler())
+        s.noise_source = DeviceNoise(seed=seed)
+        s.set_timesteps(n_steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gen(X_T, y, 64, model, s, dev)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, s.denoiser_calls
+
+    job(5, 4, 1, 1)
+    dt, uc = job(50, 40, 10, 0)
+    del model, uvit, ae
+    torch.cuda.empty_cache()
+    return dict(config="BASELINE configs[2]: U-ViT-H/2 ImageNet-256, 50 steps, M=5, uncertainty_zigzag_centered (W10), batch 64, + KL-VAE decode",
+                value=round(64 / dt, 3), unit="images/sec", seconds_per_job=round(dt, 2), executed_forwards_per_image=50 + uc,
+                dtype="f16f8 (fp16 hi + fp8 cross terms, ~15 significant bits: NOT the fp32-equivalent mode, which is wired for the ADM UNet only); "
+                      "VAE decoder bf16x3", data="synthetic, random-init weights")
+
+
+def other_config_sd(dev, a):
+    """BASELINE configs[4]: SD-1.5 latent UNet 512x512 (latents [1, 4, 64, 64], CFG batch 2), uncertainty-threshold guidance with
+    percentile 0.9 in posterior mode, 20 PLMS steps, M=5, num_steps_threshold=2 (readme.md:138).  Seconds per image, best of two
+    timed runs after one warm-up run (HIP-graph replay of the UNet forward).  Random-init weights, synthetic prompt embeddings."""
+    import torch
+    from diffusion_uncertainty_amd import uncertainty_guidance
+    from diffusion_uncertainty_amd.pipeline_uncertainty.pipeline_stable_diffusion_uncertainty_guided import StableDiffusionPipelineUncertainty
+    from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise
+    from diffusion_uncertainty_amd.schedulers_uncertainty.scheduling_pndm import PNDMScheduler
+    from diffusion_uncertainty_amd.stable_diffusion.unet_2d_condition import UNet2DConditionModel
+    from diffusion_uncertainty_amd.utils import randomize_parameters_
+    uncertainty_guidance.use_posterior = True
+    unet = randomize_parameters_(UNet2DConditionModel(), seed=15).eval().to(dev)
+    unet.precision = "f16f8"
+    unet.enable_hip_graph()
+    g = torch.Generator().manual_seed(491)
+    pe, ne = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    pipe = StableDiffusionPipelineUncertainty(unet, PNDMScheduler())
+    uncertainty_guidance.noise_source = DeviceNoise(seed=491)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=20, guidance_scale=7.5, start_step_uc=0, num_steps_uc=2,
+              percentile=0.9, num_uncertainty_samples=5, height=512, width=512)
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe(generator=torch.Generator().manual_seed(491), **kw)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    del unet, pipe
+    torch.cuda.empty_cache()
+    return dict(config="BASELINE configs[4]: SD-1.5 latent UNet 512x512, percentile-0.9 uncertainty guidance (posterior mode), 20 steps, M=5, 2 guided steps",
+                value=round(min(times[1:]), 3), unit="seconds/image", higher_is_better=False,
+                dtype="f16f8 (~15 significant bits); parity of the UNet itself unpinned (un-vendored diffusers), the guidance function is pinned (G7)",
+                data="synthetic prompt embeddings, random-init weights", first_run_incl_packing_s=round(times[0], 2))
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,6 +293,7 @@ def parse_args(argv=None):
     ap.add_argument("--secondary", default="fp32,f16f6", help="comma list of precision modes run for ONE job each after the headline (N=1 only)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the one-job runs of BASELINE configs[2] (U-ViT) and configs[4] (SD) at N=1")
     ap.add_argument("--no-profile", action="store_true")
     # launcher / test plumbing
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the launch path (needs --stub-job)")
@@ -348,6 +425,16 @@ def main(argv=None):
                                end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
                                roofline=(prof2.roofline(other) if prof2 is not None else None)))
 
+    other_configs = []
+    if world == 1 and not a.no_other_configs and not a.no_secondary:
+        del model                                   # the ADM-128 weights and packed planes (3 GB) are not needed any more
+        torch.cuda.empty_cache()
+        for leg in (other_config_uvit, other_config_sd):
+            try:
+                other_configs.append(leg(dev, a))
+            except Exception as e:                   # a side leg must never take the headline line down
+                other_configs.append(dict(config=leg.__name__, error=f"{type(e).__name__}: {e}"[:300]))
+
     if rank == 0:
         images = a.batch * world * jobs
         exec_flops = fwd_per_img * ADM128_FLOPS_PER_FWD_IMG * images
@@ -375,6 +462,8 @@ def main(argv=None):
         }
         if others:
             line["other_precision_modes"] = others
+        if other_configs:
+            line["other_configs"] = other_configs
         if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(sd, a.M, a.num_zigzag, a.generation_steps, a.num_steps_uc)
             cb["gpu_over_cpu_same_forward_count"] = round(line["value_at_reference_forward_count"] / cb["value"], 1)
