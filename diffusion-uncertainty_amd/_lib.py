@@ -23,6 +23,22 @@ class GemmArgs(_c.Structure):
                 ("transB", _I), ("act_in", _I), ("act_out", _I), ("alpha", _F), ("colsum", _P)]
 
 
+class ResBlockArgs(_c.Structure):
+    _fields_ = [("x1", _P), ("C1", _I), ("x2", _P), ("C2", _I), ("N", _I), ("H", _I), ("W", _I), ("Cout", _I),
+                ("gn1_w", _P), ("gn1_b", _P), ("conv1_packed", _P), ("conv1_b", _P), ("film", _P), ("film_ld", _L),
+                ("gn2_w", _P), ("gn2_b", _P), ("conv2_packed", _P), ("conv2_b", _P), ("skip_packed", _P), ("skip_b", _P),
+                ("x1_colsums", _P), ("x2_colsums", _P), ("updown", _I), ("dropmask", _P),
+                ("precision", _I), ("act_scale", _F), ("raw_scale", _F), ("workspace", _P), ("workspace_bytes", _Z),
+                ("y", _P), ("y_colsums", _P)]
+
+
+class AttnBlockArgs(_c.Structure):
+    _fields_ = [("x", _P), ("C", _I), ("N", _I), ("H", _I), ("W", _I), ("heads", _I), ("gn_w", _P), ("gn_b", _P),
+                ("qkv_packed", _P), ("qkv_b", _P), ("proj_packed", _P), ("proj_b", _P), ("x_colsums", _P),
+                ("precision", _I), ("act_scale", _F), ("raw_scale", _F), ("workspace", _P), ("workspace_bytes", _Z),
+                ("y", _P), ("y_colsums", _P)]
+
+
 # name -> (restype, argtypes); every symbol include/dua_hip.h declares
 SIGNATURES = {
     "dua_version": (_I, []),
@@ -86,6 +102,10 @@ SIGNATURES = {
     "dua_gemm_f16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "dua_gemm_f16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _F, _P]),
     "dua_attention_f16x3": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _F, _P]),
+    "dua_adm_resblock_workspace_bytes": (_Z, [_c.POINTER(ResBlockArgs)]),
+    "dua_adm_resblock_fwd": (_I, [_c.POINTER(ResBlockArgs), _P]),
+    "dua_adm_attnblock_workspace_bytes": (_Z, [_c.POINTER(AttnBlockArgs)]),
+    "dua_adm_attnblock_fwd": (_I, [_c.POINTER(AttnBlockArgs), _P]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),

@@ -1,0 +1,175 @@
+// Block-level entry points of the C ABI: one ADM ResBlock / AttentionBlock forward per call (SURVEY.md 8(b):
+// adm_resblock_fwd, adm_attnblock_fwd).  Pure host-side sequencing of the per-op entry points of this library on the caller's
+// stream over a caller-provided workspace: the same kernels, in the same order, with the same operands as the Python
+// composition in guided_diffusion/unet_openai.py (ResBlock.run / AttentionBlock.run), so the results are bit-identical to it.
+// Precisions: DUA_PREC_FP32 (exact fp32 MFMA) and DUA_PREC_F16X3 (the fp32-equivalent split) - the two parity modes.
+#include "common.h"
+
+namespace {
+
+struct Carver {                       // bump allocator over the caller's workspace, 256-byte aligned pieces
+    char* base;
+    size_t used, cap;
+    bool dry;                         // dry run: only add up the sizes
+    void* take(size_t bytes) {
+        size_t at = (used + 255) & ~(size_t)255;
+        used = at + bytes;
+        return (dry || used > cap) ? nullptr : base + at;
+    }
+};
+
+inline size_t colsum_floats(long M, int cout) { return (size_t)((M + 63) / 64) * 2 * cout; }
+
+// GroupNorm statistics of [x1 | x2]: from the producers' column sums when both sources carry them (and H*W % 64 == 0), else
+// by the stand-alone kernel.  `gnws` must hold dua_groupnorm_ws_floats(...) floats in the second case.
+int gn_stats(const float* x1, int C1, const float* cs1, const float* x2, int C2, const float* cs2, int N, int HW, int G, float* gnws,
+             float* stats, void* stream) {
+    if (cs1 && (C2 == 0 || cs2) && HW % 64 == 0)
+        return dua_groupnorm_stats_from_colsums(cs1, C1, C2 ? cs2 : nullptr, C2, N, HW, G, 1e-5f, stats, stream);
+    return dua_groupnorm_stats(x1, C1, C2 ? x2 : nullptr, C2, N, HW, G, 1e-5f, gnws, stats, stream);
+}
+
+int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
+    const int C = a->C1 + a->C2, G = 32;
+    const int Ho = a->updown < 0 ? a->H / 2 : (a->updown > 0 ? 2 * a->H : a->H), Wo = a->updown < 0 ? a->W / 2 : (a->updown > 0 ? 2 * a->W : a->W);
+    const long M = (long)a->N * Ho * Wo;
+    const bool f16 = a->precision == DUA_PREC_F16X3, colsum2 = a->Cout % 4 == 0;
+    float* stats1 = (float*)w.take((size_t)a->N * G * 2 * 4);
+    float* gnws = (float*)w.take(dua_groupnorm_ws_floats(a->N, a->H * a->W > Ho * Wo ? a->H * a->W : Ho * Wo, C > a->Cout ? C : a->Cout, G) * 4);
+    void* h1 = w.take((size_t)M * C * 4);                            // fp32 [N,Ho,Wo,C] or two 2-byte planes of it
+    float* xr = a->updown ? (float*)w.take((size_t)M * a->C1 * 4) : nullptr;
+    float* h2 = (float*)w.take((size_t)M * a->Cout * 4);
+    float* cs2 = colsum2 ? (float*)w.take(colsum_floats(M, a->Cout) * 4) : nullptr;
+    float* stats2 = (float*)w.take((size_t)a->N * G * 2 * 4);
+    void* h3 = w.take((size_t)M * a->Cout * 4);
+    float* res = a->skip_packed ? (float*)w.take((size_t)M * a->Cout * 4) : nullptr;
+    if (w.dry) return DUA_OK;
+    DUA_REQUIRE(w.used <= w.cap && a->workspace, "dua_adm_resblock_fwd: workspace of %zu bytes needed, %zu given", w.used, w.cap);
+    int rc;
+    // in_layers: GroupNorm32 -> SiLU (-> 2x resampling of h, :238-243) -> conv3x3                       unet_openai.py:183-187
+    if ((rc = gn_stats(a->x1, a->C1, a->x1_colsums, a->x2, a->C2, a->x2_colsums, a->N, a->H * a->W, G, gnws, stats1, stream))) return rc;
+    if (f16) rc = dua_groupnorm_apply_split_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
+                                                  nullptr, a->act_scale, h1, stream);
+    else rc = dua_groupnorm_apply(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown, nullptr,
+                                  (float*)h1, stream);
+    if (rc) return rc;
+    if (a->updown && (rc = dua_resample2x(a->x1, xr, a->N, a->H, a->W, a->C1, a->updown, stream))) return rc;          // x_upd :243
+    if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
+    else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
+    if (rc) return rc;
+    // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
+    if ((rc = gn_stats(h2, a->Cout, cs2, nullptr, 0, nullptr, a->N, Ho * Wo, G, gnws, stats2, stream))) return rc;
+    if (f16) rc = dua_groupnorm_apply_split_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
+                                                  a->dropmask, a->act_scale, h3, stream);
+    else rc = dua_groupnorm_apply(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0, a->dropmask,
+                                  (float*)h3, stream);
+    if (rc) return rc;
+    const float* xin = a->updown ? xr : a->x1;
+    const float* resid = xin;                                                                                  // identity skip :223-226
+    if (a->skip_packed) {                                                                                      // 1x1 convolution over [x | skip]
+        if (f16) {
+            rc = dua_gemm_f16x3(xin, a->C1, a->C1, a->C2 ? a->x2 : nullptr, a->C2, a->C2 > 4 ? a->C2 : 4, a->skip_packed, a->skip_b, nullptr, a->Cout,
+                                res, a->Cout, (int)M, a->Cout, 0, 0, 1.0f, nullptr, a->raw_scale, stream);
+        } else {
+            dua_gemm_args g{};
+            g.A1 = xin; g.A2 = a->C2 ? a->x2 : nullptr; g.B = (const float*)a->skip_packed; g.bias = a->skip_b; g.C = res;
+            g.M = (int)M; g.N = a->Cout; g.K1 = a->C1; g.K2 = a->C2;
+            g.lda1 = a->C1; g.lda2 = a->C2 > 4 ? a->C2 : 4; g.ldb = C; g.ldc = a->Cout; g.ldr = a->Cout;
+            g.batch = 1; g.batch_inner = 1; g.transB = 1; g.alpha = 1.0f;
+            rc = dua_gemm(&g, stream);
+        }
+        if (rc) return rc;
+        resid = res;
+    }
+    float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
+    if (f16) return dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
+    return dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
+}
+
+int attnblock_run(const dua_attnblock_args* a, Carver& w, void* stream) {
+    const int C = a->C, G = 32, T = a->H * a->W, ch = C / a->heads;
+    const long M = (long)a->N * T;
+    const bool f16 = a->precision == DUA_PREC_F16X3;
+    float* stats = (float*)w.take((size_t)a->N * G * 2 * 4);
+    float* gnws = (float*)w.take(dua_groupnorm_ws_floats(a->N, T, C, G) * 4);
+    void* xn = w.take((size_t)M * C * 4);
+    float* qkv = (float*)w.take((size_t)M * 3 * C * 4);
+    void* att = w.take((size_t)M * C * 4);
+    if (w.dry) return DUA_OK;
+    DUA_REQUIRE(w.used <= w.cap && a->workspace, "dua_adm_attnblock_fwd: workspace of %zu bytes needed, %zu given", w.used, w.cap);
+    int rc;
+    if ((rc = gn_stats(a->x, C, a->x_colsums, nullptr, 0, nullptr, a->N, T, G, gnws, stats, stream))) return rc;                       // norm :300
+    const float scale = (float)(1.0 / sqrt((double)ch));                  // the two ch^-1/4 operand scales of :349 / :382
+    float* ycs = (a->y_colsums && C % 4 == 0) ? a->y_colsums : nullptr;
+    if (f16) {
+        if ((rc = dua_groupnorm_apply_split_f16x3(a->x, C, nullptr, 0, a->N, a->H, a->W, G, stats, a->gn_w, a->gn_b, nullptr, 0, 0, 0, nullptr,
+                                                  a->act_scale, xn, stream))) return rc;
+        if ((rc = dua_gemm_f16x3_presplit(xn, a->qkv_packed, a->qkv_b, nullptr, qkv, (int)M, 3 * C, C, 0, nullptr, a->act_scale, stream))) return rc;   // qkv :301
+        if ((rc = dua_attention_f16x3(qkv, nullptr, att, a->raw_scale, a->N, T, a->heads, ch, scale, stream))) return rc;                               // :302
+        return dua_gemm_f16x3_presplit(att, a->proj_packed, a->proj_b, a->x, a->y, (int)M, C, C, 0, ycs, a->raw_scale, stream);                         // proj_out + x :303-306
+    }
+    if ((rc = dua_groupnorm_apply(a->x, C, nullptr, 0, a->N, a->H, a->W, G, stats, a->gn_w, a->gn_b, nullptr, 0, 0, 0, nullptr, (float*)xn, stream))) return rc;
+    dua_gemm_args g{};
+    g.A1 = (const float*)xn; g.B = (const float*)a->qkv_packed; g.bias = a->qkv_b; g.C = qkv;
+    g.M = (int)M; g.N = 3 * C; g.K1 = C; g.lda1 = C; g.lda2 = 4; g.ldb = C; g.ldc = 3 * C; g.ldr = 3 * C;
+    g.batch = 1; g.batch_inner = 1; g.transB = 1; g.alpha = 1.0f;
+    if ((rc = dua_gemm(&g, stream))) return rc;
+    if ((rc = dua_attention(qkv, (float*)att, a->N, T, a->heads, ch, scale, stream))) return rc;
+    dua_gemm_args p{};
+    p.A1 = (const float*)att; p.B = (const float*)a->proj_packed; p.bias = a->proj_b; p.residual = a->x; p.C = a->y;
+    p.M = (int)M; p.N = C; p.K1 = C; p.lda1 = C; p.lda2 = 4; p.ldb = C; p.ldc = C; p.ldr = C;
+    p.batch = 1; p.batch_inner = 1; p.transB = 1; p.alpha = 1.0f; p.colsum = ycs;
+    return dua_gemm(&p, stream);
+}
+
+int check_resblock(const dua_resblock_args* a) {
+    DUA_REQUIRE(a && a->x1 && a->y && a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_packed && a->conv2_packed && a->film,
+                "dua_adm_resblock_fwd: null pointer");
+    DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3, "dua_adm_resblock_fwd: precision must be DUA_PREC_FP32 or DUA_PREC_F16X3");
+    DUA_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->C1 > 0 && a->C2 >= 0 && a->Cout > 0 && (a->C1 + a->C2) % 32 == 0 && a->Cout % 32 == 0,
+                "dua_adm_resblock_fwd: channel counts must be positive multiples of 32 (GroupNorm32)");
+    DUA_REQUIRE((a->C2 == 0) == (a->x2 == nullptr), "dua_adm_resblock_fwd: x2 / C2 mismatch");
+    DUA_REQUIRE(a->updown >= -1 && a->updown <= 1 && (a->updown == 0 || (a->C2 == 0 && !a->skip_packed && !a->dropmask)),
+                "dua_adm_resblock_fwd: a resampling block takes one source, an identity skip and no dropout mask");
+    DUA_REQUIRE(a->skip_packed || a->C1 + a->C2 == a->Cout, "dua_adm_resblock_fwd: a channel-changing block needs the 1x1 skip weights");
+    DUA_REQUIRE(a->precision != DUA_PREC_F16X3 || (a->act_scale > 0.f && a->raw_scale > 0.f && a->C1 % 32 == 0), "dua_adm_resblock_fwd: f16x3 needs positive scales and C1 %% 32 == 0");
+    return DUA_OK;
+}
+
+int check_attnblock(const dua_attnblock_args* a) {
+    DUA_REQUIRE(a && a->x && a->y && a->gn_w && a->gn_b && a->qkv_packed && a->qkv_b && a->proj_packed && a->proj_b, "dua_adm_attnblock_fwd: null pointer");
+    DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3, "dua_adm_attnblock_fwd: precision must be DUA_PREC_FP32 or DUA_PREC_F16X3");
+    DUA_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->C % 32 == 0 && a->heads > 0 && a->C % a->heads == 0, "dua_adm_attnblock_fwd: bad shape");
+    const int ch = a->C / a->heads;
+    DUA_REQUIRE(a->precision == DUA_PREC_F16X3 ? (ch % 4 == 0 && ch >= 8 && ch <= 128) : (ch % 8 == 0 && ch <= 128),
+                "dua_adm_attnblock_fwd: head dim %d is outside the fused attention kernels of this precision", ch);
+    DUA_REQUIRE(a->precision != DUA_PREC_F16X3 || (a->act_scale > 0.f && a->raw_scale > 0.f), "dua_adm_attnblock_fwd: f16x3 needs positive scales");
+    return DUA_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* a) {
+    if (check_resblock(a) != DUA_OK) return 0;
+    Carver w{nullptr, 0, 0, true};
+    resblock_run(a, w, nullptr);
+    return w.used + 256;
+}
+extern "C" int dua_adm_resblock_fwd(const dua_resblock_args* a, void* stream) {
+    int rc = check_resblock(a);
+    if (rc) return rc;
+    Carver w{(char*)a->workspace, 0, a->workspace_bytes, false};
+    return resblock_run(a, w, stream);
+}
+extern "C" size_t dua_adm_attnblock_workspace_bytes(const dua_attnblock_args* a) {
+    if (check_attnblock(a) != DUA_OK) return 0;
+    Carver w{nullptr, 0, 0, true};
+    attnblock_run(a, w, nullptr);
+    return w.used + 256;
+}
+extern "C" int dua_adm_attnblock_fwd(const dua_attnblock_args* a, void* stream) {
+    int rc = check_attnblock(a);
+    if (rc) return rc;
+    Carver w{(char*)a->workspace, 0, a->workspace_bytes, false};
+    return attnblock_run(a, w, stream);
+}

@@ -91,6 +91,17 @@ class ResBlock(TimestepBlock):
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, drop, conv2 = self.out_layers[0], self.out_layers[2], self.out_layers[3]
         N, H, W, _ = x.shape
+        if ctx.block_abi and x.shape[3] % 32 == 0 and (skip is None or skip.shape[3] % 32 == 0) and self.out_channels % 32 == 0:
+            # the whole block as ONE C-ABI call (dua_adm_resblock_fwd: the same kernels in the same order, bit-identical)
+            kind3, kind1 = ("w3h", "w1h") if ctx.model.precision == "f16x3" else ("w3", "w1")
+            ident = isinstance(self.skip_connection, nn.Identity)
+            mask = ctx.dropout_mask((N, H, W, self.out_channels), drop.p) if (drop.training and drop.p > 0 and not self.updown) else None
+            if not (drop.training and drop.p > 0 and self.updown):          # (a dropout mask on a resampling block: composed path)
+                return ops.adm_resblock(x, skip, (gn1.weight, gn1.bias), ctx.packed(conv1, kind3), conv1.bias, ctx.film(self),
+                                        (gn2.weight, gn2.bias), ctx.packed(conv2, kind3), conv2.bias,
+                                        None if ident else ctx.packed(self.skip_connection, kind1),
+                                        None if ident else self.skip_connection.bias, self.out_channels, updown=self.resample,
+                                        dropmask=mask, precision=ctx.model.precision, want_colsum=ctx.model.fuse_gn_stats)
         st = ops.groupnorm_stats(x, skip)
         Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
         h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample, split=ctx.conv_split(Wc))
@@ -150,6 +161,13 @@ class AttentionBlock(nn.Module):
     def run(self, ctx, x):
         N, H, W, C = x.shape
         T = H * W
+        ch = C // self.num_heads
+        if ctx.block_abi and C % 32 == 0 and ch <= 128 and ch % 8 == 0 and ctx.model.presplit_qkv and ops.ATTENTION_MODE == "auto":
+            f16 = ctx.model.precision == "f16x3"
+            qk, bq = ctx.packed(self, "qkvh" if f16 else "qkv")
+            return ops.adm_attnblock(x, self.num_heads, (self.norm.weight, self.norm.bias), qk, bq,
+                                     ctx.packed(self.proj_out, "w1h" if f16 else "w1"), self.proj_out.bias,
+                                     precision=ctx.model.precision, want_colsum=ctx.model.fuse_gn_stats)
         st = ops.groupnorm_stats(x)
         # bf16x3 mode: the normalised tokens go straight out as split bf16 planes and the qkv projection runs on the
         # LDS-DMA kernel (one tap)
@@ -192,6 +210,8 @@ class _Ctx:
         self.presplit = model.precision != "fp32"
         self.split_acts = model.precision if model.precision in ("f16f8", "f16f6", "f16x3") else model.precision == "bf16x3"
         self.gemm_split = "f16f8" if self.split_acts == "f16f6" else self.split_acts       # one-tap GEMMs (qkv, proj_out)
+        # parity modes: whole ResBlocks / AttentionBlocks as single C-ABI calls (dua_adm_resblock_fwd / dua_adm_attnblock_fwd)
+        self.block_abi = bool(getattr(model, "use_block_abi", True)) and model.precision in ("fp32", "f16x3") and not model.activation_noise
 
     def conv_split(self, width):
         """Operand format the GroupNorm in front of a 3x3 conv of this output width writes."""
@@ -363,6 +383,7 @@ class UNetModel(nn.Module):
         # use the stand-alone statistics kernel everywhere.
         self.fuse_gn_stats = True
         self.presplit_qkv = True         # bf16x3: attention GroupNorm writes split planes, qkv runs on the LDS-DMA kernel
+        self.use_block_abi = True        # fp32 / f16x3: ResBlocks and AttentionBlocks run as ONE C-ABI call each (bit-identical to the composition)
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, check
+from ._lib import AttnBlockArgs, GemmArgs, ResBlockArgs, check
 
 
 def _stream():
@@ -780,3 +780,64 @@ def unpatchify(tok, B, L, extras, C, P):
     img = torch.empty((B, C, g * P, g * P), device=tok.device, dtype=torch.float32)
     check(_lib.lib().dua_unpatchify(_p(tok), _p(img), B, L, extras, C, P, _stream()), "dua_unpatchify")
     return img
+
+
+# ------------------------------------------------------------------ block-level entry points
+PRECISION_CODE = {"fp32": 0, "f16x3": 3}
+
+
+def _cs(t):
+    """Producer column sums attached to an NHWC tensor (or None)."""
+    return getattr(t, "_dua_colsums", None) if t is not None else None
+
+
+def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, conv2_b, skip_packed, skip_b, cout, updown=0,
+                 dropmask=None, precision="fp32", want_colsum=True):
+    """One ADM ResBlock forward through dua_adm_resblock_fwd (guided_diffusion/unet_openai.py:237-257).  x / skip NHWC fp32,
+    gn1 / gn2 = (weight, bias) pairs, weights packed for `precision`; returns y NHWC with its column sums attached."""
+    _req(x, name="x")
+    N, H, W, C1 = x.shape
+    C2 = 0 if skip is None else skip.shape[3]
+    Ho, Wo = (H // 2, W // 2) if updown < 0 else ((2 * H, 2 * W) if updown > 0 else (H, W))
+    y = torch.empty((N, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    ws_y = _colsum_ws(N * Ho * Wo, cout, x.device, want_colsum)
+    a = ResBlockArgs(x1=x.data_ptr(), C1=C1, x2=(skip.data_ptr() if skip is not None else None), C2=C2, N=N, H=H, W=W, Cout=cout,
+                     gn1_w=gn1[0].data_ptr(), gn1_b=gn1[1].data_ptr(), conv1_packed=conv1_packed.data_ptr(), conv1_b=conv1_b.data_ptr(),
+                     film=film.data_ptr(), film_ld=_film_ld(film, N, cout), gn2_w=gn2[0].data_ptr(), gn2_b=gn2[1].data_ptr(),
+                     conv2_packed=conv2_packed.data_ptr(), conv2_b=conv2_b.data_ptr(),
+                     skip_packed=(skip_packed.data_ptr() if skip_packed is not None else None),
+                     skip_b=(skip_b.data_ptr() if skip_b is not None else None),
+                     x1_colsums=(_cs(x).data_ptr() if _cs(x) is not None else None),
+                     x2_colsums=(_cs(skip).data_ptr() if _cs(skip) is not None else None), updown=int(updown),
+                     dropmask=(dropmask.data_ptr() if dropmask is not None else None), precision=PRECISION_CODE[precision],
+                     act_scale=F16X3_ACT_SCALE, raw_scale=F16X3_RAW_SCALE, workspace=None, workspace_bytes=0, y=y.data_ptr(),
+                     y_colsums=(ws_y.data_ptr() if ws_y is not None else None))
+    L = _lib.lib()
+    nbytes = L.dua_adm_resblock_workspace_bytes(ctypes.byref(a))
+    if nbytes == 0:
+        raise RuntimeError(f"dua_adm_resblock_workspace_bytes: {L.dua_last_error().decode()}")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(L.dua_adm_resblock_fwd(ctypes.byref(a), _stream()), "dua_adm_resblock_fwd")
+    return _attach_colsums(y, ws_y, Ho * Wo)
+
+
+def adm_attnblock(x, heads, gn, qkv_packed, qkv_b, proj_packed, proj_b, precision="fp32", want_colsum=True):
+    """One ADM AttentionBlock forward through dua_adm_attnblock_fwd (unet_openai.py:300-306), head dims <= 128."""
+    _req(x, name="x")
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    ws_y = _colsum_ws(N * H * W, C, x.device, want_colsum)
+    a = AttnBlockArgs(x=x.data_ptr(), C=C, N=N, H=H, W=W, heads=int(heads), gn_w=gn[0].data_ptr(), gn_b=gn[1].data_ptr(),
+                      qkv_packed=qkv_packed.data_ptr(), qkv_b=qkv_b.data_ptr(), proj_packed=proj_packed.data_ptr(), proj_b=proj_b.data_ptr(),
+                      x_colsums=(_cs(x).data_ptr() if _cs(x) is not None else None), precision=PRECISION_CODE[precision],
+                      act_scale=F16X3_ACT_SCALE, raw_scale=F16X3_RAW_SCALE, workspace=None, workspace_bytes=0, y=y.data_ptr(),
+                      y_colsums=(ws_y.data_ptr() if ws_y is not None else None))
+    L = _lib.lib()
+    nbytes = L.dua_adm_attnblock_workspace_bytes(ctypes.byref(a))
+    if nbytes == 0:
+        raise RuntimeError(f"dua_adm_attnblock_workspace_bytes: {L.dua_last_error().decode()}")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(L.dua_adm_attnblock_fwd(ctypes.byref(a), _stream()), "dua_adm_attnblock_fwd")
+    return _attach_colsums(y, ws_y, H * W)

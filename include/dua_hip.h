@@ -335,6 +335,52 @@ int dua_gemm_nt_bf16x3_batched(const float* A, long lda, long sA, long sAi, cons
 int dua_transpose_batched(const float* in, float* out, int R, int Cc, long ld_in, long ld_out, long sIn, long sIni,
                           long sOut, long sOuti, int batch, int batch_inner, void* stream);
 
+/* ---------------- block-level entry points (adm_resblock_fwd, adm_attnblock_fwd) ----------------
+ * One ADM block forward per call: host-side sequencing of the per-op entry points above on the caller's stream over a
+ * caller-provided workspace (dua_*_workspace_bytes; nothing is allocated inside).  Same kernels, order and operands as the
+ * Python composition, hence bit-identical results.  Activations NHWC fp32; weights packed by the caller for the chosen
+ * precision: DUA_PREC_FP32 - 3x3 weights from dua_pack_conv3x3_weight, 1x1 / linear weights as stored ([N][K]);
+ * DUA_PREC_F16X3 - every weight from dua_pack_weight_f16x3, act_scale / raw_scale the plane scales of GroupNorm outputs and of
+ * raw residual-stream operands (the UNet uses 64 and 16).  *_colsums: the producer's epilogue column sums (see dua_conv3x3) or
+ * NULL; y_colsums (optional, [ceil(N*H*W/64)][2][Cout] floats) receives those of the block's output. */
+#define DUA_PREC_FP32 0
+#define DUA_PREC_F16X3 3
+typedef struct {
+    const float* x1; int C1;             /* input; (x2, C2) = the skip half of the channel concat of unet_openai.py:662, or (NULL, 0) */
+    const float* x2; int C2;
+    int N, H, W, Cout;
+    const float *gn1_w, *gn1_b;          /* in_layers[0]  (GroupNorm32) */
+    const void* conv1_packed; const float* conv1_b;          /* in_layers[2] */
+    const float* film; long film_ld;     /* emb_layers(emb) rows [N][2*Cout] = (scale | shift), row stride film_ld floats   :245-253 */
+    const float *gn2_w, *gn2_b;          /* out_layers[0] */
+    const void* conv2_packed; const float* conv2_b;          /* out_layers[3] */
+    const void* skip_packed; const float* skip_b;            /* skip_connection (1x1 conv) or NULL = Identity   :223-226 */
+    const float *x1_colsums, *x2_colsums;
+    int updown;                          /* 0, +1 nearest x2, -1 2x2 average (resblock_updown, :191-196,238-243) */
+    const float* dropmask;               /* out_layers[2] keep-mask / (1-p) in NHWC, or NULL (eval) */
+    int precision; float act_scale, raw_scale;
+    void* workspace; size_t workspace_bytes;
+    float* y; float* y_colsums;          /* [N][Ho][Wo][Cout] */
+} dua_resblock_args;
+/* ResBlock.forward, guided_diffusion/unet_openai.py:237-257 (use_scale_shift_norm, resblock_updown). */
+size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* args_host);
+int dua_adm_resblock_fwd(const dua_resblock_args* args_host, void* stream);
+typedef struct {
+    const float* x; int C; int N, H, W, heads;
+    const float *gn_w, *gn_b;            /* norm */
+    const void* qkv_packed; const float* qkv_b;   /* qkv 1x1 conv, rows ordered (q | k | v), head-major inside each third (the legacy
+                                                     order of QKVAttentionLegacy is a row permutation applied by the caller)   :287,348 */
+    const void* proj_packed; const float* proj_b; /* proj_out   :295 */
+    const float* x_colsums;
+    int precision; float act_scale, raw_scale;
+    void* workspace; size_t workspace_bytes;
+    float* y; float* y_colsums;          /* x + proj_out(attention(qkv(norm(x))))   :300-306 */
+} dua_attnblock_args;
+/* AttentionBlock.forward, unet_openai.py:300-306, on the fused attention kernels: head dims <= 128 (multiple of 8 in fp32, of 4 in
+ * f16x3); wider heads are composed from dua_gemm / dua_softmax_rows by the caller. */
+size_t dua_adm_attnblock_workspace_bytes(const dua_attnblock_args* args_host);
+int dua_adm_attnblock_fwd(const dua_attnblock_args* args_host, void* stream);
+
 /* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */
 /* PatchEmbed's strided conv as im2row: x NCHW [B][C][H][W] -> rows [B*(H/P)*(W/P)][C*P*P] in the
  * (c, p1, p2) order of the flattened conv weight (uvit.py:123-135); the projection itself is dua_gemm. */

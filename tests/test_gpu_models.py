@@ -759,3 +759,29 @@ def test_flip_estimator_vs_golden(golden):
     r = gen(torch.randn(3, 3, 16, 16, generator=torch.Generator().manual_seed(1)), torch.tensor([1, 2, 3]), 2, torch.device(dev), mc, sc)
     assert r["uncertainty"].shape == (3, 3, 3, 16, 16) and r["score"].shape == (3, 3, 3, 16, 16) and sc.denoiser_calls == 6
     assert bool((r["uncertainty"] >= 0).all())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_block_level_abi_bit_identical(precision):
+    """dua_adm_resblock_fwd / dua_adm_attnblock_fwd (one C-ABI call per block) against the per-op composition in
+    Python: same kernels in the same order, so the UNet output must be bit-identical - eval and train (dropout masks) mode,
+    batch sizes that leave partial tiles, the up / down / channel-changing / attention blocks of the tiny ADM."""
+    from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise
+    m, _ = build_adm(dict(TINY_ADM, dropout=0.1), 5)
+    m.precision = precision
+    x = torch.randn(5, 3, 16, 16, generator=torch.Generator().manual_seed(3)).to(dev)
+    t, y = torch.tensor([999, 10, 500, 0, 250]).to(dev), torch.tensor([0, 1, 2, 3, 4]).to(dev)
+    outs = {}
+    for train in (False, True):
+        m.train(train)
+        for blk in (True, False):
+            m.use_block_abi = blk
+            m.dropout_mask_source = DeviceNoise(seed=11).dropout_mask          # same mask stream for both paths
+            outs[(train, blk)] = m(x, t, y=y)
+        assert torch.equal(outs[(train, True)], outs[(train, False)]), (precision, train)
+    assert not torch.equal(outs[(True, True)], outs[(False, True)])           # dropout was live
+    # argument validation happens on the host, before any launch
+    from diffusion_uncertainty_amd import _lib
+    import ctypes
+    a = _lib.ResBlockArgs()
+    assert _lib.lib().dua_adm_resblock_fwd(ctypes.byref(a), None) == -1 and b"null" in _lib.lib().dua_last_error()
