@@ -162,7 +162,7 @@ def test_step_outside_window_and_errors():
         s.config.after_step = 9
         s.set_timesteps(10)
     with pytest.raises(NotImplementedError):
-        _sched("flip", m)
+        _sched("flip_grad", m)                                     # needs denoiser backward
 
 
 @pytest.mark.parametrize("kind", ["zigzag_centered", "centered"])
