@@ -705,19 +705,20 @@ def test_inplace_weight_edit_repacks():
     x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(3)).to(dev)
     t, y = torch.tensor([500, 10]).to(dev), torch.tensor([1, 2]).to(dev)
     a = m(x, t, y=y)
-    name = "input_blocks.1.0.in_layers.2.weight"
+    name = "input_blocks.1.0.in_layers.2.weight"               # (a perturbation, not a rescaling: GroupNorm follows this conv)
+    delta = torch.randn(sd[name].shape, generator=torch.Generator().manual_seed(9)) * 0.05
     with torch.no_grad():
-        dict(m.named_parameters())[name].mul_(1.5)
+        dict(m.named_parameters())[name].add_(delta.to(dev))
     b = m(x, t, y=y)
     sd2 = {k: v.clone() for k, v in sd.items()}
-    sd2[name] = sd2[name] * 1.5
+    sd2[name] = sd2[name] + delta
     m2, _ = build_adm(TINY_ADM, 5)
     m2.load_state_dict(sd2)
     m2.precision = "f16x3"
     c = m2(x, t, y=y)
     assert (a - b).abs().max().item() > 1e-3                      # the edit is visible ...
     np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=0, atol=1e-6)     # ... and equals a fresh pack
-    dict(m.named_parameters())[name].data.mul_(2.0)                # invisible to the version counter
+    dict(m.named_parameters())[name].data.add_(delta.to(dev))      # invisible to the version counter
     m.invalidate_packed_weights()
     d = m(x, t, y=y)
     assert (d - b).abs().max().item() > 1e-3
