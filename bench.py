@@ -213,7 +213,7 @@ def other_config_uvit(dev, a):
     from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
     uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
     ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
-    uvit.precision, ae.precision = "f16f8", "bf16x3"
+    uvit.precision, ae.precision = "f16x3", "fp32"            # the parity modes: fp32-equivalent U-ViT, exact fp32 VAE decode (once per batch)
     model = UViTAE(uvit, ae).to(dev)
     X_T, y = starting_points(64, (4, 32, 32))
 
@@ -235,8 +235,8 @@ def other_config_uvit(dev, a):
     torch.cuda.empty_cache()
     return dict(config="BASELINE configs[2]: U-ViT-H/2 ImageNet-256, 50 steps, M=5, uncertainty_zigzag_centered (W10), batch 64, + KL-VAE decode",
                 value=round(64 / dt, 3), unit="images/sec", seconds_per_job=round(dt, 2), executed_forwards_per_image=50 + uc,
-                dtype="f16f8 (fp16 hi + fp8 cross terms, ~15 significant bits: NOT the fp32-equivalent mode, which is wired for the ADM UNet only); "
-                      "VAE decoder bf16x3", data="synthetic, random-init weights")
+                dtype="f16x3 (the fp32-equivalent split: LayerNorm / GELU / attention outputs as fp16 hi + lo planes, 22 significant bits); "
+                      "KL-VAE decoder exact fp32", data="synthetic, random-init weights")
 
 
 def other_config_sd(dev, a):

@@ -106,6 +106,8 @@ SIGNATURES = {
     "dua_adm_resblock_fwd": (_I, [_c.POINTER(ResBlockArgs), _P]),
     "dua_adm_attnblock_workspace_bytes": (_Z, [_c.POINTER(AttnBlockArgs)]),
     "dua_adm_attnblock_fwd": (_I, [_c.POINTER(AttnBlockArgs), _P]),
+    "dua_gemm_f16x3_presplit_planes": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
+    "dua_layernorm_split_f16x3": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _P]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),

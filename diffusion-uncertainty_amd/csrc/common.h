@@ -60,6 +60,22 @@ __device__ __forceinline__ void dua_store_f16f8_quad(void* planes, long plane_el
     *(int*)(x8 + 32) = hi8;
 }
 
+// Four consecutive columns of one row as f16x3 planes: plane 0 fp16(x * scale) (saturating), plane 1 the fp16 remainder.
+__device__ __forceinline__ void dua_store_f16x3_quad(void* planes, long plane_elems, long o, float4 w, float scale) {
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    const float f[4] = {w.x * scale, w.y * scale, w.z * scale, w.w * scale};
+    f16x4_t h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sv = fminf(fmaxf(f[j], -65504.f), 65504.f);
+        const _Float16 t = (_Float16)sv;
+        h[j] = t;
+        l[j] = (_Float16)(sv - (float)t);
+    }
+    *(f16x4_t*)((_Float16*)planes + o) = h;
+    *(f16x4_t*)((_Float16*)planes + plane_elems + o) = l;
+}
+
 // e2m3 (MXFP6) code of v * 2^(127 - sbyte): sign<<5 | eemmm, round to nearest even; magnitudes < 1 use the subnormal grid (step 1/8).
 // sbyte is the E8M0 block exponent (biased exponent of the block maximum minus two: the maximum lands in [4, 8); codes above 7.5 clamp).
 __device__ __forceinline__ unsigned dua_e2m3_code(float v, int sbyte) {

@@ -19,6 +19,7 @@ struct DConvP {
     int stagger_sleeps;
     const float* Cscale;     // FMT 3 (f16x3): per weight row 2^-s (the planes hold w * 2^s), padded to the tile grid
     float out_scale;         // FMT 3: 1 / activation plane scale; the epilogue multiplies the accumulator by Cscale[col] * out_scale
+    float split_scale;       // FMT 3 with Csplit: the output planes hold fp16 hi | lo of C * split_scale
 };
 
 // conv_f16x3.hip: the f16x3 kernel on 16x16x32 MFMA shapes (row-shift form where the image width divides 256)

@@ -726,7 +726,7 @@ extern "C" int dua_softmax_rows(float* S, long rows, int cols, long ld, void* st
 template <int PER>
 __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, const float* __restrict__ ga,
                                                    const float* __restrict__ be, float* __restrict__ y, long rows, int D, float eps,
-                                                   int split) {
+                                                   int split, float oscale) {
     long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
@@ -752,7 +752,12 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
         if (c < D) {
             const float o = (v[j] - mean) * rstd * ga[c] + be[c];
             if (!split) y[row * (long)D + c] = o;
-            else if (split == 2) {           // f16f8 planes: fp16 hi | per 32-column block [32 x e4m3(lo * 2^12) | 32 x e4m3(o)]
+            else if (split == 4) {           // f16x3 planes: fp16 hi | fp16 lo of o * oscale
+                const float sv = fminf(fmaxf(o * oscale, -65504.f), 65504.f);
+                const _Float16 h = (_Float16)sv;
+                ((_Float16*)y)[row * (long)D + c] = h;
+                ((_Float16*)y)[rows * (long)D + row * (long)D + c] = (_Float16)(sv - (float)h);
+            } else if (split == 2) {           // f16f8 planes: fp16 hi | per 32-column block [32 x e4m3(lo * 2^12) | 32 x e4m3(o)]
                 const _Float16 h = (_Float16)o;
                 ((_Float16*)y)[row * (long)D + c] = h;
                 unsigned char* x8 = (unsigned char*)((_Float16*)y + rows * (long)D) + (row * (long)D + (c & ~31)) * 2 + (c & 31);
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
 template <int PER4>
 __global__ __launch_bounds__(BLK) void k_layernorm4(const float* __restrict__ x, const float* __restrict__ ga,
                                                     const float* __restrict__ be, float* __restrict__ y, long rows, int D, float eps,
-                                                    int split) {
+                                                    int split, float oscale) {
     long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -804,6 +809,7 @@ __global__ __launch_bounds__(BLK) void k_layernorm4(const float* __restrict__ x,
             const long off = row * (long)D + c;
             if (!split) *(float4*)(y + off) = o;
             else if (split == 2) dua_store_f16f8_quad(y, rows * (long)D, off, o);
+            else if (split == 4) dua_store_f16x3_quad(y, rows * (long)D, off, o, oscale);
             else {
                 typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
                 const float f[4] = {o.x, o.y, o.z, o.w};
@@ -821,19 +827,20 @@ __global__ __launch_bounds__(BLK) void k_layernorm4(const float* __restrict__ x,
     }
 }
 
-static int layernorm_impl(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, int split, void* stream) {
+static int layernorm_impl(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, int split, void* stream,
+                          float oscale = 1.0f) {
     DUA_REQUIRE(x && gamma && beta && y && D >= 1 && D <= 2048, "dua_layernorm: D must be in [1, 2048]");
     if (rows == 0) return DUA_OK;
     unsigned grid = (unsigned)((rows + 3) / 4);
     if (D % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
-        if (D <= 256) hipLaunchKernelGGL(k_layernorm4<1>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
-        else if (D <= 1024) hipLaunchKernelGGL(k_layernorm4<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
-        else hipLaunchKernelGGL(k_layernorm4<8>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+        if (D <= 256) hipLaunchKernelGGL(k_layernorm4<1>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
+        else if (D <= 1024) hipLaunchKernelGGL(k_layernorm4<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
+        else hipLaunchKernelGGL(k_layernorm4<8>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
         return dua_check_launch("dua_layernorm");
     }
-    if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
-    else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
-    else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split);
+    if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
+    else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
+    else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
     return dua_check_launch("dua_layernorm");
 }
 extern "C" int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, void* stream) {
@@ -847,6 +854,12 @@ extern "C" int dua_layernorm_split_f16f8(const float* x, const float* gamma, con
                                          void* stream) {
     DUA_REQUIRE(D % 32 == 0, "dua_layernorm_split_f16f8: D must be a multiple of 32");
     return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 2, stream);
+}
+
+extern "C" int dua_layernorm_split_f16x3(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
+                                         float act_scale, void* stream) {
+    DUA_REQUIRE(D % 32 == 0 && act_scale > 0.f, "dua_layernorm_split_f16x3: D must be a multiple of 32, act_scale positive");
+    return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 4, stream, act_scale);
 }
 
 // =================================== embeddings ================================================

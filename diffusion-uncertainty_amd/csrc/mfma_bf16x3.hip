@@ -467,6 +467,8 @@ __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const f
     if (SPLIT) {               // the consumer is another split-operand GEMM: hand it the operand format directly
         if (FMT == 1) {
             dua_store_f16f8_quad(p.Csplit, (long)p.M * p.N, o, w);
+        } else if (FMT == 3) {
+            dua_store_f16x3_quad(p.Csplit, (long)p.M * p.N, o, w, p.split_scale);
         } else {
             bf16x4 hi, lo;
             split4(w, hi, lo);
@@ -1242,6 +1244,8 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                     if (p.Csplit) {        // the consumer is another split-operand GEMM: hand it the operand format directly
                         if (FMT == 1) {
                             dua_store_f16f8_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v);
+                        } else if (FMT == 3) {
+                            dua_store_f16x3_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v, p.split_scale);
                         } else {
                             bf16x4 hi, lo;
                             split4(v, hi, lo);
@@ -1455,7 +1459,8 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     if (fmt == 0) {
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 0>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 0>), dim3(grid), 512, 0, st, d);
-    } else if (fmt == 3 && dua_dma_conv_enabled != 6 && ((wide && (long)d.H * d.W <= 4096) || dua_dma_conv_enabled == 7)) {
+    } else if (fmt == 3 && dua_dma_conv_enabled != 6 && !d.Csplit && d.act_out == 0 &&
+               ((wide && (long)d.H * d.W <= 4096) || dua_dma_conv_enabled == 7)) {
         // f16x3, 256-channel tiles on maps up to 64^2: the 16x16x32 kernel of conv_f16x3.hip (+2..5 % there; the 128^2 layers and
         // the 128-channel tiles of the 16^2 / 8^2 levels run 2 - 15 % faster on the 32x32x16 loop below: measured per layer with
         // scripts/bench_conv_mix.py --fmt f16x3 --engine 7 / 6).  Mode 7 forces the new kernel, 6 the old one.
@@ -1623,7 +1628,8 @@ extern "C" int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packe
 // C[M][N] = A * W^T (+ bias) (+ residual) with A given as split planes (written by dua_groupnorm_apply_split / _f16f8) and W
 // packed by dua_pack_weight_bf16x3 / _f16f8: the LDS-DMA kernel with a single tap.
 static int gemm_presplit_impl(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
-                              void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream, float act_scale = 1.0f) {
+                              void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream, float act_scale = 1.0f,
+                              float split_scale = 1.0f) {
     DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm presplit: K must be a multiple of 32 (got %d)", K);
     DUA_REQUIRE(N % 4 == 0, "dua_gemm presplit: N must be a multiple of 4");
     DUA_REQUIRE(!Csplit || fmt == 0 || N % 32 == 0, "dua_gemm_f16f8_presplit: a split output needs N %% 32 == 0");
@@ -1637,6 +1643,7 @@ static int gemm_presplit_impl(const void* aplanes, const void* planes, const flo
     d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
     d.Cscale = (const float*)((const __bf16*)planes + 2 * plane);
     d.out_scale = 1.0f / act_scale;
+    d.split_scale = split_scale;
     return launch_dconv(d, fmt, as_stream(stream), "dua_gemm presplit");
 }
 extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
@@ -1652,6 +1659,12 @@ extern "C" int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, 
                                        int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream) {
     DUA_REQUIRE(act_scale > 0.f, "dua_gemm_f16x3_presplit: act_scale must be positive");
     return gemm_presplit_impl(aplanes, packed, bias, residual, C, nullptr, M, N, K, act_out, colsum, 3, stream, act_scale);
+}
+// ... with the result written as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM (U-ViT fc1 -> GELU -> fc2)
+extern "C" int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,
+                                              int act_out, float act_scale, float split_scale, void* stream) {
+    DUA_REQUIRE(act_scale > 0.f && split_scale > 0.f && Cplanes, "dua_gemm_f16x3_presplit_planes: bad arguments");
+    return gemm_presplit_impl(aplanes, packed, bias, nullptr, nullptr, Cplanes, M, N, K, act_out, nullptr, 3, stream, act_scale, split_scale);
 }
 
 extern "C" int dua_gemm_bf16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* planes,

@@ -594,8 +594,13 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
     M = 1
     for d in a.shape[:-1]:
         M *= d
+    if a.fmt == "f16x3" and split_out:
+        assert residual is None and n_out % 32 == 0
+        buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
+        check(_lib.lib().dua_gemm_f16x3_presplit_planes(_p(a.buf), _p(planes), _p(bias), _p(buf), M, n_out, K, int(act_out), a.scale,
+                                                        F16X3_RAW_SCALE, _stream()), "dua_gemm_f16x3_presplit_planes")
+        return SplitPlanes(buf, (M, n_out), "f16x3", F16X3_RAW_SCALE)
     if a.fmt == "f16x3":
-        assert not split_out, "f16x3: fp32 output only"
         c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
         ws = _colsum_ws(M, n_out, a.device, colsum)
         if ws is not None:
@@ -732,6 +737,11 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32", planes_out=False):
 def layernorm(x, gamma, beta, eps=1e-5, split=False):
     _req(x, name="x")
     D = x.shape[-1]
+    if split == "f16x3":
+        buf = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.int16)
+        check(_lib.lib().dua_layernorm_split_f16x3(_p(x), _p(gamma), _p(beta), _p(buf), x.numel() // D, D, float(eps), F16X3_ACT_SCALE, _stream()),
+              "dua_layernorm_split_f16x3")
+        return SplitPlanes(buf, tuple(x.shape), "f16x3", F16X3_ACT_SCALE)
     if split:
         fmt = "f16f8" if split == "f16f8" else "bf16x3"
         buf = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.int16)

@@ -53,11 +53,13 @@ class Block(nn.Module):
         if self.skip_linear is not None:
             x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
         # split modes: LayerNorm / GELU outputs go out in the operand format of the LDS-DMA GEMMs (bf16 planes or f16f8 planes)
-        fast = (precision if precision == "f16f8" else precision == "bf16x3") if D % 32 == 0 else False
+        # ("f16x3": the fp32-equivalent split, fp16 hi / lo planes)
+        fast = (precision if precision in ("f16f8", "f16x3") else precision == "bf16x3") if D % 32 == 0 else False
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=fast)
         qkv = lin(h, self.attn.qkv)
         a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads,
-                              precision="fp32" if precision == "fp32" else "bf16x3", planes_out=(fast == "f16f8"))   # :69-73
+                              precision=precision if precision in ("fp32", "f16x3") else "bf16x3",
+                              planes_out=(fast in ("f16f8", "f16x3")))                                               # :69-73
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, split=fast)
         h = lin(h, self.mlp.fc1, act_out=2, split_out=bool(fast))                                  # fc1 + GELU
@@ -102,7 +104,7 @@ class UViT(nn.Module):
         self.apply(self._init_weights)
         self.img_size = img_size
         self.patch_size = patch_size
-        self.precision = "fp32"          # or "bf16x3" / "f16f8" (see guided_diffusion/unet_openai.py)
+        self.precision = "fp32"          # or "f16x3" (fp32-equivalent) / "bf16x3" / "f16f8" (see guided_diffusion/unet_openai.py)
         self._planes = {}
 
     def _apply(self, fn, *a, **k):
@@ -117,11 +119,16 @@ class UViT(nn.Module):
         if isinstance(a, ops.SplitPlanes):                # operand already in a split format: LDS-DMA GEMM
             key = (id(mod), a.fmt)
             if key not in self._planes:
-                pack = ops.pack_weight_f16f8 if a.fmt == "f16f8" else ops.pack_weight_bf16x3
+                pack = {"f16f8": ops.pack_weight_f16f8, "f16x3": ops.pack_weight_f16x3}.get(a.fmt, ops.pack_weight_bf16x3)
                 self._planes[key] = pack(mod.weight.detach().contiguous())
             return ops.gemm_bf16x3_presplit(a, self._planes[key], mod.weight.shape[0], bias=mod.bias, residual=residual,
                                             act_out=act_out, split_out=split_out)
         K = a.shape[1] + (0 if a2 is None else a2.shape[1])
+        if self.precision == "f16x3" and K % 32 == 0 and a.shape[1] % 32 == 0:           # raw fp32 operand split on the fly
+            key = (id(mod), "f16x3")
+            if key not in self._planes:
+                self._planes[key] = ops.pack_weight_f16x3(mod.weight.detach().contiguous())
+            return ops.gemm_f16x3(a, self._planes[key], mod.weight.shape[0], bias=mod.bias, a2=a2, residual=residual, act_out=act_out)
         if self.precision != "fp32" and K % 32 == 0 and a.shape[1] % 32 == 0:
             if id(mod) not in self._planes:
                 self._planes[id(mod)] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())

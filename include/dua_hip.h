@@ -291,6 +291,13 @@ int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const fl
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, float act_scale, void* stream);
 int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
                             int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream);
+/* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
+ * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */
+int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,
+                                   int act_out, float act_scale, float split_scale, void* stream);
+/* LayerNorm writing f16x3 planes of y * act_scale (uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
+int dua_layernorm_split_f16x3(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
+                              float act_scale, void* stream);
 /* dua_gemm_bf16x3 on the f16x3 split: C = alpha * [A1 | A2] W^T (+bias) (+residual) with the fp32 A operand (raw residual-stream
  * activations: 1x1 skip convolution unet_openai.py:223, proj_out :295) multiplied by act_scale and split into fp16 hi + lo at
  * LDS-store time.  hi saturates at +-65504 and lo then carries the remainder, so an out-of-range operand loses precision

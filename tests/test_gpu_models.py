@@ -295,7 +295,7 @@ def test_bf16x3_mode_adm(golden, name, precision):
     assert err < {"bf16x3": 1e-4, "f16x3": 1.5e-5}.get(precision, 2.5e-4)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16f8"])
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x3", "f16f8"])
 def test_bf16x3_mode_uvit(golden, precision):
     from diffusion_uncertainty_amd.init_model import load_uvit
     from diffusion_uncertainty_amd.utils import seeded_state_dict
@@ -307,7 +307,16 @@ def test_bf16x3_mode_uvit(golden, precision):
     o = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev))
     err = np.abs(o.cpu().numpy() - g["out"]).max()
     print(f"{precision} uvit-h/2: max|hip - reference| = {err:.3e}")
-    assert err < TOL and err < 3e-4
+    assert err < TOL and err < (2e-5 if precision == "f16x3" else 3e-4)       # f16x3: the fp32-equivalent bound (exact fp32 mode: 8.9e-6)
+    if precision == "f16x3":               # batch whose token rows do not fill the 256-row tiles; tiny model with ragged shapes
+        from diffusion_uncertainty_amd.uvit.uvit import UViT
+        tm = UViT(**TINY_UVIT)
+        tm.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in tm.state_dict().items()}, 6))
+        tm.eval().to(dev)
+        gt = golden("g6_uvit")
+        tm.precision = "f16x3"
+        ot = tm(T(gt["tiny_x"]).to(dev), T(gt["tiny_t"]).to(dev), T(gt["tiny_y"]).to(dev))
+        np.testing.assert_allclose(ot.cpu().numpy(), gt["tiny_out"], rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
