@@ -111,6 +111,7 @@ def test_cli_flags_mirror_reference_defaults():
     a = cli.parse_args(["--image-size", "128", "--scheduler-type", "uncertainty_zigzag_centered", "--model-type", "unet", "--start-index", "0"])
     assert (a.num_samples, a.batch_size, a.generation_steps, a.M, a.start_step_uc, a.num_steps_uc, a.seed, a.eta, a.dropout, a.num_zigzag) == \
         (300, 32, 20, 30, 0, 20, 0, 0.0, 0.1, 3)                       # reference parse_args :150-174
+    assert a.precision == "f16x3"                                      # default engine mode: the fp32-equivalent split
     b = cli.parse_args(["--config", "imagenet128_readme_example", "-M", "7"])
     assert (b.M, b.generation_steps, b.start_step_uc, b.num_steps_uc, b.batch_size, b.image_size) == (7, 50, 40, 10, 128, 128)
     with pytest.raises(AssertionError):
@@ -199,8 +200,8 @@ def test_precision_modes_pick_operand_formats():
     from diffusion_uncertainty_amd.guided_diffusion.unet_openai import UNetModel, _Ctx
     m = UNetModel(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1, attention_resolutions=(2,),
                   channel_mult=(1, 2), num_classes=10, num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)
-    want = {"fp32": (False, False, False), "bf16x3": (True, True, True), "f16f8": ("f16f8", "f16f8", "f16f8"),
-            "f16f6": ("f16f6", "f16f8", "f16f8")}
+    want = {"fp32": (False, False, False), "f16x3": ("f16x3", "f16x3", "f16x3"), "bf16x3": (True, True, True),
+            "f16f8": ("f16f8", "f16f8", "f16f8"), "f16f6": ("f16f6", "f16f8", "f16f8")}
     for mode, (w16, w24, gemm) in want.items():
         m.precision = mode
         ctx = _Ctx(m)
