@@ -53,7 +53,10 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
     const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
 
     const unsigned OOB = 0xFFFFFFF0u;                // buffer offset beyond every record: the DMA writes zeros
-    constexpr int OOBL = 0x40000;                    // LDS byte address beyond the allocation: DS reads return zeros
+    // LDS byte address beyond the allocation: DS reads there return zeros (relied upon by the row-shift form for the image-edge
+    // lanes; -DDUA_RS_ZERO_SELECT=1 builds the data-select form instead, compared bit for bit by tests/test_gpu_ops.py)
+    constexpr int OOBL = 0x40000;
+    static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU for every fragment offset");
     const int dl_row = lane >> 2;                                        // DMA: row of the 16-row piece this lane fills
     const int dl_src = (lane & 3) ^ ((0 - (lane >> 4)) & 3);             // DMA: source chunk for this lane's LDS slot
     const int lr = lane & 15, lc = lane >> 4;                            // fragment: row of the 16-row block, K chunk
@@ -190,7 +193,13 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
                 const int r_ = 16 * i + lr + dx;                                  // row inside the wave's 64 (may be -1 / 64: neighbour rows)
                 o = r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3)) - 16 * i * 64;
                 const bool edge = (dx < 0 && ((xedge >> i) & 1u)) || (dx > 0 && ((xedge >> (4 + i)) & 1u));
+#if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
+                const h16x8 v_ = *(const h16x8*)(ldsb + (a_row0 + sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64) + o);
+                const h16x8 z_ = {0, 0, 0, 0, 0, 0, 0, 0};
+                return edge ? z_ : v_;                                              // data-select form (eight v_cndmask per fragment)
+#else
                 if (edge) return *(const h16x8*)(ldsb + OOBL + (lane & 1) * 16);   // zeros (address beyond the allocation)
+#endif
             }
             return *(const h16x8*)(ldsb + (a_row0 + sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64) + o);
         };

@@ -878,6 +878,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // LDS allocation (out-of-range DS reads return 0), four address selects per step instead of 32 data selects that would
     // sit between the ds_reads and the MFMAs that consume them (measured: 29k of 220k cycles per tile).
     constexpr int OOBL = 0x40000;
+    static_assert(OOBL >= 160 * 1024 + 256 * 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU for every fragment offset");
     auto edge = [&](int dx, int i) -> bool { return (dx < 0 && ((rsy >> (4 + i)) & 1u)) || (dx > 0 && ((rsy >> (6 + i)) & 1u)); };
     auto wait_vm = [&](int n) {        // counted wait with a run-time choice among the few counts that occur
         if (n >= NT + 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT + 4) : "memory");

@@ -554,6 +554,45 @@ def test_gemm_f16x3(ops, M, N, K1, K2):
     assert torch.isfinite(cb).all() and ((cb.cpu().double() - refb).abs() / refb.abs().amax(dim=0, keepdim=True)).max().item() < 1e-3
 
 
+def test_row_shift_zero_padding_forms_agree(ops):
+    """the row-shift conv gets its left / right zero padding from DS reads beyond the LDS allocation.  The same kernel
+    built with -DDUA_RS_ZERO_SELECT=1 (scripts/diag/build/libdua_hip_select.so, made by __graft_entry__.build()) zeroes those
+    fragments by a register select instead; both must agree bit for bit."""
+    import ctypes
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "scripts", "diag", "build", "libdua_hip_select.so")
+    if not os.path.exists(alt):
+        import __graft_entry__
+        __graft_entry__.build()
+    A = ctypes.CDLL(alt)
+    from diffusion_uncertainty_amd import _lib
+    fn = A.dua_conv3x3_f16x3_presplit
+    fn.restype, fn.argtypes = _lib.SIGNATURES["dua_conv3x3_f16x3_presplit"]
+    A.dua_set_dma_conv.restype, A.dua_set_dma_conv.argtypes = ctypes.c_int, [ctypes.c_int]
+    L = _lib.lib()
+    for (N, H, W, Cin, Cout) in [(8, 32, 32, 64, 256), (4, 64, 64, 32, 256), (16, 16, 16, 96, 256), (130, 8, 8, 64, 256)]:
+        x, w, b = rnd(50, N, Cin, H, W), rnd(51, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(52, Cout) * 0.1
+        xs = _f16x3_planes(ops, nhwc(x))
+        packed = ops.pack_weight_f16x3(w.to(dev))
+        bd = b.to(dev)
+        L.dua_set_dma_conv(7)                                # the 16x16x32 row-shift kernel for every tile class
+        A.dua_set_dma_conv(7)
+        try:
+            y0 = ops.conv3x3_bf16x3(xs, packed, bd, Cout)
+            y1 = torch.empty_like(y0)
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = fn(ctypes.c_void_p(xs.buf.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None,
+                    ctypes.c_void_p(y1.data_ptr()), N, H, W, Cin, Cout, 0, None, xs.scale, st)
+            assert rc == 0
+        finally:
+            L.dua_set_dma_conv(1)
+            A.dua_set_dma_conv(1)
+        assert torch.equal(y0, y1), (N, H, W, Cin, Cout)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        assert (nchw(y0.cpu()).double() - ref).abs().max().item() < 2e-5
+
+
 def test_f16x3_fp16_subnormal_operands(ops):
     """The lo plane of small operands is a subnormal fp16: v_mfma_f32_32x32x16_f16 must not flush it (the format's error
     analysis in include/dua_hip.h assumes at most 2^-25 absolute on the scaled operand)."""
