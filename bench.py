@@ -91,12 +91,28 @@ class ConvProfile:
     def record(self, kind, flops, e0, e1):
         self.items.append((flops, e0, e1))
 
+    def start(self):
+        """Also time the conv launches made INSIDE the block-level C-ABI calls (dua_adm_resblock_fwd): HIP events recorded by the
+        library itself on the launch stream."""
+        from diffusion_uncertainty_amd import _lib
+        _lib.lib().dua_conv_profile(1)
+
+    def stop(self):
+        import ctypes
+        from diffusion_uncertainty_amd import _lib
+        L = _lib.lib()
+        L.dua_conv_profile(0)
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        L.dua_conv_profile_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        self.c_side = (ms.value, fl.value, n.value)
+
     def summary(self):
-        if not self.items:
+        c_ms, c_fl, c_n = getattr(self, "c_side", (0.0, 0.0, 0))
+        if not self.items and not c_n:
             return None
-        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.items)
-        total_fl = sum(f for f, _, _ in self.items)
-        n = len(self.items)
+        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.items) + c_ms
+        total_fl = sum(f for f, _, _ in self.items) + c_fl
+        n = len(self.items) + c_n
         return dict(launches=n, flops_per_launch=total_fl / n, ms_per_launch=total_ms / n,
                     tflops=total_fl / (total_ms * 1e-3) / 1e12)
 
@@ -404,6 +420,8 @@ def main(argv=None):
             job(STEP_TIMESTEPS, STEP_TIMESTEPS - 1, 1, 1000 + w)
         prof = None if a.no_profile else ConvProfile()
         ops.PROFILE = prof
+        if prof is not None:
+            prof.start()
         sync()
         t0 = time.perf_counter()
         uc = 0
@@ -412,6 +430,8 @@ def main(argv=None):
         sync()
         dt = time.perf_counter() - t0
         ops.PROFILE = None
+        if prof is not None:
+            prof.stop()
         return max_over_ranks(dt, dev), uc, prof
 
     dt, uc_calls, prof = timed(a.precision, jobs, a.warmup)

@@ -108,6 +108,8 @@ SIGNATURES = {
     "dua_adm_attnblock_fwd": (_I, [_c.POINTER(AttnBlockArgs), _P]),
     "dua_gemm_f16x3_presplit_planes": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "dua_layernorm_split_f16x3": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _P]),
+    "dua_conv_profile": (_I, [_I]),
+    "dua_conv_profile_collect": (_I, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),

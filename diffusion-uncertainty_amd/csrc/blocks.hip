@@ -4,8 +4,29 @@
 // composition in guided_diffusion/unet_openai.py (ResBlock.run / AttentionBlock.run), so the results are bit-identical to it.
 // Precisions: DUA_PREC_FP32 (exact fp32 MFMA) and DUA_PREC_F16X3 (the fp32-equivalent split) - the two parity modes.
 #include "common.h"
+#include <vector>
 
 namespace {
+
+// Optional per-launch timing of the conv3x3 launches made inside the block functions (bench.py's roofline leg): HIP events on
+// the launch stream, collected and summed by dua_conv_profile_collect.  Off by default; not thread-safe (a bench facility).
+struct ConvRec { hipEvent_t a, b; double flops; };
+bool g_prof = false;
+std::vector<ConvRec> g_recs;
+struct ConvTimer {
+    hipEvent_t a = nullptr;
+    hipStream_t st;
+    explicit ConvTimer(void* stream) : st(as_stream(stream)) {
+        if (g_prof && hipEventCreate(&a) == hipSuccess) hipEventRecord(a, st); else a = nullptr;
+    }
+    void done(double flops) {
+        if (!a) return;
+        hipEvent_t b;
+        if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return; }
+        hipEventRecord(b, st);
+        g_recs.push_back({a, b, flops});
+    }
+};
 
 struct Carver {                       // bump allocator over the caller's workspace, 256-byte aligned pieces
     char* base;
@@ -36,13 +57,18 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     const bool f16 = a->precision == DUA_PREC_F16X3, colsum2 = a->Cout % 4 == 0;
     float* stats1 = (float*)w.take((size_t)a->N * G * 2 * 4);
     float* gnws = (float*)w.take(dua_groupnorm_ws_floats(a->N, a->H * a->W > Ho * Wo ? a->H * a->W : Ho * Wo, C > a->Cout ? C : a->Cout, G) * 4);
-    void* h1 = w.take((size_t)M * C * 4);                            // fp32 [N,Ho,Wo,C] or two 2-byte planes of it
+    // two activation-sized regions, reused like the per-op composition's freed tensors (a smaller live footprint keeps more of
+    // the block in the Infinity Cache): region A = conv1's input, later conv2's input; region B = conv1's output, later the skip
+    // convolution's output (conv1's output is dead once the second GroupNorm has consumed it)
+    void* regA = w.take((size_t)M * (C > a->Cout ? C : a->Cout) * 4);
     float* xr = a->updown ? (float*)w.take((size_t)M * a->C1 * 4) : nullptr;
-    float* h2 = (float*)w.take((size_t)M * a->Cout * 4);
+    float* regB = (float*)w.take((size_t)M * a->Cout * 4);
     float* cs2 = colsum2 ? (float*)w.take(colsum_floats(M, a->Cout) * 4) : nullptr;
     float* stats2 = (float*)w.take((size_t)a->N * G * 2 * 4);
-    void* h3 = w.take((size_t)M * a->Cout * 4);
-    float* res = a->skip_packed ? (float*)w.take((size_t)M * a->Cout * 4) : nullptr;
+    void* h1 = regA;                                                 // fp32 [N,Ho,Wo,C] or two 2-byte planes of it
+    float* h2 = regB;
+    void* h3 = regA;
+    float* res = a->skip_packed ? regB : nullptr;
     if (w.dry) return DUA_OK;
     DUA_REQUIRE(w.used <= w.cap && a->workspace, "dua_adm_resblock_fwd: workspace of %zu bytes needed, %zu given", w.used, w.cap);
     int rc;
@@ -54,8 +80,12 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
                                   (float*)h1, stream);
     if (rc) return rc;
     if (a->updown && (rc = dua_resample2x(a->x1, xr, a->N, a->H, a->W, a->C1, a->updown, stream))) return rc;          // x_upd :243
-    if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
-    else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
+    {
+        ConvTimer tm(stream);
+        if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
+        else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
+        tm.done(2.0 * (double)M * 9.0 * C * a->Cout);
+    }
     if (rc) return rc;
     // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
     if ((rc = gn_stats(h2, a->Cout, cs2, nullptr, 0, nullptr, a->N, Ho * Wo, G, gnws, stats2, stream))) return rc;
@@ -82,8 +112,11 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
         resid = res;
     }
     float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
-    if (f16) return dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
-    return dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
+    ConvTimer tm(stream);
+    if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
+    else rc = dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
+    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout);
+    return rc;
 }
 
 int attnblock_run(const dua_attnblock_args* a, Carver& w, void* stream) {
@@ -148,6 +181,27 @@ int check_attnblock(const dua_attnblock_args* a) {
 }
 
 }  // namespace
+
+extern "C" int dua_conv_profile(int on) {
+    const int was = g_prof ? 1 : 0;
+    g_prof = on != 0;
+    return was;
+}
+extern "C" int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches) {
+    double ms = 0.0, fl = 0.0;
+    long n = 0;
+    for (ConvRec& r : g_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; fl += r.flops; ++n; }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = n;
+    return DUA_OK;
+}
 
 extern "C" size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* a) {
     if (check_resblock(a) != DUA_OK) return 0;

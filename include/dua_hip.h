@@ -386,6 +386,11 @@ typedef struct {
 /* AttentionBlock.forward, unet_openai.py:300-306, on the fused attention kernels: head dims <= 128 (multiple of 8 in fp32, of 4 in
  * f16x3); wider heads are composed from dua_gemm / dua_softmax_rows by the caller. */
 size_t dua_adm_attnblock_workspace_bytes(const dua_attnblock_args* args_host);
+/* Bench facility: dua_conv_profile(1) makes the block functions bracket each of their conv3x3 launches with HIP events on the
+ * launch stream (returns the previous setting); dua_conv_profile_collect synchronises on them, returns the summed launch time (ms),
+ * the summed algorithmic FLOPs (2*N*H*W*9*Cin*Cout) and the number of launches since the last collect, and frees the events. */
+int dua_conv_profile(int on);
+int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches);
 int dua_adm_attnblock_fwd(const dua_attnblock_args* args_host, void* stream);
 
 /* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */
