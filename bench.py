@@ -42,6 +42,7 @@ ADM128_FLOPS_PER_FWD_IMG = 6.139e11      # BASELINE.md section 3 (2*MAC, hooks o
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table (fp32-input MFMA)
 BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md chip table (dense bf16 / fp16 MFMA)
 STEP_TIMESTEPS = 5                       # one bench step = 5 DDIM timesteps
+MC_GROUP = 1                             # set from --mc-group
 PRECISIONS = ["f16x3", "fp32", "bf16x3", "f16f8", "f16f6"]
 
 # per precision mode: (kernel description, MFMA products executed per algorithmic product at the bf16 rate, dtype string)
@@ -150,6 +151,7 @@ def make_scheduler(model, base, M, start, num, nz, seed, faithful):
     s = get_uncertainty_scheduler(args, None, model, base)
     s.noise_source = DeviceNoise(seed=seed)          # inputs/noise generated in HBM; host tape only for parity tests
     s.faithful_zigzag = faithful
+    s.mc_group = MC_GROUP
     return s
 
 
@@ -305,6 +307,7 @@ def parse_args(argv=None):
     ap.add_argument("--start-step-uc", type=int, default=40)
     ap.add_argument("--num-steps-uc", type=int, default=10)
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
+    ap.add_argument("--mc-group", type=int, default=1, help="Monte-Carlo chains of a UC step per denoiser call (stacked batch)")
     ap.add_argument("--precision", choices=PRECISIONS, default="f16x3")
     ap.add_argument("--secondary", default="fp32,f16f6", help="comma list of precision modes run for ONE job each after the headline (N=1 only)")
     ap.add_argument("--no-secondary", action="store_true")
@@ -338,6 +341,8 @@ def launch_ranks(a, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
+    global MC_GROUP
+    MC_GROUP = a.mc_group
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a, argv))
 

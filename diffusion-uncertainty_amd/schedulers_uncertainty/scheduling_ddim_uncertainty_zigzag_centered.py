@@ -43,7 +43,12 @@ class DDIMSchedulerUncertainty(DDIMUncertaintyCore):
         self.prompt_embeds = prompt_embed
         self.num_zigzag = num_zigzag
         self.faithful_zigzag = False
-        self.denoiser_calls = 0           # UC forwards actually executed (for FLOP accounting)
+        # mc_group > 1: the live forwards of that many Monte-Carlo chains of a UC step run as ONE denoiser call on the stacked
+        # batch (the chains are independent: same x_{t-1}, different noise).  Same arithmetic per sample; at 288 GB of HBM the
+        # 5x activations fit easily and the small-map layers get enough tiles for the 256-channel kernels.  Noise is still
+        # drawn in the reference's order.  Only on the predict_next branch (chains do not feed back).
+        self.mc_group = 1
+        self.denoiser_calls = 0           # UC forwards actually executed (for FLOP accounting; a grouped call counts per chain)
 
     def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
              variance_noise=None, return_dict=True):
@@ -54,7 +59,9 @@ class DDIMSchedulerUncertainty(DDIMUncertaintyCore):
         pred_epsilon, prev_sample, pred_original_sample = self._ddim(model_output, timestep, sample, eta,
                                                                      use_clipped_model_output, best_noise)
         in_window = self.in_uc_window(timestep)
-        if in_window:
+        if in_window and self.predict_next and not self.faithful_zigzag and self.mc_group > 1 and isinstance(self.prompt_embeds, torch.Tensor):
+            uncertainty = self._grouped_chains(prev_sample, pred_epsilon, timestep, sample)
+        elif in_window:
             uncertainty = torch.empty_like(pred_epsilon)
             sb_t, sa_t = self._coefficients(timestep)[:2]
             for m in range(self.M):
@@ -81,6 +88,32 @@ class DDIMSchedulerUncertainty(DDIMUncertaintyCore):
             output.uncertainty = uncertainty
             output.pred_epsilon = pred_epsilon
         return output
+
+    def _grouped_chains(self, prev_sample, pred_epsilon, timestep, sample):
+        """The M chains of :527-549 on the predict_next branch, `mc_group` chains per denoiser call (only the last re-noising of a
+        chain is live).  Draw order as upstream: num_zigzag draws per chain, chain after chain."""
+        B = sample.shape[0]
+        uncertainty = torch.empty_like(pred_epsilon)
+        labels = self.prompt_embeds
+        m = 0
+        while m < self.M:
+            g = min(self.mc_group, self.M - m)
+            xs = torch.empty((g * B,) + tuple(sample.shape[1:]), device=sample.device, dtype=torch.float32)
+            for c in range(g):
+                for j in range(self.num_zigzag):
+                    noise = self.noise_source.draw(sample.shape, sample.device)      # :532 (the first num_zigzag-1 draws are dead)
+                sb, sn = torch.sqrt(1 - self.betas[timestep]), torch.sqrt(self.betas[timestep])
+                ops.axpby(prev_sample, noise, sb, sn, out=xs[c * B:(c + 1) * B])     # :538
+            self.prompt_embeds = labels.repeat(g)
+            try:
+                out = ops._f32c(self.predict_model(self.scale_model_input(xs, timestep), timestep))
+            finally:
+                self.prompt_embeds = labels
+            self.denoiser_calls += g
+            for c in range(g):
+                ops.mc_centered_accum(out[c * B:(c + 1) * B], pred_epsilon, uncertainty, m + c, self.M)   # :549
+            m += g
+        return uncertainty
 
     def predict_model(self, x, t):
         """:561-569 (diffusers UNet2DConditionModel convention)."""

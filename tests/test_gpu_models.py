@@ -795,3 +795,34 @@ def test_block_level_abi_bit_identical(precision):
     import ctypes
     a = _lib.ResBlockArgs()
     assert _lib.lib().dua_adm_resblock_fwd(ctypes.byref(a), None) == -1 and b"null" in _lib.lib().dua_last_error()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_grouped_mc_chains_match_sequential(golden, precision):
+    """scheduler.mc_group: the M Monte-Carlo chains of a UC step as one stacked denoiser call.  Same noise tape, same per-sample
+    arithmetic: the uncertainty map must match the chain-by-chain run to fp32 rounding and the reference's own step() (G3)."""
+    g = golden("g3_uc_estimators")
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    m, _ = build_adm(TINY_ADM, 5)
+    m.precision = precision
+    n = 0
+    for c in range(int(g["n_cases"])):
+        model_name, kind, M, nz, t, seed = g[f"c{c}_meta"]
+        if model_name != "tiny_adm" or kind != "zigzag_centered":
+            continue
+        outs = []
+        for group in (1, 2, 8):
+            s = _sched("uncertainty_zigzag_centered", m, M=int(M), num_zigzag=int(nz))
+            s.mc_group = group
+            s.set_timesteps(10)
+            s.prompt_embeds = y
+            torch.manual_seed(int(seed))
+            o = s.step(T(g[f"c{c}_eps"]).to(dev), int(t), x)
+            assert s.denoiser_calls == int(M)
+            outs.append(o.uncertainty.cpu().numpy())
+            np.testing.assert_allclose(o.uncertainty.cpu().numpy(), g[f"c{c}_unc"], rtol=1e-2, atol=1e-6)
+            np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"c{c}_prev"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(outs[1], outs[0], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(outs[2], outs[0], rtol=1e-4, atol=1e-7)
+        n += 1
+    assert n >= 2
