@@ -39,6 +39,14 @@ class AttnBlockArgs(_c.Structure):
                 ("y", _P), ("y_colsums", _P)]
 
 
+class UViTBlockArgs(_c.Structure):
+    _fields_ = [("x", _P), ("skip", _P), ("B", _I), ("L", _I), ("D", _I), ("heads", _I), ("hidden", _I),
+                ("skip_packed", _P), ("skip_b", _P), ("norm1_w", _P), ("norm1_b", _P), ("norm2_w", _P), ("norm2_b", _P), ("eps", _F),
+                ("qkv_packed", _P), ("qkv_b", _P), ("proj_packed", _P), ("proj_b", _P), ("fc1_packed", _P), ("fc1_b", _P),
+                ("fc2_packed", _P), ("fc2_b", _P), ("precision", _I), ("act_scale", _F), ("raw_scale", _F),
+                ("workspace", _P), ("workspace_bytes", _Z), ("y", _P)]
+
+
 # name -> (restype, argtypes); every symbol include/dua_hip.h declares
 SIGNATURES = {
     "dua_version": (_I, []),
@@ -108,6 +116,8 @@ SIGNATURES = {
     "dua_adm_attnblock_fwd": (_I, [_c.POINTER(AttnBlockArgs), _P]),
     "dua_gemm_f16x3_presplit_planes": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "dua_layernorm_split_f16x3": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _P]),
+    "dua_uvit_block_workspace_bytes": (_Z, [_c.POINTER(UViTBlockArgs)]),
+    "dua_uvit_block_fwd": (_I, [_c.POINTER(UViTBlockArgs), _P]),
     "dua_conv_profile": (_I, [_I]),
     "dua_conv_profile_collect": (_I, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

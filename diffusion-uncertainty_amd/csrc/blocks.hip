@@ -155,6 +155,73 @@ int attnblock_run(const dua_attnblock_args* a, Carver& w, void* stream) {
     return dua_gemm(&p, stream);
 }
 
+int uvitblock_run(const dua_uvitblock_args* a, Carver& w, void* stream) {
+    const int D = a->D, ch = D / a->heads, Hd = a->hidden;
+    const long M = (long)a->B * a->L;
+    const bool f16 = a->precision == DUA_PREC_F16X3;
+    float* x1 = a->skip_packed ? (float*)w.take((size_t)M * D * 4) : nullptr;          // skip_linear(cat([x, skip]))
+    void* hn = w.take((size_t)M * D * 4);                                               // LayerNorm output (fp32 or planes), both norms
+    float* qkv = (float*)w.take((size_t)M * 3 * D * 4);
+    void* att = w.take((size_t)M * D * 4);
+    float* x2 = (float*)w.take((size_t)M * D * 4);                                      // x + proj(attention)
+    void* hid = w.take((size_t)M * Hd * 4);                                             // gelu(fc1) (fp32 or planes)
+    if (w.dry) return DUA_OK;
+    DUA_REQUIRE(w.used <= w.cap && a->workspace, "dua_uvit_block_fwd: workspace of %zu bytes needed, %zu given", w.used, w.cap);
+    int rc;
+    const float scale = (float)(1.0 / sqrt((double)ch));
+    auto gemm32 = [&](const float* A1, int K1, const float* A2, int K2, const void* W, const float* bias, const float* res, float* C, int N,
+                      int act_out) {
+        dua_gemm_args g{};
+        g.A1 = A1; g.A2 = K2 ? A2 : nullptr; g.B = (const float*)W; g.bias = bias; g.residual = res; g.C = C;
+        g.M = (int)M; g.N = N; g.K1 = K1; g.K2 = K2; g.lda1 = K1; g.lda2 = K2 > 4 ? K2 : 4; g.ldb = K1 + K2; g.ldc = N; g.ldr = N;
+        g.batch = 1; g.batch_inner = 1; g.transB = 1; g.act_out = act_out; g.alpha = 1.0f;
+        return dua_gemm(&g, stream);
+    };
+    const float* x = a->x;
+    if (a->skip_packed) {                                                                               // uvit.py:116-117
+        if (f16) rc = dua_gemm_f16x3(a->x, D, D, a->skip, D, D, a->skip_packed, a->skip_b, nullptr, D, x1, D, (int)M, D, 0, 0, 1.0f, nullptr,
+                                     a->raw_scale, stream);
+        else rc = gemm32(a->x, D, a->skip, D, a->skip_packed, a->skip_b, nullptr, x1, D, 0);
+        if (rc) return rc;
+        x = x1;
+    }
+    if (f16) {
+        if ((rc = dua_layernorm_split_f16x3(x, a->norm1_w, a->norm1_b, hn, M, D, a->eps, a->act_scale, stream))) return rc;        // :118 norm1
+        if ((rc = dua_gemm_f16x3_presplit(hn, a->qkv_packed, a->qkv_b, nullptr, qkv, (int)M, 3 * D, D, 0, nullptr, a->act_scale, stream))) return rc;
+        if ((rc = dua_attention_f16x3(qkv, nullptr, att, a->raw_scale, a->B, a->L, a->heads, ch, scale, stream))) return rc;        // :69-73
+        if ((rc = dua_gemm_f16x3_presplit(att, a->proj_packed, a->proj_b, x, x2, (int)M, D, D, 0, nullptr, a->raw_scale, stream))) return rc;
+        if ((rc = dua_layernorm_split_f16x3(x2, a->norm2_w, a->norm2_b, hn, M, D, a->eps, a->act_scale, stream))) return rc;       // :119 norm2
+        if ((rc = dua_gemm_f16x3_presplit_planes(hn, a->fc1_packed, a->fc1_b, hid, (int)M, Hd, D, 2, a->act_scale, a->raw_scale, stream))) return rc;
+        return dua_gemm_f16x3_presplit(hid, a->fc2_packed, a->fc2_b, x2, a->y, (int)M, D, Hd, 0, nullptr, a->raw_scale, stream);
+    }
+    if ((rc = dua_layernorm(x, a->norm1_w, a->norm1_b, (float*)hn, M, D, a->eps, stream))) return rc;
+    if ((rc = gemm32((const float*)hn, D, nullptr, 0, a->qkv_packed, a->qkv_b, nullptr, qkv, 3 * D, 0))) return rc;
+    if ((rc = dua_attention(qkv, (float*)att, a->B, a->L, a->heads, ch, scale, stream))) return rc;
+    if ((rc = gemm32((const float*)att, D, nullptr, 0, a->proj_packed, a->proj_b, x, x2, D, 0))) return rc;
+    if ((rc = dua_layernorm(x2, a->norm2_w, a->norm2_b, (float*)hn, M, D, a->eps, stream))) return rc;
+    if ((rc = gemm32((const float*)hn, D, nullptr, 0, a->fc1_packed, a->fc1_b, nullptr, (float*)hid, Hd, 2))) return rc;
+    {
+        dua_gemm_args g{};
+        g.A1 = (const float*)hid; g.B = (const float*)a->fc2_packed; g.bias = a->fc2_b; g.residual = x2; g.C = a->y;
+        g.M = (int)M; g.N = D; g.K1 = Hd; g.lda1 = Hd; g.lda2 = 4; g.ldb = Hd; g.ldc = D; g.ldr = D;
+        g.batch = 1; g.batch_inner = 1; g.transB = 1; g.alpha = 1.0f;
+        return dua_gemm(&g, stream);
+    }
+}
+
+int check_uvitblock(const dua_uvitblock_args* a) {
+    DUA_REQUIRE(a && a->x && a->y && a->norm1_w && a->norm1_b && a->norm2_w && a->norm2_b && a->qkv_packed && a->proj_packed && a->fc1_packed &&
+                a->fc2_packed, "dua_uvit_block_fwd: null pointer");
+    DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3, "dua_uvit_block_fwd: precision must be DUA_PREC_FP32 or DUA_PREC_F16X3");
+    DUA_REQUIRE(a->B > 0 && a->L > 0 && a->D > 0 && a->D % 32 == 0 && a->hidden > 0 && a->hidden % 32 == 0 && a->heads > 0 && a->D % a->heads == 0,
+                "dua_uvit_block_fwd: D and hidden must be positive multiples of 32");
+    const int ch = a->D / a->heads;
+    DUA_REQUIRE(ch % 8 == 0 && ch <= 128, "dua_uvit_block_fwd: head dim %d is outside the fused attention kernels", ch);
+    DUA_REQUIRE((a->skip_packed != nullptr) == (a->skip != nullptr), "dua_uvit_block_fwd: skip tokens and skip_linear weights go together");
+    DUA_REQUIRE(a->precision != DUA_PREC_F16X3 || (a->act_scale > 0.f && a->raw_scale > 0.f), "dua_uvit_block_fwd: f16x3 needs positive scales");
+    return DUA_OK;
+}
+
 int check_resblock(const dua_resblock_args* a) {
     DUA_REQUIRE(a && a->x1 && a->y && a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_packed && a->conv2_packed && a->film,
                 "dua_adm_resblock_fwd: null pointer");
@@ -226,4 +293,16 @@ extern "C" int dua_adm_attnblock_fwd(const dua_attnblock_args* a, void* stream) 
     if (rc) return rc;
     Carver w{(char*)a->workspace, 0, a->workspace_bytes, false};
     return attnblock_run(a, w, stream);
+}
+extern "C" size_t dua_uvit_block_workspace_bytes(const dua_uvitblock_args* a) {
+    if (check_uvitblock(a) != DUA_OK) return 0;
+    Carver w{nullptr, 0, 0, true};
+    uvitblock_run(a, w, nullptr);
+    return w.used + 256;
+}
+extern "C" int dua_uvit_block_fwd(const dua_uvitblock_args* a, void* stream) {
+    int rc = check_uvitblock(a);
+    if (rc) return rc;
+    Carver w{(char*)a->workspace, 0, a->workspace_bytes, false};
+    return uvitblock_run(a, w, stream);
 }

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AttnBlockArgs, GemmArgs, ResBlockArgs, check
+from ._lib import AttnBlockArgs, GemmArgs, ResBlockArgs, UViTBlockArgs, check
 
 
 def _stream():
@@ -851,3 +851,29 @@ def adm_attnblock(x, heads, gn, qkv_packed, qkv_b, proj_packed, proj_b, precisio
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     check(L.dua_adm_attnblock_fwd(ctypes.byref(a), _stream()), "dua_adm_attnblock_fwd")
     return _attach_colsums(y, ws_y, H * W)
+
+
+def uvit_block(x, skip, B, L, heads, w, precision="fp32", eps=1e-5):
+    """One U-ViT block through dua_uvit_block_fwd (uvit/uvit.py:95-120).  x / skip: [B*L, D] fp32; w: dict of device tensors
+    (skip_w, skip_b | None, norm1_w, norm1_b, norm2_w, norm2_b, qkv_w, qkv_b | None, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b),
+    the *_w entries packed for `precision`."""
+    _req(x, name="x")
+    M, D = x.shape
+    hidden = int(w["hidden"])
+    y = torch.empty_like(x)
+    ptr = lambda t: (t.data_ptr() if t is not None else None)     # noqa: E731
+    a = UViTBlockArgs(x=x.data_ptr(), skip=ptr(skip), B=B, L=L, D=D, heads=int(heads), hidden=hidden,
+                      skip_packed=ptr(w.get("skip_w")) if skip is not None else None, skip_b=ptr(w.get("skip_b")) if skip is not None else None,
+                      norm1_w=ptr(w["norm1_w"]), norm1_b=ptr(w["norm1_b"]), norm2_w=ptr(w["norm2_w"]), norm2_b=ptr(w["norm2_b"]), eps=float(eps),
+                      qkv_packed=ptr(w["qkv_w"]), qkv_b=ptr(w.get("qkv_b")), proj_packed=ptr(w["proj_w"]), proj_b=ptr(w.get("proj_b")),
+                      fc1_packed=ptr(w["fc1_w"]), fc1_b=ptr(w.get("fc1_b")), fc2_packed=ptr(w["fc2_w"]), fc2_b=ptr(w.get("fc2_b")),
+                      precision=PRECISION_CODE[precision], act_scale=F16X3_ACT_SCALE, raw_scale=F16X3_RAW_SCALE,
+                      workspace=None, workspace_bytes=0, y=y.data_ptr())
+    Lb = _lib.lib()
+    nbytes = Lb.dua_uvit_block_workspace_bytes(ctypes.byref(a))
+    if nbytes == 0:
+        raise RuntimeError(f"dua_uvit_block_workspace_bytes: {Lb.dua_last_error().decode()}")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(Lb.dua_uvit_block_fwd(ctypes.byref(a), _stream()), "dua_uvit_block_fwd")
+    return y

@@ -47,9 +47,30 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.skip_linear = nn.Linear(2 * dim, dim) if skip else None
 
-    def run(self, lin, x, B, L, skip=None, precision="fp32"):
+    def packed(self, cache, precision):
+        """Weights of this block in the layout dua_uvit_block_fwd takes for `precision` (cached on the model)."""
+        key = (id(self), "block", precision)
+        if key not in cache:
+            pk = (lambda lin_: ops.pack_weight_f16x3(lin_.weight.detach().contiguous())) if precision == "f16x3" else \
+                (lambda lin_: lin_.weight.detach().contiguous())
+            d = dict(norm1_w=self.norm1.weight, norm1_b=self.norm1.bias, norm2_w=self.norm2.weight, norm2_b=self.norm2.bias,
+                     qkv_w=pk(self.attn.qkv), qkv_b=self.attn.qkv.bias, proj_w=pk(self.attn.proj), proj_b=self.attn.proj.bias,
+                     fc1_w=pk(self.mlp.fc1), fc1_b=self.mlp.fc1.bias, fc2_w=pk(self.mlp.fc2), fc2_b=self.mlp.fc2.bias,
+                     hidden=self.mlp.fc1.weight.shape[0])
+            if self.skip_linear is not None:
+                d.update(skip_w=pk(self.skip_linear), skip_b=self.skip_linear.bias)
+            cache[key] = d
+        return cache[key]
+
+    def run(self, lin, x, B, L, skip=None, precision="fp32", block_cache=None):
         """x, skip: [B*L, D]; lin(a, linear_module, **kw) is the model's precision-aware GEMM."""
         D = x.shape[1]
+        ch = D // self.attn.num_heads
+        if (block_cache is not None and precision in ("fp32", "f16x3") and D % 32 == 0 and self.mlp.fc1.weight.shape[0] % 32 == 0 and
+                ch % 8 == 0 and ch <= 128 and ops.ATTENTION_MODE == "auto"):
+            # the whole block as ONE C-ABI call (dua_uvit_block_fwd: the same kernels in the same order, bit-identical)
+            return ops.uvit_block(x, skip if self.skip_linear is not None else None, B, L, self.attn.num_heads,
+                                  self.packed(block_cache, precision), precision=precision, eps=self.norm1.eps)
         if self.skip_linear is not None:
             x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
         # split modes: LayerNorm / GELU outputs go out in the operand format of the LDS-DMA GEMMs (bf16 planes or f16f8 planes)
@@ -105,6 +126,7 @@ class UViT(nn.Module):
         self.img_size = img_size
         self.patch_size = patch_size
         self.precision = "fp32"          # or "f16x3" (fp32-equivalent) / "bf16x3" / "f16f8" (see guided_diffusion/unet_openai.py)
+        self.use_block_abi = True        # fp32 / f16x3: every Block runs as ONE C-ABI call (bit-identical to the composition)
         self._planes = {}
 
     def _apply(self, fn, *a, **k):
@@ -165,12 +187,13 @@ class UViT(nn.Module):
         T = L + self.extras
         h = h.view(B * T, D)
         skips = []
+        bc = self._planes if self.use_block_abi else None
         for blk in self.in_blocks:
-            h = blk.run(self._lin, h, B, T, precision=self.precision)
+            h = blk.run(self._lin, h, B, T, precision=self.precision, block_cache=bc)
             skips.append(h)
-        h = self.mid_block.run(self._lin, h, B, T, precision=self.precision)
+        h = self.mid_block.run(self._lin, h, B, T, precision=self.precision, block_cache=bc)
         for blk in self.out_blocks:
-            h = blk.run(self._lin, h, B, T, skips.pop(), precision=self.precision)
+            h = blk.run(self._lin, h, B, T, skips.pop(), precision=self.precision, block_cache=bc)
         h = ops.layernorm(h, self.norm.weight, self.norm.bias, self.norm.eps)
         h = self._lin(h, self.decoder_pred)                                                # [B*T, P*P*C]
         return ops.unpatchify(h, B, L, self.extras, C, P)                                  # :228-229

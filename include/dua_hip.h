@@ -386,6 +386,23 @@ typedef struct {
 /* AttentionBlock.forward, unet_openai.py:300-306, on the fused attention kernels: head dims <= 128 (multiple of 8 in fp32, of 4 in
  * f16x3); wider heads are composed from dua_gemm / dua_softmax_rows by the caller. */
 size_t dua_adm_attnblock_workspace_bytes(const dua_attnblock_args* args_host);
+typedef struct {
+    const float* x; const float* skip;   /* tokens [B*L][D]; skip = the long-skip tokens of an out-block or NULL   uvit.py:116-117 */
+    int B, L, D, heads, hidden;
+    const void* skip_packed; const float* skip_b;            /* skip_linear [D][2D] or NULL */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; float eps;
+    const void* qkv_packed; const float* qkv_b;              /* attn.qkv [3D][D] (bias may be NULL) */
+    const void* proj_packed; const float* proj_b;            /* attn.proj */
+    const void* fc1_packed; const float* fc1_b;              /* mlp.fc1 [hidden][D] (+ GELU) */
+    const void* fc2_packed; const float* fc2_b;              /* mlp.fc2 [D][hidden] */
+    int precision; float act_scale, raw_scale;
+    void* workspace; size_t workspace_bytes;
+    float* y;
+} dua_uvitblock_args;
+/* uvit_block_fwd: Block.forward of uvit/uvit.py:95-120 (skip_linear(cat) -> x + attn(norm1 x) -> x + mlp(norm2 x)), fp32 or f16x3;
+ * weights as stored ([N][K], fp32) or packed by dua_pack_weight_f16x3; head dims multiple of 8, <= 128. */
+size_t dua_uvit_block_workspace_bytes(const dua_uvitblock_args* args_host);
+int dua_uvit_block_fwd(const dua_uvitblock_args* args_host, void* stream);
 /* Bench facility: dua_conv_profile(1) makes the block functions bracket each of their conv3x3 launches with HIP events on the
  * launch stream (returns the previous setting); dua_conv_profile_collect synchronises on them, returns the summed launch time (ms),
  * the summed algorithmic FLOPs (2*N*H*W*9*Cin*Cout) and the number of launches since the last collect, and frees the events. */

@@ -826,3 +826,22 @@ def test_grouped_mc_chains_match_sequential(golden, precision):
         np.testing.assert_allclose(outs[2], outs[0], rtol=1e-4, atol=1e-7)
         n += 1
     assert n >= 2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_uvit_block_abi_bit_identical(precision):
+    """dua_uvit_block_fwd (one C-ABI call per U-ViT block, SURVEY 8(b) uvit_block_fwd) against the per-op composition: bit-identical."""
+    from diffusion_uncertainty_amd.uvit.uvit import UViT
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    m = UViT(**TINY_UVIT)
+    m.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 6))
+    m.eval().to(dev)
+    m.precision = precision
+    x = torch.randn(3, 4, 8, 8, generator=torch.Generator().manual_seed(4)).to(dev)
+    t, y = torch.tensor([999, 3, 500]).to(dev), torch.tensor([10, 0, 5]).to(dev)
+    m.use_block_abi = True
+    a = m(x, t, y)
+    m.use_block_abi = False
+    b = m(x, t, y)
+    assert torch.equal(a, b)
+    assert float(a.abs().max()) > 0
