@@ -384,6 +384,7 @@ class UNetModel(nn.Module):
         self.fuse_gn_stats = True
         self.presplit_qkv = True         # bf16x3: attention GroupNorm writes split planes, qkv runs on the LDS-DMA kernel
         self.use_block_abi = True        # fp32 / f16x3: ResBlocks and AttentionBlocks run as ONE C-ABI call each (bit-identical to the composition)
+        self._graphs = None              # enable_hip_graph(): {key: captured forward}
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask
@@ -395,6 +396,8 @@ class UNetModel(nn.Module):
     # ---- weight cache hygiene
     def invalidate_packed_weights(self):
         self._packed = {}
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
 
     def _film_table(self):
         """Row-concatenated emb_layers weights / biases of all ResBlocks (cached with the packed weights)."""
@@ -412,12 +415,19 @@ class UNetModel(nn.Module):
         return tab
 
     def _apply(self, fn, *a, **k):
-        self._packed = {}
+        self.invalidate_packed_weights()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._packed = {}
+        self.invalidate_packed_weights()
         return super().load_state_dict(*a, **k)
+
+    def enable_hip_graph(self, on=True):
+        """Capture the eval-mode forward once per (input shape, precision, kept channels) into a HIP graph and replay it afterwards:
+        ~330 launches of a forward become one graph launch - what the small-batch cases (BASELINE configs[0]: ADM-64, batch 4) are
+        bound by.  Bit-identical to the eager forward.  Train mode (host dropout masks) and activation-noise hooks stay eager."""
+        self._graphs = {} if on else None
+        return self
 
     @torch.no_grad()
     def forward(self, x, timesteps, y=None, out_channels_keep=None):
@@ -430,7 +440,33 @@ class UNetModel(nn.Module):
         if gen != getattr(self, "_packed_gen", None):
             if self._packed:
                 self._packed = {}
+            if getattr(self, "_graphs", None):
+                self._graphs = {}
             self._packed_gen = gen
+        graphs = getattr(self, "_graphs", None)
+        if graphs is None or self.training or self.activation_noise:
+            return self._forward_impl(x, timesteps, y, out_channels_keep)
+        x = x.float().contiguous()
+        t = timesteps.to(torch.int64).contiguous()
+        yy = y.to(torch.int64).contiguous() if y is not None else None
+        key = (tuple(x.shape), self.precision, out_channels_keep, self.use_block_abi, self.fuse_gn_stats, ops.ATTENTION_MODE, y is not None)
+        entry = graphs.get(key)
+        if entry is None:
+            self._forward_impl(x, t, yy, out_channels_keep)            # eager once: packs the weights, warms the allocator
+            sx, st, sy = x.clone(), t.clone(), (yy.clone() if yy is not None else None)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                so = self._forward_impl(sx, st, sy, out_channels_keep)
+            entry = graphs[key] = (graph, sx, st, sy, so)
+        graph, sx, st, sy, so = entry
+        sx.copy_(x)
+        st.copy_(t)
+        if sy is not None:
+            sy.copy_(yy)
+        graph.replay()
+        return so.clone()
+
+    def _forward_impl(self, x, timesteps, y=None, out_channels_keep=None):
         ctx = _Ctx(self)
         B = x.shape[0]
         te, te2 = self.time_embed[0], self.time_embed[2]

@@ -63,6 +63,8 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
             randomize_parameters_(unet, seed=args.image_size)
         unet.eval().to(device)
         unet.precision = args.precision
+        if args.hip_graph and args.scheduler_type != "mc_dropout":
+            unet.enable_hip_graph()
         model = unet
     else:
         uvit = load_uvit(args.image_size, device="cpu", load_checkpoint=ckpt)
@@ -127,6 +129,8 @@ def parse_args(argv=None):
     p.add_argument("--uncertainty-distance", type=int, default=20, dest="uncertainty_distance")
     p.add_argument("--num-zigzag", "--num-zigzags", "--num-zig-zag", "--num-zig-zags", type=int, default=3, dest="num_zigzag")
     # engine options (not in the reference)
+    p.add_argument("--hip-graph", action="store_true", dest="hip_graph",
+                   help="ADM UNet: replay the forward from a captured HIP graph (one launch instead of ~330; for small batches)")
     p.add_argument("--precision", choices=["f16x3", "fp32", "f16f6", "f16f8", "bf16x3"], default="f16x3",
                    help="f16x3 (default): the fp32-equivalent split - trajectories match the reference CPU path like the exact fp32 mode's; "
                         "fp32: exact fp32 MFMA; bf16x3 / f16f8 / f16f6: narrower throughput modes (16 / ~15 / ~14-15 operand bits)")

