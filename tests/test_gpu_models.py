@@ -864,7 +864,6 @@ def test_adm_hip_graph_replay_bit_identical(precision):
     assert m(xs[0], t, y=y).shape == (3, 6, 16, 16) and len(m._graphs) == 2          # another kept-channel count: another capture
     with torch.no_grad():
         m.out[2].weight.mul_(2.0)
-    doubled = m(xs[0], t, y=y, out_channels_keep=3)
-    np.testing.assert_allclose(doubled.cpu().numpy(), 2 * eager[0].cpu().numpy() - 0 * 1, rtol=0, atol=1e-5 + 1e-5 * float(eager[0].abs().max()) + float((m.out[2].bias.abs().max()) * 2))
+    after = m(xs[0], t, y=y, out_channels_keep=3)                  # the edit dropped the captures: re-captured with the new weights
     m.enable_hip_graph(False)
-    assert torch.equal(m(xs[0], t, y=y, out_channels_keep=3), doubled)
+    assert torch.equal(m(xs[0], t, y=y, out_channels_keep=3), after) and not torch.equal(after, eager[0])
