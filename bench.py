@@ -270,7 +270,6 @@ def other_config_sd(dev, a):
     from diffusion_uncertainty_amd.utils import randomize_parameters_
     uncertainty_guidance.use_posterior = True
     unet = randomize_parameters_(UNet2DConditionModel(), seed=15).eval().to(dev)
-    unet.precision = "f16f8"
     unet.enable_hip_graph()
     g = torch.Generator().manual_seed(491)
     pe, ne = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
@@ -278,19 +277,24 @@ def other_config_sd(dev, a):
     uncertainty_guidance.noise_source = DeviceNoise(seed=491)
     kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=20, guidance_scale=7.5, start_step_uc=0, num_steps_uc=2,
               percentile=0.9, num_uncertainty_samples=5, height=512, width=512)
-    times = []
-    for _ in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipe(generator=torch.Generator().manual_seed(491), **kw)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+    res = {}
+    for mode in ("f16x3", "f16f8"):
+        unet.precision = mode
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe(generator=torch.Generator().manual_seed(491), **kw)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        res[mode] = times
     del unet, pipe
     torch.cuda.empty_cache()
     return dict(config="BASELINE configs[4]: SD-1.5 latent UNet 512x512, percentile-0.9 uncertainty guidance (posterior mode), 20 steps, M=5, 2 guided steps",
-                value=round(min(times[1:]), 3), unit="seconds/image", higher_is_better=False,
-                dtype="f16f8 (~15 significant bits); parity of the UNet itself unpinned (un-vendored diffusers), the guidance function is pinned (G7)",
-                data="synthetic prompt embeddings, random-init weights", first_run_incl_packing_s=round(times[0], 2))
+                value=round(min(res["f16x3"][1:]), 3), unit="seconds/image", higher_is_better=False,
+                dtype="f16x3 (fp32-equivalent split, as the headline); parity of the UNet itself unpinned (un-vendored diffusers), the guidance function is pinned (G7)",
+                data="synthetic prompt embeddings, random-init weights", first_run_incl_packing_s=round(res["f16x3"][0], 2),
+                f16f8_seconds_per_image=round(min(res["f16f8"][1:]), 3))
 
 
 def parse_args(argv=None):

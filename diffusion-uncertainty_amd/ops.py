@@ -282,7 +282,8 @@ def _film_ld(film, N, C):
     return film.stride(0)
 
 
-def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32, split=False):
+def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=0, dropmask=None, groups=32, split=False,
+                    split_scale=None):
     N, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
@@ -292,10 +293,11 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
         if fmt == "f16x3":
+            scale = F16X3_ACT_SCALE if split_scale is None else float(split_scale)
             check(_lib.lib().dua_groupnorm_apply_split_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
                                                              _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
-                                                             F16X3_ACT_SCALE, _p(buf), _stream()), "dua_groupnorm_apply_split_f16x3")
-            return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt, F16X3_ACT_SCALE)
+                                                             scale, _p(buf), _stream()), "dua_groupnorm_apply_split_f16x3")
+            return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt, scale)
         fn = {"f16f8": _lib.lib().dua_groupnorm_apply_split_f16f8, "f16f6": _lib.lib().dua_groupnorm_apply_split_f16f6}.get(
             fmt, _lib.lib().dua_groupnorm_apply_split)
         check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film), _film_ld(film, N, C1 + C2),

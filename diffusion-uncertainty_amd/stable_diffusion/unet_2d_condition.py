@@ -78,18 +78,18 @@ class BasicTransformerBlock(nn.Module):
         """h: [B*T, C] token rows; enc: [B, Tk, ctx_dim]."""
         C = h.shape[1]
         heads = self.attn1.heads
-        n1 = ops.layernorm(h, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        n1 = ctx.norm_rows(h, self.norm1)
         qkv = ctx.gemm(n1, ctx.cat_weight(self.attn1, ("to_q", "to_k", "to_v")), None)
-        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision, planes_out=(ctx.split_acts == "f16f8"))
+        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision, planes_out=(ctx.split_acts in ("f16f8", "f16x3")))
         h = ctx.gemm(a, self.attn1.to_out[0].weight, self.attn1.to_out[0].bias, residual=h)
-        n2 = ops.layernorm(h, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
+        n2 = ctx.norm_rows(h, self.norm2)
         q = ctx.gemm(n2, self.attn2.to_q.weight, None)
         Tk = enc.shape[1]
         e2 = enc.reshape(B * Tk, -1)
         k, v = ctx.gemm(e2, self.attn2.to_k.weight, None), ctx.gemm(e2, self.attn2.to_v.weight, None)
         a = ops.attention(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), heads).view(B * T, C)
         h = ctx.gemm(a, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, residual=h)
-        n3 = ops.layernorm(h, self.norm3.weight, self.norm3.bias, eps=self.norm3.eps)
+        n3 = ctx.norm_rows(h, self.norm3)
         g = ops.geglu(ctx.gemm(n3, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias))
         return ctx.gemm(g, self.ff.net[2].weight, self.ff.net[2].bias, residual=h)
 
@@ -105,8 +105,13 @@ class Transformer2DModel(nn.Module):
     def run(self, ctx, x, enc):
         N, H, W, C = x.shape
         st = ops.groupnorm_stats(x, groups=self.norm.num_groups, eps=self.norm.eps)
-        xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0, groups=self.norm.num_groups)
-        h = ctx.linear(xn.view(N * H * W, C), self.proj_in)
+        xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0, groups=self.norm.num_groups,
+                                 split="f16x3" if ctx.f16x3 and C % 32 == 0 else False)
+        if isinstance(xn, ops.SplitPlanes):
+            xn = ops.SplitPlanes(xn.buf, (N * H * W, C), xn.fmt, xn.scale)
+        else:
+            xn = xn.view(N * H * W, C)
+        h = ctx.linear(xn, self.proj_in)
         for blk in self.transformer_blocks:
             h = blk.run(ctx, h, N, H * W, enc)
         out2d = ctx.linear(h, self.proj_out, residual=x.view(N * H * W, C), colsum=True)
@@ -152,10 +157,11 @@ class TimestepEmbedding(nn.Module):
 class _Ctx:
     def __init__(self, model):
         self.model = model
-        assert model.precision in ("fp32", "bf16x3", "f16f8"), model.precision
-        self.split_mode = model.precision != "fp32"
-        self.split_acts = "f16f8" if model.precision == "f16f8" else model.precision == "bf16x3"
-        self.attn_precision = "fp32" if model.precision == "fp32" else "bf16x3"
+        assert model.precision in ("fp32", "bf16x3", "f16f8", "f16x3"), model.precision
+        self.f16x3 = model.precision == "f16x3"                      # fp32-equivalent fp16 hi + lo split (22 operand bits)
+        self.split_mode = model.precision in ("bf16x3", "f16f8")     # on-the-fly bf16 split of raw fp32 operands
+        self.split_acts = model.precision if model.precision in ("f16f8", "f16x3") else model.precision == "bf16x3"
+        self.attn_precision = {"fp32": "fp32", "f16x3": "f16x3"}.get(model.precision, "bf16x3")
         self.emb = None
         self.temb_all = None
 
@@ -167,7 +173,9 @@ class _Ctx:
 
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         if isinstance(h, ops.SplitPlanes):
-            if h.fmt == "f16f8":
+            if h.fmt == "f16x3":
+                w = self.packed((id(conv), "w3h"), lambda: ops.pack_weight_f16x3(conv.weight.detach().contiguous()))
+            elif h.fmt == "f16f8":
                 w = self.packed((id(conv), "w3f"), lambda: ops.pack_weight_f16f8(conv.weight.detach().contiguous()))
             else:
                 w = self.packed((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
@@ -180,16 +188,39 @@ class _Ctx:
 
     def gemm(self, a, weight, bias, a2=None, residual=None, colsum=False):
         """rows x weight^T in the model's precision (fp32 MFMA, or the split-bf16 tile engine with the operand split on the fly)."""
-        if isinstance(a, ops.SplitPlanes):           # operand already in the f16f8 format (attention output): LDS-DMA GEMM
+        if isinstance(a, ops.SplitPlanes):           # operand already split (norm / attention output): LDS-DMA GEMM
             n_out = weight.shape[0]
-            packed = self.packed((id(weight), "w1f"), lambda: ops.pack_weight_f16f8(weight.detach().reshape(n_out, -1).contiguous()))
+            kind, pack = ("w1hp", ops.pack_weight_f16x3) if a.fmt == "f16x3" else ("w1f", ops.pack_weight_f16f8)
+            packed = self.packed((id(weight), kind), lambda: pack(weight.detach().reshape(n_out, -1).contiguous()))
             return ops.gemm_bf16x3_presplit(a, packed, n_out, bias=bias, residual=residual, colsum=colsum)
         n_out, K = weight.shape[0], a.shape[1] + (0 if a2 is None else a2.shape[1])
+        if self.f16x3 and K % 32 == 0 and a.shape[1] % 32 == 0:       # raw fp32 rows split on the fly into fp16 hi + lo
+            packed = self.packed((id(weight), "w1h"), lambda: ops.pack_weight_f16x3(weight.detach().reshape(n_out, K).contiguous()))
+            return ops.gemm_f16x3(a, packed, n_out, bias=bias, a2=a2, residual=residual, colsum=colsum)
         if self.split_mode and K % 32 == 0 and a.shape[1] % 32 == 0:
             planes = self.packed((id(weight), "w1x"), lambda: ops.pack_weight_bf16x3(weight.detach().reshape(n_out, K).contiguous()))
             return ops.gemm_bf16x3(a, planes, n_out, bias=bias, a2=a2, residual=residual, colsum=colsum)
         w = self.packed((id(weight), "w1"), lambda: weight.detach().reshape(n_out, K).contiguous())
         return ops.gemm(a, w, bias=bias, a2=a2, residual=residual, colsum=colsum)
+
+    def norm_rows(self, h, norm):
+        """LayerNorm of token rows; in f16x3 mode straight into the operand planes of the next projection."""
+        split = "f16x3" if self.f16x3 and h.shape[1] % 32 == 0 else False
+        return ops.layernorm(h, norm.weight, norm.bias, eps=norm.eps, split=split)
+
+    def raw_planes(self, h, resample=0):
+        """Raw fp32 NHWC map (no norm in front of a down / up-sampler conv) -> f16x3 operand planes, optionally nearest x2:
+        the GroupNorm-apply kernel with identity statistics (mean 0, rstd 1, gamma 1, beta 0: exact) at the raw-stream scale."""
+        N, H, W, C = h.shape
+        if not (self.f16x3 and C % 32 == 0):
+            return ops.resample2x(h, 1) if resample > 0 else h
+        key = ("identity_gn", N, C)
+        if key not in self.model._packed:
+            st = torch.zeros((N, 32, 2), device=h.device, dtype=torch.float32)
+            st[:, :, 1] = 1.0
+            self.model._packed[key] = (st, torch.ones(C, device=h.device), torch.zeros(C, device=h.device))
+        st, one, zero = self.model._packed[key]
+        return ops.groupnorm_apply(h, st, one, zero, act=0, resample=resample, groups=32, split="f16x3", split_scale=ops.F16X3_RAW_SCALE)
 
     def linear(self, a, conv1x1, a2=None, residual=None, colsum=False):
         return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual, colsum=colsum)
@@ -253,7 +284,7 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(G, boc[0])
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
         self._packed = {}
-        self.precision = "fp32"          # "fp32" | "bf16x3" | "f16f8" (see guided_diffusion/unet_openai.py)
+        self.precision = "fp32"          # "fp32" | "f16x3" | "bf16x3" | "f16f8" (see guided_diffusion/unet_openai.py)
         # hipGraph replay of the forward (enable_hip_graph): at the CFG batch of 2 one forward is ~1000 launches of a few
         # microseconds each and the host cannot issue them fast enough; a captured graph removes the launch path.
         self._graphs = None
@@ -348,7 +379,7 @@ class UNet2DConditionModel(nn.Module):
                 res.append(h)
             if hasattr(blk, "downsamplers"):
                 conv = blk.downsamplers[0].conv
-                h = ops.pick_even(ctx.conv3x3(h, conv, conv.out_channels))      # stride 2 / pad 1 = stride 1 at the even pixels
+                h = ops.pick_even(ctx.conv3x3(ctx.raw_planes(h), conv, conv.out_channels))      # stride 2 / pad 1 = stride 1 at the even pixels
                 res.append(h)
         h = self.mid_block.resnets[0].run(ctx, h)
         h = self.mid_block.attentions[0].run(ctx, h, enc)
@@ -360,7 +391,7 @@ class UNet2DConditionModel(nn.Module):
                     h = blk.attentions[j].run(ctx, h, enc)
             if hasattr(blk, "upsamplers"):
                 conv = blk.upsamplers[0].conv
-                h = ctx.conv3x3(ops.resample2x(h, 1), conv, conv.out_channels, colsum=True)
+                h = ctx.conv3x3(ctx.raw_planes(h, resample=1), conv, conv.out_channels, colsum=True)
         G = self.conv_norm_out.num_groups
         st = ops.groupnorm_stats(h, groups=G, eps=self.conv_norm_out.eps)
         h = ops.groupnorm_apply(h, st, self.conv_norm_out.weight, self.conv_norm_out.bias, act=1, groups=G, split=ctx.split_acts)

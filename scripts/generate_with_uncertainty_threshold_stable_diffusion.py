@@ -29,7 +29,7 @@ def main():
     p.add_argument("--use-posterior", action="store_true", default=True)
     p.add_argument("-M", type=int, default=5)
     p.add_argument("--guidance-scale", type=float, default=7.5)
-    p.add_argument("--precision", choices=["f16f8", "bf16x3", "fp32"], default="f16f8")
+    p.add_argument("--precision", choices=["f16x3", "f16f8", "bf16x3", "fp32"], default="f16x3")
     p.add_argument("--unet-state-dict", type=str, default=None)
     p.add_argument("--prompt-embeds", type=str, default=None)
     p.add_argument("--out", type=str, default=None)
