@@ -85,6 +85,12 @@ SIGNATURES = {
     "dua_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _P]),
     "dua_gemm": (_I, [_c.POINTER(GemmArgs), _P]),
     "dua_softmax_rows": (_I, [_P, _L, _I, _L, _P]),
+    "dua_groupnorm_bwd": (_I, [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "dua_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "dua_geglu_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
+    "dua_softmax_bwd_rows": (_I, [_P, _P, _L, _I, _L, _P]),
+    "dua_place_even": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dua_mc_var_grad": (_I, [_P, _P, _I, _Z, _F, _P]),
     "dua_attention": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dua_attention_bf16x3": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dua_attention_bf16x3_planes": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),

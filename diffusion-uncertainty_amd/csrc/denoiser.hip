@@ -711,14 +711,15 @@ __global__ __launch_bounds__(BLK) void k_softmax_rows(float* __restrict__ S, lon
     }
 }
 extern "C" int dua_softmax_rows(float* S, long rows, int cols, long ld, void* stream) {
-    DUA_REQUIRE(S && rows >= 0 && cols >= 1 && cols <= 2048 && ld >= cols, "dua_softmax_rows: cols must be in [1, 2048], ld >= cols");
+    DUA_REQUIRE(S && rows >= 0 && cols >= 1 && cols <= 4096 && ld >= cols, "dua_softmax_rows: cols must be in [1, 4096], ld >= cols");
     if (rows == 0) return DUA_OK;
     unsigned grid = (unsigned)((rows + 3) / 4);
     if (cols <= 64) hipLaunchKernelGGL(k_softmax_rows<1>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
     else if (cols <= 256) hipLaunchKernelGGL(k_softmax_rows<4>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
     else if (cols <= 512) hipLaunchKernelGGL(k_softmax_rows<8>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
     else if (cols <= 1024) hipLaunchKernelGGL(k_softmax_rows<16>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
-    else hipLaunchKernelGGL(k_softmax_rows<32>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
+    else if (cols <= 2048) hipLaunchKernelGGL(k_softmax_rows<32>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
+    else hipLaunchKernelGGL(k_softmax_rows<64>, grid, BLK, 0, as_stream(stream), S, rows, cols, ld);
     return dua_check_launch("dua_softmax_rows");
 }
 

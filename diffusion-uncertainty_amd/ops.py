@@ -644,6 +644,137 @@ def softmax_rows_(S, rows, cols, ld=None):
     return S
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Input gradients (gradient-mode guidance, uncertainty_guidance.py:83-108,121-129): activations only, exact fp32.
+
+def groupnorm_bwd(x1, stats, gamma, beta, dy, x2=None, act=1, groups=32, add1=None, add2=None):
+    """Gradient of act(GroupNorm(cat(x1, x2))) w.r.t. x1 (and x2), given dy [N, H, W, C1+C2] and the forward statistics."""
+    for t, nm in ((x1, "x1"), (stats, "stats"), (dy, "dy")):
+        _req(t, name=nm)
+    N, H, W, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    assert dy.shape == (N, H, W, C1 + C2) and stats.shape == (N, groups, 2)
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    check(_lib.lib().dua_groupnorm_bwd(_p(x1), C1, _p(x2), C2, N, H * W, groups, _p(stats), _p(gamma), _p(beta), int(act), _p(dy),
+                                       _p(add1), _p(add2), _p(dx1), _p(dx2), _stream()), "dua_groupnorm_bwd")
+    return dx1, dx2
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5, add=None):
+    _req(x, name="x"), _req(dy, name="dy")
+    D = x.shape[-1]
+    assert dy.shape == x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().dua_layernorm_bwd(_p(x), _p(gamma), _p(dy), _p(add), _p(dx), x.numel() // D, D, float(eps), _stream()), "dua_layernorm_bwd")
+    return dx
+
+
+def geglu_bwd(x, dy):
+    _req(x, name="x"), _req(dy, name="dy")
+    M, F2 = x.shape
+    assert dy.shape == (M, F2 // 2)
+    dx = torch.empty_like(x)
+    check(_lib.lib().dua_geglu_bwd(_p(x), _p(dy), _p(dx), M, F2 // 2, _stream()), "dua_geglu_bwd")
+    return dx
+
+
+def softmax_bwd_rows_(P, dP, rows, cols, ld=None):
+    check(_lib.lib().dua_softmax_bwd_rows(_p(P), _p(dP), int(rows), int(cols), int(cols if ld is None else ld), _stream()), "dua_softmax_bwd_rows")
+    return dP
+
+
+def place_even(g, H, W):
+    """Adjoint of pick_even: [N, H/2, W/2, C] -> [N, H, W, C] with zeros off the even pixels."""
+    _req(g, name="g")
+    N, Ho, Wo, C = g.shape
+    assert (Ho, Wo) == (H // 2, W // 2)
+    out = torch.empty((N, H, W, C), device=g.device, dtype=torch.float32)
+    check(_lib.lib().dua_place_even(_p(g), _p(out), N, H, W, C, _stream()), "dua_place_even")
+    return out
+
+
+def mc_var_grad(stack, scale):
+    """d/d e_m of (scale/2) * sum_m (e_m - mean_m e)^2 for the stacked samples [M, ...]."""
+    _req(stack, name="stack")
+    G = torch.empty_like(stack)
+    check(_lib.lib().dua_mc_var_grad(_p(stack), _p(G), stack.shape[0], stack[0].numel(), float(scale), _stream()), "dua_mc_var_grad")
+    return G
+
+
+# logits / probabilities of a backward attention chunk are materialised in HBM; chunks of samples bound them to this many floats
+ATTN_BWD_CHUNK_FLOATS = 1 << 28
+
+
+def _attn_bwd_chunk(qp, kp, vp, dop, dqp, dkp, dvp, ldq, ldk, ldo, ldg, nb, heads, Tq, Tk, ch, dev):
+    """One chunk of nb samples.  q / k / v / dO / dq / dk / dv are base addresses of [nb*T, ld] row-major operands whose head h
+    sits at column offset h*ch; dkp / dvp = 0: keys and values are constants (cross-attention)."""
+    BH = nb * heads
+    Tp = (Tk + 3) // 4 * 4
+    alpha = 1.0 / math.sqrt(ch)
+    P = torch.empty((BH, Tq, Tp), device=dev, dtype=torch.float32)
+    dP = torch.empty((BH, Tq, Tp), device=dev, dtype=torch.float32)
+    common = dict(batch=BH, batch_inner=heads)
+    # P = softmax(alpha q k^T)
+    gemm_raw(A1=qp, B=kp, C=P.data_ptr(), M=Tq, N=Tk, K1=ch, K2=0, lda1=ldq, lda2=4, ldb=ldk, ldc=Tp, ldr=Tp, sA1=Tq * ldq, sB=Tk * ldk,
+             sC=heads * Tq * Tp, sA1i=ch, sBi=ch, sCi=Tq * Tp, transB=1, alpha=alpha, **common)
+    softmax_rows_(P, BH * Tq, Tk, Tp)
+    # dP = dO v^T, then dS in place
+    gemm_raw(A1=dop, B=vp, C=dP.data_ptr(), M=Tq, N=Tk, K1=ch, K2=0, lda1=ldo, lda2=4, ldb=ldk, ldc=Tp, ldr=Tp, sA1=Tq * ldo, sB=Tk * ldk,
+             sC=heads * Tq * Tp, sA1i=ch, sBi=ch, sCi=Tq * Tp, transB=1, alpha=1.0, **common)
+    softmax_bwd_rows_(P, dP, BH * Tq, Tk, Tp)
+    # dq = alpha dS k
+    gemm_raw(A1=dP.data_ptr(), B=kp, C=dqp, M=Tq, N=ch, K1=Tk, K2=0, lda1=Tp, lda2=4, ldb=ldk, ldc=ldg, ldr=ldg, sA1=heads * Tq * Tp,
+             sB=Tk * ldk, sC=Tq * ldg, sA1i=Tq * Tp, sBi=ch, sCi=ch, transB=0, alpha=alpha, **common)
+    if not dkp:
+        return
+    Tqp = (Tq + 3) // 4 * 4
+    Tr = torch.empty((BH, Tk, Tqp), device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    # dk = alpha dS^T q
+    check(L.dua_transpose_batched(_p(dP), _p(Tr), Tq, Tk, Tp, Tqp, heads * Tq * Tp, Tq * Tp, heads * Tk * Tqp, Tk * Tqp, BH, heads, _stream()),
+          "dua_transpose_batched")
+    gemm_raw(A1=Tr.data_ptr(), B=qp, C=dkp, M=Tk, N=ch, K1=Tq, K2=0, lda1=Tqp, lda2=4, ldb=ldq, ldc=ldg, ldr=ldg, sA1=heads * Tk * Tqp,
+             sB=Tq * ldq, sC=Tk * ldg, sA1i=Tk * Tqp, sBi=ch, sCi=ch, transB=0, alpha=alpha, **common)
+    # dv = P^T dO
+    check(L.dua_transpose_batched(_p(P), _p(Tr), Tq, Tk, Tp, Tqp, heads * Tq * Tp, Tq * Tp, heads * Tk * Tqp, Tk * Tqp, BH, heads, _stream()),
+          "dua_transpose_batched")
+    gemm_raw(A1=Tr.data_ptr(), B=dop, C=dvp, M=Tk, N=ch, K1=Tq, K2=0, lda1=Tqp, lda2=4, ldb=ldo, ldc=ldg, ldr=ldg, sA1=heads * Tk * Tqp,
+             sB=Tq * ldo, sC=Tk * ldg, sA1i=Tk * Tqp, sBi=ch, sCi=ch, transB=0, alpha=1.0, **common)
+
+
+def qkv_attention_bwd(qkv, dout, B, T, heads, ch):
+    """Gradient of qkv_attention w.r.t. the packed qkv rows [B*T, 3*heads*ch], given dout [B*T, heads*ch]: the probabilities are
+    recomputed from qkv (fp32 MFMA GEMMs, logits in HBM, a chunk of samples at a time)."""
+    _req(qkv, name="qkv"), _req(dout, name="dout")
+    C = heads * ch
+    assert qkv.shape == (B * T, 3 * C) and dout.shape == (B * T, C) and T <= 4096
+    dqkv = torch.empty_like(qkv)
+    nb = max(1, min(B, ATTN_BWD_CHUNK_FLOATS // (heads * T * ((T + 3) // 4 * 4))))
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        qb, gb, ob = qkv.data_ptr() + 4 * b0 * T * 3 * C, dqkv.data_ptr() + 4 * b0 * T * 3 * C, dout.data_ptr() + 4 * b0 * T * C
+        _attn_bwd_chunk(qb, qb + 4 * C, qb + 8 * C, ob, gb, gb + 4 * C, gb + 8 * C, 3 * C, 3 * C, C, 3 * C, n, heads, T, T, ch, qkv.device)
+    return dqkv
+
+
+def attention_bwd_q(q, k, v, dout, heads):
+    """Gradient of attention(q, k, v, heads) w.r.t. q only (cross-attention: k / v come from the constant text context)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (dout, "dout")):
+        _req(t, name=nm)
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    ch = C // heads
+    assert dout.shape == q.shape and Tk <= 4096
+    dq = torch.empty_like(q)
+    nb = max(1, min(B, ATTN_BWD_CHUNK_FLOATS // (heads * Tq * ((Tk + 3) // 4 * 4))))
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        _attn_bwd_chunk(q.data_ptr() + 4 * b0 * Tq * C, k.data_ptr() + 4 * b0 * Tk * C, v.data_ptr() + 4 * b0 * Tk * C,
+                        dout.data_ptr() + 4 * b0 * Tq * C, dq.data_ptr() + 4 * b0 * Tq * C, 0, 0, C, C, C, C, n, heads, Tq, Tk, ch, q.device)
+    return dq
+
+
 # "auto": fused kernel wherever it applies except where the split-bf16 GEMM pair is faster (see qkv_attention);
 # "fused" / "gemm" force one path (A/B measurements, tests).
 ATTENTION_MODE = "auto"

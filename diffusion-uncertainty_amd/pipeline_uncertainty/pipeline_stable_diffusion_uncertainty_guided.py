@@ -10,7 +10,9 @@ the window ``start_step_uc <= i < start_step_uc + num_steps_uc`` the percentile-
 Outside the hot path and NOT built (third-party models of the un-vendored diffusers / transformers): the CLIP tokenizer and
 text encoder (``encode_prompt``), the VAE decode and the safety checker - the caller passes ``prompt_embeds`` /
 ``negative_prompt_embeds`` ([1, 77, 768] each) and receives latents (``output_type='latent'``, the reference's own
-branch :778-782).  Gradient-mode guidance (``use_posterior=False``, the script default) needs UNet backward: out of scope.
+branch :778-782).  Both updates of the guidance function are available: the posterior blend and the gradient update
+(``uncertainty_guidance.use_posterior = False``, the reference script's default), the latter through the UNet's explicit input
+gradient (``forward_with_tape`` / ``backward_sample``).
 """
 import torch
 

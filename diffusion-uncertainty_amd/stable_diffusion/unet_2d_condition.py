@@ -28,8 +28,8 @@ class ResnetBlock2D(nn.Module):
         if cin != cout:
             self.conv_shortcut = nn.Conv2d(cin, cout, 1)
 
-    def run(self, ctx, x, skip=None):
-        """x (+ skip = second half of the channel concat of the up blocks): NHWC."""
+    def run(self, ctx, x, skip=None, tape=None):
+        """x (+ skip = second half of the channel concat of the up blocks): NHWC.  tape: list that receives what run_bwd needs."""
         N, H, W, _ = x.shape
         G = self.norm1.num_groups
         st = ops.groupnorm_stats(x, skip, groups=G, eps=self.norm1.eps)
@@ -37,6 +37,8 @@ class ResnetBlock2D(nn.Module):
         h = ctx.conv3x3(h, self.conv1, self.cout)
         ops.add_channel_bias_(h, ctx.temb(self))                       # + time_emb_proj(silu(emb))[:, :, None, None]
         st2 = ops.groupnorm_stats(h, groups=G, eps=self.norm2.eps)
+        if tape is not None:
+            tape.append((x, skip, st, h, st2))
         h = ops.groupnorm_apply(h, st2, self.norm2.weight, self.norm2.bias, act=1, groups=G, split=ctx.split_acts)
         if hasattr(self, "conv_shortcut"):
             res = ctx.linear(x.view(N * H * W, -1), self.conv_shortcut, a2=(skip.view(N * H * W, -1) if skip is not None else None))
@@ -45,6 +47,23 @@ class ResnetBlock2D(nn.Module):
             assert skip is None
             res = x
         return ctx.conv3x3(h, self.conv2, self.cout, residual=res, colsum=True)     # epilogue leaves the next GroupNorm's statistics
+
+    def run_bwd(self, ctx, saved, g):
+        """Gradient of run() w.r.t. (x, skip) given g = d/d output (NHWC)."""
+        x, skip, st, h1, st2 = saved
+        N, H, W, C1 = x.shape
+        G = self.norm1.num_groups
+        g_h2 = ctx.conv3x3_bwd(g, self.conv2)
+        g_h1, _ = ops.groupnorm_bwd(h1, st2, self.norm2.weight, self.norm2.bias, g_h2, act=1, groups=G)
+        g_n1 = ctx.conv3x3_bwd(g_h1, self.conv1)                      # the time-embedding add passes the gradient through
+        if hasattr(self, "conv_shortcut"):
+            parts = ctx.linear_bwd(g.view(N * H * W, self.cout), self.conv_shortcut.weight,
+                                   split=None if skip is None else (C1, skip.shape[3]))
+            add1 = parts[0].view(N, H, W, C1)
+            add2 = parts[1].view(N, H, W, -1) if skip is not None else None
+        else:
+            add1, add2 = g, None
+        return ops.groupnorm_bwd(x, st, self.norm1.weight, self.norm1.bias, g_n1, x2=skip, act=1, groups=G, add1=add1, add2=add2)
 
 
 class Attention(nn.Module):
@@ -74,14 +93,15 @@ class BasicTransformerBlock(nn.Module):
         self.norm2, self.attn2 = nn.LayerNorm(dim), Attention(dim, ctx_dim, heads)
         self.norm3, self.ff = nn.LayerNorm(dim), FeedForward(dim)
 
-    def run(self, ctx, h, B, T, enc):
+    def run(self, ctx, h, B, T, enc, tape=None):
         """h: [B*T, C] token rows; enc: [B, Tk, ctx_dim]."""
         C = h.shape[1]
+        h0 = h
         heads = self.attn1.heads
         n1 = ctx.norm_rows(h, self.norm1)
         qkv = ctx.gemm(n1, ctx.cat_weight(self.attn1, ("to_q", "to_k", "to_v")), None)
         a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision, planes_out=(ctx.split_acts in ("f16f8", "f16x3")))
-        h = ctx.gemm(a, self.attn1.to_out[0].weight, self.attn1.to_out[0].bias, residual=h)
+        h = h1 = ctx.gemm(a, self.attn1.to_out[0].weight, self.attn1.to_out[0].bias, residual=h)
         n2 = ctx.norm_rows(h, self.norm2)
         q = ctx.gemm(n2, self.attn2.to_q.weight, None)
         Tk = enc.shape[1]
@@ -90,8 +110,26 @@ class BasicTransformerBlock(nn.Module):
         a = ops.attention(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), heads).view(B * T, C)
         h = ctx.gemm(a, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, residual=h)
         n3 = ctx.norm_rows(h, self.norm3)
-        g = ops.geglu(ctx.gemm(n3, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias))
-        return ctx.gemm(g, self.ff.net[2].weight, self.ff.net[2].bias, residual=h)
+        u = ctx.gemm(n3, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
+        if tape is not None:
+            tape.append((B, T, h0, qkv, h1, q, k, v, h, u))
+        return ctx.gemm(ops.geglu(u), self.ff.net[2].weight, self.ff.net[2].bias, residual=h)
+
+    def run_bwd(self, ctx, saved, g):
+        """Gradient of run() w.r.t. the token rows h given g = d/d output [B*T, C]; exact fp32."""
+        B, T, h0, qkv, h1, q, k, v, h2, u = saved
+        C = h0.shape[1]
+        heads = self.attn1.heads
+        g_u = ops.geglu_bwd(u, ctx.linear_bwd(g, self.ff.net[2].weight)[0])
+        g_h2 = ops.layernorm_bwd(h2, self.norm3.weight, ctx.linear_bwd(g_u, self.ff.net[0].proj.weight)[0], eps=self.norm3.eps, add=g)
+        g_a2 = ctx.linear_bwd(g_h2, self.attn2.to_out[0].weight)[0]
+        Tk = k.shape[0] // B
+        g_q = ops.attention_bwd_q(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), g_a2.view(B, T, C), heads).view(B * T, C)
+        g_h1 = ops.layernorm_bwd(h1, self.norm2.weight, ctx.linear_bwd(g_q, self.attn2.to_q.weight)[0], eps=self.norm2.eps, add=g_h2)
+        g_a = ctx.linear_bwd(g_h1, self.attn1.to_out[0].weight)[0]
+        g_qkv = ops.qkv_attention_bwd(qkv, g_a, B, T, heads, C // heads)
+        g_n1 = ctx.linear_bwd(g_qkv, ctx.cat_weight(self.attn1, ("to_q", "to_k", "to_v")), key=(id(self.attn1), "qkv_t"))[0]
+        return ops.layernorm_bwd(h0, self.norm1.weight, g_n1, eps=self.norm1.eps, add=g_h1)
 
 
 class Transformer2DModel(nn.Module):
@@ -102,9 +140,11 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, ctx_dim, heads)])
         self.proj_out = nn.Conv2d(dim, dim, 1)
 
-    def run(self, ctx, x, enc):
+    def run(self, ctx, x, enc, tape=None):
         N, H, W, C = x.shape
         st = ops.groupnorm_stats(x, groups=self.norm.num_groups, eps=self.norm.eps)
+        if tape is not None:
+            tape.append((x, st))
         xn = ops.groupnorm_apply(x, st, self.norm.weight, self.norm.bias, act=0, groups=self.norm.num_groups,
                                  split="f16x3" if ctx.f16x3 and C % 32 == 0 else False)
         if isinstance(xn, ops.SplitPlanes):
@@ -113,13 +153,23 @@ class Transformer2DModel(nn.Module):
             xn = xn.view(N * H * W, C)
         h = ctx.linear(xn, self.proj_in)
         for blk in self.transformer_blocks:
-            h = blk.run(ctx, h, N, H * W, enc)
+            h = blk.run(ctx, h, N, H * W, enc, tape=tape)
         out2d = ctx.linear(h, self.proj_out, residual=x.view(N * H * W, C), colsum=True)
         out = out2d.view(N, H, W, C)
         ws = getattr(out2d, "_dua_colsums_rows", None)
         if ws is not None and (H * W) % 64 == 0:
             out._dua_colsums = ws                     # statistics for the next block's GroupNorm
         return out
+
+    def run_bwd(self, ctx, tape, g):
+        """Pops this block's records off the tape (reverse order of run) and returns d/d x."""
+        N, H, W, C = g.shape
+        g_h = ctx.linear_bwd(g.view(N * H * W, C), self.proj_out.weight)[0]
+        for blk in reversed(self.transformer_blocks):
+            g_h = blk.run_bwd(ctx, tape.pop(), g_h)
+        x, st = tape.pop()
+        g_xn = ctx.linear_bwd(g_h, self.proj_in.weight)[0].view(N, H, W, C)
+        return ops.groupnorm_bwd(x, st, self.norm.weight, self.norm.bias, g_xn, act=0, groups=self.norm.num_groups, add1=g)[0]
 
 
 class Downsample2D(nn.Module):
@@ -221,6 +271,27 @@ class _Ctx:
             self.model._packed[key] = (st, torch.ones(C, device=h.device), torch.zeros(C, device=h.device))
         st, one, zero = self.model._packed[key]
         return ops.groupnorm_apply(h, st, one, zero, act=0, resample=resample, groups=32, split="f16x3", split_scale=ops.F16X3_RAW_SCALE)
+
+    def conv3x3_bwd(self, g, conv):
+        """d/d input of a stride-1 / pad-1 3x3 convolution: the same convolution with the kernels rotated by 180 degrees and the
+        channel roles swapped, on the exact fp32 MFMA engine (gradients have no fixed scale to split at)."""
+        def flipped():
+            return ops.pack_conv3x3_weight(conv.weight.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous())
+        return ops.conv3x3(g, self.packed((id(conv), "w3t"), flipped), None, conv.in_channels)
+
+    def linear_bwd(self, g, weight, split=None, key=None):
+        """d/d rows of rows x weight^T: g [M, n_out] x weight [n_out, K] -> ([M, K],), or its column blocks (K1, K2) as two dense
+        tensors when the forward operand was a concat."""
+        n_out = weight.shape[0]
+        w2 = weight.detach().reshape(n_out, -1)
+        kid = key if key is not None else (id(weight), "w1t")
+        if split is None:
+            wt = self.packed(kid, lambda: w2.t().contiguous())
+            return (ops.gemm(g, wt),)
+        K1 = split[0]
+        wa = self.packed((kid, 0), lambda: w2[:, :K1].t().contiguous())
+        wb = self.packed((kid, 1), lambda: w2[:, K1:].t().contiguous())
+        return ops.gemm(g, wa), ops.gemm(g, wb)
 
     def linear(self, a, conv1x1, a2=None, residual=None, colsum=False):
         return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual, colsum=colsum)
@@ -360,8 +431,9 @@ class UNet2DConditionModel(nn.Module):
             return UNet2DConditionOutput(sample=out)
         return (out,)
 
-    def _forward_impl(self, sample, t, enc):
-        """sample [B,4,h,w] fp32, t [B] int64, enc [B,Tk,ctx] fp32, all on the GPU -> [B,4,h,w]."""
+    def _forward_impl(self, sample, t, enc, tape=None):
+        """sample [B,4,h,w] fp32, t [B] int64, enc [B,Tk,ctx] fp32, all on the GPU -> [B,4,h,w].  tape: list receiving the
+        activations backward_sample() needs (None: nothing is kept)."""
         ctx = _Ctx(self)
         te = self.time_embedding
         emb = ops.timestep_embedding(t, self.conv_in.out_channels)        # [cos | sin], freq_shift 0: the ADM embedding
@@ -373,29 +445,90 @@ class UNet2DConditionModel(nn.Module):
         res = [h]
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
-                h = r.run(ctx, h)
+                h = r.run(ctx, h, tape=tape)
                 if hasattr(blk, "attentions"):
-                    h = blk.attentions[j].run(ctx, h, enc)
+                    h = blk.attentions[j].run(ctx, h, enc, tape=tape)
                 res.append(h)
             if hasattr(blk, "downsamplers"):
                 conv = blk.downsamplers[0].conv
                 h = ops.pick_even(ctx.conv3x3(ctx.raw_planes(h), conv, conv.out_channels))      # stride 2 / pad 1 = stride 1 at the even pixels
                 res.append(h)
-        h = self.mid_block.resnets[0].run(ctx, h)
-        h = self.mid_block.attentions[0].run(ctx, h, enc)
-        h = self.mid_block.resnets[1].run(ctx, h)
+        h = self.mid_block.resnets[0].run(ctx, h, tape=tape)
+        h = self.mid_block.attentions[0].run(ctx, h, enc, tape=tape)
+        h = self.mid_block.resnets[1].run(ctx, h, tape=tape)
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
-                h = r.run(ctx, h, res.pop())
+                h = r.run(ctx, h, res.pop(), tape=tape)
                 if hasattr(blk, "attentions"):
-                    h = blk.attentions[j].run(ctx, h, enc)
+                    h = blk.attentions[j].run(ctx, h, enc, tape=tape)
             if hasattr(blk, "upsamplers"):
                 conv = blk.upsamplers[0].conv
                 h = ctx.conv3x3(ctx.raw_planes(h, resample=1), conv, conv.out_channels, colsum=True)
         G = self.conv_norm_out.num_groups
         st = ops.groupnorm_stats(h, groups=G, eps=self.conv_norm_out.eps)
+        if tape is not None:
+            tape.append((h, st))
         h = ops.groupnorm_apply(h, st, self.conv_norm_out.weight, self.conv_norm_out.bias, act=1, groups=G, split=ctx.split_acts)
         return ctx.conv3x3(h, self.conv_out, self.conv_out.out_channels, nchw_out=True)
+
+    # ---- input gradient (gradient-mode guidance, reference uncertainty_guidance.py:83-108,121-129)
+    @torch.no_grad()
+    def forward_with_tape(self, sample, timestep, encoder_hidden_states):
+        """Eager forward in the model's precision that also returns the tape backward_sample() consumes:
+        ``out, tape = unet.forward_with_tape(x, t, enc)``.  The tape holds fp32 activations (GroupNorm / LayerNorm inputs,
+        qkv rows, GEGLU pre-activations) of this call; it is used once."""
+        if not sample.is_cuda:
+            raise RuntimeError("UNet2DConditionModel.forward_with_tape: the HIP path needs GPU tensors; this package has no CPU fallback")
+        B = sample.shape[0]
+        t = torch.as_tensor(timestep, device=sample.device)
+        t = (t.reshape(1).expand(B) if t.ndim == 0 else t).to(torch.int64).contiguous()
+        gen = params_generation(self)
+        if gen != getattr(self, "_packed_gen", None):
+            if self._packed:
+                self.invalidate_packed_weights()
+            self._packed_gen = gen
+        tape = []
+        out = self._forward_impl(sample.float().contiguous(), t, encoder_hidden_states.to(torch.float32).contiguous(), tape=tape)
+        return out, tape
+
+    @torch.no_grad()
+    def backward_sample(self, tape, grad_out):
+        """Vector-Jacobian product of the forward that recorded ``tape``: d<grad_out, unet(sample)>/d sample, [B,4,h,w] fp32.
+        Every product of this pass runs on the exact fp32 engines (dua_conv3x3 / dua_gemm with flipped / transposed weights,
+        attention probabilities recomputed from the taped qkv rows); weights get no gradient."""
+        ctx = _Ctx(self)
+        tape = list(tape)
+        G = self.conv_norm_out.num_groups
+        g = ctx.conv3x3_bwd(ops.nchw_to_nhwc(ops._f32c(grad_out), self.conv_out.out_channels), self.conv_out)
+        h, st = tape.pop()
+        g = ops.groupnorm_bwd(h, st, self.conv_norm_out.weight, self.conv_norm_out.bias, g, act=1, groups=G)[0]
+        gres = []                                                     # gradients of the skip tensors, in the order the down path consumes them
+        for blk in reversed(self.up_blocks):
+            if hasattr(blk, "upsamplers"):
+                gu = ctx.conv3x3_bwd(g, blk.upsamplers[0].conv)       # adjoint of nearest x2: sum over each 2x2 cell
+                pooled = ops.resample2x(gu, -1)
+                g = ops.axpby(pooled, pooled, 4.0, 0.0)
+            for j in reversed(range(len(blk.resnets))):
+                if hasattr(blk, "attentions"):
+                    g = blk.attentions[j].run_bwd(ctx, tape, g)
+                g, gs = blk.resnets[j].run_bwd(ctx, tape.pop(), g)
+                gres.append(gs)
+        g, _ = self.mid_block.resnets[1].run_bwd(ctx, tape.pop(), g)
+        g = self.mid_block.attentions[0].run_bwd(ctx, tape, g)
+        g, _ = self.mid_block.resnets[0].run_bwd(ctx, tape.pop(), g)
+        for blk in reversed(self.down_blocks):
+            if hasattr(blk, "downsamplers"):
+                g = ops.axpby(g, gres.pop(), 1.0, 1.0)
+                N, Ho, Wo, _ = g.shape
+                g = ctx.conv3x3_bwd(ops.place_even(g, 2 * Ho, 2 * Wo), blk.downsamplers[0].conv)
+            for j in reversed(range(len(blk.resnets))):
+                g = ops.axpby(g, gres.pop(), 1.0, 1.0)
+                if hasattr(blk, "attentions"):
+                    g = blk.attentions[j].run_bwd(ctx, tape, g)
+                g, _ = blk.resnets[j].run_bwd(ctx, tape.pop(), g)
+        g = ops.axpby(g, gres.pop(), 1.0, 1.0)
+        assert not tape and not gres
+        return ops.nhwc_to_nchw(ctx.conv3x3_bwd(g, self.conv_in))
 
 
 class UNet2DConditionOutput(dict):

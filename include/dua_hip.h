@@ -188,7 +188,7 @@ typedef struct {
 } dua_gemm_args;
 int dua_gemm(const dua_gemm_args* args_host, void* stream);
 
-/* Row softmax in place over the first `cols` entries of each row of S (row stride ld floats), fp32
+/* Row softmax in place over the first `cols` (<= 4096) entries of each row of S (row stride ld floats), fp32
  * (unet_openai.py:353 / :388; uvit/uvit.py:73). */
 int dua_softmax_rows(float* S, long rows, int cols, long ld, void* stream);
 
@@ -421,6 +421,30 @@ int dua_uvit_assemble(const float* patches, const float* time_tok, const float* 
 /* tok [B][extras+L][P*P*C] -> NCHW image, dropping the extras tokens:
  * 'B (h w) (p1 p2 C) -> B C (h p1) (w p2)' (uvit.py:46-51,228-229). */
 int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C, int P, void* stream);
+
+/* ---------------- input gradients (gradient-mode guidance, uncertainty_guidance.py:83-108,121-129) ----------------
+ * use_posterior = False (the default of scripts/generate_with_uncertainty_threshold_stable_diffusion.py:16-17) calls
+ * uncertainty.backward() through the M denoiser calls and reads pred_epsilon.grad.  Only gradients w.r.t. activations are
+ * needed; convolutions / linears of that pass are dua_conv3x3 / dua_gemm on flipped / transposed weights. */
+
+/* Input gradient of y = act(GroupNorm(cat(x1, x2))) (act 0: identity, 1: SiLU) given dy [N][HW][C1+C2] and the forward
+ * statistics (mean, rstd per (sample, group)).  dx1 / dx2 receive the gradient (+ add1 / add2 when given: the other branch of
+ * a fan-out).  torch.nn.functional.group_norm backward, input term only. */
+int dua_groupnorm_bwd(const float* x1, int C1, const float* x2, int C2, int N, long HW, int G, const float* stats,
+                      const float* gamma, const float* beta, int act, const float* dy, const float* add1, const float* add2,
+                      float* dx1, float* dx2, void* stream);
+/* Input gradient of LayerNorm over the last dim (rows x D, D <= 2048): dx = rstd*(dy*gamma - mean(.) - xh*mean(. * xh)) (+ add). */
+int dua_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* add, float* dx, long rows, int D, float eps,
+                      void* stream);
+/* Input gradient of dua_geglu: x [M][2F], dy [M][F] -> dx [M][2F]. */
+int dua_geglu_bwd(const float* x, const float* dy, float* dx, long M, int F, void* stream);
+/* Softmax input gradient in place on dP: dS = P * (dP - sum_j dP_j P_j) per row (cols <= 4096). */
+int dua_softmax_bwd_rows(const float* P, float* dP, long rows, int cols, long ld, void* stream);
+/* Adjoint of dua_pick_even: g [N][H/2][W/2][C] -> out [N][H][W][C], zero off the even pixels. */
+int dua_place_even(const float* g, float* out, int N, int H, int W, int C, void* stream);
+/* grad[m] = scale * (stack[m] - mean_m stack): d/d e_m of (scale/2) * sum_m (e_m - mean)^2, i.e. of the unbiased variance over
+ * M samples summed over pixels and averaged over B samples when scale = 2 / ((M-1) * B) (uncertainty_guidance.py:106-107). */
+int dua_mc_var_grad(const float* stack, float* grad, int M, size_t n, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,3 +67,31 @@ def guided_score_percentile(eps, x, denoise_cfg, alpha_hat_t, percentile, M, dra
     u = st.var(axis=0, ddof=1, dtype=np.float32)
     mask, q = quantile_mask(u, percentile)
     return posterior_blend(eps, u, mask, M, alpha_hat_t), u, mask, q
+
+
+def guided_score_percentile_gradient(eps, x, unet, t, y, guidance_scale, alpha_hat_t, percentile, M, draw, lr=1.0):
+    """:83-108,121-129 with use_posterior = False (the reference script's default, scripts/generate_with_uncertainty_threshold_
+    stable_diffusion.py:16-17), model_type='stable-diffusion', as written: torch autograd through the M CFG denoiser calls.
+
+    ``unet(x2 [2,4,h,w], t, y [2,77,ctx]) -> [2,4,h,w]`` must be autograd-traceable (oracle.sd_unet.forward_autograd);
+    eps [1,4,h,w], x the CFG-doubled latent [2,4,h,w], ``draw(like)`` = torch.randn_like.  Returns (final, grad, u, mask).
+    """
+    import torch
+    pe = eps.detach().clone().float().requires_grad_(True)
+    a = torch.as_tensor(alpha_hat_t, dtype=torch.float32)
+    hats = []
+    with torch.enable_grad():
+        x0 = (x - torch.sqrt(1 - a) * pe) / torch.sqrt(a)                                   # :86
+        for _ in range(M):
+            x_hat = torch.sqrt(a) * x0 + torch.sqrt(1 - a) * draw(pe)                       # :88
+            out = unet(x_hat, t, y)
+            un, tx = out.chunk(2)                                                           # :142-145
+            hats.append(un + guidance_scale * (tx - un))
+        st = torch.stack(hats, dim=0)                                                       # :103 (nothing appended in this mode)
+        u = torch.var(st, dim=0)                                                            # :106
+        u.mean(dim=0).sum().backward()                                                      # :107-108
+    ud = u.detach()
+    q = torch.quantile(ud.float().flatten(1), percentile, dim=1, keepdim=True).view(ud.shape[0], *([1] * (ud.ndim - 1)))
+    mask = (ud > q).float()                                                                 # :112-113
+    grad = pe.grad * 1                                                                      # :122
+    return (pe.detach() + lr * grad * mask), grad, ud, mask                                 # :129

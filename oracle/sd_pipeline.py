@@ -56,8 +56,9 @@ class PNDM:
 
 @torch.no_grad()
 def sample(unet, latents, prompt_embeds, negative_prompt_embeds, n_steps, guidance_scale, start_step_uc, num_steps_uc,
-           percentile, M, draw=torch.randn_like):
-    """``unet(x [2B,4,h,w], t [2B], enc [2B,77,768]) -> eps``; returns the final latents."""
+           percentile, M, draw=torch.randn_like, use_posterior=True, lr=1.0):
+    """``unet(x [2B,4,h,w], t [2B], enc [2B,77,768]) -> eps``; returns the final latents.  use_posterior=False: the gradient
+    update (the reference script's default), ``unet`` must then be autograd-traceable."""
     sch = PNDM()
     sch.set_timesteps(n_steps)
     pe = torch.cat([negative_prompt_embeds, prompt_embeds])
@@ -72,6 +73,12 @@ def sample(unet, latents, prompt_embeds, negative_prompt_embeds, n_steps, guidan
         eps = cfg(x_in, t)
         if start_step_uc <= i < start_step_uc + num_steps_uc:
             a = float(sch.alphas_cumprod[int(t)])
+            if not use_posterior:
+                eps = guidance.guided_score_percentile_gradient(
+                    eps, x_in, lambda xh, tt, yy: unet(xh, torch.full((xh.shape[0],), int(tt), dtype=torch.long), yy), t, pe,
+                    guidance_scale, a, percentile, M, draw, lr=lr)[0]
+                latents = sch.step(eps, t, latents)
+                continue
             new, _, _, _ = guidance.guided_score_percentile(
                 eps.numpy(), x_in.numpy(), lambda xh: cfg(torch.from_numpy(xh), t).numpy(), a, percentile, M,
                 lambda like: draw(torch.from_numpy(like)).numpy())

@@ -123,12 +123,12 @@ def _transformer(sd, p, x, ctx, heads, G):
     return F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]) + x
 
 
-@torch.no_grad()
-def forward(sd, cfg, sample, timesteps, encoder_hidden_states):
-    """UNet2DConditionModel.forward(sample [B,4,h,w], timestep [B], encoder_hidden_states [B,77,ctx]) -> [B,4,h,w]."""
+def forward_autograd(sd, cfg, sample, timesteps, encoder_hidden_states):
+    """UNet2DConditionModel.forward(sample [B,4,h,w], timestep [B], encoder_hidden_states [B,77,ctx]) -> [B,4,h,w], recorded by
+    torch autograd when the caller enables it (gradient-mode guidance, reference uncertainty_guidance.py:83-108)."""
     boc, L, G, eps, heads = (cfg["block_out_channels"], cfg["layers_per_block"], cfg["norm_num_groups"], cfg["norm_eps"],
                              cfg["attention_head_dim"])
-    emb = F.linear(timestep_embedding(timesteps, boc[0]), sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
+    emb = F.linear(timestep_embedding(timesteps, boc[0]).to(sample.dtype), sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
     emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
     h = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
     res = [h]
@@ -154,3 +154,17 @@ def forward(sd, cfg, sample, timesteps, encoder_hidden_states):
             h = F.conv2d(h, sd[f"up_blocks.{i}.upsamplers.0.conv.weight"], sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
     h = F.silu(F.group_norm(h, G, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps))
     return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+@torch.no_grad()
+def forward(sd, cfg, sample, timesteps, encoder_hidden_states):
+    return forward_autograd(sd, cfg, sample, timesteps, encoder_hidden_states)
+
+
+def input_vjp(sd, cfg, sample, timesteps, encoder_hidden_states, grad_out):
+    """(out, d<grad_out, out>/d sample) by torch autograd: the checker of UNet2DConditionModel.backward_sample."""
+    x = sample.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        out = forward_autograd(sd, cfg, x, timesteps, encoder_hidden_states)
+        (out * grad_out).sum().backward()
+    return out.detach(), x.grad.detach()

@@ -7,8 +7,9 @@ Same sampling flags as the reference script (--num-steps, --start-step-threshold
 ``runwayml/stable-diffusion-v1-5`` checkpoint and the CLIP text encoder / VAE are third-party models that are not built, so
 ``--synthetic`` (default) runs seeded random-init UNet weights on seeded random prompt embeddings and returns latents; with
 ``--unet-state-dict`` a real diffusers UNet state dict is loaded strictly, ``--prompt-embeds`` takes a saved
-{'prompt_embeds', 'negative_prompt_embeds'} file.  Gradient-mode guidance (the reference default) needs UNet backward:
-only ``--use-posterior`` is available.
+{'prompt_embeds', 'negative_prompt_embeds'} file.  As in the reference, gradient-mode guidance is the default
+(uncertainty_guidance.use_posterior = args.use_posterior, reference script :16-17) and ``--use-posterior`` selects the posterior
+update; the gradient is an explicit vector-Jacobian product on the HIP library (UNet2DConditionModel.backward_sample).
 """
 import argparse
 import os
@@ -26,7 +27,8 @@ def main():
     p.add_argument("--start-step-threshold", type=int, default=0)
     p.add_argument("--num-steps-threshold", type=int, default=2)
     p.add_argument("--percentile", "--perc", "-p", type=float, default=0.9, dest="percentile")
-    p.add_argument("--use-posterior", action="store_true", default=True)
+    p.add_argument("--use-posterior", action="store_true", help="posterior update instead of the gradient update (reference script :88)")
+    p.add_argument("--lr", type=float, default=1.0, help="step of the gradient update (reference pipeline argument lr)")
     p.add_argument("-M", type=int, default=5)
     p.add_argument("--guidance-scale", type=float, default=7.5)
     p.add_argument("--precision", choices=["f16x3", "f16f8", "bf16x3", "fp32"], default="f16x3")
@@ -63,7 +65,7 @@ def main():
     uncertainty_guidance.noise_source = DeviceNoise(seed=a.seed)
     kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=a.num_steps, guidance_scale=a.guidance_scale,
               start_step_uc=a.start_step_threshold, num_steps_uc=a.num_steps_threshold, percentile=a.percentile,
-              num_uncertainty_samples=a.M, height=512, width=512)
+              num_uncertainty_samples=a.M, height=512, width=512, lr=a.lr)
     times = []
     for r in range(a.repeats + 1):
         g = torch.Generator().manual_seed(a.seed)
@@ -74,8 +76,9 @@ def main():
         times.append(time.perf_counter() - t0)
     best = min(times[1:]) if a.repeats else times[0]
     print(f"SD-1.5 latent UNet 512x512, {a.num_steps} PLMS steps (+1 repeated), guided steps {a.num_steps_threshold} x M={a.M}, "
-          f"percentile {a.percentile}, precision {a.precision}: {best:.3f} s per image ({1.0 / best:.3f} images/s; "
-          f"{a.num_steps + 1} CFG UNet calls of batch 2 + {a.num_steps_threshold} Monte-Carlo calls of batch {2 * a.M}); "
+          f"percentile {a.percentile}, {'posterior' if a.use_posterior else 'gradient'} update, precision {a.precision}: {best:.3f} s per image ({1.0 / best:.3f} images/s; "
+          f"{a.num_steps + 1} CFG UNet calls of batch 2 + {a.num_steps_threshold} Monte-Carlo calls of batch {2 * a.M}"
+          f"{'' if a.use_posterior else ' with their input-gradient passes'}); "
           f"first run incl. weight packing {times[0]:.2f} s")
     if a.out:
         torch.save(out.images.cpu(), a.out)

@@ -194,6 +194,36 @@ def test_oracle_sd_unet_runs_on_cpu():
     assert not torch.allclose(a[0], sd_unet.forward(sd, cfg, x, torch.tensor([900, 900]), enc)[0])     # the timestep matters
 
 
+def test_oracle_sd_input_vjp_and_gradient_guidance_on_cpu():
+    """The oracle's input gradient (torch autograd through the restatement) agrees with a central finite difference along a
+    random direction (float64), and the gradient-mode guidance restatement (uncertainty_guidance.py:83-108,121-129) only moves
+    pixels inside the percentile mask."""
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    from oracle import guidance, sd_unet
+    cfg = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64), layers_per_block=1,
+               down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+               attention_head_dim=4, cross_attention_dim=32, norm_num_groups=32, norm_eps=1e-5)
+    sd = {k: v.double() for k, v in seeded_state_dict(sd_unet.state_shapes(cfg), 3).items()}
+    g = torch.Generator().manual_seed(0)
+    x, enc = torch.randn(2, 4, 8, 8, generator=g).double(), torch.randn(2, 5, 32, generator=g).double()
+    gout, d = torch.randn(2, 4, 8, 8, generator=g).double(), torch.randn(2, 4, 8, 8, generator=g).double()
+    t = torch.tensor([10, 900])
+    _, grad = sd_unet.input_vjp(sd, cfg, x, t, enc, gout)
+    h = 1e-5
+    f = lambda z: (sd_unet.forward(sd, cfg, z, t, enc) * gout).sum().item()
+    fd = (f(x + h * d) - f(x - h * d)) / (2 * h)
+    assert abs(fd - (grad * d).sum().item()) < 1e-6 * max(1.0, abs(fd))
+    sd32 = {k: v.float() for k, v in sd.items()}
+    eps, lat = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    torch.manual_seed(1)
+    final, grad, u, mask = guidance.guided_score_percentile_gradient(
+        eps, torch.cat([lat] * 2), lambda xh, tt, yy: sd_unet.forward_autograd(sd32, cfg, xh, torch.full((2,), int(tt)), yy),
+        torch.tensor(500), enc.float(), 7.5, 0.4, 0.9, 3, torch.randn_like, lr=0.5)
+    assert final.shape == eps.shape and torch.isfinite(final).all() and grad.abs().max() > 0
+    assert int(mask.sum()) == 26 and torch.equal(final[mask == 0], eps[mask == 0])      # 10 % of 256 pixels above the 0.9 quantile
+    assert torch.allclose(final[mask == 1], (eps + 0.5 * grad)[mask == 1])
+
+
 def test_precision_modes_pick_operand_formats():
     """Which operand format each GroupNorm in front of a matrix-core kernel writes, per precision mode (host logic only: no kernel
     runs).  f16f6 planes go to the row-shift 3x3 convolutions only (image width divides 256); the one-tap GEMMs stay f16f8."""
