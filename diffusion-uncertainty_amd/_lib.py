@@ -89,6 +89,7 @@ SIGNATURES = {
     "dua_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_geglu_bwd": (_I, [_P, _P, _P, _L, _I, _P]),
     "dua_softmax_bwd_rows": (_I, [_P, _P, _L, _I, _L, _P]),
+    "dua_softmax_fwd_bwd_rows": (_I, [_P, _P, _L, _I, _L, _P]),
     "dua_place_even": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dua_mc_var_grad": (_I, [_P, _P, _I, _Z, _F, _P]),
     "dua_attention": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),

@@ -180,6 +180,50 @@ __global__ __launch_bounds__(BLK) void k_softmax_bwd(const float* __restrict__ P
     }
 }
 
+// One wave per row: S holds logits on entry; on exit S = P = softmax(S) and dP = dS = P * (dP - sum_j dP_j P_j).  One pass over
+// the two matrices instead of a softmax pass followed by the gradient pass.
+template <int PER>
+__global__ __launch_bounds__(BLK) void k_softmax_fwd_bwd(float* __restrict__ S, float* __restrict__ dP, long rows, int cols, long ld) {
+    const long row = (long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float* pr = S + row * ld;
+    float* dr = dP + row * ld;
+    float pv[PER], dv[PER];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = lane + 64 * j;
+        pv[j] = c < cols ? pr[c] : -INFINITY;
+        dv[j] = c < cols ? dr[c] : 0.f;
+        m = fmaxf(m, pv[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        pv[j] = expf(pv[j] - m);                  // exp(-inf) = 0 on the padding lanes
+        z += pv[j];
+    }
+    const float inv = 1.0f / wsum(z);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        pv[j] *= inv;
+        s += pv[j] * dv[j];
+    }
+    s = wsum(s);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int c = lane + 64 * j;
+        if (c < cols) {
+            pr[c] = pv[j];
+            dr[c] = pv[j] * (dv[j] - s);
+        }
+    }
+}
+
 // adjoint of y[n][i][j] = x[n][2i][2j]: the gradient lands on the even pixels, zero elsewhere
 __global__ __launch_bounds__(BLK) void k_place_even(const float* __restrict__ g, float* __restrict__ out, int N, int H, int W, int C) {
     const int Q = C / 4, Ho = H / 2, Wo = W / 2;
@@ -249,6 +293,18 @@ extern "C" int dua_softmax_bwd_rows(const float* P, float* dP, long rows, int co
     else if (cols <= 2048) hipLaunchKernelGGL(k_softmax_bwd<32>, grid, BLK, 0, as_stream(stream), P, dP, rows, cols, ld);
     else hipLaunchKernelGGL(k_softmax_bwd<64>, grid, BLK, 0, as_stream(stream), P, dP, rows, cols, ld);
     return dua_check_launch("dua_softmax_bwd_rows");
+}
+
+extern "C" int dua_softmax_fwd_bwd_rows(float* S, float* dP, long rows, int cols, long ld, void* stream) {
+    DUA_REQUIRE(S && dP && rows >= 0 && cols >= 1 && cols <= 4096 && ld >= cols, "dua_softmax_fwd_bwd_rows: cols must be in [1, 4096], ld >= cols");
+    if (rows == 0) return DUA_OK;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (cols <= 64) hipLaunchKernelGGL(k_softmax_fwd_bwd<1>, grid, BLK, 0, as_stream(stream), S, dP, rows, cols, ld);
+    else if (cols <= 256) hipLaunchKernelGGL(k_softmax_fwd_bwd<4>, grid, BLK, 0, as_stream(stream), S, dP, rows, cols, ld);
+    else if (cols <= 1024) hipLaunchKernelGGL(k_softmax_fwd_bwd<16>, grid, BLK, 0, as_stream(stream), S, dP, rows, cols, ld);
+    else if (cols <= 2048) hipLaunchKernelGGL(k_softmax_fwd_bwd<32>, grid, BLK, 0, as_stream(stream), S, dP, rows, cols, ld);
+    else hipLaunchKernelGGL(k_softmax_fwd_bwd<64>, grid, BLK, 0, as_stream(stream), S, dP, rows, cols, ld);
+    return dua_check_launch("dua_softmax_fwd_bwd_rows");
 }
 
 extern "C" int dua_place_even(const float* g, float* out, int N, int H, int W, int C, void* stream) {

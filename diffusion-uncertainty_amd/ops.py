@@ -708,39 +708,41 @@ ATTN_BWD_CHUNK_FLOATS = 1 << 28
 
 def _attn_bwd_chunk(qp, kp, vp, dop, dqp, dkp, dvp, ldq, ldk, ldo, ldg, nb, heads, Tq, Tk, ch, dev):
     """One chunk of nb samples.  q / k / v / dO / dq / dk / dv are base addresses of [nb*T, ld] row-major operands whose head h
-    sits at column offset h*ch; dkp / dvp = 0: keys and values are constants (cross-attention)."""
+    sits at column offset h*ch; dkp / dvp = 0: keys and values are constants (cross-attention).  The two [Tq, Tk] matrices
+    (P and dP -> dS) are written once by their GEMMs, rewritten once by the fused softmax pass and read once by each gradient
+    GEMM; dk / dv are formed transposed ([ch, Tk] = q^T dS, dO^T P: K-major reads of the big matrices as they lie) so that
+    neither matrix is ever transposed - only the [T, ch] operands are."""
     BH = nb * heads
     Tp = (Tk + 3) // 4 * 4
     alpha = 1.0 / math.sqrt(ch)
     P = torch.empty((BH, Tq, Tp), device=dev, dtype=torch.float32)
     dP = torch.empty((BH, Tq, Tp), device=dev, dtype=torch.float32)
     common = dict(batch=BH, batch_inner=heads)
-    # P = softmax(alpha q k^T)
+    L = _lib.lib()
+    # logits alpha q k^T and dP = dO v^T, then P = softmax(logits), dS in place of dP
     gemm_raw(A1=qp, B=kp, C=P.data_ptr(), M=Tq, N=Tk, K1=ch, K2=0, lda1=ldq, lda2=4, ldb=ldk, ldc=Tp, ldr=Tp, sA1=Tq * ldq, sB=Tk * ldk,
              sC=heads * Tq * Tp, sA1i=ch, sBi=ch, sCi=Tq * Tp, transB=1, alpha=alpha, **common)
-    softmax_rows_(P, BH * Tq, Tk, Tp)
-    # dP = dO v^T, then dS in place
     gemm_raw(A1=dop, B=vp, C=dP.data_ptr(), M=Tq, N=Tk, K1=ch, K2=0, lda1=ldo, lda2=4, ldb=ldk, ldc=Tp, ldr=Tp, sA1=Tq * ldo, sB=Tk * ldk,
              sC=heads * Tq * Tp, sA1i=ch, sBi=ch, sCi=Tq * Tp, transB=1, alpha=1.0, **common)
-    softmax_bwd_rows_(P, dP, BH * Tq, Tk, Tp)
+    check(L.dua_softmax_fwd_bwd_rows(_p(P), _p(dP), BH * Tq, Tk, Tp, _stream()), "dua_softmax_fwd_bwd_rows")
     # dq = alpha dS k
     gemm_raw(A1=dP.data_ptr(), B=kp, C=dqp, M=Tq, N=ch, K1=Tk, K2=0, lda1=Tp, lda2=4, ldb=ldk, ldc=ldg, ldr=ldg, sA1=heads * Tq * Tp,
              sB=Tk * ldk, sC=Tq * ldg, sA1i=Tq * Tp, sBi=ch, sCi=ch, transB=0, alpha=alpha, **common)
     if not dkp:
         return
     Tqp = (Tq + 3) // 4 * 4
-    Tr = torch.empty((BH, Tk, Tqp), device=dev, dtype=torch.float32)
-    L = _lib.lib()
-    # dk = alpha dS^T q
-    check(L.dua_transpose_batched(_p(dP), _p(Tr), Tq, Tk, Tp, Tqp, heads * Tq * Tp, Tq * Tp, heads * Tk * Tqp, Tk * Tqp, BH, heads, _stream()),
-          "dua_transpose_batched")
-    gemm_raw(A1=Tr.data_ptr(), B=qp, C=dkp, M=Tk, N=ch, K1=Tq, K2=0, lda1=Tqp, lda2=4, ldb=ldq, ldc=ldg, ldr=ldg, sA1=heads * Tk * Tqp,
-             sB=Tq * ldq, sC=Tk * ldg, sA1i=Tk * Tqp, sBi=ch, sCi=ch, transB=0, alpha=alpha, **common)
-    # dv = P^T dO
-    check(L.dua_transpose_batched(_p(P), _p(Tr), Tq, Tk, Tp, Tqp, heads * Tq * Tp, Tq * Tp, heads * Tk * Tqp, Tk * Tqp, BH, heads, _stream()),
-          "dua_transpose_batched")
-    gemm_raw(A1=Tr.data_ptr(), B=dop, C=dvp, M=Tk, N=ch, K1=Tq, K2=0, lda1=Tqp, lda2=4, ldb=ldo, ldc=ldg, ldr=ldg, sA1=heads * Tk * Tqp,
-             sB=Tq * ldo, sC=Tk * ldg, sA1i=Tk * Tqp, sBi=ch, sCi=ch, transB=0, alpha=1.0, **common)
+    small = torch.empty((2, BH, ch, Tqp), device=dev, dtype=torch.float32)          # q^T | dO^T
+    outT = torch.empty((2, BH, ch, Tp), device=dev, dtype=torch.float32)            # dk^T | dv^T
+    for src, ld, dst in ((qp, ldq, small[0]), (dop, ldo, small[1])):
+        check(L.dua_transpose_batched(src, _p(dst), Tq, ch, ld, Tqp, Tq * ld, ch, heads * ch * Tqp, ch * Tqp, BH, heads, _stream()),
+              "dua_transpose_batched")
+    for a_t, big, o_t, al in ((small[0], dP, outT[0], alpha), (small[1], P, outT[1], 1.0)):
+        gemm_raw(A1=a_t.data_ptr(), B=big.data_ptr(), C=o_t.data_ptr(), M=ch, N=Tp, K1=Tq, K2=0, lda1=Tqp, lda2=4, ldb=Tp, ldc=Tp, ldr=Tp,
+                 sA1=heads * ch * Tqp, sB=heads * Tq * Tp, sC=heads * ch * Tp, sA1i=ch * Tqp, sBi=Tq * Tp, sCi=ch * Tp, transB=0,
+                 alpha=al, **common)
+    for o_t, dst in ((outT[0], dkp), (outT[1], dvp)):
+        check(L.dua_transpose_batched(_p(o_t), dst, ch, Tk, Tp, ldg, heads * ch * Tp, ch * Tp, Tk * ldg, ch, BH, heads, _stream()),
+              "dua_transpose_batched")
 
 
 def qkv_attention_bwd(qkv, dout, B, T, heads, ch):

@@ -276,8 +276,10 @@ class _Ctx:
         """d/d input of a stride-1 / pad-1 3x3 convolution: the same convolution with the kernels rotated by 180 degrees and the
         channel roles swapped, on the exact fp32 MFMA engine (gradients have no fixed scale to split at)."""
         def flipped():
-            return ops.pack_conv3x3_weight(conv.weight.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous())
-        return ops.conv3x3(g, self.packed((id(conv), "w3t"), flipped), None, conv.in_channels)
+            return conv.weight.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous()
+        if self.model.backward_precision == "bf16x3" and g.shape[3] % 32 == 0:
+            return ops.conv3x3_bf16x3(g, self.packed((id(conv), "w3tx"), lambda: ops.pack_weight_bf16x3(flipped())), None, conv.in_channels)
+        return ops.conv3x3(g, self.packed((id(conv), "w3t"), lambda: ops.pack_conv3x3_weight(flipped())), None, conv.in_channels)
 
     def linear_bwd(self, g, weight, split=None, key=None):
         """d/d rows of rows x weight^T: g [M, n_out] x weight [n_out, K] -> ([M, K],), or its column blocks (K1, K2) as two dense
@@ -285,13 +287,17 @@ class _Ctx:
         n_out = weight.shape[0]
         w2 = weight.detach().reshape(n_out, -1)
         kid = key if key is not None else (id(weight), "w1t")
+        split16 = self.model.backward_precision == "bf16x3" and n_out % 32 == 0      # gradient rows split on the fly into bf16 hi + lo
+
+        def mm(sub, cols):
+            wt = lambda: cols.t().contiguous()
+            if split16:
+                return ops.gemm_bf16x3(g, self.packed((kid, sub, "x"), lambda: ops.pack_weight_bf16x3(wt())), cols.shape[1])
+            return ops.gemm(g, self.packed((kid, sub), wt))
         if split is None:
-            wt = self.packed(kid, lambda: w2.t().contiguous())
-            return (ops.gemm(g, wt),)
+            return (mm(-1, w2),)
         K1 = split[0]
-        wa = self.packed((kid, 0), lambda: w2[:, :K1].t().contiguous())
-        wb = self.packed((kid, 1), lambda: w2[:, K1:].t().contiguous())
-        return ops.gemm(g, wa), ops.gemm(g, wb)
+        return mm(0, w2[:, :K1]), mm(1, w2[:, K1:])
 
     def linear(self, a, conv1x1, a2=None, residual=None, colsum=False):
         return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual, colsum=colsum)
@@ -359,6 +365,9 @@ class UNet2DConditionModel(nn.Module):
         # hipGraph replay of the forward (enable_hip_graph): at the CFG batch of 2 one forward is ~1000 launches of a few
         # microseconds each and the host cannot issue them fast enough; a captured graph removes the launch path.
         self._graphs = None
+        # products of backward_sample(): "fp32" exact fp32 MFMA, "bf16x3" split-bf16 (fp32 exponent range, so gradients need no
+        # scale; ~2^-16 per product) for the convolutions / linears; the attention gradients are exact fp32 in both
+        self.backward_precision = "fp32"
 
     def invalidate_packed_weights(self):
         """Drop the packed weights (and the captured graphs that hold them); the next forward repacks."""

@@ -440,6 +440,9 @@ int dua_layernorm_bwd(const float* x, const float* gamma, const float* dy, const
 int dua_geglu_bwd(const float* x, const float* dy, float* dx, long M, int F, void* stream);
 /* Softmax input gradient in place on dP: dS = P * (dP - sum_j dP_j P_j) per row (cols <= 4096). */
 int dua_softmax_bwd_rows(const float* P, float* dP, long rows, int cols, long ld, void* stream);
+/* Both in one pass: on entry S = logits, dP = d/dP; on exit S = P = softmax(S) and dP = dS (what the attention gradient needs:
+ * P for dV, dS for dQ / dK). */
+int dua_softmax_fwd_bwd_rows(float* S, float* dP, long rows, int cols, long ld, void* stream);
 /* Adjoint of dua_pick_even: g [N][H/2][W/2][C] -> out [N][H][W][C], zero off the even pixels. */
 int dua_place_even(const float* g, float* out, int N, int H, int W, int C, void* stream);
 /* grad[m] = scale * (stack[m] - mean_m stack): d/d e_m of (scale/2) * sum_m (e_m - mean)^2, i.e. of the unbiased variance over

@@ -132,6 +132,11 @@ def test_sd_unet_input_vjp_vs_oracle(cfg, hw, Tk, precision):
     e_out, e_grad = (out.cpu() - ref_out).abs().max().item(), rel_err(grad.cpu(), ref_grad)
     print(f"sd-unet vjp {precision} hw={hw}: out err {e_out:.3e}, grad rel err {e_grad:.3e} (|grad|max {ref_grad.abs().max().item():.3e})")
     assert grad.shape == x.shape and e_out < 1e-3 and e_grad < 1e-3
+    m.backward_precision = "bf16x3"                 # convolutions / linears of the backward pass on the split-bf16 engine
+    out2, tape = m.forward_with_tape(x.to(dev), t.to(dev), enc.to(dev))
+    e_grad16 = rel_err(m.backward_sample(tape, gout.to(dev)).cpu(), ref_grad)
+    print(f"    backward_precision bf16x3: grad rel err {e_grad16:.3e}")
+    assert e_grad16 < 1e-3
     # the taped forward is the plain forward
     plain = m(x.to(dev), t.to(dev), encoder_hidden_states=enc.to(dev), return_dict=False)[0]
     np.testing.assert_array_equal(plain.cpu().numpy(), out.cpu().numpy())
@@ -219,3 +224,8 @@ def test_sd15_full_size_input_vjp_vs_oracle():
     e_out, e_grad = (out.cpu() - ref_out).abs().max().item(), rel_err(grad.cpu(), ref_grad)
     print(f"sd-1.5 unet vjp f16x3: out err {e_out:.3e}, grad rel err {e_grad:.3e} (|grad|max {ref_grad.abs().max().item():.3e})")
     assert e_out < 1e-3 and e_grad < 1e-3
+    m.backward_precision = "bf16x3"
+    out, tape = m.forward_with_tape(x.to(dev), t.to(dev), enc.to(dev))
+    e_grad16 = rel_err(m.backward_sample(tape, gout.to(dev)).cpu(), ref_grad)
+    print(f"    backward_precision bf16x3: grad rel err {e_grad16:.3e}")
+    assert e_grad16 < 1e-3
