@@ -288,13 +288,33 @@ def other_config_sd(dev, a):
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         res[mode] = times
+    # the reference script's default update (use_posterior = False): gradient of the summed variance through the M denoiser calls
+    unet.precision = "f16x3"
+    uncertainty_guidance.use_posterior = False
+    try:
+        for bwd in ("fp32", "bf16x3"):
+            unet.backward_precision = bwd
+            times = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipe(generator=torch.Generator().manual_seed(491), **kw)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            res["grad_" + bwd] = times
+    finally:
+        uncertainty_guidance.use_posterior = True
     del unet, pipe
     torch.cuda.empty_cache()
     return dict(config="BASELINE configs[4]: SD-1.5 latent UNet 512x512, percentile-0.9 uncertainty guidance (posterior mode), 20 steps, M=5, 2 guided steps",
                 value=round(min(res["f16x3"][1:]), 3), unit="seconds/image", higher_is_better=False,
                 dtype="f16x3 (fp32-equivalent split, as the headline); parity of the UNet itself unpinned (un-vendored diffusers), the guidance function is pinned (G7)",
                 data="synthetic prompt embeddings, random-init weights", first_run_incl_packing_s=round(res["f16x3"][0], 2),
-                f16f8_seconds_per_image=round(min(res["f16f8"][1:]), 3))
+                f16f8_seconds_per_image=round(min(res["f16f8"][1:]), 3),
+                gradient_update_seconds_per_image=round(min(res["grad_fp32"][1:]), 3),
+                gradient_update_bf16x3_backward_seconds_per_image=round(min(res["grad_bf16x3"][1:]), 3),
+                gradient_update_note="use_posterior=False (the reference script's default): taped forward of batch 2M in f16x3 + input-gradient "
+                                     "pass (exact fp32 MFMA, or convs / linears on the split-bf16 engine) per guided step")
 
 
 def parse_args(argv=None):

@@ -32,6 +32,8 @@ def main():
     p.add_argument("-M", type=int, default=5)
     p.add_argument("--guidance-scale", type=float, default=7.5)
     p.add_argument("--precision", choices=["f16x3", "f16f8", "bf16x3", "fp32"], default="f16x3")
+    p.add_argument("--backward-precision", choices=["fp32", "bf16x3"], default="fp32",
+                   help="products of the input-gradient pass of the gradient update: exact fp32 MFMA, or split-bf16 convs / linears")
     p.add_argument("--unet-state-dict", type=str, default=None)
     p.add_argument("--prompt-embeds", type=str, default=None)
     p.add_argument("--out", type=str, default=None)
@@ -53,6 +55,7 @@ def main():
         randomize_parameters_(unet, seed=15)
     unet.eval().to("cuda")
     unet.precision = a.precision
+    unet.backward_precision = a.backward_precision
     if not a.no_graph:
         unet.enable_hip_graph()
     if a.prompt_embeds:
