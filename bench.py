@@ -240,6 +240,9 @@ def other_config_uvit(dev, a):
                                   predict_next=True, eta=0.0, num_zigzag=3, uncertainty_distance=1)
         s = get_uncertainty_scheduler(args, y.to(dev), model, load_uvit_scheduler())
         s.noise_source = DeviceNoise(seed=seed)
+        # the 5 Monte-Carlo chains of a UC step as ONE denoiser call of batch 320 (identical outputs): at batch 64 the N = 1152
+        # projections are 585 tiles on 256 CUs (3 rounds, 76 % occupied); at 320 rows x 5 they are 2907 (12 rounds, 95 %): +4.6 %
+        s.mc_group = int(getattr(a, "uvit_mc_group", 5))
         s.set_timesteps(n_steps)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -253,6 +256,7 @@ def other_config_uvit(dev, a):
     torch.cuda.empty_cache()
     return dict(config="BASELINE configs[2]: U-ViT-H/2 ImageNet-256, 50 steps, M=5, uncertainty_zigzag_centered (W10), batch 64, + KL-VAE decode",
                 value=round(64 / dt, 3), unit="images/sec", seconds_per_job=round(dt, 2), executed_forwards_per_image=50 + uc,
+                mc_group=int(getattr(a, "uvit_mc_group", 5)),
                 dtype="f16x3 (the fp32-equivalent split: LayerNorm / GELU / attention outputs as fp16 hi + lo planes, 22 significant bits); "
                       "KL-VAE decoder exact fp32", data="synthetic, random-init weights")
 

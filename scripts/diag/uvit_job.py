@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Run bench.py's BASELINE configs[2] leg (U-ViT-H/2, batch 64, 50 steps, M=5, W10 + VAE decode) alone, for profiling."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+
+ns = argparse.Namespace(uvit_mc_group=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+print(json.dumps(bench.other_config_uvit("cuda", ns)))
