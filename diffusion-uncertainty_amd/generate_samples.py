@@ -38,6 +38,14 @@ def predict_model(model, sample, t_tensor, y):
     return _eps3(model, sample, t_tensor, y)
 
 
+def _to_host_async(t):
+    """Stream-ordered D2H into pinned memory (torch's caching host allocator): the host does not stall the launch queue the way
+    the reference's ``.cpu()`` on pageable memory does; _loop synchronises once before it returns."""
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    return h
+
+
 def _loop(x, y_batch, model_call, scheduler, device, intermediates=None):
     is_uc = isinstance(scheduler, SchedulerUncertaintyMixin)
     uncertanties, scores = [], []
@@ -53,9 +61,11 @@ def _loop(x, y_batch, model_call, scheduler, device, intermediates=None):
         if intermediates is not None:
             intermediates.append(output.prev_sample.cpu())
         if is_uc and scheduler.timestep_after_step >= t >= scheduler.timestep_end_step:
-            uncertanties.append(output.uncertainty.cpu())                 # :193-194 (D2H every UC step)
-            scores.append(output.pred_epsilon.cpu())
+            uncertanties.append(_to_host_async(output.uncertainty))       # :193-194 (D2H every UC step)
+            scores.append(_to_host_async(output.pred_epsilon))
         x = output.prev_sample
+    if uncertanties:
+        torch.cuda.current_stream(x.device).synchronize()
     return x, uncertanties, scores
 
 
