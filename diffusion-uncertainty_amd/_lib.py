@@ -85,6 +85,7 @@ SIGNATURES = {
     "dua_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _P]),
     "dua_gemm": (_I, [_c.POINTER(GemmArgs), _P]),
     "dua_softmax_rows": (_I, [_P, _L, _I, _L, _P]),
+    "dua_set_splitk_workspace": (_I, [_P, _Z]),
     "dua_groupnorm_bwd": (_I, [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "dua_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_geglu_bwd": (_I, [_P, _P, _P, _L, _I, _P]),

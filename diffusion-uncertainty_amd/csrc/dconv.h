@@ -20,6 +20,11 @@ struct DConvP {
     const float* Cscale;     // FMT 3 (f16x3): per weight row 2^-s (the planes hold w * 2^s), padded to the tile grid
     float out_scale;         // FMT 3: 1 / activation plane scale; the epilogue multiplies the accumulator by Cscale[col] * out_scale
     float split_scale;       // FMT 3 with Csplit: the output planes hold fp16 hi | lo of C * split_scale
+    // Split-K (k_xconv_dma, per-tap form of the bf16x3 / f16x3 loops only): ksplit > 1 makes every (tile, part) pair a work item of
+    // its own; part s runs K steps [s*nk/ksplit, (s+1)*nk/ksplit) and stores its SCALED accumulators (no bias / residual) to
+    // kpart[s][M][N]; k_splitk_reduce then folds the parts in index order (deterministic) and applies the epilogue.
+    int ksplit;
+    float* kpart;
 };
 
 // conv_f16x3.hip: the f16x3 kernel on 16x16x32 MFMA shapes (row-shift form where the image width divides 256)

@@ -561,6 +561,12 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     if ((size_t)N * Ho * Wo == 0) return DUA_OK;
     int cp, nc;
     gn_chunking(N, Ho * Wo, &cp, &nc);
+    if ((long)N * Ho * Wo <= 65536 && cp > 8) {
+        // small maps (SD's CFG batch of 2, row views of a few hundred tokens): a 16-pixel chunk is 16 dependent iterations of one
+        // workgroup (11 - 20 us for under a megabyte); 4-pixel chunks put the same work on 4x the workgroups
+        cp = (long)Ho * Wo >= 4096 ? 8 : 4;              // (the 8-channel kernel covers 6 - 8 pixels per iteration)
+        nc = (Ho * Wo + cp - 1) / cp;
+    }
     // the 16-byte-store kernel wins on the large maps (+11 % at 128^2, +5 % at 64^2) and loses on the small ones, where its
     // fewer, fatter lanes leave part of a workgroup idle
     const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && (split != 2 || (C1 % 16 == 0 && C2 % 16 == 0)) &&

@@ -564,7 +564,9 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // blockIdx % 8) own one contiguous chunk of tiles and sweep it side by side, so concurrently running workgroups
     // of an XCD work on neighbouring tiles (shared halo rows / weight panel in that XCD's L2).  A workgroup moves to
     // its next tile right after issuing its output stores: they drain while the next tile's first DMA is in flight.
-    const int ntiles = p.ntm * p.ntn;
+    constexpr bool KSPLIT_OK = (FMT == 0 || FMT == 3) && !RS;
+    const int S = KSPLIT_OK && p.ksplit > 1 ? p.ksplit : 1;          // split-K parts per tile (see DConvP::ksplit)
+    const int ntiles = p.ntm * p.ntn * S;
     const int nk = p.K / BK;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
     const int cq = ntiles >> 3, cr = ntiles & 7;
@@ -638,12 +640,19 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
   };
   for (int ti = slot; ti < chunk_n; ti += nslot) {
     const int lid = chunk0 + ti;
-    const int tn = lid % p.ntn, tm = lid / p.ntn;
+    const int part = KSPLIT_OK ? lid % S : 0, tl = KSPLIT_OK ? lid / S : lid;       // parts of a tile are neighbours: they share its operands in L2
+    const int tn = tl % p.ntn, tm = tl / p.ntn;
     const int m0 = tm * DBM, n0 = tn * DBN;
     DUA_STAMP(0)
     const int lrow = lane >> 2;
     const int csrc = (lane & 3) ^ ((lane >> 4) & 3);
     if (!a_prefetched) a_geom(m0);
+    const int kb = KSPLIT_OK && S > 1 ? (int)((long)part * nk / S) : 0;            // first K step of this work item
+    const int nkt = KSPLIT_OK && S > 1 ? (int)((long)(part + 1) * nk / S) - kb : nk;
+    if (KSPLIT_OK && S > 1) {
+        tap = kb % p.ntaps;
+        cb = kb / p.ntaps;
+    }
     unsigned boff[NT / 2];
     // Every workgroup of the chip streams the SAME weight tile at about the same time: rotate which 16-row group a wave
     // fetches by the workgroup's slot, so that at a given moment the workgroups of an XCD ask different L2 channels.
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
     for (int j = 0; j < NT / 2; ++j) {
         bgrp[j] = ((NT / 2) * wave + j + brot) % (4 * NT);
-        boff[j] = (unsigned)(((long)(n0 + 16 * bgrp[j] + lrow) * p.K + 8 * csrc) * 2);
+        boff[j] = (unsigned)(((long)(n0 + 16 * bgrp[j] + lrow) * p.K + 8 * csrc + (long)kb * BK) * 2);
     }
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (p.dbg_norec & 2) ? 0 : (int)(2 * p.b_plane * 2), 0x00020000);
     const int b_lo = (int)(p.b_plane * 2);                                   // byte distance hi -> lo weight plane
@@ -770,23 +779,23 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 
     issue_a(0);
     issue_b(0);
-    if (nk > 1) {
+    if (nkt > 1) {
         issue_a(1);
         if (NT == 2) issue_b(1);
     }
-    DWAIT_TILE(nk > 1)
+    DWAIT_TILE(nkt > 1)
     __builtin_amdgcn_s_barrier();
     DUA_STAMP(1)
     int sa = 0, sb = 0;
     LD_AL(0, 0)
     LD_BH(0, 0)
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nkt; ++kt) {
         int sa2 = sa + 2;                                // activation stage of tile kt+2
         if (sa2 >= RA) sa2 -= RA;
         int sbn = sb + (RB - 1);                         // weight stage of tile kt+2 (NT = 2) / kt+1 (NT = 4)
         if (sbn >= RB) sbn -= RB;
-        const bool preA = kt + 2 < nk;
-        const bool preB = NT == 4 ? kt + 1 < nk : kt + 2 < nk;
+        const bool preA = kt + 2 < nkt;
+        const bool preB = NT == 4 ? kt + 1 < nkt : kt + 2 < nkt;
         if (preA) dma_setup();
         int piece = 0;
         SBAR();
@@ -1163,7 +1172,39 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     asm volatile("" : "+v"(lane_e));
     const int lr_e = lane_e & 31, kh_e = lane_e >> 5;
     const bool full_tile = m0 + DBM <= p.M && n0 + DBN <= p.N && !p.nchw_out && !(p.res && (p.act_out == 2 || p.Csplit));
-    if (full_tile) {
+    if (KSPLIT_OK && S > 1) {
+        // ---- split-K work item: the scaled accumulators go to this part's slab of the workspace, rows re-laid through a private
+        // LDS patch (16 B per lane, whole rows); bias / residual / statistics belong to k_splitk_reduce
+        constexpr int WC = 32 * NT;
+        float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WC);
+        const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);
+        constexpr int RPI = 64 / (WC / 4);
+        const int colq = n0 + wn * WC + 4 * c4;
+        float4 sq = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (FMT == 3) {
+            sq = *(const float4*)(p.Cscale + colq);
+            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+        }
+        float* slab = p.kpart + (long)part * p.M * p.N;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * kh_e) * WC + ni * 32 + lr_e] = acc[mi][ni][r];
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int rl = it * RPI + rr;
+                const int row = m0 + wm * 64 + mi * 32 + rl;
+                float4 v = *(const float4*)(patch + rl * WC + 4 * c4);
+                if (row < p.M && colq < p.N) {
+                    v.x *= sq.x; v.y *= sq.y; v.z *= sq.z; v.w *= sq.w;
+                    *(float4*)(slab + (long)row * p.N + colq) = v;
+                }
+            }
+        }
+    } else if (full_tile) {
         constexpr int WC = 32 * NT, WCP = WC + DUA_PATCH_PAD;
         float* patch = reinterpret_cast<float*>(lds) + wave * (32 * WCP);
         const int c4 = lane_e % (WC / 4), rr = lane_e / (WC / 4);
@@ -1444,6 +1485,71 @@ static void dconv_set_stagger(DConvP& d, bool wide, int ntiles, int grid) {
     d.stagger_sleeps = (int)((step + 4064) / 8128);
 }
 
+// ---- split-K for launches that cannot fill the chip (small batches: SD's CFG batch of 2 gives the 32^2 / 16^2 / 8^2 levels 10 - 40
+// tiles for 256 CUs, and a launch lasts one whole tile whatever the tile count).  Opt-in: the caller registers a workspace.
+static float* dua_splitk_ws = nullptr;
+static size_t dua_splitk_ws_bytes = 0;
+extern "C" int dua_set_splitk_workspace(void* ws, size_t bytes) {
+    DUA_REQUIRE((ws == nullptr) == (bytes == 0) && ((uintptr_t)ws & 15) == 0, "dua_set_splitk_workspace: a 16-byte aligned buffer, or (NULL, 0) to switch split-K off");
+    dua_splitk_ws = (float*)ws;
+    dua_splitk_ws_bytes = bytes;
+    return DUA_OK;
+}
+// One workgroup per (64-row block, 64-column block): C = sum_s part[s] (index order) + bias (+ residual), and the block's column
+// sums / sums of squares in the layout of the conv epilogue.  Thread = (column quad cq, row lane rl): rows rl, rl + 16, rl + 32, rl + 48.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ part, int S, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, float* __restrict__ C, float* __restrict__ colsum,
+                                                       int M, int N) {
+    __shared__ float4 sh[2][16][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int r0 = blockIdx.x * 64, col = blockIdx.y * 64 + 4 * cq;
+    const long slab = (long)M * N;
+    const bool live = col < N;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f), cs = b, cq2 = b;
+    if (live && bias) b = *(const float4*)(bias + col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rl + 16 * i;
+        if (!live || r >= M) continue;
+        const long o = (long)r * N + col;
+        float4 v = *(const float4*)(part + o);
+        for (int s_ = 1; s_ < S; ++s_) {
+            const float4 w = *(const float4*)(part + s_ * slab + o);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (res) {
+            const float4 w = *(const float4*)(res + o);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *(float4*)(C + o) = v;
+        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+    }
+    if (!colsum) return;
+    sh[0][rl][cq] = cs;
+    sh[1][rl][cq] = cq2;
+    __syncthreads();
+    if (rl < 2 && live) {                  // rl 0: sums, rl 1: sums of squares; fixed order over the 16 row lanes
+        float4 t = sh[rl][0][cq];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            const float4 w = sh[rl][j][cq];
+            t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+        }
+        *(float4*)(colsum + (long)blockIdx.x * 2 * N + (long)rl * N + col) = t;
+    }
+}
+// parts per tile for a launch of `ntiles` tiles and nk K steps: fill the 256 CUs, keep >= 12 K steps per part, fit the workspace
+static int splitk_parts(const DConvP& d, int fmt, int ntiles, int nk) {
+    if (!dua_splitk_ws || !(fmt == 0 || fmt == 3) || d.nchw_out || d.Csplit || d.act_out != 0 || (d.N & 3) || ntiles > 128) return 1;
+    int S = 256 / ntiles;
+    if (S > nk / 12) S = nk / 12;
+    if (S > 16) S = 16;
+    while (S > 1 && (size_t)S * d.M * d.N * sizeof(float) > dua_splitk_ws_bytes) --S;
+    return S < 2 ? 1 : S;
+}
+
 static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     d.ntm = (d.M + DBM - 1) / DBM;
     // 256-wide column tiles (half the L2->LDS bytes per MFMA) when they tile N exactly and still give every CU
@@ -1467,6 +1573,16 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
         // scripts/bench_conv_mix.py --fmt f16x3 --engine 7 / 6).  Mode 7 forces the new kernel, 6 the old one.
         return dua_launch_hconv(d, st, what);
     } else if (fmt == 3) {                                                        // (mode 6, A/B: the bf16x3 loop on fp16 planes, 32x32x16 shape)
+        const int S = splitk_parts(d, fmt, ntiles, d.K / BK);
+        if (S > 1) {
+            d.ksplit = S;
+            d.kpart = dua_splitk_ws;
+            const int items = ntiles * S;
+            if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(items < 256 ? items : 256), 512, 0, st, d);
+            else hipLaunchKernelGGL((k_xconv_dma<2, 3>), dim3(items < 256 ? items : 256), 512, 0, st, d);
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((d.M + 63) / 64, (d.N + 63) / 64), 256, 0, st, d.kpart, S, d.bias, d.res, d.C, d.colsum, d.M, d.N);
+            return dua_check_launch(what);
+        }
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 3>), dim3(grid), 512, 0, st, d);
     } else if (fmt == 2) {                                                        // MXFP6 cross terms: row-shift convolutions only

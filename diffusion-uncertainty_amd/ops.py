@@ -389,6 +389,30 @@ F16X3_ACT_SCALE = 64.0
 F16X3_RAW_SCALE = 16.0
 
 
+# Split-K workspace of the f16x3 LDS-DMA launches (dua_set_splitk_workspace): S * M * N floats with S * tiles <= 256, i.e. at most
+# 256 tiles of 256 x 128 floats = 32 MiB.  One buffer per device, kept for the life of the process (captured HIP graphs hold its address).
+_SPLITK_WS = {}
+_SPLITK_ON = False
+
+
+def set_split_k(on, device=None):
+    """Switch split-K of under-filled f16x3 conv / presplit-GEMM launches on or off (process-global); returns the previous setting.
+    On: results differ from the single-pass kernels by fp32 summation order and are no longer bit-identical across batch sizes."""
+    global _SPLITK_ON
+    prev = _SPLITK_ON
+    if on:
+        dev = torch.device(device if device is not None else "cuda")
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in _SPLITK_WS:
+            _SPLITK_WS[key] = torch.empty(40 << 20, device=dev, dtype=torch.uint8)
+        ws = _SPLITK_WS[key]
+        check(_lib.lib().dua_set_splitk_workspace(_p(ws), ws.numel()), "dua_set_splitk_workspace")
+    else:
+        check(_lib.lib().dua_set_splitk_workspace(None, 0), "dua_set_splitk_workspace")
+    _SPLITK_ON = bool(on)
+    return prev
+
+
 # Optional per-launch timing hook used by bench.py: an object with .record(kind, flops, start_evt, end_evt).
 PROFILE = None
 

@@ -244,6 +244,12 @@ class _Ctx:
             packed = self.packed((id(weight), kind), lambda: pack(weight.detach().reshape(n_out, -1).contiguous()))
             return ops.gemm_bf16x3_presplit(a, packed, n_out, bias=bias, residual=residual, colsum=colsum)
         n_out, K = weight.shape[0], a.shape[1] + (0 if a2 is None else a2.shape[1])
+        if self.f16x3 and self.model.split_k and K % 32 == 0 and a.shape[1] % 4 == 0 and -(-a.shape[0] // 256) * -(-n_out // 128) <= 128:
+            # few rows (the CFG batch): one small pass writes the rows as f16x3 planes, then the LDS-DMA GEMM, which splits along K when
+            # its tiles cannot fill the chip - the on-the-fly engine below would run these on 6 - 80 of the 256 CUs
+            kind = "w1hp"
+            packed = self.packed((id(weight), kind), lambda: ops.pack_weight_f16x3(weight.detach().reshape(n_out, K).contiguous()))
+            return ops.gemm_bf16x3_presplit(self.row_planes(a, a2), packed, n_out, bias=bias, residual=residual, colsum=colsum)
         if self.f16x3 and K % 32 == 0 and a.shape[1] % 32 == 0:       # raw fp32 rows split on the fly into fp16 hi + lo
             packed = self.packed((id(weight), "w1h"), lambda: ops.pack_weight_f16x3(weight.detach().reshape(n_out, K).contiguous()))
             return ops.gemm_f16x3(a, packed, n_out, bias=bias, a2=a2, residual=residual, colsum=colsum)
@@ -298,6 +304,25 @@ class _Ctx:
             return (mm(-1, w2),)
         K1 = split[0]
         return mm(0, w2[:, :K1]), mm(1, w2[:, K1:])
+
+    def row_planes(self, a, a2=None):
+        """Raw fp32 rows [M, K1] (| [M, K2]) -> f16x3 operand planes [M, K1 + K2] at the raw-stream scale (identity GroupNorm-apply
+        over a [1, M, 1, K] view, the concat never materialised)."""
+        M, K1 = a.shape
+        K = K1 + (0 if a2 is None else a2.shape[1])
+        if a2 is None and K > 2048:                      # the kernel takes up to 3072 channels: fold wide rows (same memory)
+            r = next(r for r in (2, 4, 8, 16) if K % (32 * r) == 0 and K // r <= 2048)
+            pl = self.row_planes(a.view(M * r, K // r))
+            return ops.SplitPlanes(pl.buf, (M, K), pl.fmt, pl.scale)
+        key = ("identity_gn", 1, K)
+        if key not in self.model._packed:
+            st = torch.zeros((1, 32, 2), device=a.device, dtype=torch.float32)
+            st[:, :, 1] = 1.0
+            self.model._packed[key] = (st, torch.ones(K, device=a.device), torch.zeros(K, device=a.device))
+        st, one, zero = self.model._packed[key]
+        pl = ops.groupnorm_apply(a.view(1, M, 1, K1), st, one, zero, x2=None if a2 is None else a2.view(1, M, 1, -1), act=0, groups=32,
+                                 split="f16x3", split_scale=ops.F16X3_RAW_SCALE)
+        return ops.SplitPlanes(pl.buf, (M, K), pl.fmt, pl.scale)
 
     def linear(self, a, conv1x1, a2=None, residual=None, colsum=False):
         return self.gemm(a, conv1x1.weight, conv1x1.bias, a2=a2, residual=residual, colsum=colsum)
@@ -368,6 +393,9 @@ class UNet2DConditionModel(nn.Module):
         # products of backward_sample(): "fp32" exact fp32 MFMA, "bf16x3" split-bf16 (fp32 exponent range, so gradients need no
         # scale; ~2^-16 per product) for the convolutions / linears; the attention gradients are exact fp32 in both
         self.backward_precision = "fp32"
+        # f16x3: launches that cannot fill the chip (the CFG batch of 2 gives the 32^2 / 16^2 / 8^2 levels 10 - 40 tiles for 256 CUs)
+        # run split along K with a deterministic second-stage sum (dua_set_splitk_workspace): ~1.6x on the whole sampling job
+        self.split_k = True
 
     def invalidate_packed_weights(self):
         """Drop the packed weights (and the captured graphs that hold them); the next forward repacks."""
@@ -423,7 +451,7 @@ class UNet2DConditionModel(nn.Module):
         if self._graphs is None:
             out = self._forward_impl(sample, t, enc)
         else:
-            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE)
+            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE, bool(self.split_k))
             entry = self._graphs.get(key)
             if entry is None:
                 self._forward_impl(sample, t, enc)                     # eager once: packs the weights, warms the allocator
@@ -443,6 +471,13 @@ class UNet2DConditionModel(nn.Module):
     def _forward_impl(self, sample, t, enc, tape=None):
         """sample [B,4,h,w] fp32, t [B] int64, enc [B,Tk,ctx] fp32, all on the GPU -> [B,4,h,w].  tape: list receiving the
         activations backward_sample() needs (None: nothing is kept)."""
+        prev_split_k = ops.set_split_k(self.split_k and self.precision == "f16x3", sample.device)
+        try:
+            return self._forward_body(sample, t, enc, tape)
+        finally:
+            ops.set_split_k(prev_split_k, sample.device)
+
+    def _forward_body(self, sample, t, enc, tape):
         ctx = _Ctx(self)
         te = self.time_embedding
         emb = ops.timestep_embedding(t, self.conv_in.out_channels)        # [cos | sin], freq_shift 0: the ADM embedding

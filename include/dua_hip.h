@@ -422,6 +422,13 @@ int dua_uvit_assemble(const float* patches, const float* time_tok, const float* 
  * 'B (h w) (p1 p2 C) -> B C (h p1) (w p2)' (uvit.py:46-51,228-229). */
 int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C, int P, void* stream);
 
+/* Split-K for the f16x3 LDS-DMA conv / presplit GEMM launches that cannot fill the chip (fewer than 128 tiles of 256 rows: small
+ * batches, e.g. SD's CFG batch of 2): with a workspace registered, such a launch runs every tile as up to 16 K parts on separate
+ * workgroups and a second kernel folds the parts in index order (deterministic) and applies bias / residual / statistics.
+ * Results differ from the single-pass kernel by fp32 summation order only; the choice depends on the row count, so outputs are no
+ * longer bit-identical across batch sizes while it is on.  Process-global, one stream at a time; (NULL, 0) switches it off (default). */
+int dua_set_splitk_workspace(void* ws, size_t bytes);
+
 /* ---------------- input gradients (gradient-mode guidance, uncertainty_guidance.py:83-108,121-129) ----------------
  * use_posterior = False (the default of scripts/generate_with_uncertainty_threshold_stable_diffusion.py:16-17) calls
  * uncertainty.backward() through the M denoiser calls and reads pred_epsilon.grad.  Only gradients w.r.t. activations are
