@@ -115,7 +115,10 @@ static void gn_chunking(int N, int HW, int* chunk_px, int* nchunks) {
     // aim for >= ~2048 workgroups, at least 16 pixels per chunk
     int want = (2048 + N - 1) / N;
     int cp = (HW + want - 1) / want;
-    if (cp < 16) cp = 16;
+    // small maps (SD's CFG batch of 2, row views of a few hundred tokens): a 16-pixel chunk is 16 dependent iterations of one workgroup
+    // (11 - 20 us for under a megabyte of data); 4 - 8 pixel chunks put the same work on more workgroups
+    const int floor_px = (long)N * HW > 65536 ? 16 : (HW >= 4096 ? 8 : 4);
+    if (cp < floor_px) cp = floor_px;
     if (cp > HW) cp = HW;
     *chunk_px = cp;
     *nchunks = (HW + cp - 1) / cp;
@@ -561,12 +564,6 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     if ((size_t)N * Ho * Wo == 0) return DUA_OK;
     int cp, nc;
     gn_chunking(N, Ho * Wo, &cp, &nc);
-    if ((long)N * Ho * Wo <= 65536 && cp > 8) {
-        // small maps (SD's CFG batch of 2, row views of a few hundred tokens): a 16-pixel chunk is 16 dependent iterations of one
-        // workgroup (11 - 20 us for under a megabyte); 4-pixel chunks put the same work on 4x the workgroups
-        cp = (long)Ho * Wo >= 4096 ? 8 : 4;              // (the 8-channel kernel covers 6 - 8 pixels per iteration)
-        nc = (Ho * Wo + cp - 1) / cp;
-    }
     // the 16-byte-store kernel wins on the large maps (+11 % at 128^2, +5 % at 64^2) and loses on the small ones, where its
     // fewer, fatter lanes leave part of a workgroup idle
     const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && (split != 2 || (C1 % 16 == 0 && C2 % 16 == 0)) &&
@@ -609,6 +606,24 @@ __global__ __launch_bounds__(BLK) void k_geglu(const float* __restrict__ x, floa
         auto ge = [](float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); };
         ((float4*)y)[i] = make_float4(a.x * ge(g.x), a.y * ge(g.y), a.z * ge(g.z), a.w * ge(g.w));
     }
+}
+// ... with the result written as f16x3 operand planes (fp16 hi | lo of y * scale) for the presplit GEMM that consumes it
+__global__ __launch_bounds__(BLK) void k_geglu_split(const float* __restrict__ x, void* __restrict__ planes, long M, int F, float scale) {
+    const int Q = F / 4;
+    size_t total = (size_t)M * Q, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t m = i / Q;
+        const int q = (int)(i % Q);
+        const float4 a = *(const float4*)(x + m * 2 * F + 4 * q), g = *(const float4*)(x + m * 2 * F + F + 4 * q);
+        auto ge = [](float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); };
+        dua_store_f16x3_quad(planes, (long)M * F, (long)(4 * i), make_float4(a.x * ge(g.x), a.y * ge(g.y), a.z * ge(g.z), a.w * ge(g.w)), scale);
+    }
+}
+extern "C" int dua_geglu_split_f16x3(const float* x, void* planes, long M, int F, float scale, void* stream) {
+    DUA_REQUIRE(x && planes && M > 0 && F > 0 && F % 4 == 0, "dua_geglu_split_f16x3: F must be a positive multiple of 4");
+    DUA_REQUIRE(scale > 0.f && (__builtin_bit_cast(unsigned, scale) & 0x7FFFFFu) == 0, "dua_geglu_split_f16x3: scale must be a power of two");
+    hipLaunchKernelGGL(k_geglu_split, stream_grid((size_t)M * (F / 4), BLK), BLK, 0, as_stream(stream), x, planes, M, F, scale);
+    return dua_check_launch("dua_geglu_split_f16x3");
 }
 extern "C" int dua_geglu(const float* x, float* y, long M, int F, void* stream) {
     DUA_REQUIRE(x && y && M > 0 && F > 0 && F % 4 == 0, "dua_geglu: F must be a positive multiple of 4");

@@ -330,10 +330,14 @@ def add_channel_bias_(x, bias):
     return x
 
 
-def geglu(x):
-    """[M, 2F] -> [M, F]: x[:, :F] * gelu(x[:, F:])."""
+def geglu(x, split=False):
+    """[M, 2F] -> [M, F]: x[:, :F] * gelu(x[:, F:]); split="f16x3": as operand planes at the raw-stream scale."""
     _req(x, name="x")
     M, F2 = x.shape
+    if split == "f16x3":
+        buf = torch.empty((2, M, F2 // 2), device=x.device, dtype=torch.int16)
+        check(_lib.lib().dua_geglu_split_f16x3(_p(x), _p(buf), M, F2 // 2, F16X3_RAW_SCALE, _stream()), "dua_geglu_split_f16x3")
+        return SplitPlanes(buf, (M, F2 // 2), "f16x3", F16X3_RAW_SCALE)
     y = torch.empty((M, F2 // 2), device=x.device, dtype=torch.float32)
     check(_lib.lib().dua_geglu(_p(x), _p(y), M, F2 // 2, _stream()), "dua_geglu")
     return y

@@ -113,7 +113,8 @@ class BasicTransformerBlock(nn.Module):
         u = ctx.gemm(n3, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
         if tape is not None:
             tape.append((B, T, h0, qkv, h1, q, k, v, h, u))
-        return ctx.gemm(ops.geglu(u), self.ff.net[2].weight, self.ff.net[2].bias, residual=h)
+        g = ops.geglu(u, split="f16x3" if ctx.f16x3 and u.shape[1] % 64 == 0 else False)
+        return ctx.gemm(g, self.ff.net[2].weight, self.ff.net[2].bias, residual=h)
 
     def run_bwd(self, ctx, saved, g):
         """Gradient of run() w.r.t. the token rows h given g = d/d output [B*T, C]; exact fp32."""

@@ -149,6 +149,8 @@ int dua_resample2x(const float* x, float* y, int N, int H, int W, int C, int res
 int dua_add_channel_bias(float* x, const float* bias, long bias_ld, int N, int HW, int C, void* stream);
 /* GEGLU feed-forward gate: y[m][f] = x[m][f] * gelu(x[m][F + f]) for x [M][2F] (exact erf GELU). */
 int dua_geglu(const float* x, float* y, long M, int F, void* stream);
+/* ... written as f16x3 operand planes ([M][F] fp16 hi | lo of y * scale, scale a power of two) for dua_gemm_f16x3_presplit. */
+int dua_geglu_split_f16x3(const float* x, void* planes, long M, int F, float scale, void* stream);
 /* y[n][i][j][c] = x[n][2i][2j][c]  (Downsample2D's stride-2 / pad-1 conv = the stride-1 conv at the even pixels). */
 int dua_pick_even(const float* x, float* y, int N, int H, int W, int C, void* stream);
 

@@ -285,6 +285,21 @@ def test_conv3x3(ops, N, H, W, Cin, Cout):
     np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
 
 
+def test_geglu_and_split_planes(ops):
+    """GEGLU (diffusers activations.GEGLU, exact erf GELU) in fp32 and as f16x3 operand planes (hi + lo = 22 significant bits of y * scale)."""
+    u = rnd(70, 37, 256) * 3
+    a, g = u.chunk(2, dim=-1)
+    ref = (a.double() * F.gelu(g.double()))
+    y = ops.geglu(u.to(dev)).cpu()
+    assert (y.double() - ref).abs().max().item() < 1e-5
+    pl = ops.geglu(u.to(dev), split="f16x3")
+    assert pl.fmt == "f16x3" and pl.shape == (37, 128) and pl.scale == ops.F16X3_RAW_SCALE
+    buf = pl.buf.view(torch.uint8).reshape(2, -1).cpu()
+    hi, lo = buf[0].view(torch.float16).reshape(37, 128).double(), buf[1].view(torch.float16).reshape(37, 128).double()
+    np.testing.assert_array_equal(hi.float().numpy(), (y * pl.scale).half().float().numpy())
+    assert ((hi + lo) / pl.scale - y.double()).abs().max().item() <= 2.0 ** -25 / pl.scale + 2.0 ** -21 * y.abs().max().item()
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 1280, 1280), (2, 32, 32, 640, 320), (1, 8, 8, 1280, 1280), (3, 20, 20, 96, 200),
                                              (2, 64, 64, 320, 320)])
 def test_conv3x3_f16x3_split_k(ops, N, H, W, Cin, Cout):
@@ -565,6 +580,21 @@ def test_conv3x3_f16x3(ops, N, H, W, Cin, Cout):
     c32 = ops.gemm(nhwc(x).reshape(-1, Cin).to(dev), w1.to(dev), bias=b.to(dev))
     e1, e32 = (c.cpu().double() - ref1).abs().max().item(), (c32.cpu().double() - ref1).abs().max().item()
     assert e1 < max(2 * e32, 2e-6 * ref1.abs().max().item()), (e1, e32)
+
+
+def test_geglu_and_split_planes(ops):
+    """GEGLU (diffusers activations.GEGLU, exact erf GELU) in fp32 and as f16x3 operand planes (hi + lo = 22 significant bits of y * scale)."""
+    u = rnd(70, 37, 256) * 3
+    a, g = u.chunk(2, dim=-1)
+    ref = (a.double() * F.gelu(g.double()))
+    y = ops.geglu(u.to(dev)).cpu()
+    assert (y.double() - ref).abs().max().item() < 1e-5
+    pl = ops.geglu(u.to(dev), split="f16x3")
+    assert pl.fmt == "f16x3" and pl.shape == (37, 128) and pl.scale == ops.F16X3_RAW_SCALE
+    buf = pl.buf.view(torch.uint8).reshape(2, -1).cpu()
+    hi, lo = buf[0].view(torch.float16).reshape(37, 128).double(), buf[1].view(torch.float16).reshape(37, 128).double()
+    np.testing.assert_array_equal(hi.float().numpy(), (y * pl.scale).half().float().numpy())
+    assert ((hi + lo) / pl.scale - y.double()).abs().max().item() <= 2.0 ** -25 / pl.scale + 2.0 ** -21 * y.abs().max().item()
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 1280, 1280), (2, 32, 32, 640, 320), (1, 8, 8, 1280, 1280), (3, 20, 20, 96, 200),
