@@ -385,6 +385,10 @@ class UNetModel(nn.Module):
         self.presplit_qkv = True         # bf16x3: attention GroupNorm writes split planes, qkv runs on the LDS-DMA kernel
         self.use_block_abi = True        # fp32 / f16x3: ResBlocks and AttentionBlocks run as ONE C-ABI call each (bit-identical to the composition)
         self._graphs = None              # enable_hip_graph(): {key: captured forward}
+        # f16x3, small batches: conv / presplit-GEMM launches with fewer than 128 tiles run split along K (ops.set_split_k; deterministic,
+        # but the result then depends on the batch size at fp32-rounding level, so it is opt-in here: the Monte-Carlo chains of a
+        # UC step stay bit-identical whether they run one by one or stacked)
+        self.split_k = False
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask
@@ -449,7 +453,8 @@ class UNetModel(nn.Module):
         x = x.float().contiguous()
         t = timesteps.to(torch.int64).contiguous()
         yy = y.to(torch.int64).contiguous() if y is not None else None
-        key = (tuple(x.shape), self.precision, out_channels_keep, self.use_block_abi, self.fuse_gn_stats, ops.ATTENTION_MODE, y is not None)
+        key = (tuple(x.shape), self.precision, out_channels_keep, self.use_block_abi, self.fuse_gn_stats, ops.ATTENTION_MODE, y is not None,
+               bool(self.split_k))
         entry = graphs.get(key)
         if entry is None:
             self._forward_impl(x, t, yy, out_channels_keep)            # eager once: packs the weights, warms the allocator
@@ -467,6 +472,15 @@ class UNetModel(nn.Module):
         return so.clone()
 
     def _forward_impl(self, x, timesteps, y=None, out_channels_keep=None):
+        if not (self.split_k and self.precision == "f16x3"):
+            return self._forward_body(x, timesteps, y, out_channels_keep)
+        prev = ops.set_split_k(True, x.device)
+        try:
+            return self._forward_body(x, timesteps, y, out_channels_keep)
+        finally:
+            ops.set_split_k(prev, x.device)
+
+    def _forward_body(self, x, timesteps, y=None, out_channels_keep=None):
         ctx = _Ctx(self)
         B = x.shape[0]
         te, te2 = self.time_embed[0], self.time_embed[2]

@@ -63,6 +63,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
             randomize_parameters_(unet, seed=args.image_size)
         unet.eval().to(device)
         unet.precision = args.precision
+        unet.split_k = bool(args.split_k)
         if args.hip_graph and args.scheduler_type != "mc_dropout":
             unet.enable_hip_graph()
         model = unet
@@ -135,6 +136,8 @@ def parse_args(argv=None):
     # engine options (not in the reference)
     p.add_argument("--hip-graph", action="store_true", dest="hip_graph",
                    help="ADM UNet: replay the forward from a captured HIP graph (one launch instead of ~330; for small batches)")
+    p.add_argument("--split-k", action="store_true", dest="split_k",
+                   help="ADM UNet, f16x3, small batches: split the K range of conv launches that cannot fill the 256 CUs")
     p.add_argument("--mc-group", type=int, default=1, dest="mc_group",
                    help="uncertainty_zigzag_centered: Monte-Carlo chains of a UC step per denoiser call (stacked batch, identical outputs; "
                         "helps U-ViT at batch 64: +4.6 %% with 5)")
