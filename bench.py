@@ -231,7 +231,7 @@ def other_config_uvit(dev, a):
     from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
     uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
     ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
-    uvit.precision, ae.precision = "f16x3", "fp32"            # the parity modes: fp32-equivalent U-ViT, exact fp32 VAE decode (once per batch)
+    uvit.precision, ae.precision = "f16x3", "f16x3"           # the fp32-equivalent split for the U-ViT and the VAE decode (once per batch)
     model = UViTAE(uvit, ae).to(dev)
     X_T, y = starting_points(64, (4, 32, 32))
 
@@ -258,7 +258,7 @@ def other_config_uvit(dev, a):
                 value=round(64 / dt, 3), unit="images/sec", seconds_per_job=round(dt, 2), executed_forwards_per_image=50 + uc,
                 mc_group=int(getattr(a, "uvit_mc_group", 5)),
                 dtype="f16x3 (the fp32-equivalent split: LayerNorm / GELU / attention outputs as fp16 hi + lo planes, 22 significant bits); "
-                      "KL-VAE decoder exact fp32", data="synthetic, random-init weights")
+                      "KL-VAE decoder in the same format (its single-head attention, head dim 512, exact fp32)", data="synthetic, random-init weights")
 
 
 def other_config_sd(dev, a):

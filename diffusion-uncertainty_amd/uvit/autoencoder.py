@@ -157,7 +157,7 @@ class FrozenAutoencoderKL(nn.Module):
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.embed_dim = embed_dim
         self.scale_factor = scale_factor
-        self.precision = "fp32"          # or "bf16x3"
+        self.precision = "fp32"          # or "f16x3" (fp32-equivalent fp16 hi + lo split) or "bf16x3"
         self._packed = {}
         if pretrained_path is not None:
             m, u = self.load_state_dict(torch.load(pretrained_path, map_location="cpu"))
@@ -176,7 +176,21 @@ class FrozenAutoencoderKL(nn.Module):
     # ---- precision-aware FLOP carriers (same contract as guided_diffusion.unet_openai._Ctx)
     @property
     def split_acts(self):
-        return self.precision == "bf16x3"
+        return "f16x3" if self.precision == "f16x3" else self.precision == "bf16x3"
+
+    def raw_planes(self, h, resample=0):
+        """Raw fp32 NHWC map (no norm in front of the up-sampler conv) -> f16x3 operand planes, optionally nearest x2: the
+        GroupNorm-apply kernel with identity statistics (exact) at the raw-stream scale."""
+        N, H, W, C = h.shape
+        if not (self.precision == "f16x3" and C % 32 == 0):
+            return ops.resample2x(h, 1) if resample > 0 else h
+        key = ("identity_gn", N, C)
+        if key not in self._packed:
+            st = torch.zeros((N, 32, 2), device=h.device, dtype=torch.float32)
+            st[:, :, 1] = 1.0
+            self._packed[key] = (st, torch.ones(C, device=h.device), torch.zeros(C, device=h.device))
+        st, one, zero = self._packed[key]
+        return ops.groupnorm_apply(h, st, one, zero, act=0, resample=resample, groups=32, split="f16x3", split_scale=ops.F16X3_RAW_SCALE)
 
     def _pack(self, key, fn):
         if key not in self._packed:
@@ -184,6 +198,9 @@ class FrozenAutoencoderKL(nn.Module):
         return self._packed[key]
 
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False):
+        if isinstance(h, ops.SplitPlanes) and h.fmt == "f16x3":
+            packed = self._pack((id(conv), "w3h"), lambda: ops.pack_weight_f16x3(conv.weight.detach().contiguous()))
+            return ops.conv3x3_bf16x3(h, packed, conv.bias, cout, residual=residual, nchw_out=nchw_out)
         if isinstance(h, ops.SplitPlanes) or (self.precision == "bf16x3" and h.shape[3] % 32 == 0):
             planes = self._pack((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
             return ops.conv3x3_bf16x3(h, planes, conv.bias, cout, residual=residual, nchw_out=nchw_out)
@@ -192,6 +209,9 @@ class FrozenAutoencoderKL(nn.Module):
 
     def linear(self, a, mod, residual=None, alpha=1.0):
         n_out = mod.weight.shape[0]
+        if self.precision == "f16x3" and a.shape[1] % 32 == 0:
+            packed = self._pack((id(mod), "w1h"), lambda: ops.pack_weight_f16x3(mod.weight.detach().reshape(n_out, -1).contiguous()))
+            return ops.gemm_f16x3(a, packed, n_out, bias=mod.bias, residual=residual, alpha=alpha)
         if self.precision == "bf16x3" and a.shape[1] % 32 == 0:
             planes = self._pack((id(mod), "w1x"), lambda: ops.pack_weight_bf16x3(mod.weight.detach().reshape(n_out, -1).contiguous()))
             return ops.gemm_bf16x3(a, planes, n_out, bias=mod.bias, residual=residual, alpha=alpha)
@@ -205,6 +225,9 @@ class FrozenAutoencoderKL(nn.Module):
             b = torch.cat([blk.q.bias.detach(), blk.k.bias.detach(), blk.v.bias.detach()])
             return w.contiguous(), b.contiguous()
         w, b = self._pack((id(blk), "qkv"), cat)
+        if self.precision == "f16x3" and xn.shape[1] % 32 == 0:
+            return ops.gemm_f16x3(xn, self._pack((id(blk), "qkvh"), lambda: ops.pack_weight_f16x3(w)), w.shape[0], bias=b,
+                                  act_scale=ops.F16X3_ACT_SCALE)
         if self.precision == "bf16x3" and xn.shape[1] % 32 == 0:
             planes = self._pack((id(blk), "qkvx"), lambda: ops.pack_weight_bf16x3(w))
             return ops.gemm_bf16x3(xn, planes, w.shape[0], bias=b)
@@ -236,9 +259,8 @@ class FrozenAutoencoderKL(nn.Module):
             for blk in d.up[i_level].block:
                 h = blk.run(self, h)
             if i_level != 0:
-                h = ops.resample2x(h, 1)                                                         # nearest x2 (:38)
-                up = d.up[i_level].upsample.conv
-                h = self.conv3x3(h, up, up.out_channels)
+                up = d.up[i_level].upsample.conv                                                 # nearest x2 (:38)
+                h = self.conv3x3(self.raw_planes(h, resample=1), up, up.out_channels)
         st = ops.groupnorm_stats(h, eps=1e-6)
         h = ops.groupnorm_apply(h, st, d.norm_out.weight, d.norm_out.bias, act=1, split=self.split_acts)
         return self.conv3x3(h, d.conv_out, d.conv_out.out_channels, nchw_out=True)

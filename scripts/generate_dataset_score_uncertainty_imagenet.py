@@ -75,7 +75,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         if not ckpt:
             randomize_parameters_(ae, seed=9)
         uvit.precision = "f16f8" if args.precision == "f16f6" else args.precision            # f16f6 is a 3x3-conv format: ADM only
-        ae.precision = "fp32" if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch): exact fp32 in the parity modes
+        ae.precision = args.precision if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch)
         model = UViTAE(uvit, ae).to(device)
         scheduler = load_uvit_scheduler()
     uc_scheduler = get_uncertainty_scheduler(args, y.to(device), model, scheduler)

@@ -339,7 +339,7 @@ def test_bf16x3_mode_uvit(golden, precision):
         np.testing.assert_allclose(ot.cpu().numpy(), gt["tiny_out"], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3"])
 def test_vae_decode_vs_golden(golden, precision):
     """KL-VAE decoder: full-size f8 decoder, 32x32 latents -> 256x256, vs the reference's output."""
     from diffusion_uncertainty_amd.uvit.autoencoder import FrozenAutoencoderKL, get_model
