@@ -26,6 +26,11 @@ struct AttnP {
     void* out_planes;        // split kernel only: write the result as f16f8 planes [B*T][C] (operand of the presplit proj GEMM)
     long plane_elems;
     float planes_scale;      // f16x3 kernel: out_planes holds fp16 hi | fp16 lo of out * planes_scale
+    // split kernels only: keys / values from their own tensors (cross-attention).  k == NULL: the packed (q | k | v) rows above.
+    // q rows at qkv + (b*T + t)*ldq, keys at k + (b*Tk + s)*ldkv, values at v + (b*Tk + s)*ldkv; head h at column h*ch.
+    const float *k, *v;
+    long ldq, ldkv;
+    int Tk;
 };
 
 template <int CT /* 32-channel tiles: ceil(ch/32) */, int QW /* waves (32 queries each) per workgroup */>
@@ -218,13 +223,17 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     const int lr = lane & 31, kh = lane >> 5;
     const int b = blockIdx.y / p.heads, h = blockIdx.y % p.heads;
     const int q0 = blockIdx.x * (QW * 32);
-    const float* base = p.qkv + (long)b * T * 3 * C + h * ch;
+    const int Tk = p.k ? p.Tk : T;                                       // keys (cross-attention: its own count and tensors)
+    const long ldq = p.k ? p.ldq : 3L * C, ldk = p.k ? p.ldkv : 3L * C;
+    const float* base = p.qkv + (long)b * T * ldq + h * ch;
+    const float* kbase = p.k ? p.k + (long)b * Tk * ldk + h * ch : base + C;
+    const float* vbase = p.k ? p.v + (long)b * Tk * ldk + h * ch : base + 2 * C;
     constexpr int nthr = 64 * QW;
 
     // ---- this lane's query row, scaled and split once: element j of step c = channel 16c + 8kh + j
     abf16x8 qh[CT16], ql[CT16];
     {
-        const float* qrow = base + (long)min(q0 + wave * 32 + lr, T - 1) * 3 * C;
+        const float* qrow = base + (long)min(q0 + wave * 32 + lr, T - 1) * ldq;
 #pragma unroll
         for (int c = 0; c < CT16; ++c) {
             const int c0 = 16 * c + 8 * kh;
@@ -260,27 +269,27 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
         const int i = tid + j * nthr;
         const bool live = i < 32 * c4;
         const int r = live ? i / c4 : 0, c = live ? 4 * (i % c4) : 0;
-        goff[j] = r * 3 * C + C + c;
+        goff[j] = r * (int)ldk + c;
         kcol[j] = c;
         krow[j] = live ? r : (1 << 30);
     }
     float4 kr[NL], vr[NL];
 #define DUA_ATTNX_FETCH(KT)                                                                                          \
     {                                                                                                                \
-        const long adv = (long)(KT) * 32 * 3 * C;                                                                    \
+        const long adv = (long)(KT) * 32 * ldk;                                                                      \
         _Pragma("unroll") for (int j = 0; j < NL; ++j) {                                                             \
-            const bool ok = (KT) * 32 + krow[j] < T;                                                                 \
+            const bool ok = (KT) * 32 + krow[j] < Tk;                                                                \
             kr[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
             vr[j] = kr[j];                                                                                           \
             if (ok) {                                                                                                \
-                kr[j] = *(const float4*)(base + adv + goff[j]);                                                      \
-                vr[j] = *(const float4*)(base + adv + goff[j] + C);                                                  \
+                kr[j] = *(const float4*)(kbase + adv + goff[j]);                                                     \
+                vr[j] = *(const float4*)(vbase + adv + goff[j]);                                                     \
             }                                                                                                        \
         }                                                                                                            \
     }
     DUA_ATTNX_FETCH(0)
 
-    const int nkt = (T + 31) / 32;
+    const int nkt = (Tk + 31) / 32;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                     // previous tile's readers are done
 #pragma unroll
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            s[r] = key < T ? (F16 ? s[r] * (1.0f / (DUA_AX_SQ * DUA_AX_SK)) : s[r]) : -INFINITY;
+            s[r] = key < Tk ? (F16 ? s[r] * (1.0f / (DUA_AX_SQ * DUA_AX_SK)) : s[r]) : -INFINITY;
             mloc = fmaxf(mloc, s[r]);
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
@@ -402,6 +411,20 @@ extern "C" int dua_attention_f16x3(const float* qkv, float* out, void* out_plane
     DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_f16x3: B*heads must be <= 65535");
     DUA_REQUIRE(!out_planes || planes_scale > 0.f, "dua_attention_f16x3: planes_scale must be positive");
     AttnP p{qkv, out, T, heads, ch, scale, out_planes, (long)B * T * heads * ch, planes_scale};
+    return attention_x_launch(p, B, stream, true);
+}
+
+/* Cross-attention on the same kernel: queries [B*Tq][ldq], keys / values [B*Tk][ldkv] from their own tensors (Tk: e.g. 77 text tokens). */
+extern "C" int dua_cross_attention_f16x3(const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, void* out_planes,
+                                         float planes_scale, int B, int Tq, int Tk, int heads, int ch, float scale, void* stream) {
+    DUA_REQUIRE(q && k && v && (out || out_planes) && B > 0 && Tq > 0 && Tk > 0 && heads > 0, "dua_cross_attention_f16x3: bad arguments");
+    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_cross_attention_f16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
+    DUA_REQUIRE(ldq >= (long)heads * ch && ldkv >= (long)heads * ch && ldq % 4 == 0 && ldkv % 4 == 0 && ldkv * 32 < (1L << 31),
+                "dua_cross_attention_f16x3: row strides must cover heads*ch and be multiples of 4");
+    DUA_REQUIRE(((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0), "dua_cross_attention_f16x3: operands must be 16-byte aligned");
+    DUA_REQUIRE((long)B * heads <= 65535, "dua_cross_attention_f16x3: B*heads must be <= 65535");
+    DUA_REQUIRE(!out_planes || planes_scale > 0.f, "dua_cross_attention_f16x3: planes_scale must be positive");
+    AttnP p{q, out, Tq, heads, ch, scale, out_planes, (long)B * Tq * heads * ch, planes_scale, k, v, ldq, ldkv, Tk};
     return attention_x_launch(p, B, stream, true);
 }
 

@@ -352,16 +352,27 @@ def pick_even(x):
     return y
 
 
-def attention(q, k, v, heads):
+def attention(q, k, v, heads, precision="fp32", planes_out=False):
     """Multi-head attention with separate operands (cross-attention): q [B, Tq, C], k / v [B, Tk, C], heads of C/heads
-    channels, softmax(q k^T / sqrt(ch)) v -> [B, Tq, C].  fp32 MFMA products with the logits in HBM (the SD-1.5 shapes
-    are small: Tk = 77 for the text context)."""
+    channels, softmax(q k^T / sqrt(ch)) v -> [B, Tq, C].  fp32: MFMA products with the logits in HBM (the SD-1.5 shapes
+    are small: Tk = 77 for the text context).  precision="f16x3" (head dims <= 128): the split flash kernel in ONE launch,
+    optionally with the result as f16x3 planes [B*Tq, C] (operand of the presplit to_out GEMM)."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):
         _req(t, name=nm)
     B, Tq, C = q.shape
     Tk = k.shape[1]
     ch = C // heads
     assert k.shape == (B, Tk, C) and v.shape == (B, Tk, C) and C % heads == 0 and ch % 4 == 0 and B * heads <= 65535
+    if precision == "f16x3" and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
+        if planes_out and C % 32 == 0:
+            buf = torch.empty((2, B * Tq, C), device=q.device, dtype=torch.int16)
+            check(_lib.lib().dua_cross_attention_f16x3(_p(q), C, _p(k), _p(v), C, None, _p(buf), F16X3_RAW_SCALE, B, Tq, Tk, heads, ch,
+                                                       1.0 / math.sqrt(ch), _stream()), "dua_cross_attention_f16x3")
+            return SplitPlanes(buf, (B * Tq, C), "f16x3", F16X3_RAW_SCALE)
+        out = torch.empty((B, Tq, C), device=q.device, dtype=torch.float32)
+        check(_lib.lib().dua_cross_attention_f16x3(_p(q), C, _p(k), _p(v), C, _p(out), None, 0.0, B, Tq, Tk, heads, ch,
+                                                   1.0 / math.sqrt(ch), _stream()), "dua_cross_attention_f16x3")
+        return out
     Tp = (Tk + 3) // 4 * 4
     S = torch.empty((B * heads, Tq, Tp), device=q.device, dtype=torch.float32)
     out = torch.empty((B, Tq, C), device=q.device, dtype=torch.float32)

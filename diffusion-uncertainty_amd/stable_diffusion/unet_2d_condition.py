@@ -107,7 +107,10 @@ class BasicTransformerBlock(nn.Module):
         Tk = enc.shape[1]
         e2 = enc.reshape(B * Tk, -1)
         k, v = ctx.gemm(e2, self.attn2.to_k.weight, None), ctx.gemm(e2, self.attn2.to_v.weight, None)
-        a = ops.attention(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), heads).view(B * T, C)
+        a = ops.attention(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), heads, precision=ctx.attn_precision,
+                          planes_out=ctx.f16x3)
+        if not isinstance(a, ops.SplitPlanes):
+            a = a.view(B * T, C)
         h = ctx.gemm(a, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias, residual=h)
         n3 = ctx.norm_rows(h, self.norm3)
         u = ctx.gemm(n3, self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)

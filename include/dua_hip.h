@@ -313,6 +313,10 @@ int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, 
  * dua_gemm_f16x3_presplit (proj_out, unet_openai.py:295); otherwise fp32 `out`. */
 int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float planes_scale, int B, int T, int heads, int ch,
                         float scale, void* stream);
+/* ... with keys / values from their own tensors (cross-attention, diffusers Attention with encoder_hidden_states): q rows
+ * [B*Tq][ldq], k / v rows [B*Tk][ldkv], head h at column h*ch of each; Tk any (77 text tokens). */
+int dua_cross_attention_f16x3(const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, void* out_planes,
+                              float planes_scale, int B, int Tq, int Tk, int heads, int ch, float scale, void* stream);
 /* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
 int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                               void* stream);

@@ -285,58 +285,6 @@ def test_conv3x3(ops, N, H, W, Cin, Cout):
     np.testing.assert_allclose(y.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5)
 
 
-def test_geglu_and_split_planes(ops):
-    """GEGLU (diffusers activations.GEGLU, exact erf GELU) in fp32 and as f16x3 operand planes (hi + lo = 22 significant bits of y * scale)."""
-    u = rnd(70, 37, 256) * 3
-    a, g = u.chunk(2, dim=-1)
-    ref = (a.double() * F.gelu(g.double()))
-    y = ops.geglu(u.to(dev)).cpu()
-    assert (y.double() - ref).abs().max().item() < 1e-5
-    pl = ops.geglu(u.to(dev), split="f16x3")
-    assert pl.fmt == "f16x3" and pl.shape == (37, 128) and pl.scale == ops.F16X3_RAW_SCALE
-    buf = pl.buf.view(torch.uint8).reshape(2, -1).cpu()
-    hi, lo = buf[0].view(torch.float16).reshape(37, 128).double(), buf[1].view(torch.float16).reshape(37, 128).double()
-    np.testing.assert_array_equal(hi.float().numpy(), (y * pl.scale).half().float().numpy())
-    assert ((hi + lo) / pl.scale - y.double()).abs().max().item() <= 2.0 ** -25 / pl.scale + 2.0 ** -21 * y.abs().max().item()
-
-
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 1280, 1280), (2, 32, 32, 640, 320), (1, 8, 8, 1280, 1280), (3, 20, 20, 96, 200),
-                                             (2, 64, 64, 320, 320)])
-def test_conv3x3_f16x3_split_k(ops, N, H, W, Cin, Cout):
-    """Split-K of launches that cannot fill the chip (dua_set_splitk_workspace): the K range of every tile on several workgroups, the
-    parts folded in index order by a second kernel together with bias / residual / GroupNorm statistics.  Held to the single-pass
-    kernel's error against fp64; statistics equal those recomputed from the output; two runs bit-identical."""
-    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
-    res = rnd(23, N, Cout, H, W)
-    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
-    xs = _f16x3_planes(ops, nhwc(x))
-    packed = ops.pack_weight_f16x3(w.to(dev))
-    single = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
-    prev = ops.set_split_k(True, dev)
-    try:
-        y = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
-        y2 = ops.conv3x3_bf16x3(xs, packed, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
-        st = ops.groupnorm_stats(y, groups=Cout // 8 if Cout % 8 == 0 else 4)          # from the reducer's column sums
-        w1 = rnd(24, Cout, Cin) / math.sqrt(Cin)
-        c = ops.gemm_bf16x3_presplit(xs, ops.pack_weight_f16x3(w1.to(dev)), Cout, bias=b.to(dev))
-    finally:
-        ops.set_split_k(prev, dev)
-    e_split = (nchw(y.cpu()).double() - ref).abs().max().item()
-    e_single = (nchw(single.cpu()).double() - ref).abs().max().item()
-    print(f"split-K err {e_split:.2e}  single-pass err {e_single:.2e}  differ: {not torch.equal(y, single)}")
-    assert e_split < max(2 * e_single, 2e-6 * ref.abs().max().item())
-    np.testing.assert_array_equal(y.cpu().numpy(), y2.cpu().numpy())
-    y_plain = y.clone()                                                        # (no attached statistics: the stand-alone kernels)
-    st_ref = ops.groupnorm_stats(y_plain, groups=Cout // 8 if Cout % 8 == 0 else 4)
-    if (H * W) % 64 == 0:
-        assert getattr(y, "_dua_colsums", None) is not None
-    np.testing.assert_allclose(st.cpu().numpy(), st_ref.cpu().numpy(), rtol=2e-4, atol=2e-5)
-    ref1 = nhwc(x).reshape(-1, Cin).double() @ w1.double().t() + b.double()
-    c32 = ops.gemm(nhwc(x).reshape(-1, Cin).to(dev), w1.to(dev), bias=b.to(dev))
-    e1, e32 = (c.cpu().double() - ref1).abs().max().item(), (c32.cpu().double() - ref1).abs().max().item()
-    assert e1 < max(2 * e32, 2e-6 * ref1.abs().max().item()), (e1, e32)
-
-
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0),
                                        (258, 1152, 16, 0), (130, 260, 100, 0)])
 def test_gemm(ops, M, N, K1, K2):
@@ -580,6 +528,26 @@ def test_conv3x3_f16x3(ops, N, H, W, Cin, Cout):
     c32 = ops.gemm(nhwc(x).reshape(-1, Cin).to(dev), w1.to(dev), bias=b.to(dev))
     e1, e32 = (c.cpu().double() - ref1).abs().max().item(), (c32.cpu().double() - ref1).abs().max().item()
     assert e1 < max(2 * e32, 2e-6 * ref1.abs().max().item()), (e1, e32)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,heads,ch", [(2, 256, 77, 8, 40), (1, 64, 7, 4, 8), (3, 1024, 77, 8, 80), (2, 100, 33, 2, 128)])
+def test_cross_attention_f16x3(ops, B, Tq, Tk, heads, ch):
+    """The split flash kernel with keys / values from their own tensors (cross-attention: Tk != Tq, e.g. 77 text tokens): against fp64,
+    held to the error of the fp32 GEMM path; planes output decodes to the same values."""
+    C = heads * ch
+    q, k, v = rnd(80, B, Tq, C), rnd(81, B, Tk, C), rnd(82, B, Tk, C)
+    sp = lambda z: z.double().reshape(B, z.shape[1], heads, ch).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, Tq, C)
+    o32 = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads).cpu()
+    o = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads, precision="f16x3").cpu()
+    e32, e = (o32.double() - ref).abs().max().item(), (o.double() - ref).abs().max().item()
+    print(f"cross-attention f16x3 err {e:.2e}  fp32 GEMM path {e32:.2e}")
+    assert e < max(3 * e32, 3e-6)
+    if C % 32 == 0:
+        pl = ops.attention(q.to(dev), k.to(dev), v.to(dev), heads, precision="f16x3", planes_out=True)
+        buf = pl.buf.view(torch.uint8).reshape(2, -1).cpu()
+        dec = (buf[0].view(torch.float16).double() + buf[1].view(torch.float16).double()).reshape(B, Tq, C) / pl.scale
+        assert (dec - o.double()).abs().max().item() < 1e-6
 
 
 def test_geglu_and_split_planes(ops):
