@@ -539,7 +539,8 @@ extern "C" int dua_debug_tile_times(unsigned long long* host) {
 //   outside the image (zero): the taps read the same LDS stage at rows r-1, r, r+1 and zero the lanes at the image's left /
 //   right edge in registers.  Activation traffic L2 -> LDS drops to a third (the taps of a stage used to be re-fetched from L2:
 //   92 % L2 hits but 8 TB/s through the L2s, the limiter of the f16f8 K loop next to the matrix cores).
-template <int NT, int FMT, bool RS = false>
+template <int NT, int FMT, bool RS = false, bool KS = false /* split-K work items (DConvP::ksplit): its own instantiation, so that the
+                                                               single-pass kernels compile exactly as they did without it */>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
     constexpr int DBN = 64 * NT;
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
     // blockIdx % 8) own one contiguous chunk of tiles and sweep it side by side, so concurrently running workgroups
     // of an XCD work on neighbouring tiles (shared halo rows / weight panel in that XCD's L2).  A workgroup moves to
     // its next tile right after issuing its output stores: they drain while the next tile's first DMA is in flight.
-    constexpr bool KSPLIT_OK = (FMT == 0 || FMT == 3) && !RS;
+    constexpr bool KSPLIT_OK = KS;
+    static_assert(!KS || ((FMT == 0 || FMT == 3) && !RS), "split-K is built for the per-tap bf16x3 / f16x3 loops");
     const int S = KSPLIT_OK && p.ksplit > 1 ? p.ksplit : 1;          // split-K parts per tile (see DConvP::ksplit)
     const int ntiles = p.ntm * p.ntn * S;
     const int nk = p.K / BK;
@@ -1578,8 +1580,8 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
             d.ksplit = S;
             d.kpart = dua_splitk_ws;
             const int items = ntiles * S;
-            if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(items < 256 ? items : 256), 512, 0, st, d);
-            else hipLaunchKernelGGL((k_xconv_dma<2, 3>), dim3(items < 256 ? items : 256), 512, 0, st, d);
+            if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3, false, true>), dim3(items < 256 ? items : 256), 512, 0, st, d);
+            else hipLaunchKernelGGL((k_xconv_dma<2, 3, false, true>), dim3(items < 256 ? items : 256), 512, 0, st, d);
             hipLaunchKernelGGL(k_splitk_reduce, dim3((d.M + 63) / 64, (d.N + 63) / 64), 256, 0, st, d.kpart, S, d.bias, d.res, d.C, d.colsum, d.M, d.N);
             return dua_check_launch(what);
         }
