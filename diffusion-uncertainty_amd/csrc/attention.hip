@@ -209,6 +209,18 @@ template <> struct AT<true> { typedef _Float16 e; typedef af16x8 v8; typedef af1
 #define DUA_AX_SP 4096.0f
 #define DUA_AX_SV 16.0f
 
+// Two ds_read_b64_tr_b16 (gfx950 transposed LDS read; EXEC must be full): 4 + 4 sixteen-bit elements -> one 8-element MFMA operand
+template <typename V8, typename E>
+__device__ __forceinline__ V8 tr_pair(const E* a, const E* b) {
+    typedef short s4_t __attribute__((__vector_size__(4 * sizeof(short))));
+    const s4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)a);
+    const s4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t*)b);
+    struct { s4_t lo, hi; } pr{x, y};
+    V8 r;
+    __builtin_memcpy(&r, &pr, 16);
+    return r;
+}
+
 template <int CT16 /* 16-channel steps: ceil(ch/16) */, int QW, bool F16 = false>
 __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     typedef typename AT<F16>::e el;
@@ -216,8 +228,12 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     typedef typename AT<F16>::v4 abf16x4;
     constexpr int CHP = CT16 * 16, CT32 = (CHP + 31) / 32;
     constexpr int KP = CHP + 8;          // K tile row pitch (bf16): 16-byte reads of 16 consecutive rows hit distinct banks
-    constexpr int VP = 40;               // V^T row pitch (32 keys + 8)
-    __shared__ __attribute__((aligned(16))) el Kh[32 * KP], Kl[32 * KP], Vh[CT32 * 32 * VP], Vl[CT32 * 32 * VP];
+    // V tile row-major [key][channel] like K, read TRANSPOSED by ds_read_b64_tr_b16 (a 16-lane group fetches a 4-key x 16-channel block
+    // and every lane receives its channel's 4 keys): the staging writes are 8-byte row writes instead of 2-byte column writes, which
+    // were 16-way bank-conflicted (80 % of the LDS cycles of this kernel were conflict cycles).  Row pitch = 32 or 96 (mod 128)
+    // elements: the 4 key rows of a block then start 16 dwords apart (mod 64) and a 32-lane half covers all 64 banks once.
+    constexpr int VPR = CT32 * 32 <= 32 ? 32 : (CT32 * 32 <= 96 ? 96 : 160);
+    __shared__ __attribute__((aligned(16))) el Kh[32 * KP], Kl[32 * KP], Vh[32 * VPR], Vl[32 * VPR];
     const int ch = p.ch, C = p.heads * ch, T = p.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, kh = lane >> 5;
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     }
     // ---- zero the padded channel columns of the K tile (they meet zero Q channels: must not be NaN patterns) and all of V^T
     for (int i = tid; i < 32 * KP; i += nthr) { Kh[i] = (el)0.f; Kl[i] = (el)0.f; }
-    for (int i = tid; i < CT32 * 32 * VP; i += nthr) { Vh[i] = (el)0.f; Vl[i] = (el)0.f; }
+    for (int i = tid; i < 32 * VPR; i += nthr) { Vh[i] = (el)0.f; Vl[i] = (el)0.f; }
 
     f32x16 o[CT32];
 #pragma unroll
@@ -302,15 +318,11 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
                 for (int u = 0; u < 4; ++u) { el x_, y_; asplit(F16 ? kf[u] * DUA_AX_SK : kf[u], x_, y_); a_[u] = x_; b_[u] = y_; }
                 *(abf16x4*)(Kh + r * KP + c) = a_;
                 *(abf16x4*)(Kl + r * KP + c) = b_;
-                // V^T with the key order of the accumulator rows: key = 16s + 8(j>>2) + 4h + (j&3)  <->  position 16s + 8h + j
-                const int kk = r & 15, pos = (r & 16) + 8 * ((kk >> 2) & 1) + 4 * (kk >> 3) + (kk & 3);
+                abf16x4 c_, d_;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    el x_, y_;
-                    asplit(F16 ? vf[u] * DUA_AX_SV : vf[u], x_, y_);
-                    Vh[(c + u) * VP + pos] = x_;
-                    Vl[(c + u) * VP + pos] = y_;
-                }
+                for (int u = 0; u < 4; ++u) { el x_, y_; asplit(F16 ? vf[u] * DUA_AX_SV : vf[u], x_, y_); c_[u] = x_; d_[u] = y_; }
+                *(abf16x4*)(Vh + r * VPR + c) = c_;
+                *(abf16x4*)(Vl + r * VPR + c) = d_;
             }
         __syncthreads();
         DUA_ATTNX_FETCH(kt + 1)
@@ -359,8 +371,10 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
         for (int t = 0; t < CT32; ++t)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const abf16x8 vh = *(const abf16x8*)(Vh + (32 * t + lr) * VP + 16 * s2 + 8 * kh),
-                              vl = *(const abf16x8*)(Vl + (32 * t + lr) * VP + 16 * s2 + 8 * kh);
+                // A operand of O^T += V^T P^T: lane (lr, kh) = channel 32t + lr, k index j = key 16 s2 + 8 (j >> 2) + 4 kh + (j & 3) of the
+                // tile (the order of the accumulator rows that hold P): two transposed 4-key blocks, keys r0 .. r0+3 and r0+8 .. r0+11
+                const int vo = (16 * s2 + 4 * kh + ((lr >> 2) & 3)) * VPR + 32 * t + 16 * (lr >> 4) + 4 * (lr & 3);
+                const abf16x8 vh = tr_pair<abf16x8>(Vh + vo, Vh + vo + 8 * VPR), vl = tr_pair<abf16x8>(Vl + vo, Vl + vo + 8 * VPR);
                 o[t] = amfma(vl, ph[s2], o[t]);
                 o[t] = amfma(vh, pl[s2], o[t]);
                 o[t] = amfma(vh, ph[s2], o[t]);
