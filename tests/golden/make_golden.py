@@ -597,6 +597,52 @@ def g13():
     save("g13_adm128_chain", **out)
 
 
+def g17():
+    """Full-size U-ViT-H/2 + full KL-VAE decoder through the REFERENCE latent driver (generate_samples.py:469-570) and the reference
+    scheduler (uncertainty_zigzag_centered, U-ViT scheduler config): B=1, 10 DDIM steps, M=2, num_zigzag=3, UC window (after_step 6,
+    3 steps), seeded weights; torch's CPU generator re-seeded before every scheduler.step() (seed 7000 + step index) like G13."""
+    with _quiet:
+        from diffusion_uncertainty.uvit import autoencoder as ref_ae
+        from diffusion_uncertainty.uvit.uvit_ae import UViTAE as RefUViTAE
+
+    class RefKL(ref_ae.FrozenAutoencoderKL):
+        def __init__(self, ddconfig, embed_dim, scale_factor):
+            torch.nn.Module.__init__(self)
+            self.encoder = ref_ae.Encoder(**ddconfig)
+            self.decoder = ref_ae.Decoder(**ddconfig)
+            self.quant_conv = torch.nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+            self.post_quant_conv = torch.nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+            self.embed_dim, self.scale_factor = embed_dim, scale_factor
+
+    uvit = build_uvit(UVIT_H2, 7)
+    dd = dict(double_z=True, z_channels=4, in_channels=3, out_ch=3, attn_resolutions=[], dropout=0.0, resolution=256, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2)
+    with _quiet:
+        ae = RefKL(dd, 4, 0.18215)
+    ae.load_state_dict(seeded_state_dict({k: v.shape for k, v in ae.state_dict().items()}, 9))
+    ae.eval()
+    model = RefUViTAE(uvit, ae)
+    X_T, y = randn(171, 1, 4, 32, 32), torch.tensor([417])
+    with _quiet:
+        s = RefZigzag.from_config(CONFIGS["uvit"], M=2, after_step=6, num_steps_uc=3, unet=model, num_zigzag=3)
+        s.set_timesteps(10)
+    ref_step, k = s.step, [0]
+
+    def seeded_step(*a, **kw):
+        torch.manual_seed(7000 + k[0])
+        k[0] += 1
+        return ref_step(*a, **kw)
+
+    s.step = seeded_step
+    with _quiet, torch.no_grad():
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(X_T, y, 1, model, s, "cpu")
+    u = r["uncertainty"][:, -1]
+    q = torch.quantile(u.flatten(1).float(), 0.9, dim=1)
+    save("g17_uvit_h2_chain", X_T=X_T, y=y, uvit_seed=7, vae_seed=9, timesteps=s.timesteps, gen_images=r["gen_images"],
+         uncertainty=r["uncertainty"], score=r["score"], window=np.array([6, 3, s.timestep_after_step, s.timestep_end_step]),
+         final_mask=(u > q.reshape(-1, 1, 1, 1)).to(torch.uint8))
+
+
 def g14():
     """Dataset-level pixel-wise thresholds from the reference script itself: scripts/compute_threshold_pixel_wise.py
     ``load_uncertainty_datasets`` (:118-165) run on temporary folders of ``uncertainty_*.pth`` / ``gen_images_*.pth`` files."""
@@ -700,6 +746,6 @@ def g16():
 
 
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -688,6 +688,52 @@ def test_full_size_chain_vs_golden(golden, precision):
     assert es < tol_s and eu < tol_u and d.max() <= tol_lsb and agree >= tol_mask
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16f8"])
+def test_uvit_full_size_chain_vs_golden(golden, precision):
+    """BASELINE configs[2] end to end at full size: U-ViT-H/2 + the full KL-VAE decoder through the latent driver, 10 DDIM steps,
+    M=2, num_zigzag=3, window (6, 3), free-running against the REFERENCE driver's own run (G17: reference U-ViT, scheduler, driver and
+    VAE; same seeded weights, same noise tape).  The fp32-equivalent modes are held to the north star's 1e-3 on the score maps."""
+    from diffusion_uncertainty_amd import ops
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_uvit_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import load_autoencoder_uvit, load_uvit, load_uvit_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
+    g = golden("g17_uvit_h2_chain")
+    uvit = load_uvit(256, device="cpu", load_checkpoint=False)
+    uvit.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in uvit.state_dict().items()}, int(g["uvit_seed"])))
+    ae = load_autoencoder_uvit(device="cpu", load_checkpoint=False)
+    ae.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in ae.state_dict().items()}, int(g["vae_seed"])), strict=True)
+    uvit.precision = precision
+    ae.precision = precision if precision in ("fp32", "f16x3") else "bf16x3"
+    model = UViTAE(uvit, ae).to(dev)
+    after, num = int(g["window"][0]), int(g["window"][1])
+    a = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=2, start_step_uc=after, num_steps_uc=num, predict_next=True,
+                           eta=0.0, num_zigzag=3, uncertainty_distance=1)
+    s = get_uncertainty_scheduler(a, None, model, load_uvit_scheduler())
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == [int(t) for t in g["timesteps"]]
+    assert (s.timestep_after_step, s.timestep_end_step) == (int(g["window"][2]), int(g["window"][3]))
+    inner, k = s.step, [0]
+
+    def seeded_step(*aa, **kw):
+        torch.manual_seed(7000 + k[0])
+        k[0] += 1
+        return inner(*aa, **kw)
+
+    s.step = seeded_step
+    r = gen(T(g["X_T"]), T(g["y"]), 1, model, s, device=dev)
+    es = np.abs(r["score"].numpy() - g["score"]).max()
+    eu = (np.abs(r["uncertainty"].numpy() - g["uncertainty"]) / (np.abs(g["uncertainty"]) + 1e-3 * np.abs(g["uncertainty"]).max())).max()
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["gen_images"].astype(int))
+    mask, _q = ops.quantile_mask(r["uncertainty"][:, -1].contiguous().to(dev), 0.9)
+    agree = (mask.cpu().numpy() == g["final_mask"]).mean()
+    print(f"uvit-h/2 chain {precision}: score err {es:.2e} (|score|max {np.abs(g['score']).max():.2f}), uncertainty rel err {eu:.2e}, "
+          f"image LSB diffs {(d > 0).mean():.2e} (max {d.max()}), percentile-0.9 mask agreement {100 * agree:.3f} %")
+    tol_s, tol_u, tol_lsb, tol_mask = {"fp32": (1e-3, 2.5e-2, 1, 0.99), "f16x3": (1e-3, 2.5e-2, 1, 0.99), "f16f8": (1e-2, 0.6, 3, 0.95)}[precision]
+    assert es < tol_s and eu < tol_u and d.max() <= tol_lsb and agree >= tol_mask
+
+
 def test_thresholds_vs_reference_script(golden):
     """a15: dua_pixelwise_order_statistic against the reference script's own load_uncertainty_datasets outputs (G14), bit for bit."""
     from diffusion_uncertainty_amd.thresholds import compute_threshold_pixel_wise

@@ -467,3 +467,21 @@ def test_g16_flip(golden):
             seen += 1
             np.testing.assert_allclose(o["uncertainty"].numpy(), g[f"c{c}_unc"], rtol=1e-4, atol=1e-7)
     assert seen == 4
+
+
+def test_g13_g17_chain_fixtures_are_self_consistent(golden):
+    """The free-running full-size chain fixtures (G13 ADM-128, G17 U-ViT-H/2 + VAE; reference driver outputs): the timestep grid
+    is the oracle's for the model's scheduler config, the UC window bounds follow from it, and the stored percentile-0.9 mask is the
+    oracle's exact quantile mask of the last uncertainty map (the GPU tests compare against these fields)."""
+    from oracle import guidance, schedule
+    for name, kw in (("g13_adm128_chain", {}), ("g17_uvit_h2_chain", dict(steps_offset=1))):
+        g = golden(name)
+        ts = [int(t) for t in g["timesteps"]]
+        assert ts == [int(t) for t in schedule.leading_timesteps(1000, 10, **kw)], name
+        after, num = int(g["window"][0]), int(g["window"][1])
+        assert (int(g["window"][2]), int(g["window"][3])) == schedule.uc_window(ts, after, num)
+        u = np.ascontiguousarray(g["uncertainty"][:, -1]).astype(np.float32)
+        assert g["uncertainty"].shape[1] == num and np.isfinite(u).all() and (u >= 0).all()
+        mask, _q = guidance.quantile_mask(u, 0.9)
+        np.testing.assert_array_equal(mask, g["final_mask"])
+        assert g["gen_images"].dtype == np.uint8
