@@ -643,6 +643,36 @@ def g17():
          final_mask=(u > q.reshape(-1, 1, 1, 1)).to(torch.uint8))
 
 
+def g18():
+    """BASELINE configs[0] as it stands ("ADM ImageNet-64, 10 DDIM steps, M=2, batch 4 on CPU reference path"),
+    full-size ADM-64 (dropout 0.1) through the REFERENCE driver and schedulers, UC window = all 10 steps, synthetic starting points
+    exactly as scripts/generate_diffusion_starting_data.py:27-49 (seed 49394 + 0), torch.manual_seed(0) before the driver (script
+    default --seed 0): (a) uncertainty_zigzag_centered, num_zigzag=3 (70 forwards), (b) mc_dropout (30 forwards, masks from the CPU
+    generator).  Kept: images, and the score / uncertainty maps of steps 0, 5, 9 plus per-step means of all ten."""
+    CONFIGS["adm64"]["trained_betas"] = cosine_trained_betas()
+    m = build_adm(ADM64, 64)
+    gen = torch.Generator("cpu").manual_seed(49394 + 0)
+    X_T = torch.randn(4, 3, 64, 64, generator=gen)
+    y = torch.randint(0, 1000, (4,), generator=gen)
+    out = dict(X_T=X_T, y=y, seed=64, kept=np.array([0, 5, 9]))
+    for tag, Cls, kw in (("zz", RefZigzag, dict(num_zigzag=3)), ("mc", RefMCDropout, dict(y=None))):
+        with _quiet:
+            s = Cls.from_config(CONFIGS["adm64"], M=2, after_step=0, num_steps_uc=10, unet=m, **kw)
+            s.set_timesteps(10)
+            torch.manual_seed(0)
+            with torch.no_grad():
+                r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, 4, torch.device("cpu"), m, s)
+        m.eval()
+        assert r["uncertainty"].shape == (4, 10, 3, 64, 64)
+        out[f"{tag}_timesteps"] = s.timesteps
+        out[f"{tag}_gen_images"] = r["gen_images"]
+        out[f"{tag}_uncertainty"] = r["uncertainty"][:, [0, 5, 9]]
+        out[f"{tag}_score"] = r["score"][:, [0, 5, 9]]
+        out[f"{tag}_unc_step_mean"] = r["uncertainty"].mean(dim=(0, 2, 3, 4))
+        out[f"{tag}_score_step_absmean"] = r["score"].abs().mean(dim=(0, 2, 3, 4))
+    save("g18_adm64_config0", **out)
+
+
 def g14():
     """Dataset-level pixel-wise thresholds from the reference script itself: scripts/compute_threshold_pixel_wise.py
     ``load_uncertainty_datasets`` (:118-165) run on temporary folders of ``uncertainty_*.pth`` / ``gen_images_*.pth`` files."""
@@ -746,6 +776,6 @@ def g16():
 
 
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()
