@@ -673,6 +673,26 @@ def g18():
     save("g18_adm64_config0", **out)
 
 
+def g19():
+    """One uncertainty step of the headline scheduler at the Monte-Carlo counts of BASELINE configs[1] (M=5) and configs[3] (M=10):
+    reference DDIMSchedulerUncertaintyImagenetClassConditioned.step() (zigzag_centered.py:527-549) on full-size ADM-128, B=1,
+    num_zigzag=3, 50-step grid, a timestep inside the window (40, 10); CPU generator seeded before the step."""
+    m = build_adm(ADM128, 128)
+    x, y = randn(191, 1, 3, 128, 128), torch.tensor([88])
+    out = dict(x=x, y=y, seed=128)
+    with _quiet, torch.no_grad():
+        for M in (5, 10):
+            s = RefZigzag.from_config(CONFIGS["adm128"], M=M, after_step=40, num_steps_uc=10, unet=m, num_zigzag=3)
+            s.set_timesteps(50)
+            s.prompt_embeds = y
+            t = int(s.timesteps[44])
+            eps = m(x, torch.full((1,), t, dtype=torch.long), y=y)[:, :3]
+            torch.manual_seed(1900 + M)
+            o = s.step(eps, t, x)
+            out.update({f"M{M}_t": t, f"M{M}_eps": eps, f"M{M}_prev": o.prev_sample, f"M{M}_unc": o.uncertainty, f"M{M}_x0": o.pred_original_sample})
+    save("g19_adm128_uc_step_m5_m10", **out)
+
+
 def g14():
     """Dataset-level pixel-wise thresholds from the reference script itself: scripts/compute_threshold_pixel_wise.py
     ``load_uncertainty_datasets`` (:118-165) run on temporary folders of ``uncertainty_*.pth`` / ``gen_images_*.pth`` files."""
@@ -776,6 +796,6 @@ def g16():
 
 
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

@@ -771,6 +771,41 @@ def test_baseline_config0_vs_reference_driver(golden, kind, precision):
     m.split_k = False
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16f6"])
+def test_uc_step_m5_m10_full_size_vs_golden(golden, precision):
+    """One uncertainty step of the headline scheduler at the Monte-Carlo counts of BASELINE configs[1] (M=5) and configs[3] (M=10) on
+    full-size ADM-128 (50-step grid, window (40, 10), num_zigzag=3), against the reference scheduler's own step() (G19), same
+    noise tape; one chain per denoiser call and the chains stacked (mc_group)."""
+    from oracle import adm
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    g = golden("g19_adm128_uc_step_m5_m10")
+    m, _ = build_adm(dict(adm.ADM128), int(g["seed"]))
+    m.precision = precision
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    tol_eps, tol_u = {"fp32": (1e-3, 1e-2), "f16x3": (1e-3, 1e-2), "f16f6": (1e-3, 0.3)}[precision]
+    for M in (5, 10):
+        t = int(g[f"M{M}_t"])
+        a = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=M, start_step_uc=40, num_steps_uc=10, predict_next=True,
+                               eta=0.0, num_zigzag=3, uncertainty_distance=1)
+        eps = m(x, torch.full((1,), t, dtype=torch.long, device=dev), y=y, out_channels_keep=3)
+        e_eps = np.abs(eps.cpu().numpy() - g[f"M{M}_eps"]).max()
+        assert e_eps < tol_eps
+        for group in (1, M):
+            s = get_uncertainty_scheduler(a, None, m, init_scheduler_imagenet128())
+            s.set_timesteps(50)
+            s.prompt_embeds = y
+            s.mc_group = group
+            assert s.timestep_after_step >= t >= s.timestep_end_step
+            torch.manual_seed(1900 + M)
+            o = s.step(T(g[f"M{M}_eps"]).to(dev), t, x)
+            ref_u = g[f"M{M}_unc"]
+            eu = (np.abs(o.uncertainty.cpu().numpy() - ref_u) / (np.abs(ref_u) + 1e-3 * np.abs(ref_u).max())).max()
+            np.testing.assert_allclose(o.prev_sample.cpu().numpy(), g[f"M{M}_prev"], rtol=0, atol=1e-5)
+            print(f"M={M} mc_group={group} {precision}: eps err {e_eps:.2e}, uncertainty rel err {eu:.2e}")
+            assert eu < tol_u
+
+
 def test_thresholds_vs_reference_script(golden):
     """a15: dua_pixelwise_order_statistic against the reference script's own load_uncertainty_datasets outputs (G14), bit for bit."""
     from diffusion_uncertainty_amd.thresholds import compute_threshold_pixel_wise
