@@ -25,6 +25,7 @@ struct DConvP {
     // kpart[s][M][N]; k_splitk_reduce then folds the parts in index order (deterministic) and applies the epilogue.
     int ksplit;
     float* kpart;
+    int tail_pass;           // host side only: this launch is one half of a head | tail split of the rows (launch_dconv)
 };
 
 // conv_f16x3.hip: the f16x3 kernel on 16x16x32 MFMA shapes (row-shift form where the image width divides 256)

@@ -1559,6 +1559,30 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
     const bool wide = dua_dma_conv_enabled != 2 && d.N % 256 == 0 && (long)d.ntm * (d.N / 256) >= 512;
     d.ntn = wide ? d.N / 256 : (d.N + BN - 1) / BN;
     const int ntiles = d.ntm * d.ntn, grid = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
+    // Tail split (plain GEMMs, split-K workspace registered): when the last round of tiles would be at most ~60 % full, the rows are
+    // cut into a head whose tiles fill whole rounds and a tail of <= 128 tiles that runs split along K on all CUs (U-ViT-H/2 at batch
+    // 64: the N = 1152 projections are 585 tiles = 2.29 rounds -> 504 tiles in two rounds + 81 tiles x 3 K parts in a third of one).
+    if (fmt == 3 && dua_splitk_ws && !d.tail_pass && d.ntaps == 1 && !d.Csplit && d.act_out == 0 && !d.nchw_out && (d.N & 3) == 0 &&
+        ntiles > 256 && dua_dma_conv_enabled != 6 && dua_dma_conv_enabled != 7) {
+        const int r_full = ntiles / 256, rem = ntiles - 256 * r_full;
+        const int head_rt = (256 * r_full) / d.ntn, tail_rt = d.ntm - head_rt;
+        const int tail_tiles = tail_rt * ((d.N + BN - 1) / BN);
+        DConvP t = d;
+        t.M = d.M - head_rt * DBM;
+        t.tail_pass = 1;
+        if (rem > 0 && rem <= 160 && head_rt > 0 && tail_tiles <= 128 && splitk_parts(t, fmt, tail_tiles, d.K / BK) >= 2) {
+            DConvP h = d;
+            h.M = head_rt * DBM;
+            h.tail_pass = 1;
+            const long r0 = (long)head_rt * DBM;
+            t.A = d.A + r0 * d.K;                                   // (the lo plane stays a_plane elements behind)
+            t.C = d.C + r0 * d.N;
+            if (d.res) t.res = d.res + r0 * d.N;
+            if (d.colsum) t.colsum = d.colsum + (r0 / 64) * 2 * d.N;
+            const int rc = launch_dconv(h, fmt, st, what);
+            return rc != DUA_OK ? rc : launch_dconv(t, fmt, st, what);
+        }
+    }
 #ifdef DUA_CONV_TIMING
     d.dbg_norec = dua_dma_conv_enabled == 3 ? 3 : (dua_dma_conv_enabled == 4 ? 1 : (dua_dma_conv_enabled == 5 ? 2 : 0));   // 4: A only, 5: B only
 #else

@@ -127,6 +127,10 @@ class UViT(nn.Module):
         self.patch_size = patch_size
         self.precision = "fp32"          # or "f16x3" (fp32-equivalent) / "bf16x3" / "f16f8" (see guided_diffusion/unet_openai.py)
         self.use_block_abi = True        # fp32 / f16x3: every Block runs as ONE C-ABI call (bit-identical to the composition)
+        # f16x3: register the split-K workspace for the forward (ops.set_split_k): GEMM launches whose last round of tiles would be
+        # mostly idle (N = 1152 projections at batch 64: 585 tiles on 256 CUs) run their tail rows split along K.  Opt-in: results
+        # then depend on the batch size at fp32-rounding level
+        self.split_k = False
         self._planes = {}
 
     def _apply(self, fn, *a, **k):
@@ -170,6 +174,15 @@ class UViT(nn.Module):
     def forward(self, x, timesteps, y=None):
         if not x.is_cuda:
             raise RuntimeError("UViT.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        if not (self.split_k and self.precision == "f16x3"):
+            return self._forward_body(x, timesteps, y)
+        prev = ops.set_split_k(True, x.device)
+        try:
+            return self._forward_body(x, timesteps, y)
+        finally:
+            ops.set_split_k(prev, x.device)
+
+    def _forward_body(self, x, timesteps, y=None):
         B, C, H, W = x.shape
         P, D = self.patch_size, self.embed_dim
         rows = ops.patchify(x.float().contiguous(), P)                                     # [B*L, C*P*P]

@@ -8,5 +8,5 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 
-ns = argparse.Namespace(uvit_mc_group=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+ns = argparse.Namespace(uvit_mc_group=int(sys.argv[1]) if len(sys.argv) > 1 else 1, uvit_split_k=(len(sys.argv) > 2 and sys.argv[2] == "1"))
 print(json.dumps(bench.other_config_uvit("cuda", ns)))

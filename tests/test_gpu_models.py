@@ -125,6 +125,13 @@ def test_uvit_h2_full_vs_golden(golden):
     err = np.abs(o.cpu().numpy() - g["out"]).max()
     print(f"uvit-h/2: max|hip - reference| = {err:.3e}")
     assert err < TOL
+    m.precision, m.split_k = "f16x3", True                 # one image = 258 token rows: every GEMM launch runs split along K
+    o2 = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev))
+    err2 = np.abs(o2.cpu().numpy() - g["out"]).max()
+    m.split_k = False
+    o3 = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev))
+    print(f"uvit-h/2 f16x3: split-K {err2:.3e}, single-pass {np.abs(o3.cpu().numpy() - g['out']).max():.3e}, differ: {not torch.equal(o2, o3)}")
+    assert err2 < TOL and not torch.equal(o2, o3)
 
 
 def _sched(kind, model, **kw):

@@ -550,6 +550,34 @@ def test_cross_attention_f16x3(ops, B, Tq, Tk, heads, ch):
         assert (dec - o.double()).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(16512, 1152, 1152), (16512, 1152, 4608), (20000, 640, 320)])
+def test_gemm_f16x3_tail_split(ops, M, N, K):
+    """Head | tail split of the rows of a presplit GEMM whose last round of tiles would be mostly idle (U-ViT-H/2 at batch 64:
+    585 tiles on 256 CUs): the tail runs split along K.  Same error against fp64 as the single launch; statistics consistent;
+    deterministic."""
+    a = rnd(90, M, K) * torch.logspace(-2, 1, K)
+    w, b, res = rnd(91, N, K) / math.sqrt(K), rnd(92, N) * 0.1, rnd(93, M, N)
+    ref = a.double() @ w.double().t() + b.double() + res.double()
+    r = 1 if K <= 2048 else 4                                     # (the plane writer takes up to 3072 channels: fold wide rows)
+    pl = ops.SplitPlanes(_f16x3_planes(ops, a.view(1, M * r, 1, K // r)).buf, (M, K), "f16x3", ops.F16X3_ACT_SCALE)
+    packed = ops.pack_weight_f16x3(w.to(dev))
+    single = ops.gemm_bf16x3_presplit(pl, packed, N, bias=b.to(dev), residual=res.to(dev), colsum=True)
+    prev = ops.set_split_k(True, dev)
+    try:
+        c = ops.gemm_bf16x3_presplit(pl, packed, N, bias=b.to(dev), residual=res.to(dev), colsum=True)
+        c2 = ops.gemm_bf16x3_presplit(pl, packed, N, bias=b.to(dev), residual=res.to(dev), colsum=True)
+    finally:
+        ops.set_split_k(prev, dev)
+    e, e1 = (c.cpu().double() - ref).abs().max().item(), (single.cpu().double() - ref).abs().max().item()
+    print(f"tail split err {e:.2e}  single launch {e1:.2e}  differ: {not torch.equal(c, single)}")
+    assert e < max(2 * e1, 2e-6 * ref.abs().max().item())
+    np.testing.assert_array_equal(c.cpu().numpy(), c2.cpu().numpy())
+    ws = c._dua_colsums_rows.cpu().double()                       # [ceil(M/64)][2][N] column sums / sums of squares per 64-row block
+    blocks = c.cpu().double()[: (M // 64) * 64].reshape(M // 64, 64, N)
+    np.testing.assert_allclose(ws[: M // 64, 0].numpy(), blocks.sum(1).numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(ws[: M // 64, 1].numpy(), (blocks ** 2).sum(1).numpy(), rtol=1e-4, atol=1e-2)
+
+
 def test_geglu_and_split_planes(ops):
     """GEGLU (diffusers activations.GEGLU, exact erf GELU) in fp32 and as f16x3 operand planes (hi + lo = 22 significant bits of y * scale)."""
     u = rnd(70, 37, 256) * 3
