@@ -105,8 +105,7 @@ class BasicTransformerBlock(nn.Module):
         n2 = ctx.norm_rows(h, self.norm2)
         q = ctx.gemm(n2, self.attn2.to_q.weight, None)
         Tk = enc.shape[1]
-        e2 = enc.reshape(B * Tk, -1)
-        k, v = ctx.gemm(e2, self.attn2.to_k.weight, None), ctx.gemm(e2, self.attn2.to_v.weight, None)
+        k, v = ctx.context_kv(self, enc)
         a = ops.attention(q.view(B, T, C), k.view(B, Tk, C), v.view(B, Tk, C), heads, precision=ctx.attn_precision,
                           planes_out=ctx.f16x3)
         if not isinstance(a, ops.SplitPlanes):
@@ -218,6 +217,7 @@ class _Ctx:
         self.attn_precision = {"fp32": "fp32", "f16x3": "f16x3"}.get(model.precision, "bf16x3")
         self.emb = None
         self.temb_all = None
+        self.kv = None                   # {id(transformer block): (k, v)} of the current text context, or None
 
     def packed(self, key, make):
         cache = self.model._packed
@@ -338,6 +338,14 @@ class _Ctx:
             self.model._packed[key] = torch.cat([getattr(attn, n).weight.detach() for n in names]).contiguous()
         return self.model._packed[key]
 
+    def context_kv(self, blk, enc):
+        """to_k / to_v of the text context for one transformer block: from the per-context cache when the forward was given one
+        (they depend on neither the sample nor the timestep), else computed here."""
+        if self.kv is not None:
+            return self.kv[id(blk)]
+        e2 = enc.reshape(enc.shape[0] * enc.shape[1], -1)
+        return self.gemm(e2, blk.attn2.to_k.weight, None), self.gemm(e2, blk.attn2.to_v.weight, None)
+
     def temb(self, resnet):
         """time_emb_proj(silu(emb)) of one ResnetBlock2D: a column block of ONE GEMM over all blocks (same emb everywhere)."""
         tab = self.model._temb_table()
@@ -400,10 +408,35 @@ class UNet2DConditionModel(nn.Module):
         # f16x3: launches that cannot fill the chip (the CFG batch of 2 gives the 32^2 / 16^2 / 8^2 levels 10 - 40 tiles for 256 CUs)
         # run split along K with a deterministic second-stage sum (dua_set_splitk_workspace): ~1.6x on the whole sampling job
         self.split_k = True
+        # to_k / to_v of the text context computed once per context tensor instead of in every denoiser call (identical values)
+        self.cache_context = True
+        self._kv_cache = []
+
+    def _context_kv(self, enc):
+        """Keys / values of every cross-attention for this text context, computed once per (context tensor, precision): the reference
+        pipeline passes the same prompt embeddings to all 21 denoiser calls of a job.  Held per context TENSOR OBJECT (identity +
+        in-place version counter; the cache keeps the tensor alive, so its identity cannot be recycled); two entries (prompt, stacked
+        Monte-Carlo prompt)."""
+        if not self.cache_context:
+            return None
+        key = (id(enc), enc._version, tuple(enc.shape), self.precision, bool(self.split_k))
+        for k_, ref, kv in self._kv_cache:
+            if k_ == key and ref is enc:
+                return kv
+        ctx = _Ctx(self)
+        prev = ops.set_split_k(self.split_k and self.precision == "f16x3", enc.device)
+        try:
+            blocks = [b for m in self.modules() if isinstance(m, Transformer2DModel) for b in m.transformer_blocks]
+            kv = {id(b): ctx.context_kv(b, enc) for b in blocks}
+        finally:
+            ops.set_split_k(prev, enc.device)
+        self._kv_cache = [(key, enc, kv)] + self._kv_cache[:1]
+        return kv
 
     def invalidate_packed_weights(self):
         """Drop the packed weights (and the captured graphs that hold them); the next forward repacks."""
         self._packed = {}
+        self._kv_cache = []
         if getattr(self, "_graphs", None) is not None:
             self._graphs = {}
 
@@ -414,12 +447,14 @@ class UNet2DConditionModel(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = {}
+        self._kv_cache = []
         if getattr(self, "_graphs", None) is not None:
             self._graphs = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = {}
+        self._kv_cache = []
         if getattr(self, "_graphs", None) is not None:
             self._graphs = {}
         return super().load_state_dict(*a, **k)
@@ -452,37 +487,46 @@ class UNet2DConditionModel(nn.Module):
             if self._packed:
                 self.invalidate_packed_weights()
             self._packed_gen = gen
+        kv = self._context_kv(enc)                                     # cross-attention keys / values of this context (cached), or None
         if self._graphs is None:
-            out = self._forward_impl(sample, t, enc)
+            out = self._forward_impl(sample, t, enc, kv=kv)
         else:
-            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE, bool(self.split_k))
+            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE, bool(self.split_k), kv is not None)
             entry = self._graphs.get(key)
             if entry is None:
-                self._forward_impl(sample, t, enc)                     # eager once: packs the weights, warms the allocator
+                self._forward_impl(sample, t, enc, kv=kv)              # eager once: packs the weights, warms the allocator
                 sx, st, se = sample.clone(), t.clone(), enc.clone()
+                skv = None if kv is None else {b: (k_.clone(), v_.clone()) for b, (k_, v_) in kv.items()}
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    so = self._forward_impl(sx, st, se)
-                entry = self._graphs[key] = (graph, sx, st, se, so)
-            graph, sx, st, se, so = entry
-            sx.copy_(sample), st.copy_(t), se.copy_(enc)
+                    so = self._forward_impl(sx, st, se, kv=skv)
+                entry = self._graphs[key] = [graph, sx, st, se, so, skv, kv]
+            graph, sx, st, se, so, skv, last_kv = entry
+            sx.copy_(sample), st.copy_(t)
+            if skv is None:
+                se.copy_(enc)
+            elif kv is not last_kv:                                    # another context: refresh the graph's static keys / values
+                for b, (k_, v_) in kv.items():
+                    skv[b][0].copy_(k_), skv[b][1].copy_(v_)
+                entry[6] = kv
             graph.replay()
             out = so.clone()
         if return_dict:
             return UNet2DConditionOutput(sample=out)
         return (out,)
 
-    def _forward_impl(self, sample, t, enc, tape=None):
+    def _forward_impl(self, sample, t, enc, tape=None, kv=None):
         """sample [B,4,h,w] fp32, t [B] int64, enc [B,Tk,ctx] fp32, all on the GPU -> [B,4,h,w].  tape: list receiving the
-        activations backward_sample() needs (None: nothing is kept)."""
+        activations backward_sample() needs (None: nothing is kept); kv: cached cross-attention keys / values of enc."""
         prev_split_k = ops.set_split_k(self.split_k and self.precision == "f16x3", sample.device)
         try:
-            return self._forward_body(sample, t, enc, tape)
+            return self._forward_body(sample, t, enc, tape, kv)
         finally:
             ops.set_split_k(prev_split_k, sample.device)
 
-    def _forward_body(self, sample, t, enc, tape):
+    def _forward_body(self, sample, t, enc, tape, kv=None):
         ctx = _Ctx(self)
+        ctx.kv = kv
         te = self.time_embedding
         emb = ops.timestep_embedding(t, self.conv_in.out_channels)        # [cos | sin], freq_shift 0: the ADM embedding
         emb = ops.gemm(emb, te.linear_1.weight, bias=te.linear_1.bias)
@@ -536,7 +580,8 @@ class UNet2DConditionModel(nn.Module):
                 self.invalidate_packed_weights()
             self._packed_gen = gen
         tape = []
-        out = self._forward_impl(sample.float().contiguous(), t, encoder_hidden_states.to(torch.float32).contiguous(), tape=tape)
+        enc = encoder_hidden_states.to(torch.float32).contiguous()
+        out = self._forward_impl(sample.float().contiguous(), t, enc, tape=tape, kv=self._context_kv(enc))
         return out, tape
 
     @torch.no_grad()

@@ -115,3 +115,28 @@ def test_pndm_and_guided_pipeline_vs_oracle():
     assert (d > TOL).float().mean().item() < 5e-3 and d.median().item() < 1e-4
     with pytest.raises(NotImplementedError):
         pipe(prompt="a photo of a cat")
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_context_kv_cache(graph):
+    """UNet2DConditionModel.cache_context: to_k / to_v of the text context computed once per context tensor (identity + in-place
+    version): same bits as computing them in every call; another tensor, or an in-place edit of the cached one, is picked up."""
+    m, _ = build(MID, 11)
+    m.precision = "f16x3"
+    x, t, enc = inputs(MID, 2, 32, 77, 3)
+    x, t, e1 = x.to(dev), t.to(dev), enc.to(dev)
+    e2 = (enc * 0.5 + 0.1).to(dev)
+    m.cache_context = False
+    ref1 = m(x, t, encoder_hidden_states=e1, return_dict=False)[0]
+    ref2 = m(x, t, encoder_hidden_states=e2, return_dict=False)[0]
+    assert not torch.equal(ref1, ref2)
+    m.cache_context = True
+    if graph:
+        m.enable_hip_graph()
+    for _ in range(2):
+        np.testing.assert_array_equal(m(x, t, encoder_hidden_states=e1, return_dict=False)[0].cpu().numpy(), ref1.cpu().numpy())
+    assert len(m._kv_cache) == 1
+    np.testing.assert_array_equal(m(x, t, encoder_hidden_states=e2, return_dict=False)[0].cpu().numpy(), ref2.cpu().numpy())
+    np.testing.assert_array_equal(m(x, t, encoder_hidden_states=e1, return_dict=False)[0].cpu().numpy(), ref1.cpu().numpy())
+    e1.copy_(e2)                                                 # in-place edit of a cached context: the version counter moves
+    np.testing.assert_array_equal(m(x, t, encoder_hidden_states=e1, return_dict=False)[0].cpu().numpy(), ref2.cpu().numpy())
