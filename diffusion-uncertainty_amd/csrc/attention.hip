@@ -464,9 +464,11 @@ static int attention_x_launch(const AttnP& p, int B, void* stream, bool f16) {
     const int T = p.T, ch = p.ch;
     hipStream_t s = as_stream(stream);
     const bool small = T <= 512;
+    // short sequences: 64 queries per workgroup, or 96 when that pads fewer (U-ViT-H/2: 258 tokens = 5 x 64 with 62 idle rows, 3 x 96 with 30)
+    const bool three = small && (T + 95) / 96 * 96 < (T + 63) / 64 * 64;
 #define ATTNX_CASE(CTV) \
-    case CTV: return f16 ? (small ? launch_attn_x<CTV, 2, true>(p, B, s) : launch_attn_x<CTV, 4, true>(p, B, s)) \
-                         : (small ? launch_attn_x<CTV, 2>(p, B, s) : launch_attn_x<CTV, 4>(p, B, s));
+    case CTV: return f16 ? (three ? launch_attn_x<CTV, 3, true>(p, B, s) : small ? launch_attn_x<CTV, 2, true>(p, B, s) : launch_attn_x<CTV, 4, true>(p, B, s)) \
+                         : (three ? launch_attn_x<CTV, 3>(p, B, s) : small ? launch_attn_x<CTV, 2>(p, B, s) : launch_attn_x<CTV, 4>(p, B, s));
     switch ((ch + 15) / 16) {
         ATTNX_CASE(1) ATTNX_CASE(2) ATTNX_CASE(3) ATTNX_CASE(4) ATTNX_CASE(5) ATTNX_CASE(6) ATTNX_CASE(7) ATTNX_CASE(8)
     }
