@@ -234,6 +234,11 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     // elements: the 4 key rows of a block then start 16 dwords apart (mod 64) and a 32-lane half covers all 64 banks once.
     constexpr int VPR = CT32 * 32 <= 32 ? 32 : (CT32 * 32 <= 96 ? 96 : 160);
     __shared__ __attribute__((aligned(16))) el Kh[32 * KP], Kl[32 * KP], Vh[32 * VPR], Vl[32 * VPR];
+    // Wide heads (>= 112 channels): the lo halves of the wave's queries live in LDS (lane-private 16-byte slots, re-read once per
+    // key tile and step) instead of 32 registers - with them the kernel spilled (40 - 300 bytes of scratch per lane)
+    constexpr bool QL_LDS = CT16 >= 7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds_raw_[];
+    el* const qlds = reinterpret_cast<el*>(qlds_raw_);
     const int ch = p.ch, C = p.heads * ch, T = p.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, kh = lane >> 5;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
     constexpr int nthr = 64 * QW;
 
     // ---- this lane's query row, scaled and split once: element j of step c = channel 16c + 8kh + j
-    abf16x8 qh[CT16], ql[CT16];
+    abf16x8 qh[CT16], ql[QL_LDS ? 1 : CT16];
     {
         const float* qrow = base + (long)min(q0 + wave * 32 + lr, T - 1) * ldq;
 #pragma unroll
@@ -261,8 +266,11 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
                 const float qs = F16 ? p.scale * DUA_AX_SQ : p.scale;
                 v[j] = t.x * qs; v[j + 1] = t.y * qs; v[j + 2] = t.z * qs; v[j + 3] = t.w * qs;
             }
+            abf16x8 lo_;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { el a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; ql[c][j] = b_; }
+            for (int j = 0; j < 8; ++j) { el a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; lo_[j] = b_; }
+            if (QL_LDS) *(abf16x8*)(qlds + ((wave * CT16 + c) * 64 + lane) * 8) = lo_;
+            else ql[QL_LDS ? 0 : c] = lo_;
         }
     }
     // ---- zero the padded channel columns of the K tile (they meet zero Q channels: must not be NaN patterns) and all of V^T
@@ -334,8 +342,9 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
 #pragma unroll
         for (int c = 0; c < CT16; ++c) {
             const abf16x8 ah = *(const abf16x8*)(Kh + lr * KP + 16 * c + 8 * kh), al = *(const abf16x8*)(Kl + lr * KP + 16 * c + 8 * kh);
+            const abf16x8 qlc = QL_LDS ? *(const abf16x8*)(qlds + ((wave * CT16 + c) * 64 + lane) * 8) : ql[QL_LDS ? 0 : c];
             s = amfma(al, qh[c], s);
-            s = amfma(ah, ql[c], s);
+            s = amfma(ah, qlc, s);
             s = amfma(ah, qh[c], s);
         }
         // ---- online softmax (query = lane; this lane holds keys (r&3) + 8(r>>2) + 4kh of the tile)
@@ -410,7 +419,16 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
 template <int CT16, int QW, bool F16 = false>
 static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
     dim3 grid((p.T + QW * 32 - 1) / (QW * 32), B * p.heads);
-    hipLaunchKernelGGL((k_flash_attn_x<CT16, QW, F16>), grid, 64 * QW, 0, s, p);
+    constexpr size_t qlds = CT16 >= 7 ? (size_t)QW * CT16 * 64 * 16 : 0;        // lo halves of the queries (wide heads)
+    if (qlds) {
+        static bool raised = false;            // (per instantiation; static + dynamic LDS exceeds the 64 KB default)
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_flash_attn_x<CT16, QW, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)qlds);
+            if (e != hipSuccess) { dua_set_error("dua_attention (split): cannot reserve %zu bytes of LDS: %s", qlds, hipGetErrorString(e)); return DUA_EHIP; }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((k_flash_attn_x<CT16, QW, F16>), grid, 64 * QW, qlds, s, p);
     return dua_check_launch("dua_attention_bf16x3");
 }
 
