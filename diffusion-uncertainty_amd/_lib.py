@@ -82,6 +82,8 @@ SIGNATURES = {
     "dua_resample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dua_conv3x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_groupnorm_stats_from_colsums": (_I, [_P, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "dua_groupnorm_stats_from_colsums_bias": (_I, [_P, _I, _I, _I, _I, _F, _P, _L, _P, _P]),
+    "dua_groupnorm_apply_prebias_split_f16x3": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _F, _P, _P]),
     "dua_conv3x3_packed_floats": (_Z, [_I, _I]),
     "dua_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _P]),
     "dua_gemm": (_I, [_c.POINTER(GemmArgs), _P]),

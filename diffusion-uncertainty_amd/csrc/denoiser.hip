@@ -177,6 +177,42 @@ __global__ __launch_bounds__(BLK) void k_gn_from_colsums(const float* __restrict
         stats[2 * ((size_t)n * G + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
+// ... of x + t for a per-(sample, channel) bias t: per 64-row block and channel, sum(x + t) = S1 + 64 t, sum((x + t)^2) = S2 + 2 t S1 + 64 t^2
+__global__ __launch_bounds__(BLK) void k_gn_from_colsums_bias(const float* __restrict__ ws, int C, const float* __restrict__ tb, long tld,
+                                                              int HW, int G, float eps, float* __restrict__ stats) {
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G, nb = HW >> 6;
+    double a = 0, b = 0;
+    for (int i = tid; i < nb * cpg; i += BLK) {
+        const int blk = i / cpg, c = g * cpg + i % cpg;
+        const long row = (long)n * nb + blk;
+        const double s1 = ws[row * 2 * C + c], s2 = ws[row * 2 * C + C + c], t = tb[(size_t)n * tld + c];
+        a += s1 + 64.0 * t;
+        b += s2 + 2.0 * t * s1 + 64.0 * t * t;
+    }
+    __shared__ double sa[BLK], sb[BLK];
+    sa[tid] = a;
+    sb[tid] = b;
+    __syncthreads();
+    for (int o = BLK / 2; o > 0; o >>= 1) {
+        if (tid < o) { sa[tid] += sa[tid + o]; sb[tid] += sb[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)HW * cpg, mean = sa[0] / cnt;
+        double var = sb[0] / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * ((size_t)n * G + g)] = (float)mean;
+        stats[2 * ((size_t)n * G + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+extern "C" int dua_groupnorm_stats_from_colsums_bias(const float* ws, int C, int N, int HW, int G, float eps, const float* tbias, long tbias_ld,
+                                                     float* stats, void* stream) {
+    DUA_REQUIRE(ws && tbias && stats && N > 0 && G > 0 && HW > 0 && HW % 64 == 0 && C % G == 0 && tbias_ld >= C,
+                "dua_groupnorm_stats_from_colsums_bias: HW must be a positive multiple of 64, C a multiple of G");
+    hipLaunchKernelGGL(k_gn_from_colsums_bias, dim3(G, N), BLK, 0, as_stream(stream), ws, C, tbias, tbias_ld, HW, G, eps, stats);
+    return dua_check_launch("dua_groupnorm_stats_from_colsums_bias");
+}
 extern "C" int dua_groupnorm_stats_from_colsums(const float* ws1, int C1, const float* ws2, int C2, int N, int HW, int G, float eps,
                                                 float* stats, void* stream) {
     DUA_REQUIRE(ws1 && stats && N > 0 && G > 0 && HW > 0 && HW % 64 == 0, "dua_groupnorm_stats_from_colsums: HW must be a positive multiple of 64 (got %d)", HW);
@@ -197,6 +233,8 @@ struct GnApplyP {
     long plane;              // elements per plane
     long film_ld;            // row stride of film in floats (>= 2*C)
     float oscale;            // split == 4 (f16x3): planes hold fp16 hi | fp16 lo of y * oscale (a power of two)
+    int film_pre;            // 1: `film` is a per-(sample, channel) bias added BEFORE the normalisation (rows of film_ld floats):
+                             //    y = act(((x + t) - mean) * rstd * gamma + beta), the statistics being those of x + t
 };
 
 typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
@@ -288,7 +326,9 @@ __global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p, int chunk_px) {
             const float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + ch / cpg));
             float a = st.y * p.gamma[ch];
             float b = p.beta[ch] - st.x * a;
-            if (p.film) {
+            if (p.film && p.film_pre) {
+                b += p.film[(size_t)n * p.film_ld + ch] * a;
+            } else if (p.film) {
                 const float sc = 1.0f + p.film[(size_t)n * p.film_ld + ch];
                 a *= sc;
                 b = b * sc + p.film[(size_t)n * p.film_ld + C + ch];
@@ -451,7 +491,9 @@ __global__ __launch_bounds__(BLK) void k_gn_apply8(GnApplyP p, int chunk_px) {
         const float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + ch / cpg));
         float a = st.y * p.gamma[ch];
         float b = p.beta[ch] - st.x * a;
-        if (p.film) {
+        if (p.film && p.film_pre) {
+            b += p.film[(size_t)n * p.film_ld + ch] * a;
+        } else if (p.film) {
             const float sc = 1.0f + p.film[(size_t)n * p.film_ld + ch];
             a *= sc;
             b = b * sc + p.film[(size_t)n * p.film_ld + C + ch];
@@ -507,7 +549,7 @@ static int gn_apply_wide = 1;          // 0: always the 4-channel-per-lane kerne
 extern "C" int dua_set_gn_apply_wide(int on) { int o = gn_apply_wide; gn_apply_wide = on; return o; }
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                          const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                         int resample, const float* dropmask, float* y, int split, void* stream, float oscale = 1.0f);
+                         int resample, const float* dropmask, float* y, int split, void* stream, float oscale = 1.0f, int film_pre = 0);
 
 extern "C" int dua_groupnorm_apply(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
@@ -544,17 +586,28 @@ extern "C" int dua_groupnorm_apply_split_f16x3(const float* x1, int C1, const fl
     return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 4, stream, act_scale);
 }
 
+// ... of x + t, t a per-(sample, channel) bias [N][tbias_ld] (diffusers ResnetBlock2D: hidden + time_emb_proj(..)[:, :, None, None] in front
+// of norm2): the add never makes its own pass over the tensor.  Statistics: dua_groupnorm_stats_from_colsums_bias.
+extern "C" int dua_groupnorm_apply_prebias_split_f16x3(const float* x, int C, int N, int H, int W, int G, const float* stats, const float* gamma,
+                                                       const float* beta, const float* tbias, long tbias_ld, int act, float act_scale,
+                                                       void* yplanes, void* stream) {
+    DUA_REQUIRE(tbias && tbias_ld >= C, "dua_groupnorm_apply_prebias_split_f16x3: tbias rows of at least C floats");
+    DUA_REQUIRE(act_scale > 0.f && (__builtin_bit_cast(unsigned, act_scale) & 0x7FFFFFu) == 0, "dua_groupnorm_apply_prebias_split_f16x3: act_scale must be a power of two");
+    return gn_apply_impl(x, C, nullptr, 0, N, H, W, G, stats, gamma, beta, tbias, tbias_ld, act, 0, nullptr, (float*)yplanes, 4, stream, act_scale, 1);
+}
+
 static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                          const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                         int resample, const float* dropmask, float* y, int split, void* stream, float oscale) {
+                         int resample, const float* dropmask, float* y, int split, void* stream, float oscale, int film_pre) {
     int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && y, "dua_groupnorm_apply: null pointer");
     DUA_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0, "dua_groupnorm_apply: unsupported channels");
     DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply: x2/C2 mismatch");
     DUA_REQUIRE(resample >= 0 || (H % 2 == 0 && W % 2 == 0), "dua_groupnorm_apply: pooling needs even H, W");
     DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply: dropout mask with resampling unsupported");
-    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0, film_ld ? film_ld : 2L * (C1 + C2), oscale};
-    DUA_REQUIRE(p.film_ld >= 2L * (C1 + C2), "dua_groupnorm_apply: film_ld < 2*C");
+    GnApplyP p{x1, x2, stats, gamma, beta, film, dropmask, y, C1, C2, N, H, W, G, act, resample, split, 0, film_ld ? film_ld : 2L * (C1 + C2), oscale,
+               film_pre};
+    DUA_REQUIRE(p.film_ld >= (film_pre ? 1L : 2L) * (C1 + C2), "dua_groupnorm_apply: film_ld too small");
     {
         long Hy = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wy = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
         p.plane = (long)N * Hy * Wy * C;

@@ -241,6 +241,28 @@ def _attach_colsums(y, ws, hw):
     return y
 
 
+def groupnorm_prebias_planes(x, tbias, gamma, beta, act=1, groups=32, eps=1e-5):
+    """act(GroupNorm(x + tbias[:, None, None, :])) as f16x3 planes WITHOUT materialising x + tbias (diffusers ResnetBlock2D: the
+    time-embedding projection is added in front of norm2): statistics from the column sums x's producer left behind, the bias
+    folded into them and into the affine coefficients.  None when x carries no column sums (the caller then adds the bias itself)."""
+    _req(x, name="x")
+    N, H, W, C = x.shape
+    cs = getattr(x, "_dua_colsums", None)
+    if cs is None or (H * W) % 64 or C % 32:
+        return None
+    assert tbias.is_cuda and tbias.dtype == torch.float32 and tbias.shape == (N, C) and tbias.stride(1) == 1
+    stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    check(L.dua_groupnorm_stats_from_colsums_bias(_p(cs), C, N, H * W, groups, float(eps), _p(tbias), tbias.stride(0), _p(stats), _stream()),
+          "dua_groupnorm_stats_from_colsums_bias")
+    buf = torch.empty((2, N, H, W, C), device=x.device, dtype=torch.int16)
+    check(L.dua_groupnorm_apply_prebias_split_f16x3(_p(x), C, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(tbias), tbias.stride(0),
+                                                    int(act), F16X3_ACT_SCALE, _p(buf), _stream()), "dua_groupnorm_apply_prebias_split_f16x3")
+    pl = SplitPlanes(buf, (N, H, W, C), "f16x3", F16X3_ACT_SCALE)
+    pl.stats = stats                                  # (mean, rstd) of x + tbias per (sample, group): what a backward pass needs
+    return pl
+
+
 def groupnorm_stats(x1, x2=None, groups=32, eps=1e-5):
     _req(x1, name="x1")
     N, H, W, C1 = x1.shape

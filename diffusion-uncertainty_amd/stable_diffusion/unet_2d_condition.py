@@ -34,12 +34,20 @@ class ResnetBlock2D(nn.Module):
         G = self.norm1.num_groups
         st = ops.groupnorm_stats(x, skip, groups=G, eps=self.norm1.eps)
         h = ops.groupnorm_apply(x, st, self.norm1.weight, self.norm1.bias, x2=skip, act=1, groups=G, split=ctx.split_acts)
-        h = ctx.conv3x3(h, self.conv1, self.cout)
-        ops.add_channel_bias_(h, ctx.temb(self))                       # + time_emb_proj(silu(emb))[:, :, None, None]
-        st2 = ops.groupnorm_stats(h, groups=G, eps=self.norm2.eps)
-        if tape is not None:
-            tape.append((x, skip, st, h, st2))
-        h = ops.groupnorm_apply(h, st2, self.norm2.weight, self.norm2.bias, act=1, groups=G, split=ctx.split_acts)
+        fold = ctx.f16x3 and ctx.model.fold_temb
+        h = ctx.conv3x3(h, self.conv1, self.cout, colsum=fold)
+        hp = ops.groupnorm_prebias_planes(h, ctx.temb(self), self.norm2.weight, self.norm2.bias, act=1, groups=G, eps=self.norm2.eps) if fold else None
+        if hp is not None and tape is not None:                         # a taped forward keeps hidden + temb for the backward pass
+            ops.add_channel_bias_(h, ctx.temb(self))                   # (after the apply above has read h, in stream order)
+            tape.append((x, skip, st, h, hp.stats))
+        if hp is None:
+            ops.add_channel_bias_(h, ctx.temb(self))                   # + time_emb_proj(silu(emb))[:, :, None, None]
+            st2 = ops.groupnorm_stats(h, groups=G, eps=self.norm2.eps)
+            if tape is not None:
+                tape.append((x, skip, st, h, st2))
+            h = ops.groupnorm_apply(h, st2, self.norm2.weight, self.norm2.bias, act=1, groups=G, split=ctx.split_acts)
+        else:
+            h = hp                                                     # norm2(hidden + temb) from the conv's column sums: no add / statistics passes
         if hasattr(self, "conv_shortcut"):
             res = ctx.linear(x.view(N * H * W, -1), self.conv_shortcut, a2=(skip.view(N * H * W, -1) if skip is not None else None))
             res = res.view(N, H, W, self.cout)
@@ -409,6 +417,9 @@ class UNet2DConditionModel(nn.Module):
         # run split along K with a deterministic second-stage sum (dua_set_splitk_workspace): ~1.6x on the whole sampling job
         self.split_k = True
         # to_k / to_v of the text context computed once per context tensor instead of in every denoiser call (identical values)
+        # f16x3: norm2(hidden + temb) of a ResnetBlock2D from the column sums of conv1's epilogue with the time-embedding bias folded into
+        # the statistics and the affine coefficients (no add pass, no statistics passes)
+        self.fold_temb = True
         self.cache_context = True
         self._kv_cache = []
 
@@ -491,7 +502,7 @@ class UNet2DConditionModel(nn.Module):
         if self._graphs is None:
             out = self._forward_impl(sample, t, enc, kv=kv)
         else:
-            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE, bool(self.split_k), kv is not None)
+            key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE, bool(self.split_k), kv is not None, bool(self.fold_temb))
             entry = self._graphs.get(key)
             if entry is None:
                 self._forward_impl(sample, t, enc, kv=kv)              # eager once: packs the weights, warms the allocator

@@ -166,6 +166,10 @@ int dua_conv3x3(const float* x, const float* wp, const float* bias, const float*
  * output with Cout % 4 == 0; consumed by dua_groupnorm_stats_from_colsums when H*W % 64 == 0. */
 int dua_groupnorm_stats_from_colsums(const float* ws1, int C1, const float* ws2, int C2, int N, int HW, int G, float eps,
                                      float* stats, void* stream);
+/* ... of x + t for a per-(sample, channel) bias t [N][tbias_ld] that is added in front of the norm (diffusers ResnetBlock2D :
+ * hidden + time_emb_proj(silu(emb))[:, :, None, None] before norm2): folded into the block sums, x + t is never materialised. */
+int dua_groupnorm_stats_from_colsums_bias(const float* ws, int C, int N, int HW, int G, float eps, const float* tbias, long tbias_ld,
+                                          float* stats, void* stream);
 /* OIHW [Cout][CinReal][3][3] -> packed form above (CinPad is 4 for CinReal<=4, else CinReal). */
 size_t dua_conv3x3_packed_floats(int Cout, int Cin);
 int dua_pack_conv3x3_weight(const float* w_oihw, float* wp, int Cout, int CinReal, void* stream);
@@ -289,6 +293,10 @@ int dua_pack_weight_f16x3(const float* w, void* packed, int N, int K, int conv_c
 int dua_groupnorm_apply_split_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                                     const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                     int resample, const float* dropmask, float act_scale, void* yplanes, void* stream);
+/* y = act(GroupNorm(x + t)) as f16x3 planes, the bias t [N][tbias_ld] folded into the affine coefficients; stats are those of x + t. */
+int dua_groupnorm_apply_prebias_split_f16x3(const float* x, int C, int N, int H, int W, int G, const float* stats, const float* gamma,
+                                            const float* beta, const float* tbias, long tbias_ld, int act, float act_scale, void* yplanes,
+                                            void* stream);
 int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, float act_scale, void* stream);
 int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,

@@ -18,6 +18,9 @@ precision = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 graph = len(sys.argv) > 2 and sys.argv[2] == "graph"
 unet = randomize_parameters_(UNet2DConditionModel(), seed=15).eval().to("cuda")
 unet.precision = precision
+for kv in sys.argv[3:]:                      # e.g. fold_temb=0 cache_context=0 split_k=0
+    k_, v_ = kv.split("=")
+    setattr(unet, k_, bool(int(v_)))
 if graph:
     unet.enable_hip_graph()
 g = torch.Generator().manual_seed(491)

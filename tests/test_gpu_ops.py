@@ -578,6 +578,26 @@ def test_gemm_f16x3_tail_split(ops, M, N, K):
     np.testing.assert_allclose(ws[: M // 64, 1].numpy(), (blocks ** 2).sum(1).numpy(), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 16, 320), (3, 8, 8, 64), (2, 32, 32, 1280)])
+def test_groupnorm_prebias_planes(ops, N, H, W, C):
+    """silu(GroupNorm(x + t)) for a per-(sample, channel) bias t with neither the sum nor its statistics materialised (column sums of
+    x from the conv epilogue, t folded in): against torch in fp64 through the plane decode."""
+    x = rnd(95, N, 32, H, W)
+    w = rnd(96, C, 32, 3, 3) / math.sqrt(9 * 32)
+    t, ga, be = rnd(97, N, C) * 2, rnd(98, C), rnd(99, C)
+    h = ops.conv3x3_bf16x3(_f16x3_planes(ops, nhwc(x)), ops.pack_weight_f16x3(w.to(dev)), None, C, colsum=True)      # carries its column sums
+    pl = ops.groupnorm_prebias_planes(h, t.to(dev), ga.to(dev), be.to(dev), act=1, groups=32, eps=1e-5)
+    assert pl is not None and pl.fmt == "f16x3"
+    hh = nchw(h.cpu()).double() + t.double()[:, :, None, None]
+    ref = F.silu(F.group_norm(hh, 32, ga.double(), be.double(), 1e-5))
+    buf = pl.buf.view(torch.uint8).reshape(2, -1).cpu()
+    dec = (buf[0].view(torch.float16).double() + buf[1].view(torch.float16).double()).reshape(N, H, W, C) / pl.scale
+    err = (nchw(dec) - ref).abs().max().item()
+    print(f"prebias GroupNorm planes: max err {err:.2e}")
+    assert err < 2e-5
+    assert ops.groupnorm_prebias_planes(h.clone(), t.to(dev), ga.to(dev), be.to(dev)) is None        # no column sums: the caller's slow path
+
+
 def test_geglu_and_split_planes(ops):
     """GEGLU (diffusers activations.GEGLU, exact erf GELU) in fp32 and as f16x3 operand planes (hi + lo = 22 significant bits of y * scale)."""
     u = rnd(70, 37, 256) * 3
