@@ -63,7 +63,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
             randomize_parameters_(unet, seed=args.image_size)
         unet.eval().to(device)
         unet.precision = args.precision
-        unet.split_k = bool(args.split_k)
+        unet.split_k = args.split_k == "on" or (args.split_k == "auto" and args.batch_size <= 32)
         if args.hip_graph and args.scheduler_type != "mc_dropout":
             unet.enable_hip_graph()
         model = unet
@@ -75,6 +75,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         if not ckpt:
             randomize_parameters_(ae, seed=9)
         uvit.precision = "f16f8" if args.precision == "f16f6" else args.precision            # f16f6 is a 3x3-conv format: ADM only
+        uvit.split_k = args.split_k != "off"                                                 # (tail split of under-filled GEMM rounds)
         ae.precision = args.precision if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch)
         model = UViTAE(uvit, ae).to(device)
         scheduler = load_uvit_scheduler()
@@ -136,8 +137,9 @@ def parse_args(argv=None):
     # engine options (not in the reference)
     p.add_argument("--hip-graph", action="store_true", dest="hip_graph",
                    help="ADM UNet: replay the forward from a captured HIP graph (one launch instead of ~330; for small batches)")
-    p.add_argument("--split-k", action="store_true", dest="split_k",
-                   help="ADM UNet, f16x3, small batches: split the K range of conv launches that cannot fill the 256 CUs")
+    p.add_argument("--split-k", choices=["auto", "on", "off"], default="auto", dest="split_k",
+                   help="f16x3: split the K range of conv / GEMM launches that cannot fill the 256 CUs (deterministic; results then depend on "
+                        "the batch size at fp32-rounding level).  auto: on for batches of at most 32 images (2x on batch 4)")
     p.add_argument("--mc-group", type=int, default=1, dest="mc_group",
                    help="uncertainty_zigzag_centered: Monte-Carlo chains of a UC step per denoiser call (stacked batch, identical outputs; "
                         "helps U-ViT at batch 64: +4.6 %% with 5)")
