@@ -1,0 +1,601 @@
+// f16x3 3x3 convolution with a Winograd F(2,3) transform ALONG Y (gfx950): two output rows cost four 1x3 row convolutions
+// instead of six, i.e. 6 instead of 9 matrix-core taps per output pixel (x 3 fp16 products each) at unchanged operand precision
+// (22 significant bits per operand, fp32 accumulation; the transform adds / halves are exact or one fp32 rounding).
+//
+//   d0..d3 = input rows 2j-1, 2j, 2j+1, 2j+2 (zero outside the image)        g0..g2 = kernel rows (dy = -1, 0, +1)
+//   V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3                U0 = g0  U1 = (g0+g1+g2)/2  U2 = (g0-g1+g2)/2  U3 = g2
+//   M_f = conv1x3_x(V_f, U_f)  (zero padding in x)                           out row 2j = M0 + M1 + M2,  out row 2j+1 = M1 - M2 - M3
+//
+// Three pieces:
+//   k_gn_apply_wino      GroupNorm * gamma + beta (+FiLM, SiLU, dropout mask, 2x resampling, virtual concat) -> the four V_f images
+//                        as f16x3 planes [f][hi|lo][N*(H/2)*W][C] (the sliding window over y keeps every input element read once)
+//   k_pack_wino          OIHW fp32 weights -> U_f, per-output-row power-of-two scale, fp16 hi | lo planes in the tile order below
+//   k_wconv              LDS-DMA implicit GEMM on v_mfma_f32_16x16x32_f16 (the loop of conv_f16x3.hip's row-shift kernel): a
+//                        workgroup tile = 128 positions of the V images (whole image rows of W | 128 positions) x 128 output channels
+//                        x 4 frequencies = 65 536 accumulators.  Waves 0-3 hold f = 1, 2 and waves 4-7 f = 0, 3 of 64 positions x 64
+//                        channels each; K steps (channel block, fi, dx): ONE 256-row activation stage [group][128 positions] per
+//                        (channel block, fi) serves the three dx taps through row-shifted fragment addresses (edge lanes read zeros
+//                        through an LDS address beyond the allocation), one 256-row weight stage [group][128 channels] per step.
+//                        The epilogue exchanges P = M1 + M2 / M3 between partner waves through LDS, so the f = 1, 2 wave stores the
+//                        odd output row (M1 - M2) - M3 and the f = 0, 3 wave the even row M0 + P, with scale, bias, residual and the
+//                        next GroupNorm's column sums as in the direct kernels.
+// LDS image, swizzle, DMA piece shape and ring discipline are those of k_hconv<4, true> (conv_f16x3.hip).
+#include "common.h"
+
+#define BLK 256
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WConvP {
+    const _Float16* V;       // [4 f][2 planes][Mv][Cin]
+    const _Float16* B;       // packed weights: hi plane [ntn*256][K], lo plane, then the row scales
+    const float *bias, *res, *Cscale;
+    float* C;
+    float* colsum;
+    long v_plane;            // Mv * Cin
+    long b_plane;            // ntn * 256 * K
+    int Mv, N, Cin, K, H, W, ntm, ntn;
+    float out_scale;
+};
+
+#define WROWS 256
+#define WLD 32
+
+__global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int RA = 2, RB = 3;
+    constexpr int SA = WROWS * WLD, SB = WROWS * WLD;      // halves per plane of a stage
+    constexpr int BOFF = 0, AOFF = RB * 2 * SB;            // weight ring first: a shifted row -1 of activation stage 0 stays inside LDS
+    constexpr int NBP = 4;                                 // weight DMA pieces per wave and stage
+    __shared__ __attribute__((aligned(16))) _Float16 lds[RA * 2 * SA + RB * 2 * SB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;               // wm = 2 * group + position half
+    const int grp_w = wave >> 2, ph = wm & 1;
+    const int ntiles = p.ntm * p.ntn;
+    const int nk = p.K / 32;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
+
+    constexpr int OOBL = 0x40000;                          // LDS byte address beyond the allocation: DS reads there return zeros
+    static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU");
+    const int dl_row = lane >> 2;
+    const int dl_src = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    const int lr = lane & 15, lc = lane >> 4;
+
+    // ---- DMA state
+    unsigned abase[2] = {0, 0}, boff[2] = {0, 0};
+    auto ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, 0, 0x00020000);
+    auto ra1 = ra0;
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
+    const int b_lo = (int)(p.b_plane * 2);
+    const int a_lo = (int)(p.v_plane * 2);
+    int grpA = 0;                                          // next activation group to request: channel block grpA >> 1, fi = grpA & 1
+    unsigned vo0 = 0, vo1 = 0;
+    bool prefetched = false;
+    const int f_a = grp_w == 0 ? 1 : 0, f_b = grp_w == 0 ? 2 : 3;        // this wave's frequencies for fi = 0 / 1
+
+    auto tile_geom = [&](int m0_, int tn_) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 16 * ((2 * wave + j) & 7) + dl_row;             // position row of the tile this lane fills
+            const int m = min(m0_ + r, p.Mv - 1);
+            abase[j] = (unsigned)(((long)(m - m0_) * p.Cin + 8 * dl_src) * 2);
+            boff[j] = (unsigned)(((long)(tn_ * 256 + 16 * (2 * wave + j) + dl_row) * p.K + 8 * dl_src) * 2);
+        }
+        const long rem = (2L * p.Mv - m0_) * p.Cin * 2;                   // bytes from the rebased origin to the end of the lo plane
+        const int rec = (int)(unsigned)(rem < 0xFFFFFFF0L ? rem : 0xFFFFFFF0L);   // num_records is an unsigned 32-bit field
+        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (2L * f_a * p.Mv + m0_) * p.Cin), 0, rec, 0x00020000);
+        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (2L * f_b * p.Mv + m0_) * p.Cin), 0, rec, 0x00020000);
+        grpA = 0;
+    };
+    bool fiA = false;
+    auto a_setup = [&]() {
+        const unsigned toff = (unsigned)((grpA >> 1) * 64);
+        vo0 = abase[0] + toff;
+        vo1 = abase[1] + toff;
+        fiA = (grpA & 1) != 0;
+        ++grpA;
+    };
+    auto dma_a = [&](int sa, int i) {
+        _Float16* st = lds + AOFF + sa * 2 * SA;
+        const auto r = fiA ? ra1 : ra0;
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, st + (16 * (2 * wave)) * WLD, 16, vo0, 0, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, st + (16 * (2 * wave)) * WLD + SA, 16, vo0, a_lo, 0, 0);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, st + (16 * (2 * wave + 1)) * WLD, 16, vo1, 0, 0, 0);
+        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, st + (16 * (2 * wave + 1)) * WLD + SA, 16, vo1, a_lo, 0, 0);
+    };
+    auto dma_b = [&](int sb, int i) {
+        _Float16* st = lds + BOFF + sb * 2 * SB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            _Float16* dst = st + (16 * (2 * wave + j)) * WLD;
+            if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
+            if (i == 2 * j + 1) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);
+                boff[j] += 64;
+            }
+        }
+    };
+    auto issue_a = [&](int sa) {
+        a_setup();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(sa, i);
+    };
+    auto issue_b = [&](int sb) {
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) dma_b(sb, i);
+    };
+    auto issue_prologue = [&]() {          // A(group 0) B(0) B(1)
+        issue_a(0);
+        issue_b(0);
+        issue_b(1);
+    };
+
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const int off_l = lr * 64 + 16 * (lc ^ ((0 - (lr >> 2)) & 3));
+    const int a_row0 = AOFF * 2 + wm * 64 * 64, b_row0 = BOFF * 2 + (grp_w * 128 + wn * 64) * 64;     // bytes, wave-uniform
+
+    for (int ti = slot; ti < chunk_n; ti += nslot) {
+        const int lid = chunk0 + ti;
+        const int tn = lid % p.ntn, tm = lid / p.ntn;
+        const int m0 = tm * 128, n0 = tn * 128;
+        if (!prefetched) {
+            tile_geom(m0, tn);
+            issue_prologue();
+        }
+        prefetched = false;
+
+        f32x4 acc0[4][4], acc1[4][4];                // [channel block][position block] of fi = 0 / 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc0[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+        unsigned xedge = 0;                          // bit i: position block i at x == 0; bit 4 + i: at x == W - 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x_ = (m0 + ph * 64 + 16 * i + lr) & (p.W - 1);
+            xedge |= (x_ == 0 ? 1u : 0u) << i | (x_ == p.W - 1 ? 1u : 0u) << (4 + i);
+        }
+        h16x8 xh[4], xl[4], wh[4], wl[4];
+        auto rd_x = [&](int sa, int pl, int i, int dx) -> h16x8 {
+            const int r_ = 16 * i + lr + dx;                                  // row inside the wave's 64 (may be -1 / 64)
+            const int o = r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3)) - 16 * i * 64;
+            const bool edge = (dx < 0 && ((xedge >> i) & 1u)) || (dx > 0 && ((xedge >> (4 + i)) & 1u));
+            if (edge) return *(const h16x8*)(ldsb + OOBL + (lane & 1) * 16);   // zeros
+            return *(const h16x8*)(ldsb + (a_row0 + sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64) + o);
+        };
+        auto rd_w = [&](int sb, int pl, int jj) -> h16x8 {
+            return *(const h16x8*)(ldsb + (b_row0 + sb * 2 * SB * 2 + pl * SB * 2 + 16 * jj * 64) + off_l);
+        };
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int sa = 0, sb = 0, dxi = 0, grp = 0, s = 0;
+        const int ngroups = nk / 3;
+        bool a_inflight = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xl[i] = rd_x(0, 1, i, -1); xh[i] = rd_x(0, 0, i, -1); }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { wh[jj] = rd_w(0, 0, jj); wl[jj] = rd_w(0, 1, jj); }
+        WSB();
+
+        // one K step = (channel block, fi, dx): 48 MFMAs into the accumulators of fi
+        auto step = [&](f32x4 (&A)[4][4]) __attribute__((always_inline)) {
+            const bool preA = dxi == 0 && grp + 1 < ngroups;
+            const bool preB = s + 2 < nk;
+            const int sa_n = sa ^ 1;
+            const int sb_n = sb + 2 >= RB ? sb + 2 - RB : sb + 2;
+            if (preA) a_setup();
+            auto early_piece = [&](int q) {
+                if (q < NBP) { if (preB) dma_b(sb_n, q); }
+                else if (q < NBP + 4) { if (preA) dma_a(sa_n, q - NBP); }
+            };
+            int dxn = dxi, sa_r = sa;                                          // dx (-1, 0, +1 as dxi - 1) / stage of the NEXT step's fragments
+            if (dxi == 2) { dxn = -1; sa_r = sa ^ 1; }
+            const int sb_r = sb + 1 == RB ? 0 : sb + 1;
+            const bool more = s + 1 < nk;
+            WSB();
+            // P1: w_hi * x_lo | the DMA pieces of this step
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xl[i], A[jj][i], 0, 0, 0);
+                    WSB();
+                    const int m_ = jj * 4 + i;
+                    if ((m_ & 1) == 0) early_piece(m_ >> 1);
+                    WSB();
+                }
+            // every read of stage s was issued during the previous step: publish stage s + 1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (preA) a_inflight = true;
+            {
+                const int keep = (preB ? NBP : 0) + ((a_inflight && dxi != 2) ? 4 : 0);
+                if (keep >= NBP + 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (keep >= NBP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            WSB();
+            // P2: w_hi * x_hi | x_lo and w_hi of the next step
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xh[i], A[jj][i], 0, 0, 0);
+                    WSB();
+                    if (jj == 0 && more) { xl[i] = rd_x(sa_r, 1, i, dxn); WSB(); }
+                }
+                if (more) wh[jj] = rd_w(sb_r, 0, jj);
+                WSB();
+            }
+            // P3: w_lo * x_hi | w_lo and x_hi of the next step
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[jj], xh[i], A[jj][i], 0, 0, 0);
+                    WSB();
+                    if (jj == 3 && more) { xh[i] = rd_x(sa_r, 0, i, dxn); WSB(); }
+                }
+                if (more) wl[jj] = rd_w(sb_r, 1, jj);
+                WSB();
+            }
+            sb = sb_r;
+            if (dxi == 2) { sa ^= 1; dxi = 0; ++grp; a_inflight = false; } else ++dxi;
+            ++s;
+        };
+        while (s < nk) {
+#pragma nounroll
+            for (int d = 0; d < 3; ++d) step(acc0);
+#pragma nounroll
+            for (int d = 0; d < 3; ++d) step(acc1);
+        }
+        // the last barrier of the tile has retired every LDS read: request the first stages of the next tile now (they go to
+        // activation stage 0 and weight stages 0, 1; the epilogue uses activation stage 1 and weight stage 2)
+        if (ti + nslot < chunk_n) {
+            const int nl = chunk0 + ti + nslot;
+            tile_geom((nl / p.ntn) * 128, nl % p.ntn);
+            issue_prologue();
+            prefetched = true;
+        }
+#undef WSB
+
+        // ---- epilogue.  Inverse transform across the partner waves (wave ^ 4: same positions and channels, other frequencies):
+        // the f = 1, 2 wave sends P = M1 + M2 and finishes the ODD output row (M1 - M2) - M3, the f = 0, 3 wave sends M3 and
+        // finishes the EVEN row M0 + P.  Two rounds of 8 KB per wave through activation stage 1 / weight stage 2.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        char* ldsw = reinterpret_cast<char*>(lds);
+        auto slot_of = [&](int w) -> char* {
+            return ldsw + (w < 4 ? (AOFF + 1 * 2 * SA) * 2 + w * 8192 : (BOFF + 2 * 2 * SB) * 2 + (w - 4) * 8192);
+        };
+        char* mine = slot_of(wave);
+        char* theirs = slot_of(wave ^ 4);
+        const bool odd = grp_w == 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int jj = 2 * h + (k >> 2), i = k & 3;
+                const f32x4 v = odd ? acc0[jj][i] + acc1[jj][i] : acc1[jj][i];
+                *(f32x4*)(mine + k * 1024 + lane_e * 16) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int jj = 2 * h + (k >> 2), i = k & 3;
+                const f32x4 r = *(const f32x4*)(theirs + k * 1024 + lane_e * 16);
+                acc0[jj][i] = odd ? (acc0[jj][i] - acc1[jj][i]) - r : acc0[jj][i] + r;
+            }
+            if (h == 0) __syncthreads();
+        }
+        // ---- stores: channel-block pairs (32 channels) of one 16-position block through a 16 x 144-byte patch (in the partner's
+        // slot, which only this wave still reads), so that residual reads and output stores move whole 128-byte rows
+        const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
+        const int pos0 = m0 + ph * 64;
+        char* pw = theirs;
+        const int pr_e = lane_e >> 3, pc_e = lane_e & 7;
+        const long oddoff = odd ? p.W : 0;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
+            const bool cok = c < p.N;
+            float4 sq = *(const float4*)(p.Cscale + c);                      // (padded to the tile grid)
+            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && cok) bq = *(const float4*)(p.bias + c);
+            float4 rq[2], rn[2];
+            auto opix = [&](int i, int h) -> long {
+                const int pos = pos0 + 16 * i + 8 * h + pr_e;
+                return pos < p.Mv ? (long)pos + (pos & ~(p.W - 1)) + oddoff : -1L;
+            };
+            auto res_ld = [&](int i, float4 (&dst)[2]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const long row = opix(i, h);
+                    dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.res && cok && row >= 0) dst[h] = *(const float4*)(p.res + row * p.N + c);
+                }
+            };
+            res_ld(0, rn);
+            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rq[0] = rn[0]; rq[1] = rn[1];
+                if (i < 3) res_ld(i + 1, rn);
+                *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc0[2 * jp][i];
+                *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc0[2 * jp + 1][i];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
+                    const long row = opix(i, h);
+                    float4 v;
+                    v.x = a[0] * sq.x + bq.x + rq[h].x;
+                    v.y = a[1] * sq.y + bq.y + rq[h].y;
+                    v.z = a[2] * sq.z + bq.z + rq[h].z;
+                    v.w = a[3] * sq.w + bq.w + rq[h].w;
+                    if (cok && row >= 0) {
+                        *(float4*)(p.C + row * p.N + c) = v;
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+                    }
+                }
+            }
+            if (p.colsum) {
+                // The wave's 64 positions are 64 output pixels of ONE image (H*W % 128 == 0), every other row of a block of 128
+                // consecutive output pixels = two 64-pixel slots of the column-sum array; this wave fills the slot of its parity.
+                // The consumer (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
+                float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    t[u] += __shfl_xor(t[u], 8);
+                    t[u] += __shfl_xor(t[u], 16);
+                    t[u] += __shfl_xor(t[u], 32);
+                }
+                if (pr_e == 0 && cok && pos0 < p.Mv) {
+                    float* o = p.colsum + ((long)(pos0 >> 5) + (odd ? 1 : 0)) * 2 * p.N + c;
+                    *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
+                    *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
+                }
+            }
+        }
+        // the next tile's fragment reads wait for its opening barrier; the patches above must be done before another wave's
+        // exchange writes of the next tile land in them: that barrier orders them too (the writes come after the K loop)
+    }
+#endif
+}
+
+// =================================== weight packer ===========================================
+// frequency of (group, fi): group 0 (waves 0-3) holds f = 1, 2; group 1 holds f = 0, 3
+__device__ __forceinline__ double wino_u(const float* __restrict__ w, int cout, int ci, int dx, int f, int Cin) {
+    const float* g = w + ((size_t)cout * Cin + ci) * 9 + dx;             // OIHW: [ky][kx], kx = dx
+    const double g0 = g[0], g1 = g[3], g2 = g[6];
+    return f == 0 ? g0 : (f == 1 ? 0.5 * (g0 + g1 + g2) : (f == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+}
+__global__ __launch_bounds__(256) void k_wino_row_scale(const float* __restrict__ w, float* __restrict__ inv_scale, int Cout, int Cin) {
+    const int n = blockIdx.x;
+    float m = 0.f;
+    if (n < Cout)
+        for (int k = threadIdx.x; k < Cin * 3; k += blockDim.x) {
+            const int ci = k / 3, dx = k % 3;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) m = fmaxf(m, fabsf((float)wino_u(w, n, ci, dx, f, Cin)));
+        }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (red[0] > 0.f) e = 14 - (int)((__float_as_uint(red[0]) >> 23) & 0xff) + 127;
+        e = max(-100, min(100, e));
+        inv_scale[n] = __uint_as_float((unsigned)(127 - e) << 23);
+    }
+}
+__global__ void k_pack_wino(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                            const float* __restrict__ inv_scale, int Cout, int Cin, int ntn) {
+    const int K = 6 * Cin;
+    const size_t total = (size_t)ntn * 256 * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int R = (int)(i / K), k = (int)(i % K);
+        const int tn = R >> 8, g = (R >> 7) & 1, cout = tn * 128 + (R & 127);
+        const int cb = k / 192, t = (k % 192) / 32, c = k % 32;
+        const int fi = t / 3, dx = t % 3, ci = cb * 32 + c;
+        const int f = g == 0 ? (fi == 0 ? 1 : 2) : (fi == 0 ? 0 : 3);
+        float v = 0.f;
+        if (cout < Cout) v = (float)wino_u(w, cout, ci, dx, f, Cin) * (1.0f / inv_scale[cout]);
+        const _Float16 h = (_Float16)v;
+        hi[i] = h;
+        lo[i] = (_Float16)(v - (float)h);
+    }
+}
+
+static inline int wino_ntn(int Cout) { return (Cout + 127) / 128; }
+extern "C" size_t dua_f16x3_wino_weight_bytes(int Cout, int Cin) {
+    return 4 * (size_t)wino_ntn(Cout) * 256 * 6 * Cin + 4 * (size_t)((Cout + 255) / 256 * 256);
+}
+extern "C" int dua_pack_weight_f16x3_wino(const float* w, void* packed, int Cout, int Cin, void* stream) {
+    DUA_REQUIRE(w && packed && Cout > 0 && Cin >= 32 && Cin % 32 == 0, "dua_pack_weight_f16x3_wino: Cin must be a positive multiple of 32 (got %d)", Cin);
+    const int ntn = wino_ntn(Cout), Nsc = (Cout + 255) / 256 * 256;
+    const size_t plane = (size_t)ntn * 256 * 6 * Cin;
+    _Float16* hi = (_Float16*)packed;
+    float* inv_scale = (float*)(hi + 2 * plane);
+    hipLaunchKernelGGL(k_wino_row_scale, dim3(Nsc), 256, 0, as_stream(stream), w, inv_scale, Cout, Cin);
+    hipLaunchKernelGGL(k_pack_wino, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, hi + plane, inv_scale, Cout, Cin, ntn);
+    return dua_check_launch("dua_pack_weight_f16x3_wino");
+}
+
+extern "C" int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % 32 || Cout <= 0 || Cout % 4) return 0;
+    if (H % 2 || W < 2 || W > 128 || (W & (W - 1)) || ((long)H * W) % 128) return 0;
+    const long Mv = (long)N * (H / 2) * W;
+    if (Mv >= (1L << 30) || (2 * Mv + 256) * Cin * 2 >= 0xFFFFFFF0L) return 0;      // hi | lo planes of one frequency behind one 32-bit buffer range
+    if ((size_t)wino_ntn(Cout) * 256 * 6 * Cin * 4 >= 0x7FFFFFF0ull) return 0;
+    return 1;
+}
+
+extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
+                                      int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
+    DUA_REQUIRE(vplanes && packed && y, "dua_conv3x3_f16x3_wino: null pointer");
+    DUA_REQUIRE(v_scale > 0.f, "dua_conv3x3_f16x3_wino: v_scale must be positive");
+    DUA_REQUIRE(dua_conv3x3_f16x3_wino_supported(N, H, W, Cin, Cout),
+                "dua_conv3x3_f16x3_wino: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (H even, W a power of two <= 128, H*W %% 128 == 0, "
+                "Cin %% 32 == 0, Cout %% 4 == 0)", N, H, W, Cin, Cout);
+    WConvP p{};
+    p.V = (const _Float16*)vplanes; p.B = (const _Float16*)packed; p.bias = bias; p.res = residual; p.C = y; p.colsum = colsum;
+    p.Mv = N * (H / 2) * W; p.N = Cout; p.Cin = Cin; p.K = 6 * Cin; p.H = H; p.W = W;
+    p.v_plane = (long)p.Mv * Cin;
+    p.ntm = (p.Mv + 127) / 128; p.ntn = wino_ntn(Cout);
+    p.b_plane = (long)p.ntn * 256 * p.K;
+    p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
+    p.out_scale = 1.0f / v_scale;
+    const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(k_wconv, dim3(grid), 512, 0, as_stream(stream), p);
+    return dua_check_launch("dua_conv3x3_f16x3_wino");
+}
+
+// =================================== GroupNorm apply -> V planes ===========================================
+struct GnWinoP {
+    const float *x1, *x2, *stats, *gamma, *beta, *film, *drop;
+    _Float16* v;
+    int C1, C2, N, H, W, G, act, resample;
+    long plane;              // Mv * C
+    long film_ld;
+    float oscale;
+    int JC;                  // row pairs per chunk
+};
+
+__global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
+    const int C = p.C1 + p.C2, O = C / 8, cpg = C / p.G;
+    const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
+    const int P = Ho / 2;
+    const int nxb = (Wo * O + BLK - 1) / BLK;
+    const int n = blockIdx.y, jc = blockIdx.x / nxb, item = (blockIdx.x % nxb) * BLK + threadIdx.x;
+    if (item >= Wo * O) return;
+    const int xo = item / O, c = 8 * (item % O);
+    const bool second = c >= p.C1;
+    const float* src = second ? p.x2 : p.x1;
+    const int cs = second ? p.C2 : p.C1, cq = second ? c - p.C1 : c;
+    float ca[8], cb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = c + j;
+        const float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + ch / cpg));
+        float a = st.y * p.gamma[ch];
+        float b = p.beta[ch] - st.x * a;
+        if (p.film) {
+            const float sc = 1.0f + p.film[(size_t)n * p.film_ld + ch];
+            a *= sc;
+            b = b * sc + p.film[(size_t)n * p.film_ld + C + ch];
+        }
+        ca[j] = a;
+        cb[j] = b;
+    }
+    const size_t img_in = (size_t)n * p.H * p.W;
+    auto xf = [&](size_t pix, float (&r)[8]) {
+        const float4 v0 = *(const float4*)(src + pix * cs + cq), v1 = *(const float4*)(src + pix * cs + cq + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r[j] = v[j] * ca[j] + cb[j];
+            if (p.act == 1) r[j] = silu_f(r[j]);
+        }
+        if (p.drop) {
+            const float4 d0 = *(const float4*)(p.drop + pix * C + c), d1 = *(const float4*)(p.drop + pix * C + c + 4);
+            r[0] *= d0.x; r[1] *= d0.y; r[2] *= d0.z; r[3] *= d0.w; r[4] *= d1.x; r[5] *= d1.y; r[6] *= d1.z; r[7] *= d1.w;
+        }
+    };
+    // value of the conv's input image (after the optional 2x resampling) at row yo of this thread's column, zero outside
+    auto val = [&](int yo, float (&r)[8]) {
+        if (yo < 0 || yo >= Ho) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = 0.f;
+            return;
+        }
+        if (p.resample == 0) {
+            xf(img_in + (size_t)yo * p.W + xo, r);
+        } else if (p.resample > 0) {
+            xf(img_in + (size_t)(yo >> 1) * p.W + (xo >> 1), r);
+        } else {
+            const size_t pix = img_in + (size_t)(2 * yo) * p.W + 2 * xo;
+            float a[8], b[8], d[8], e[8];
+            xf(pix, a); xf(pix + 1, b); xf(pix + p.W, d); xf(pix + p.W + 1, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (a[j] + b[j] + d[j] + e[j]) * 0.25f;
+        }
+    };
+    auto put = [&](int f, size_t m, const float (&v)[8]) {
+        h16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sv = fminf(fmaxf(v[j] * p.oscale, -65504.f), 65504.f);
+            const _Float16 t = (_Float16)sv;
+            h[j] = t;
+            l[j] = (_Float16)(sv - (float)t);
+        }
+        _Float16* o = p.v + (size_t)(2 * f) * p.plane + m * C + c;
+        *(h16x8*)o = h;
+        *(h16x8*)(o + p.plane) = l;
+    };
+    const int j0 = jc * p.JC, j1 = min(P, j0 + p.JC);
+    float dA[8], dB[8], dC[8], dD[8];
+    val(2 * j0 - 1, dA);
+    val(2 * j0, dB);
+    for (int j = j0; j < j1; ++j) {
+        val(2 * j + 1, dC);
+        val(2 * j + 2, dD);
+        const size_t m = ((size_t)n * P + j) * Wo + xo;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = dA[q] - dC[q];
+        put(0, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = dB[q] + dC[q];
+        put(1, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = dC[q] - dB[q];
+        put(2, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = dB[q] - dD[q];
+        put(3, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { dA[q] = dC[q]; dB[q] = dD[q]; }
+    }
+}
+
+// bytes of the V planes of a conv input [N][Ho][Wo][C] (Ho, Wo after the resampling): 4 frequencies x 2 planes x N*(Ho/2)*Wo*C halves
+extern "C" size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C) { return (size_t)16 * N * (Ho / 2) * Wo * C; }
+
+extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                              const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                              int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+    const int C = C1 + C2;
+    DUA_REQUIRE(x1 && stats && gamma && beta && vplanes, "dua_groupnorm_apply_wino_f16x3: null pointer");
+    DUA_REQUIRE(C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % 32 == 0, "dua_groupnorm_apply_wino_f16x3: channel counts must be multiples of 8 (sum of 32)");
+    DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply_wino_f16x3: x2/C2 mismatch");
+    DUA_REQUIRE(resample >= -1 && resample <= 1 && (resample >= 0 || (H % 2 == 0 && W % 2 == 0)), "dua_groupnorm_apply_wino_f16x3: pooling needs even H, W");
+    DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply_wino_f16x3: dropout mask with resampling unsupported");
+    DUA_REQUIRE(v_scale > 0.f && (__builtin_bit_cast(unsigned, v_scale) & 0x7FFFFFu) == 0, "dua_groupnorm_apply_wino_f16x3: v_scale must be a power of two");
+    const int Ho = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wo = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
+    DUA_REQUIRE(Ho >= 2 && Ho % 2 == 0, "dua_groupnorm_apply_wino_f16x3: the conv input needs an even number of rows (got %d)", Ho);
+    if ((size_t)N * Ho * Wo == 0) return DUA_OK;
+    GnWinoP p{x1, x2, stats, gamma, beta, film, dropmask, (_Float16*)vplanes, C1, C2, N, H, W, G, act, resample, 0, film_ld ? film_ld : 2L * C, v_scale, 0};
+    DUA_REQUIRE(p.film_ld >= 2L * C, "dua_groupnorm_apply_wino_f16x3: film_ld too small");
+    const int P = Ho / 2;
+    p.plane = (long)N * P * Wo * C;
+    const int nxb = (Wo * (C / 8) + BLK - 1) / BLK;
+    int JC = P;
+    while ((long)N * nxb * ((P + JC - 1) / JC) < 1024 && JC > 4) JC = (JC + 1) / 2;
+    p.JC = JC;
+    hipLaunchKernelGGL(k_gn_apply_wino, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
+    return dua_check_launch("dua_groupnorm_apply_wino_f16x3");
+}

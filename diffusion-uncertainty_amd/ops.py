@@ -314,6 +314,14 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
         buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
+        if split == "f16x3w":
+            # Winograd F(2,3)-along-y operand of conv3x3 (csrc/conv_wino_f16x3.hip): the four V_f images as f16x3 planes of V * scale
+            scale = 0.5 * F16X3_ACT_SCALE if split_scale is None else float(split_scale)
+            vbuf = torch.empty((4, 2, N, Ho // 2, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
+            check(_lib.lib().dua_groupnorm_apply_wino_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                                                            _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
+                                                            scale, _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f16x3")
+            return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), "f16x3w", scale)
         if fmt == "f16x3":
             scale = F16X3_ACT_SCALE if split_scale is None else float(split_scale)
             check(_lib.lib().dua_groupnorm_apply_split_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
@@ -548,6 +556,23 @@ def pack_weight_f16x3(w):
     return packed
 
 
+def pack_weight_f16x3_wino(w):
+    """OIHW 3x3 conv weight -> the packed Winograd F(2,3)-along-y weight of dua_conv3x3_f16x3_wino (U_f * 2^s as fp16 hi | lo planes in
+    the kernel's tile order, per-output-channel 2^-s floats) in one uint8 buffer."""
+    _req(w, name="w")
+    assert w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    L = _lib.lib()
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(L.dua_f16x3_wino_weight_bytes(cout, cin), device=w.device, dtype=torch.uint8)
+    check(L.dua_pack_weight_f16x3_wino(_p(w), _p(packed), cout, cin, _stream()), "dua_pack_weight_f16x3_wino")
+    return packed
+
+
+def conv3x3_wino_supported(N, H, W, cin, cout):
+    """Shapes dua_conv3x3_f16x3_wino takes (H, W = the conv's input / output size)."""
+    return bool(_lib.lib().dua_conv3x3_f16x3_wino_supported(int(N), int(H), int(W), int(cin), int(cout)))
+
+
 def pack_weight_f16f6(w):
     """As pack_weight_f16f8 with the cross plane in MXFP6 (e2m3 + E8M0 exponent per 32-k block); same buffer size."""
     _req(w, name="w")
@@ -606,7 +631,11 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if pre and x.fmt == "f16x3":
+    if pre and x.fmt == "f16x3w":
+        assert not nchw_out, "the Winograd conv writes NHWC"
+        check(_lib.lib().dua_conv3x3_f16x3_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, _p(ws), x.scale,
+                                                _stream()), "dua_conv3x3_f16x3_wino")
+    elif pre and x.fmt == "f16x3":
         check(_lib.lib().dua_conv3x3_f16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
                                                     _p(ws), x.scale, _stream()), "dua_conv3x3_f16x3_presplit")
     elif pre:

@@ -301,6 +301,28 @@ int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const fl
                                int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, float act_scale, void* stream);
 int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
                             int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream);
+/* ---- Winograd F(2,3) along y for the f16x3 3x3 convolutions (csrc/conv_wino_f16x3.hip) ------------------------------------
+ * The same convolution (unet_openai.py:186,212) with 6 instead of 9 matrix-core taps per output pixel at unchanged operand
+ * precision: input rows d0..d3 = 2j-1 .. 2j+2 -> V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3; kernel rows g0..g2 ->
+ * U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2; M_f = conv1x3(V_f, U_f); out row 2j = M0+M1+M2, row 2j+1 = M1-M2-M3.
+ * dua_groupnorm_apply_wino_f16x3: dua_groupnorm_apply_split_f16x3 writing the four V_f images as f16x3 planes
+ *   [f][hi|lo][N*(Ho/2)*Wo][C] of V * v_scale (dua_f16x3_wino_act_bytes bytes; Ho, Wo = the conv's input size after `resample`);
+ *   v_scale a power of two (|V| <= 2 max|activation|: the UNet uses act_scale / 2).
+ * dua_pack_weight_f16x3_wino: OIHW fp32 weights -> U_f * 2^s as fp16 hi | lo planes in the kernel's tile order, then
+ *   round_up(Cout, 256) floats 2^-s (s per output channel over all 12 (f, dx) taps); dua_f16x3_wino_weight_bytes bytes.
+ * dua_conv3x3_f16x3_wino: y[N][H][W][Cout] = conv3x3(x) + bias (+ residual) from those two operands; colsum as dua_conv3x3 except
+ *   that a 64-pixel slot holds the sums of every other row of a 128-pixel block (the per-image totals, which is what
+ *   dua_groupnorm_stats_from_colsums folds, are exact).  Shapes: dua_conv3x3_f16x3_wino_supported (H even, W a power of two
+ *   <= 128, H*W % 128 == 0, Cin % 32 == 0, Cout % 4 == 0); anything else goes through dua_conv3x3_f16x3_presplit. */
+size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C);
+size_t dua_f16x3_wino_weight_bytes(int Cout, int Cin);
+int dua_pack_weight_f16x3_wino(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
+int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                   const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                   int resample, const float* dropmask, float v_scale, void* vplanes, void* stream);
+int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, int Cout);
+int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
+                           int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
 /* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
  * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */
 int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,

@@ -1,0 +1,167 @@
+"""Winograd F(2,3)-along-y form of the f16x3 3x3 convolution (csrc/conv_wino_f16x3.hip) through the C ABI: the V-plane writer
+against a plain torch restatement of GroupNorm-apply + transform, the packed weights against the transform of the kernel rows, and
+the convolution against fp64 torch, held to the error of the exact fp32 MFMA engine (the bar of the direct f16x3 kernel)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+dev = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diffusion_uncertainty_amd import ops as o
+    return o
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def v_reference(a):
+    """a: the conv's input image [N][H][W][C] (fp64) -> the four F(2,3) input transforms over row pairs, [4][N][H/2][W][C]."""
+    N, H, W, C = a.shape
+    ap = F.pad(a, (0, 0, 0, 0, 1, 1))                         # one zero row above and below
+    d0, d1, d2, d3 = ap[:, 0:H:2], ap[:, 1:H + 1:2], ap[:, 2:H + 2:2], ap[:, 3:H + 3:2]
+    return torch.stack([d0 - d2, d1 + d2, d2 - d1, d1 - d3])
+
+
+def decode_v(pl):
+    buf = pl.buf.cpu()
+    f4, two, N, P, W, C = buf.shape
+    h = buf.view(torch.float16).double()
+    return (h[:, 0] + h[:, 1]) / pl.scale
+
+
+def identity_stats(N, groups=32):
+    return torch.tensor([0.0, 1.0], device=dev).repeat(N * groups, 1).contiguous()
+
+
+@pytest.mark.parametrize("N,H,W,C1,C2,resample,film,drop", [
+    (2, 16, 16, 64, 0, 0, False, False), (1, 32, 32, 32, 32, 0, True, False), (3, 8, 16, 96, 0, 0, True, True),
+    (2, 16, 16, 64, 0, 1, False, False), (2, 32, 32, 64, 0, -1, False, False), (1, 64, 64, 256, 0, 0, True, False),
+    (2, 16, 16, 768, 512, 0, False, False)])
+def test_wino_writer_vs_torch(ops, N, H, W, C1, C2, resample, film, drop):
+    """GroupNorm * gamma + beta (+FiLM) -> SiLU (-> dropout mask / 2x resampling) -> V_f planes: against the same chain in fp64 torch
+    (virtual concat, both resampling modes, FiLM, dropout mask); hi + lo carries 22 bits of V * scale."""
+    C = C1 + C2
+    x1 = rnd(1, N, H, W, C1) * 2
+    x2 = rnd(2, N, H, W, C2) if C2 else None
+    gamma, beta = 1 + 0.3 * rnd(3, C), 0.2 * rnd(4, C)
+    fl = 0.2 * rnd(5, N, 2 * C) if film else None
+    dm = (torch.rand(N, H, W, C, generator=torch.Generator().manual_seed(6)) > 0.1).float() / 0.9 if drop else None
+    dv = lambda t: None if t is None else t.to(dev)
+    stats = ops.groupnorm_stats(dv(x1), dv(x2))
+    pl = ops.groupnorm_apply(dv(x1), stats, dv(gamma), dv(beta), x2=dv(x2), film=dv(fl), act=1, resample=resample, dropmask=dv(dm),
+                             split="f16x3w")
+    assert pl.fmt == "f16x3w" and pl.scale == 0.5 * ops.F16X3_ACT_SCALE
+    # reference chain from the kernel's own statistics (they have their own parity test)
+    st = stats.cpu().double().reshape(N, 32, 2)
+    x = (x1 if x2 is None else torch.cat([x1, x2], -1)).double()
+    cpg = C // 32
+    mean, rstd = st[:, :, 0].repeat_interleave(cpg, 1)[:, None, None, :], st[:, :, 1].repeat_interleave(cpg, 1)[:, None, None, :]
+    y = (x - mean) * rstd * gamma.double() + beta.double()
+    if film:
+        y = y * (1 + fl[:, None, None, :C].double()) + fl[:, None, None, C:].double()
+    y = F.silu(y)
+    if drop:
+        y = y * dm.double()
+    if resample > 0:
+        y = y.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    elif resample < 0:
+        y = nhwc(F.avg_pool2d(nchw(y), 2))
+    assert pl.shape == tuple(y.shape)
+    ref = v_reference(y)
+    got = decode_v(pl)
+    err = (got - ref).abs().max().item()
+    print(f"V planes max abs err {err:.2e} (|V| max {ref.abs().max().item():.1f})")
+    assert err < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_wino_weight_pack(ops):
+    """The packed weights decode to U_f = G g over the kernel rows, in the tile order [column tile][group][128 channels] x
+    [channel block][fi][dx][32 channels], scaled per output channel by a power of two."""
+    Cout, Cin = 160, 64
+    w = rnd(7, Cout, Cin, 3, 3) * torch.logspace(-2, 1, Cout).reshape(-1, 1, 1, 1)
+    packed = ops.pack_weight_f16x3_wino(w.to(dev)).cpu()
+    ntn, K = 2, 6 * Cin
+    plane = ntn * 256 * K
+    h = packed[:4 * plane].view(torch.float16).double().reshape(2, ntn, 2, 128, Cin // 32, 2, 3, 32)
+    inv = packed[4 * plane:].view(torch.float32).double()
+    assert inv.numel() == 256
+    val = (h[0] + h[1])                                                          # [tn][g][col][cb][fi][dx][c]
+    g0, g1, g2 = w[:, :, 0].double(), w[:, :, 1].double(), w[:, :, 2].double()    # [Cout][Cin][dx]
+    U = [g0, 0.5 * (g0 + g1 + g2), 0.5 * (g0 - g1 + g2), g2]
+    fmap = {(0, 0): 1, (0, 1): 2, (1, 0): 0, (1, 1): 3}
+    for (g, fi), f in fmap.items():
+        got = val[:, g, :, :, fi]                                                # [tn][col][cb][dx][c]
+        got = got.permute(0, 1, 2, 4, 3).reshape(ntn * 128, Cin, 3)[:Cout] * inv[:Cout, None, None]
+        err = ((got - U[f]).abs() / U[f].abs().amax(dim=(1, 2), keepdim=True)).max().item()
+        assert err < 2.0 ** -20, (g, fi, err)
+        pad = val[:, g, :, :, fi].permute(0, 1, 2, 4, 3).reshape(ntn * 128, Cin, 3)[Cout:]
+        assert (pad == 0).all()
+    e = torch.log2(inv[:Cout])
+    assert (e == e.round()).all()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (2, 8, 16, 96, 64), (1, 32, 32, 256, 256),
+                                             (5, 16, 16, 128, 512), (3, 64, 64, 64, 256), (2, 128, 128, 32, 128), (4, 16, 8, 64, 36),
+                                             (130, 16, 16, 64, 64)])
+def test_conv3x3_wino_vs_fp64(ops, N, H, W, Cin, Cout):
+    """The whole Winograd path (writer -> packed weights -> kernel) against fp64, next to the direct f16x3 kernel and the exact fp32
+    MFMA engine on the same problem: same bar as test_conv3x3_f16x3 (within 2x of the fp32 engine's error)."""
+    assert ops.conv3x3_wino_supported(N, H, W, Cin, Cout)
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    w = w * torch.logspace(-3, 1, Cout).reshape(-1, 1, 1, 1)
+    x = x * torch.logspace(-4, 1.5, Cin).reshape(1, -1, 1, 1)
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    scale_out = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+    st = identity_stats(N)
+    one, zero = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    xd = nhwc(x).to(dev)
+    xv = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3w")
+    xs = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3")
+    y = ops.conv3x3_bf16x3(xv, ops.pack_weight_f16x3_wino(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    yd = ops.conv3x3_bf16x3(xs, ops.pack_weight_f16x3(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    y32 = ops.conv3x3(xd, ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err = ((nchw(y.cpu()).double() - ref).abs() / scale_out).max().item()
+    errd = ((nchw(yd.cpu()).double() - ref).abs() / scale_out).max().item()
+    err32 = ((nchw(y32.cpu()).double() - ref).abs() / scale_out).max().item()
+    print(f"winograd f16x3 rel err {err:.2e}  direct f16x3 {errd:.2e}  fp32-MFMA {err32:.2e}")
+    assert err < max(2 * err32, 2e-6), (err, errd, err32)
+    # GroupNorm statistics from the epilogue's column sums equal those recomputed from the output
+    if (H * W) % 64 == 0 and Cout % 32 == 0:
+        assert getattr(y, "_dua_colsums", None) is not None
+        s1 = ops.groupnorm_stats(y)
+        s2 = ops.groupnorm_stats(y.clone())
+        np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    # no residual / no bias / no statistics
+    y0 = ops.conv3x3_bf16x3(xv, ops.pack_weight_f16x3_wino(w.to(dev)), None, Cout)
+    ref0 = F.conv2d(x.double(), w.double(), padding=1)
+    assert ((nchw(y0.cpu()).double() - ref0).abs() / scale_out).max().item() < max(2 * err32, 2e-6)
+    # deterministic
+    y1 = ops.conv3x3_bf16x3(xv, ops.pack_weight_f16x3_wino(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    assert torch.equal(y, y1)
+
+
+def test_conv3x3_wino_unsupported_shapes(ops):
+    assert not ops.conv3x3_wino_supported(2, 8, 8, 64, 64)          # H*W % 128
+    assert not ops.conv3x3_wino_supported(2, 15, 16, 64, 64)        # odd H
+    assert not ops.conv3x3_wino_supported(2, 16, 24, 64, 64)        # W not a power of two
+    assert not ops.conv3x3_wino_supported(1, 256, 256, 128, 128)    # W > 128
+    assert not ops.conv3x3_wino_supported(2, 16, 16, 48, 64)        # Cin % 32
+    assert ops.conv3x3_wino_supported(128, 128, 128, 512, 256)
