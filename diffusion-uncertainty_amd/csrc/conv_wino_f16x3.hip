@@ -21,6 +21,7 @@
 //                        next GroupNorm's column sums as in the direct kernels.
 // LDS image, swizzle, DMA piece shape and ring discipline are those of k_hconv<4, true> (conv_f16x3.hip).
 #include "common.h"
+#include <type_traits>
 
 #define BLK 256
 
@@ -41,6 +42,11 @@ struct WConvP {
 
 #define WROWS 256
 #define WLD 32
+// Timing-only diagnostic builds (scripts/wconv_diag.py; WRONG results, never in the product library): WCONV_DIAG bit 0 drops the
+// per-step barrier, bit 1 the in-loop weight DMA, bit 2 the in-loop activation DMA, bit 3 the in-loop fragment reads.
+#ifndef WCONV_DIAG
+#define WCONV_DIAG 0
+#endif
 
 __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (2L * f_b * p.Mv + m0_) * p.Cin), 0, rec, 0x00020000);
         grpA = 0;
     };
-    bool fiA = false;
+    bool fiA = false;                                     // frequency index of the group being requested (selects the descriptor)
     auto a_setup = [&]() {
         const unsigned toff = (unsigned)((grpA >> 1) * 64);
         vo0 = abase[0] + toff;
@@ -137,6 +143,23 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
     const char* ldsb = reinterpret_cast<const char*>(lds);
     const int off_l = lr * 64 + 16 * (lc ^ ((0 - (lr >> 2)) & 3));
     const int a_row0 = AOFF * 2 + wm * 64 * 64, b_row0 = BOFF * 2 + (grp_w * 128 + wn * 64) * 64;     // bytes, wave-uniform
+    // Loop-invariant fragment addresses.  A tile is 128 consecutive positions starting at a multiple of 128 and W divides 128, so the x
+    // coordinate of (position half, block i, lane row) - hence which lanes sit at the image's left / right edge - is the same for
+    // every tile.  Row r + dx of the wave's 64 rows: the swizzle term depends on (lr + dx) only (16 i is a multiple of 4 rows * 4).
+    auto x_off = [&](int dx) -> int {
+        const int r_ = lr + dx;                                           // -1 .. 16
+        return r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3));
+    };
+    const int zero_addr = OOBL + (lane & 1) * 16;
+    const int ax0 = a_row0 + x_off(0);
+    int axm[4], axp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x_ = (ph * 64 + 16 * i + lr) & (p.W - 1);
+        axm[i] = x_ == 0 ? zero_addr : a_row0 + x_off(-1);
+        axp[i] = x_ == p.W - 1 ? zero_addr : a_row0 + x_off(1);
+    }
+    const int aw0 = b_row0 + off_l, aw2 = aw0 + 2 * 2 * SB * 2;
 
     for (int ti = slot; ti < chunk_n; ti += nslot) {
         const int lid = chunk0 + ti;
@@ -154,51 +177,42 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc0[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-        unsigned xedge = 0;                          // bit i: position block i at x == 0; bit 4 + i: at x == W - 1
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int x_ = (m0 + ph * 64 + 16 * i + lr) & (p.W - 1);
-            xedge |= (x_ == 0 ? 1u : 0u) << i | (x_ == p.W - 1 ? 1u : 0u) << (4 + i);
-        }
         h16x8 xh[4], xl[4], wh[4], wl[4];
+        // fragment reads: one ds_read_b128 each, the address a loop-invariant per-lane register (ax*: activation rows shifted by dx,
+        // with the image-edge lanes already pointed at the zero region; aw*: weight rows) plus an immediate (stage, plane, block)
         auto rd_x = [&](int sa, int pl, int i, int dx) -> h16x8 {
-            const int r_ = 16 * i + lr + dx;                                  // row inside the wave's 64 (may be -1 / 64)
-            const int o = r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3)) - 16 * i * 64;
-            const bool edge = (dx < 0 && ((xedge >> i) & 1u)) || (dx > 0 && ((xedge >> (4 + i)) & 1u));
-            if (edge) return *(const h16x8*)(ldsb + OOBL + (lane & 1) * 16);   // zeros
-            return *(const h16x8*)(ldsb + (a_row0 + sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64) + o);
+            const int a = dx < 0 ? axm[i] : (dx > 0 ? axp[i] : ax0);
+            return *(const h16x8*)(ldsb + a + (sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64));
         };
         auto rd_w = [&](int sb, int pl, int jj) -> h16x8 {
-            return *(const h16x8*)(ldsb + (b_row0 + sb * 2 * SB * 2 + pl * SB * 2 + 16 * jj * 64) + off_l);
+            return *(const h16x8*)(ldsb + (sb == 2 ? aw2 : aw0) + ((sb == 2 ? 0 : sb * 2 * SB * 2) + pl * SB * 2 + 16 * jj * 64));
         };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        int sa = 0, sb = 0, dxi = 0, grp = 0, s = 0;
-        const int ngroups = nk / 3;
-        bool a_inflight = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xl[i] = rd_x(0, 1, i, -1); xh[i] = rd_x(0, 0, i, -1); }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) { wh[jj] = rd_w(0, 0, jj); wl[jj] = rd_w(0, 1, jj); }
         WSB();
 
-        // one K step = (channel block, fi, dx): 48 MFMAs into the accumulators of fi
-        auto step = [&](f32x4 (&A)[4][4]) __attribute__((always_inline)) {
-            const bool preA = dxi == 0 && grp + 1 < ngroups;
-            const bool preB = s + 2 < nk;
-            const int sa_n = sa ^ 1;
-            const int sb_n = sb + 2 >= RB ? sb + 2 - RB : sb + 2;
-            if (preA) a_setup();
+        // One K step = (channel block, fi, dx): 48 MFMAs into the accumulators of fi.  Ring slots are static: the activation stage of
+        // (channel block, fi) lives in slot fi, the weight stage of step dxi in slot dxi (three steps per group, ring of three).
+        // LAST = the tile's final group (nothing further to request after its first step, nothing to read after its last).
+        auto step = [&](auto fi_c, auto dxi_c, auto last_c, f32x4 (&A)[4][4]) __attribute__((always_inline)) {
+            constexpr int FI = decltype(fi_c)::value, DXI = decltype(dxi_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            constexpr bool preA = !LAST && DXI == 0;                            // request the next group's activation stage
+            constexpr bool preB = !LAST || DXI == 0;                            // request the weight stage of step s + 2
+            constexpr bool more = (!LAST || DXI < 2) && !(WCONV_DIAG & 8);
+            constexpr int sa_n = FI ^ 1, sb_n = (DXI + 2) % 3;
+            constexpr int sa_r = DXI == 2 ? (FI ^ 1) : FI, sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;   // the NEXT step's fragments
+            if (preA) { a_setup(); fiA = FI == 0; }
             auto early_piece = [&](int q) {
-                if (q < NBP) { if (preB) dma_b(sb_n, q); }
-                else if (q < NBP + 4) { if (preA) dma_a(sa_n, q - NBP); }
+                if (q < NBP) { if (preB && !(WCONV_DIAG & 2)) dma_b(sb_n, q); }
+                else if (q < NBP + 4) { if (preA && !(WCONV_DIAG & 4)) dma_a(sa_n, q - NBP); }
             };
-            int dxn = dxi, sa_r = sa;                                          // dx (-1, 0, +1 as dxi - 1) / stage of the NEXT step's fragments
-            if (dxi == 2) { dxn = -1; sa_r = sa ^ 1; }
-            const int sb_r = sb + 1 == RB ? 0 : sb + 1;
-            const bool more = s + 1 < nk;
             WSB();
             // P1: w_hi * x_lo | the DMA pieces of this step
 #pragma unroll
@@ -213,14 +227,13 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
                 }
             // every read of stage s was issued during the previous step: publish stage s + 1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (preA) a_inflight = true;
             {
-                const int keep = (preB ? NBP : 0) + ((a_inflight && dxi != 2) ? 4 : 0);
+                constexpr int keep = (preB ? NBP : 0) + ((!LAST && DXI != 2) ? 4 : 0);
                 if (keep >= NBP + 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (keep >= NBP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            if (!(WCONV_DIAG & 1)) __builtin_amdgcn_s_barrier();
             WSB();
             // P2: w_hi * x_hi | x_lo and w_hi of the next step
 #pragma unroll
@@ -246,16 +259,20 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
                 if (more) wl[jj] = rd_w(sb_r, 1, jj);
                 WSB();
             }
-            sb = sb_r;
-            if (dxi == 2) { sa ^= 1; dxi = 0; ++grp; a_inflight = false; } else ++dxi;
-            ++s;
         };
-        while (s < nk) {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using BF = std::integral_constant<bool, false>;
+        using BT = std::integral_constant<bool, true>;
+        const int ncb = nk / 6;
 #pragma nounroll
-            for (int d = 0; d < 3; ++d) step(acc0);
-#pragma nounroll
-            for (int d = 0; d < 3; ++d) step(acc1);
+        for (int cbi = 0; cbi < ncb - 1; ++cbi) {
+            step(I0{}, I0{}, BF{}, acc0); step(I0{}, I1{}, BF{}, acc0); step(I0{}, I2{}, BF{}, acc0);
+            step(I1{}, I0{}, BF{}, acc1); step(I1{}, I1{}, BF{}, acc1); step(I1{}, I2{}, BF{}, acc1);
         }
+        step(I0{}, I0{}, BF{}, acc0); step(I0{}, I1{}, BF{}, acc0); step(I0{}, I2{}, BF{}, acc0);
+        step(I1{}, I0{}, BT{}, acc1); step(I1{}, I1{}, BT{}, acc1); step(I1{}, I2{}, BT{}, acc1);
         // the last barrier of the tile has retired every LDS read: request the first stages of the next tile now (they go to
         // activation stage 0 and weight stages 0, 1; the epilogue uses activation stage 1 and weight stage 2)
         if (ti + nslot < chunk_n) {
