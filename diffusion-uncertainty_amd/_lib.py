@@ -29,7 +29,7 @@ class ResBlockArgs(_c.Structure):
                 ("gn2_w", _P), ("gn2_b", _P), ("conv2_packed", _P), ("conv2_b", _P), ("skip_packed", _P), ("skip_b", _P),
                 ("x1_colsums", _P), ("x2_colsums", _P), ("updown", _I), ("dropmask", _P),
                 ("precision", _I), ("act_scale", _F), ("raw_scale", _F), ("workspace", _P), ("workspace_bytes", _Z),
-                ("y", _P), ("y_colsums", _P)]
+                ("y", _P), ("y_colsums", _P), ("conv1_wino", _P), ("conv2_wino", _P)]
 
 
 class AttnBlockArgs(_c.Structure):

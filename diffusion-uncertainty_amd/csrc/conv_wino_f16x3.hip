@@ -610,7 +610,9 @@ extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const flo
     const int P = Ho / 2;
     p.plane = (long)N * P * Wo * C;
     const int nxb = (Wo * (C / 8) + BLK - 1) / BLK;
-    int JC = P;
+    // Row pairs per workgroup chunk: 8 (two halo rows re-read per 16 = +12 % reads) keeps enough workgroups in flight on the large
+    // maps (128^2 x 256 channels: 1.26 ms against 1.60 ms with one chunk per column; scripts/bench_gn_apply.py f16x3w)
+    int JC = P < 8 ? P : 8;
     while ((long)N * nxb * ((P + JC - 1) / JC) < 1024 && JC > 4) JC = (JC + 1) / 2;
     p.JC = JC;
     hipLaunchKernelGGL(k_gn_apply_wino, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);

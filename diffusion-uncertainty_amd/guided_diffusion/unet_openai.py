@@ -97,14 +97,22 @@ class ResBlock(TimestepBlock):
             ident = isinstance(self.skip_connection, nn.Identity)
             mask = ctx.dropout_mask((N, H, W, self.out_channels), drop.p) if (drop.training and drop.p > 0 and not self.updown) else None
             if not (drop.training and drop.p > 0 and self.updown):          # (a dropout mask on a resampling block: composed path)
+                Hb, Wb = (2 * H, 2 * W) if self.resample > 0 else ((H // 2, W // 2) if self.resample < 0 else (H, W))
+                cin = x.shape[3] + (0 if skip is None else skip.shape[3])
+                w1 = ctx.packed(conv1, "w3w") if ctx.wino_ok(N, Hb, Wb, cin, self.out_channels) else None
+                w2 = ctx.packed(conv2, "w3w") if ctx.wino_ok(N, Hb, Wb, self.out_channels, self.out_channels) else None
                 return ops.adm_resblock(x, skip, (gn1.weight, gn1.bias), ctx.packed(conv1, kind3), conv1.bias, ctx.film(self),
                                         (gn2.weight, gn2.bias), ctx.packed(conv2, kind3), conv2.bias,
                                         None if ident else ctx.packed(self.skip_connection, kind1),
                                         None if ident else self.skip_connection.bias, self.out_channels, updown=self.resample,
-                                        dropmask=mask, precision=ctx.model.precision, want_colsum=ctx.model.fuse_gn_stats)
+                                        dropmask=mask, precision=ctx.model.precision, want_colsum=ctx.model.fuse_gn_stats,
+                                        conv1_wino=w1, conv2_wino=w2)
         st = ops.groupnorm_stats(x, skip)
+        Hc = H * 2 if self.resample > 0 else (H // 2 if self.resample < 0 else H)
         Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
-        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample, split=ctx.conv_split(Wc))
+        cin = x.shape[3] + (0 if skip is None else skip.shape[3])
+        h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample,
+                                split=ctx.conv_split(Wc, (N, Hc, Wc, cin, self.out_channels)))
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
         h = ctx.conv3x3(h, conv1, self.out_channels, colsum=True)      # epilogue leaves GroupNorm statistics for out_layers[0]
@@ -113,7 +121,8 @@ class ResBlock(TimestepBlock):
         mask = None
         if drop.training and drop.p > 0:
             mask = ctx.dropout_mask(h.shape, drop.p)
-        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask, split=ctx.conv_split(Wc))  # :249-253
+        h = ops.groupnorm_apply(h, st2, gn2.weight, gn2.bias, film=film, act=1, dropmask=mask,
+                                split=ctx.conv_split(Wc, (N, Hc, Wc, self.out_channels, self.out_channels)))                  # :249-253
         if isinstance(self.skip_connection, nn.Identity):
             assert skip is None
             res = x
@@ -213,10 +222,17 @@ class _Ctx:
         # parity modes: whole ResBlocks / AttentionBlocks as single C-ABI calls (dua_adm_resblock_fwd / dua_adm_attnblock_fwd)
         self.block_abi = bool(getattr(model, "use_block_abi", True)) and model.precision in ("fp32", "f16x3") and not model.activation_noise
 
-    def conv_split(self, width):
-        """Operand format the GroupNorm in front of a 3x3 conv of this output width writes."""
+    def wino_ok(self, N, H, W, cin, cout):
+        """This 3x3 conv (input / output size H x W) runs in the Winograd F(2,3)-along-y form of the f16x3 kernel."""
+        return self.model.precision == "f16x3" and bool(getattr(self.model, "winograd", True)) and ops.conv3x3_wino_supported(N, H, W, cin, cout)
+
+    def conv_split(self, width, conv_shape=None):
+        """Operand format the GroupNorm in front of a 3x3 conv of this output width writes (conv_shape = (N, H, W, Cin, Cout) lets
+        the f16x3 mode pick the Winograd operand where the kernel takes the shape)."""
         if self.split_acts == "f16f6" and 256 % width != 0:
             return "f16f8"
+        if conv_shape is not None and self.wino_ok(*conv_shape):
+            return "f16x3w"
         return self.split_acts
 
     def packed(self, mod, kind):
@@ -236,6 +252,8 @@ class _Ctx:
                 cache[key] = ops.pack_weight_f16f6(mod.weight.detach().contiguous())
             elif kind == "w3h":
                 cache[key] = ops.pack_weight_f16x3(mod.weight.detach().contiguous())
+            elif kind == "w3w":
+                cache[key] = ops.pack_weight_f16x3_wino(mod.weight.detach().contiguous())
             elif kind == "qkvh":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16x3(wq), bq)
@@ -289,7 +307,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16f8": "w3f", "f16f6": "w3s", "f16x3": "w3h"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16f8": "w3f", "f16f6": "w3s", "f16x3": "w3h", "f16x3w": "w3w"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -389,6 +407,9 @@ class UNetModel(nn.Module):
         # but the result then depends on the batch size at fp32-rounding level, so it is opt-in here: the Monte-Carlo chains of a
         # UC step stay bit-identical whether they run one by one or stacked)
         self.split_k = False
+        # f16x3: 3x3 convs in the Winograd F(2,3)-along-y form where the kernel takes the shape (csrc/conv_wino_f16x3.hip: 6 instead of
+        # 9 matrix-core taps per pixel at the same operand precision; results differ from the direct form at fp32-rounding level)
+        self.winograd = True
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask
@@ -454,7 +475,7 @@ class UNetModel(nn.Module):
         t = timesteps.to(torch.int64).contiguous()
         yy = y.to(torch.int64).contiguous() if y is not None else None
         key = (tuple(x.shape), self.precision, out_channels_keep, self.use_block_abi, self.fuse_gn_stats, ops.ATTENTION_MODE, y is not None,
-               bool(self.split_k))
+               bool(self.split_k), bool(getattr(self, "winograd", True)))
         entry = graphs.get(key)
         if entry is None:
             self._forward_impl(x, t, yy, out_channels_keep)            # eager once: packs the weights, warms the allocator

@@ -1027,7 +1027,7 @@ def _cs(t):
 
 
 def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, conv2_b, skip_packed, skip_b, cout, updown=0,
-                 dropmask=None, precision="fp32", want_colsum=True):
+                 dropmask=None, precision="fp32", want_colsum=True, conv1_wino=None, conv2_wino=None):
     """One ADM ResBlock forward through dua_adm_resblock_fwd (guided_diffusion/unet_openai.py:237-257).  x / skip NHWC fp32,
     gn1 / gn2 = (weight, bias) pairs, weights packed for `precision`; returns y NHWC with its column sums attached."""
     _req(x, name="x")
@@ -1046,7 +1046,9 @@ def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, c
                      x2_colsums=(_cs(skip).data_ptr() if _cs(skip) is not None else None), updown=int(updown),
                      dropmask=(dropmask.data_ptr() if dropmask is not None else None), precision=PRECISION_CODE[precision],
                      act_scale=F16X3_ACT_SCALE, raw_scale=F16X3_RAW_SCALE, workspace=None, workspace_bytes=0, y=y.data_ptr(),
-                     y_colsums=(ws_y.data_ptr() if ws_y is not None else None))
+                     y_colsums=(ws_y.data_ptr() if ws_y is not None else None),
+                     conv1_wino=(conv1_wino.data_ptr() if conv1_wino is not None else None),
+                     conv2_wino=(conv2_wino.data_ptr() if conv2_wino is not None else None))
     L = _lib.lib()
     nbytes = L.dua_adm_resblock_workspace_bytes(ctypes.byref(a))
     if nbytes == 0:

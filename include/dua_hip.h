@@ -404,6 +404,9 @@ typedef struct {
     int precision; float act_scale, raw_scale;
     void* workspace; size_t workspace_bytes;
     float* y; float* y_colsums;          /* [N][Ho][Wo][Cout] */
+    const void *conv1_wino, *conv2_wino; /* DUA_PREC_F16X3, optional: the 3x3 weights also packed by dua_pack_weight_f16x3_wino; a conv whose
+                                            shape dua_conv3x3_f16x3_wino_supported accepts then runs in the Winograd form (conv*_packed
+                                            stays required: it serves every other shape) */
 } dua_resblock_args;
 /* ResBlock.forward, guided_diffusion/unet_openai.py:237-257 (use_scale_shift_norm, resblock_updown). */
 size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* args_host);
