@@ -47,9 +47,10 @@ PRECISIONS = ["f16x3", "fp32", "bf16x3", "f16f8", "f16f6"]
 
 # per precision mode: (kernel description, MFMA products executed per algorithmic product at the bf16 rate, dtype string)
 MODES = {
-    "f16x3": ("k_xconv_dma<NT, 3> (32x32x16 shape) / k_hconv<NT, RS> (16x16x32 shape, 256-channel tiles on maps <= 64^2): LDS-DMA "
-              "implicit-GEMM conv3x3 on fp16 hi / lo planes of the scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs per "
-              "product, fp32 accumulate", 3.0,
+    "f16x3": ("k_wconv (csrc/conv_wino_f16x3.hip): LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
+              "v_mfma_f32_16x16x32_f16 - four 1x3 row convolutions per two output rows (6 instead of 9 taps per pixel) on fp16 hi / lo "
+              "planes of the transformed, scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs per product, fp32 accumulate; the "
+              "8x8 level and the in / out convs on the direct kernels k_xconv_dma<NT, 3> / k_hconv<NT, RS>", 3.0,
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
               "with head dims <= 128 in this format, wider heads / embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
@@ -79,7 +80,7 @@ def pmc_traffic(precision):
             continue
         if d.get("precision", "f16f6" if "r01k" in f or "r01l" in f else None) != precision:
             continue
-        k = d.get("kernels", {}).get("k_xconv_dma") or d.get("kernels", {}).get("conv")
+        k = d.get("kernels", {}).get("k_wconv") or d.get("kernels", {}).get("k_xconv_dma") or d.get("kernels", {}).get("conv")
         if k and "hbm_side_bytes_per_launch" in k:
             best = (float(k["hbm_side_bytes_per_launch"]), os.path.relpath(f, ROOT))
     return best
@@ -90,7 +91,7 @@ class ConvProfile:
         self.items = []
 
     def record(self, kind, flops, e0, e1):
-        self.items.append((flops, e0, e1))
+        self.items.append((flops, e0, e1, kind))
 
     def start(self):
         """Also time the conv launches made INSIDE the block-level C-ABI calls (dua_adm_resblock_fwd): HIP events recorded by the
@@ -103,34 +104,42 @@ class ConvProfile:
         from diffusion_uncertainty_amd import _lib
         L = _lib.lib()
         L.dua_conv_profile(0)
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
-        L.dua_conv_profile_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-        self.c_side = (ms.value, fl.value, n.value)
+        ms, fl, n, mf = ctypes.c_double(), ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+        L.dua_conv_profile_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n), ctypes.byref(mf))
+        self.c_side = (ms.value, fl.value, n.value, mf.value)
 
-    def summary(self):
-        c_ms, c_fl, c_n = getattr(self, "c_side", (0.0, 0.0, 0))
+    def summary(self, mult=None):
+        """mult: matrix-core product FLOPs per algorithmic FLOP of the mode's direct kernels (Winograd launches: 2/3 of it)."""
+        c_ms, c_fl, c_n, c_mf = getattr(self, "c_side", (0.0, 0.0, 0, 0.0))
         if not self.items and not c_n:
             return None
-        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.items) + c_ms
-        total_fl = sum(f for f, _, _ in self.items) + c_fl
+        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in self.items) + c_ms
+        total_fl = sum(f for f, _, _, _ in self.items) + c_fl
         n = len(self.items) + c_n
-        return dict(launches=n, flops_per_launch=total_fl / n, ms_per_launch=total_ms / n,
-                    tflops=total_fl / (total_ms * 1e-3) / 1e12)
+        out = dict(launches=n, flops_per_launch=total_fl / n, ms_per_launch=total_ms / n, tflops=total_fl / (total_ms * 1e-3) / 1e12)
+        if mult:
+            py_mf = sum(f * (mult * 2.0 / 3.0 if k == "conv3x3_wino" else mult) for f, _, _, k in self.items)
+            # the library's own count is exact for fp32 / f16x3 (the block-level path); the narrower modes run per-op only
+            out["mfma_tflops"] = (py_mf + c_mf) / (total_ms * 1e-3) / 1e12
+        return out
 
     def roofline(self, precision):
-        cs = self.summary()
+        kernel, mult, _ = MODES[precision]
+        cs = self.summary(mult)
         if cs is None:
             return None
-        kernel, mult, _ = MODES[precision]
         peak = FP32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
         tr = pmc_traffic(precision)
         r = dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(cs["tflops"] / peak, 4),
                  traffic=(tr[0] if tr else None), traffic_source=(tr[1] if tr else None), kernel=kernel, launches=cs["launches"],
                  flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
         if mult:
-            r.update(executed_mfma_tflops=round(mult * cs["tflops"], 1), executed_frac=round(mult * cs["tflops"] / peak, 4),
-                     note=f"achieved counts ALGORITHMIC fp32 FLOPs; each costs the matrix-core cycles of {mult:g} bf16-rate products, "
-                          f"so frac <= 1/{mult:g} against the 2.5 PF fp16/bf16 peak by construction")
+            eff = cs["mfma_tflops"] / cs["tflops"]                 # executed matrix-core products per algorithmic product (measured mix)
+            r.update(executed_mfma_tflops=round(cs["mfma_tflops"], 1), executed_frac=round(cs["mfma_tflops"] / peak, 4),
+                     executed_products_per_algorithmic_product=round(eff, 3),
+                     note=f"achieved counts ALGORITHMIC fp32 FLOPs (2*N*H*W*9*Cin*Cout); the launches of this job execute {eff:.2f} "
+                          f"bf16-rate matrix-core products per algorithmic product ({mult:g} per tap in the direct kernels, 6 of 9 taps in the "
+                          f"Winograd form), so frac <= 1/{eff:.2f} against the 2.5 PF fp16/bf16 peak by construction")
         return r
 
 

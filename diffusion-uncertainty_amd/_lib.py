@@ -137,7 +137,7 @@ SIGNATURES = {
     "dua_uvit_block_workspace_bytes": (_Z, [_c.POINTER(UViTBlockArgs)]),
     "dua_uvit_block_fwd": (_I, [_c.POINTER(UViTBlockArgs), _P]),
     "dua_conv_profile": (_I, [_I]),
-    "dua_conv_profile_collect": (_I, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
+    "dua_conv_profile_collect": (_I, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.POINTER(_c.c_double)]),
     "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),

@@ -10,7 +10,7 @@ namespace {
 
 // Optional per-launch timing of the conv3x3 launches made inside the block functions (bench.py's roofline leg): HIP events on
 // the launch stream, collected and summed by dua_conv_profile_collect.  Off by default; not thread-safe (a bench facility).
-struct ConvRec { hipEvent_t a, b; double flops; };
+struct ConvRec { hipEvent_t a, b; double flops, mfma; };
 bool g_prof = false;
 std::vector<ConvRec> g_recs;
 struct ConvTimer {
@@ -19,12 +19,14 @@ struct ConvTimer {
     explicit ConvTimer(void* stream) : st(as_stream(stream)) {
         if (g_prof && hipEventCreate(&a) == hipSuccess) hipEventRecord(a, st); else a = nullptr;
     }
-    void done(double flops) {
+    // flops: algorithmic (2*M*9*Cin*Cout); mfma_mult: matrix-core product FLOPs executed per algorithmic FLOP (direct f16x3: 3 fp16
+    // products; Winograd form: 6 of 9 taps x 3 = 2; exact fp32 MFMA: 1)
+    void done(double flops, double mfma_mult) {
         if (!a) return;
         hipEvent_t b;
         if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return; }
         hipEventRecord(b, st);
-        g_recs.push_back({a, b, flops});
+        g_recs.push_back({a, b, flops, flops * mfma_mult});
     }
 };
 
@@ -92,7 +94,7 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
         if (wino1) rc = dua_conv3x3_f16x3_wino(h1, a->conv1_wino, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.5f * a->act_scale, stream);
         else if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
         else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
-        tm.done(2.0 * (double)M * 9.0 * C * a->Cout);
+        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, wino1 ? 2.0 : (f16 ? 3.0 : 1.0));
     }
     if (rc) return rc;
     // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
@@ -126,7 +128,7 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
     else if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
     else rc = dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
-    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout);
+    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, wino2 ? 2.0 : (f16 ? 3.0 : 1.0));
     return rc;
 }
 
@@ -265,12 +267,12 @@ extern "C" int dua_conv_profile(int on) {
     g_prof = on != 0;
     return was;
 }
-extern "C" int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches) {
-    double ms = 0.0, fl = 0.0;
+extern "C" int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches, double* total_mfma_flops) {
+    double ms = 0.0, fl = 0.0, mf = 0.0;
     long n = 0;
     for (ConvRec& r : g_recs) {
         float t = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; fl += r.flops; ++n; }
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; fl += r.flops; mf += r.mfma; ++n; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
     }
@@ -278,6 +280,7 @@ extern "C" int dua_conv_profile_collect(double* total_ms, double* total_flops, l
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
     if (launches) *launches = n;
+    if (total_mfma_flops) *total_mfma_flops = mf;
     return DUA_OK;
 }
 

@@ -8,7 +8,9 @@
 //
 // Three pieces:
 //   k_gn_apply_wino      GroupNorm * gamma + beta (+FiLM, SiLU, dropout mask, 2x resampling, virtual concat) -> the four V_f images
-//                        as f16x3 planes [f][hi|lo][N*(H/2)*W][C] (the sliding window over y keeps every input element read once)
+//                        as f16x3 planes [f][N*(H/2)*W][C/32][hi 32 | lo 32] - one 128-byte line per (position, channel block),
+//                        so a K step of the conv consumes whole cache lines (the sliding window over y keeps every input
+//                        element read once)
 //   k_pack_wino          OIHW fp32 weights -> U_f, per-output-row power-of-two scale, fp16 hi | lo planes in the tile order below
 //   k_wconv              LDS-DMA implicit GEMM on v_mfma_f32_16x16x32_f16 (the loop of conv_f16x3.hip's row-shift kernel): a
 //                        workgroup tile = 128 positions of the V images (whole image rows of W | 128 positions) x 128 output channels
@@ -29,12 +31,11 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WConvP {
-    const _Float16* V;       // [4 f][2 planes][Mv][Cin]
+    const _Float16* V;       // [4 f][Mv][Cin / 32][hi 32 | lo 32]: one 128-byte line per (position, 32-channel block)
     const _Float16* B;       // packed weights: hi plane [ntn*256][K], lo plane, then the row scales
     const float *bias, *res, *Cscale;
     float* C;
     float* colsum;
-    long v_plane;            // Mv * Cin
     long b_plane;            // ntn * 256 * K
     int Mv, N, Cin, K, H, W, ntm, ntn;
     float out_scale;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
     auto ra1 = ra0;
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
     const int b_lo = (int)(p.b_plane * 2);
-    const int a_lo = (int)(p.v_plane * 2);
+    const int a_lo = 64;                                   // byte distance hi -> lo halves inside a line
     int grpA = 0;                                          // next activation group to request: channel block grpA >> 1, fi = grpA & 1
     unsigned vo0 = 0, vo1 = 0;
     bool prefetched = false;
@@ -88,18 +89,18 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         for (int j = 0; j < 2; ++j) {
             const int r = 16 * ((2 * wave + j) & 7) + dl_row;             // position row of the tile this lane fills
             const int m = min(m0_ + r, p.Mv - 1);
-            abase[j] = (unsigned)(((long)(m - m0_) * p.Cin + 8 * dl_src) * 2);
+            abase[j] = (unsigned)((long)(m - m0_) * p.Cin * 4 + 16 * dl_src);     // row = Cin / 32 lines of 128 B: [hi 32 | lo 32] halves
             boff[j] = (unsigned)(((long)(tn_ * 256 + 16 * (2 * wave + j) + dl_row) * p.K + 8 * dl_src) * 2);
         }
-        const long rem = (2L * p.Mv - m0_) * p.Cin * 2;                   // bytes from the rebased origin to the end of the lo plane
+        const long rem = ((long)p.Mv - m0_) * p.Cin * 4;                  // bytes from the rebased origin to the end of this frequency's image
         const int rec = (int)(unsigned)(rem < 0xFFFFFFF0L ? rem : 0xFFFFFFF0L);   // num_records is an unsigned 32-bit field
-        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (2L * f_a * p.Mv + m0_) * p.Cin), 0, rec, 0x00020000);
-        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (2L * f_b * p.Mv + m0_) * p.Cin), 0, rec, 0x00020000);
+        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + ((long)f_a * p.Mv + m0_) * p.Cin * 2), 0, rec, 0x00020000);
+        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + ((long)f_b * p.Mv + m0_) * p.Cin * 2), 0, rec, 0x00020000);
         grpA = 0;
     };
     bool fiA = false;                                     // frequency index of the group being requested (selects the descriptor)
     auto a_setup = [&]() {
-        const unsigned toff = (unsigned)((grpA >> 1) * 64);
+        const unsigned toff = (unsigned)((grpA >> 1) * 128);              // channel block cb: the cb-th 128-byte line of every row
         vo0 = abase[0] + toff;
         vo1 = abase[1] + toff;
         fiA = (grpA & 1) != 0;
@@ -455,7 +456,7 @@ extern "C" int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, in
     if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % 32 || Cout <= 0 || Cout % 4) return 0;
     if (H % 2 || W < 2 || W > 128 || (W & (W - 1)) || ((long)H * W) % 128) return 0;
     const long Mv = (long)N * (H / 2) * W;
-    if (Mv >= (1L << 30) || (2 * Mv + 256) * Cin * 2 >= 0xFFFFFFF0L) return 0;      // hi | lo planes of one frequency behind one 32-bit buffer range
+    if (Mv >= (1L << 30) || (Mv + 128) * Cin * 4 >= 0xFFFFFFF0L) return 0;          // one frequency's image behind one 32-bit buffer range
     if ((size_t)wino_ntn(Cout) * 256 * 6 * Cin * 4 >= 0x7FFFFFF0ull) return 0;
     return 1;
 }
@@ -470,7 +471,6 @@ extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, c
     WConvP p{};
     p.V = (const _Float16*)vplanes; p.B = (const _Float16*)packed; p.bias = bias; p.res = residual; p.C = y; p.colsum = colsum;
     p.Mv = N * (H / 2) * W; p.N = Cout; p.Cin = Cin; p.K = 6 * Cin; p.H = H; p.W = W;
-    p.v_plane = (long)p.Mv * Cin;
     p.ntm = (p.Mv + 127) / 128; p.ntn = wino_ntn(Cout);
     p.b_plane = (long)p.ntn * 256 * p.K;
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
@@ -499,6 +499,7 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
     const int n = blockIdx.y, jc = blockIdx.x / nxb, item = (blockIdx.x % nxb) * BLK + threadIdx.x;
     if (item >= Wo * O) return;
     const int xo = item / O, c = 8 * (item % O);
+    const bool oddq = (threadIdx.x >> 2) & 1;              // (Wo * O is a multiple of 8: a pair of quads is never split by the exit above)
     const bool second = c >= p.C1;
     const float* src = second ? p.x2 : p.x1;
     const int cs = second ? p.C2 : p.C1, cq = second ? c - p.C1 : c;
@@ -559,9 +560,20 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
             h[j] = t;
             l[j] = (_Float16)(sv - (float)t);
         }
-        _Float16* o = p.v + (size_t)(2 * f) * p.plane + m * C + c;
-        *(h16x8*)o = h;
-        *(h16x8*)(o + p.plane) = l;
+        // line (m, c / 32) = [hi 32 | lo 32] halves, this lane's 16-byte piece k = (c & 31) / 8 of either half.  The four lanes of a
+        // line (a quad) would write it as two 64-byte halves in two instructions; instead quads pair up (lane ^ 4: the even quad hands
+        // over its lo pieces and takes the odd quad's hi pieces), so that each store instruction writes whole 128-byte lines.
+        const size_t lb = ((size_t)f * p.plane + m * C) * 2 + (size_t)(c >> 5) * 64 + (c & 31);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 hu = __builtin_bit_cast(u32x4, h), lu = __builtin_bit_cast(u32x4, l);
+        const u32x4 give = oddq ? hu : lu;
+        u32x4 got;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 4);
+        const unsigned lb_lo = (unsigned)lb, lb_hi = (unsigned)(lb >> 32);
+        const size_t lbp = ((size_t)(unsigned)__shfl_xor((int)lb_hi, 4) << 32) | (unsigned)__shfl_xor((int)lb_lo, 4);
+        *(u32x4*)(p.v + (oddq ? lbp + 32 : lb)) = oddq ? got : hu;        // the even quad's line: its hi pieces | its lo pieces
+        *(u32x4*)(p.v + (oddq ? lb + 32 : lbp)) = oddq ? lu : got;        // the odd quad's line
     };
     const int j0 = jc * p.JC, j1 = min(P, j0 + p.JC);
     float dA[8], dB[8], dC[8], dD[8];

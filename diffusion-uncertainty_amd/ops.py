@@ -317,7 +317,7 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
         if split == "f16x3w":
             # Winograd F(2,3)-along-y operand of conv3x3 (csrc/conv_wino_f16x3.hip): the four V_f images as f16x3 planes of V * scale
             scale = 0.5 * F16X3_ACT_SCALE if split_scale is None else float(split_scale)
-            vbuf = torch.empty((4, 2, N, Ho // 2, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
+            vbuf = torch.empty((4, N, Ho // 2, Wo, (C1 + C2) // 32, 2, 32), device=x1.device, dtype=torch.int16)   # [.., hi 32 | lo 32]
             check(_lib.lib().dua_groupnorm_apply_wino_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
                                                             _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
                                                             scale, _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f16x3")
@@ -648,7 +648,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
                                             _p(ws), _stream()), "dua_conv3x3_bf16x3")
     if PROFILE is not None:
         e1.record()
-        PROFILE.record("conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
+        PROFILE.record("conv3x3_wino" if (pre and x.fmt == "f16x3w") else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
     return _attach_colsums(y, ws, H * W)
 
 

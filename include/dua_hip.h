@@ -306,7 +306,8 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  * precision: input rows d0..d3 = 2j-1 .. 2j+2 -> V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3; kernel rows g0..g2 ->
  * U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2; M_f = conv1x3(V_f, U_f); out row 2j = M0+M1+M2, row 2j+1 = M1-M2-M3.
  * dua_groupnorm_apply_wino_f16x3: dua_groupnorm_apply_split_f16x3 writing the four V_f images as f16x3 planes
- *   [f][hi|lo][N*(Ho/2)*Wo][C] of V * v_scale (dua_f16x3_wino_act_bytes bytes; Ho, Wo = the conv's input size after `resample`);
+ *   [f][N*(Ho/2)*Wo][C/32][hi 32 | lo 32] of V * v_scale - one 128-byte line per (position, 32-channel block) -
+ *   (dua_f16x3_wino_act_bytes bytes; Ho, Wo = the conv's input size after `resample`);
  *   v_scale a power of two (|V| <= 2 max|activation|: the UNet uses act_scale / 2).
  * dua_pack_weight_f16x3_wino: OIHW fp32 weights -> U_f * 2^s as fp16 hi | lo planes in the kernel's tile order, then
  *   round_up(Cout, 256) floats 2^-s (s per output channel over all 12 (f, dx) taps); dua_f16x3_wino_weight_bytes bytes.
@@ -444,9 +445,10 @@ size_t dua_uvit_block_workspace_bytes(const dua_uvitblock_args* args_host);
 int dua_uvit_block_fwd(const dua_uvitblock_args* args_host, void* stream);
 /* Bench facility: dua_conv_profile(1) makes the block functions bracket each of their conv3x3 launches with HIP events on the
  * launch stream (returns the previous setting); dua_conv_profile_collect synchronises on them, returns the summed launch time (ms),
- * the summed algorithmic FLOPs (2*N*H*W*9*Cin*Cout) and the number of launches since the last collect, and frees the events. */
+ * the summed algorithmic FLOPs (2*N*H*W*9*Cin*Cout), the number of launches since the last collect and the matrix-core product
+ * FLOPs those launches executed (3 fp16 products per tap in f16x3, 6 of 9 taps in the Winograd form), and frees the events. */
 int dua_conv_profile(int on);
-int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches);
+int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches, double* total_mfma_flops);
 int dua_adm_attnblock_fwd(const dua_attnblock_args* args_host, void* stream);
 
 /* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */

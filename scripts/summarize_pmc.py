@@ -29,10 +29,13 @@ def pmc(out, tag, precision="f16x3"):
         for db in glob.glob(f"{out}/{tag}_pmc_{counter}/**/*.db", recursive=True):
             c = sqlite3.connect(db)
             for name, value in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
-                if "k_xconv_dma" not in name and "k_hconv" not in name:
+                if "k_xconv_dma" not in name and "k_hconv" not in name and "k_wconv" not in name:
                     continue
-                fam = "k_hconv" if "k_hconv" in name else "k_xconv_dma"
-                key = fam + ("<4>" if ("<4>" in name or "<4," in name) else "<2>")
+                if "k_wconv" in name:
+                    key = "k_wconv"                  # the Winograd-form conv3x3 (csrc/conv_wino_f16x3.hip): conv3x3 launches only
+                else:
+                    fam = "k_hconv" if "k_hconv" in name else "k_xconv_dma"
+                    key = fam + ("<4>" if ("<4>" in name or "<4," in name) else "<2>")
                 for k in (key, "conv"):              # "conv": every launch of the LDS-DMA conv / one-tap GEMM kernels
                     acc[k] += float(value)
                     cnt[k] += 1

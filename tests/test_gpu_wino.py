@@ -40,10 +40,10 @@ def v_reference(a):
 
 
 def decode_v(pl):
-    buf = pl.buf.cpu()
-    f4, two, N, P, W, C = buf.shape
+    buf = pl.buf.cpu()                                       # [f][N][H/2][W][C/32][hi | lo][32]
     h = buf.view(torch.float16).double()
-    return (h[:, 0] + h[:, 1]) / pl.scale
+    v = (h[..., 0, :] + h[..., 1, :]) / pl.scale
+    return v.reshape(*v.shape[:4], -1)
 
 
 def identity_stats(N, groups=32):
