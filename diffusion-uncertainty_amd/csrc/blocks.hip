@@ -64,13 +64,14 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     // convolution's output (conv1's output is dead once the second GroupNorm has consumed it)
     // Winograd form of a 3x3 conv (csrc/conv_wino_f16x3.hip) where its packed weights are given and the shape allows: the GroupNorm
     // in front writes the four transformed images (8 bytes per element instead of 4)
-    const bool wino1 = f16 && a->conv1_wino && dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, C, a->Cout);
-    const bool wino2 = f16 && a->conv2_wino && dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout);
+    const int wsup1 = (f16 && a->conv1_wino) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, C, a->Cout) : 0;
+    const int wsup2 = (f16 && a->conv2_wino) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
+    const bool wino1 = wsup1 != 0, wino2 = wsup2 != 0;          // (== 2: no column sums from that conv; the statistics kernel runs instead)
     const size_t szA1 = (size_t)M * C * (wino1 ? 8 : 4), szA2 = (size_t)M * a->Cout * (wino2 ? 8 : 4);
     void* regA = w.take(szA1 > szA2 ? szA1 : szA2);
     float* xr = a->updown ? (float*)w.take((size_t)M * a->C1 * 4) : nullptr;
     float* regB = (float*)w.take((size_t)M * a->Cout * 4);
-    float* cs2 = colsum2 ? (float*)w.take(colsum_floats(M, a->Cout) * 4) : nullptr;
+    float* cs2 = (colsum2 && wsup1 != 2) ? (float*)w.take(colsum_floats(M, a->Cout) * 4) : nullptr;
     float* stats2 = (float*)w.take((size_t)a->N * G * 2 * 4);
     void* h1 = regA;                                                 // fp32 [N,Ho,Wo,C] or two 2-byte planes of it
     float* h2 = regB;
@@ -124,6 +125,7 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
         resid = res;
     }
     float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
+    DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0");
     ConvTimer tm(stream);
     if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
     else if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         auto step = [&](auto fi_c, auto dxi_c, auto last_c, f32x4 (&A)[4][4]) __attribute__((always_inline)) {
             constexpr int FI = decltype(fi_c)::value, DXI = decltype(dxi_c)::value;
             constexpr bool LAST = decltype(last_c)::value;
-            constexpr bool preA = !LAST && DXI == 0;                            // request the next group's activation stage
+            constexpr bool preA = !LAST && DXI == 0;                            // set up the next group's activation stage ...
+            constexpr bool pieceA = !LAST && DXI < 2;                           // ... requested half in this group's first, half in its second step
             constexpr bool preB = !LAST || DXI == 0;                            // request the weight stage of step s + 2
             constexpr bool more = (!LAST || DXI < 2) && !(WCONV_DIAG & 8);
             constexpr int sa_n = FI ^ 1, sb_n = (DXI + 2) % 3;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             if (preA) { a_setup(); fiA = FI == 0; }
             auto early_piece = [&](int q) {
                 if (q < NBP) { if (preB && !(WCONV_DIAG & 2)) dma_b(sb_n, q); }
-                else if (q < NBP + 4) { if (preA && !(WCONV_DIAG & 4)) dma_a(sa_n, q - NBP); }
+                else if (q < NBP + 2) { if (pieceA && !(WCONV_DIAG & 4)) dma_a(sa_n, q - NBP + 2 * DXI); }
             };
             WSB();
             // P1: w_hi * x_lo | the DMA pieces of this step
@@ -229,9 +230,12 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             // every read of stage s was issued during the previous step: publish stage s + 1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             {
-                constexpr int keep = (preB ? NBP : 0) + ((!LAST && DXI != 2) ? 4 : 0);
-                if (keep >= NBP + 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (keep >= NBP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                // in issue order: [B(s+1) x4, A x2] of the previous step, [B(s+2) x4, A x2] of this one.  B(s+1) must have landed;
+                // the group's last step also needs all four activation pieces
+                constexpr int keep = LAST ? (preB ? NBP : 0) : (DXI == 0 ? NBP + 2 : (DXI == 1 ? NBP + 4 : NBP));
+                if (keep == NBP + 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (keep == NBP + 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (keep == NBP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (!(WCONV_DIAG & 1)) __builtin_amdgcn_s_barrier();
@@ -452,22 +456,25 @@ extern "C" int dua_pack_weight_f16x3_wino(const float* w, void* packed, int Cout
     return dua_check_launch("dua_pack_weight_f16x3_wino");
 }
 
+// 0 = not supported, 1 = supported, 2 = supported without the column-sum output (maps smaller than 128 pixels: a wave's 64
+// positions then span several images)
 extern "C" int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % 32 || Cout <= 0 || Cout % 4) return 0;
-    if (H % 2 || W < 2 || W > 128 || (W & (W - 1)) || ((long)H * W) % 128) return 0;
+    if (H % 2 || W < 2 || W > 128 || (W & (W - 1))) return 0;
     const long Mv = (long)N * (H / 2) * W;
     if (Mv >= (1L << 30) || (Mv + 128) * Cin * 4 >= 0xFFFFFFF0L) return 0;          // one frequency's image behind one 32-bit buffer range
     if ((size_t)wino_ntn(Cout) * 256 * 6 * Cin * 4 >= 0x7FFFFFF0ull) return 0;
-    return 1;
+    return ((long)H * W) % 128 == 0 ? 1 : 2;
 }
 
 extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
                                       int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
     DUA_REQUIRE(vplanes && packed && y, "dua_conv3x3_f16x3_wino: null pointer");
     DUA_REQUIRE(v_scale > 0.f, "dua_conv3x3_f16x3_wino: v_scale must be positive");
-    DUA_REQUIRE(dua_conv3x3_f16x3_wino_supported(N, H, W, Cin, Cout),
-                "dua_conv3x3_f16x3_wino: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (H even, W a power of two <= 128, H*W %% 128 == 0, "
+    const int sup = dua_conv3x3_f16x3_wino_supported(N, H, W, Cin, Cout);
+    DUA_REQUIRE(sup, "dua_conv3x3_f16x3_wino: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (H even, W a power of two <= 128, "
                 "Cin %% 32 == 0, Cout %% 4 == 0)", N, H, W, Cin, Cout);
+    DUA_REQUIRE(!colsum || sup == 1, "dua_conv3x3_f16x3_wino: the column-sum output needs H*W %% 128 == 0 (got %d x %d)", H, W);
     WConvP p{};
     p.V = (const _Float16*)vplanes; p.B = (const _Float16*)packed; p.bias = bias; p.res = residual; p.C = y; p.colsum = colsum;
     p.Mv = N * (H / 2) * W; p.N = Cout; p.Cin = Cin; p.K = 6 * Cin; p.H = H; p.W = W;

@@ -633,6 +633,8 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
         e0.record()
     if pre and x.fmt == "f16x3w":
         assert not nchw_out, "the Winograd conv writes NHWC"
+        if (H * W) % 128:
+            ws = None                                  # small maps: no column sums from the Winograd kernel
         check(_lib.lib().dua_conv3x3_f16x3_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, _p(ws), x.scale,
                                                 _stream()), "dua_conv3x3_f16x3_wino")
     elif pre and x.fmt == "f16x3":
@@ -1035,7 +1037,7 @@ def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, c
     C2 = 0 if skip is None else skip.shape[3]
     Ho, Wo = (H // 2, W // 2) if updown < 0 else ((2 * H, 2 * W) if updown > 0 else (H, W))
     y = torch.empty((N, Ho, Wo, cout), device=x.device, dtype=torch.float32)
-    ws_y = _colsum_ws(N * Ho * Wo, cout, x.device, want_colsum)
+    ws_y = _colsum_ws(N * Ho * Wo, cout, x.device, want_colsum and not (conv2_wino is not None and (Ho * Wo) % 128))
     a = ResBlockArgs(x1=x.data_ptr(), C1=C1, x2=(skip.data_ptr() if skip is not None else None), C2=C2, N=N, H=H, W=W, Cout=cout,
                      gn1_w=gn1[0].data_ptr(), gn1_b=gn1[1].data_ptr(), conv1_packed=conv1_packed.data_ptr(), conv1_b=conv1_b.data_ptr(),
                      film=film.data_ptr(), film_ld=_film_ld(film, N, cout), gn2_w=gn2[0].data_ptr(), gn2_b=gn2[1].data_ptr(),

@@ -313,8 +313,9 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  *   round_up(Cout, 256) floats 2^-s (s per output channel over all 12 (f, dx) taps); dua_f16x3_wino_weight_bytes bytes.
  * dua_conv3x3_f16x3_wino: y[N][H][W][Cout] = conv3x3(x) + bias (+ residual) from those two operands; colsum as dua_conv3x3 except
  *   that a 64-pixel slot holds the sums of every other row of a 128-pixel block (the per-image totals, which is what
- *   dua_groupnorm_stats_from_colsums folds, are exact).  Shapes: dua_conv3x3_f16x3_wino_supported (H even, W a power of two
- *   <= 128, H*W % 128 == 0, Cin % 32 == 0, Cout % 4 == 0); anything else goes through dua_conv3x3_f16x3_presplit. */
+ *   dua_groupnorm_stats_from_colsums folds, are exact).  Shapes: dua_conv3x3_f16x3_wino_supported returns 1 for H even, W a power
+ *   of two <= 128, Cin % 32 == 0, Cout % 4 == 0, H*W % 128 == 0, and 2 for the same with a smaller map (colsum must then be NULL);
+ *   0 = not taken, the conv goes through dua_conv3x3_f16x3_presplit. */
 size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C);
 size_t dua_f16x3_wino_weight_bytes(int Cout, int Cin);
 int dua_pack_weight_f16x3_wino(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
