@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WConvP {
     const _Float16* V;       // [4 f][Mv][Cin / 32][hi 32 | lo 32]: one 128-byte line per (position, 32-channel block)
-    const _Float16* B;       // packed weights: hi plane [ntn*256][K], lo plane, then the row scales
+    const _Float16* B;       // packed weights [ntn][K / 32 steps][hi | lo][256 rows][32], then the row scales
     const float *bias, *res, *Cscale;
     float* C;
     float* colsum;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
     auto ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, 0, 0x00020000);
     auto ra1 = ra0;
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
-    const int b_lo = (int)(p.b_plane * 2);
+    const int b_lo = 256 * 32 * 2;                         // byte distance hi -> lo image inside a weight stage
     const int a_lo = 64;                                   // byte distance hi -> lo halves inside a line
     int grpA = 0;                                          // next activation group to request: channel block grpA >> 1, fi = grpA & 1
     unsigned vo0 = 0, vo1 = 0;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             const int r = 16 * ((2 * wave + j) & 7) + dl_row;             // position row of the tile this lane fills
             const int m = min(m0_ + r, p.Mv - 1);
             abase[j] = (unsigned)((long)(m - m0_) * p.Cin * 4 + 16 * dl_src);     // row = Cin / 32 lines of 128 B: [hi 32 | lo 32] halves
-            boff[j] = (unsigned)(((long)(tn_ * 256 + 16 * (2 * wave + j) + dl_row) * p.K + 8 * dl_src) * 2);
+            boff[j] = (unsigned)((long)tn_ * (p.K / 32) * 32768 + (16 * (2 * wave + j) + dl_row) * 64 + 16 * dl_src);   // stage 0 of the column tile
         }
         const long rem = ((long)p.Mv - m0_) * p.Cin * 4;                  // bytes from the rebased origin to the end of this frequency's image
         const int rec = (int)(unsigned)(rem < 0xFFFFFFF0L ? rem : 0xFFFFFFF0L);   // num_records is an unsigned 32-bit field
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
             if (i == 2 * j + 1) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);
-                boff[j] += 64;
+                boff[j] += 32768;                          // the next K step's stage
             }
         }
     };
@@ -423,21 +423,27 @@ __global__ __launch_bounds__(256) void k_wino_row_scale(const float* __restrict_
         inv_scale[n] = __uint_as_float((unsigned)(127 - e) << 23);
     }
 }
-__global__ void k_pack_wino(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                            const float* __restrict__ inv_scale, int Cout, int Cin, int ntn) {
-    const int K = 6 * Cin;
-    const size_t total = (size_t)ntn * 256 * K;
+// Packed layout: [column tile][K step = (channel block, fi, dx)][hi | lo][256 rows = group * 128 + channel][32 channels] - the
+// 32 KB weight stage of a K step is one contiguous block in the order of its LDS image, so every 1-KB DMA piece reads eight whole
+// 128-byte lines.
+__global__ void k_pack_wino(const float* __restrict__ w, _Float16* __restrict__ packed, const float* __restrict__ inv_scale, int Cout,
+                            int Cin, int ntn) {
+    const int nk = 6 * (Cin / 32);
+    const size_t total = (size_t)ntn * nk * 256 * 32;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int R = (int)(i / K), k = (int)(i % K);
-        const int tn = R >> 8, g = (R >> 7) & 1, cout = tn * 128 + (R & 127);
-        const int cb = k / 192, t = (k % 192) / 32, c = k % 32;
+        const int c = (int)(i & 31), R = (int)((i >> 5) & 255);
+        const size_t st = i >> 13;                                       // (column tile, step)
+        const int tn = (int)(st / nk), s = (int)(st % nk);
+        const int g = R >> 7, cout = tn * 128 + (R & 127);
+        const int cb = s / 6, t = s % 6;
         const int fi = t / 3, dx = t % 3, ci = cb * 32 + c;
         const int f = g == 0 ? (fi == 0 ? 1 : 2) : (fi == 0 ? 0 : 3);
         float v = 0.f;
         if (cout < Cout) v = (float)wino_u(w, cout, ci, dx, f, Cin) * (1.0f / inv_scale[cout]);
         const _Float16 h = (_Float16)v;
-        hi[i] = h;
-        lo[i] = (_Float16)(v - (float)h);
+        _Float16* o = packed + st * (2 * 256 * 32) + R * 32 + c;
+        o[0] = h;
+        o[256 * 32] = (_Float16)(v - (float)h);
     }
 }
 
@@ -452,7 +458,7 @@ extern "C" int dua_pack_weight_f16x3_wino(const float* w, void* packed, int Cout
     _Float16* hi = (_Float16*)packed;
     float* inv_scale = (float*)(hi + 2 * plane);
     hipLaunchKernelGGL(k_wino_row_scale, dim3(Nsc), 256, 0, as_stream(stream), w, inv_scale, Cout, Cin);
-    hipLaunchKernelGGL(k_pack_wino, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, hi + plane, inv_scale, Cout, Cin, ntn);
+    hipLaunchKernelGGL(k_pack_wino, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, inv_scale, Cout, Cin, ntn);
     return dua_check_launch("dua_pack_weight_f16x3_wino");
 }
 

@@ -309,7 +309,8 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  *   [f][N*(Ho/2)*Wo][C/32][hi 32 | lo 32] of V * v_scale - one 128-byte line per (position, 32-channel block) -
  *   (dua_f16x3_wino_act_bytes bytes; Ho, Wo = the conv's input size after `resample`);
  *   v_scale a power of two (|V| <= 2 max|activation|: the UNet uses act_scale / 2).
- * dua_pack_weight_f16x3_wino: OIHW fp32 weights -> U_f * 2^s as fp16 hi | lo planes in the kernel's tile order, then
+ * dua_pack_weight_f16x3_wino: OIHW fp32 weights -> U_f * 2^s as fp16 hi | lo images in the kernel's stage order
+ *   ([column tile of 128][K step = (channel block, fi, dx)][hi | lo][group * 128 + channel][32]: 32 KB contiguous per step), then
  *   round_up(Cout, 256) floats 2^-s (s per output channel over all 12 (f, dx) taps); dua_f16x3_wino_weight_bytes bytes.
  * dua_conv3x3_f16x3_wino: y[N][H][W][Cout] = conv3x3(x) + bias (+ residual) from those two operands; colsum as dua_conv3x3 except
  *   that a 64-pixel slot holds the sums of every other row of a 128-pixel block (the per-image totals, which is what

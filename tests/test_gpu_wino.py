@@ -92,17 +92,17 @@ def test_wino_writer_vs_torch(ops, N, H, W, C1, C2, resample, film, drop):
 
 
 def test_wino_weight_pack(ops):
-    """The packed weights decode to U_f = G g over the kernel rows, in the tile order [column tile][group][128 channels] x
-    [channel block][fi][dx][32 channels], scaled per output channel by a power of two."""
+    """The packed weights decode to U_f = G g over the kernel rows, in the stage order [column tile][channel block][fi][dx] x
+    [hi | lo][group][128 channels][32 channels], scaled per output channel by a power of two."""
     Cout, Cin = 160, 64
     w = rnd(7, Cout, Cin, 3, 3) * torch.logspace(-2, 1, Cout).reshape(-1, 1, 1, 1)
     packed = ops.pack_weight_f16x3_wino(w.to(dev)).cpu()
     ntn, K = 2, 6 * Cin
     plane = ntn * 256 * K
-    h = packed[:4 * plane].view(torch.float16).double().reshape(2, ntn, 2, 128, Cin // 32, 2, 3, 32)
+    h = packed[:4 * plane].view(torch.float16).double().reshape(ntn, Cin // 32, 2, 3, 2, 2, 128, 32)   # [tn][cb][fi][dx][hi|lo][g][col][c]
     inv = packed[4 * plane:].view(torch.float32).double()
     assert inv.numel() == 256
-    val = (h[0] + h[1])                                                          # [tn][g][col][cb][fi][dx][c]
+    val = (h[:, :, :, :, 0] + h[:, :, :, :, 1]).permute(0, 4, 5, 1, 2, 3, 6)      # [tn][g][col][cb][fi][dx][c]
     g0, g1, g2 = w[:, :, 0].double(), w[:, :, 1].double(), w[:, :, 2].double()    # [Cout][Cin][dx]
     U = [g0, 0.5 * (g0 + g1 + g2), 0.5 * (g0 - g1 + g2), g2]
     fmap = {(0, 0): 1, (0, 1): 2, (1, 0): 0, (1, 1): 3}
