@@ -67,7 +67,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     const int wsup1 = (f16 && a->conv1_wino) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, C, a->Cout) : 0;
     const int wsup2 = (f16 && a->conv2_wino) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
     const bool wino1 = wsup1 != 0, wino2 = wsup2 != 0;          // (== 2: no column sums from that conv; the statistics kernel runs instead)
-    const size_t szA1 = (size_t)M * C * (wino1 ? 8 : 4), szA2 = (size_t)M * a->Cout * (wino2 ? 8 : 4);
+    const size_t szA1 = wino1 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, C) : (size_t)M * C * 4;             // (whole tiles of 128 positions)
+    const size_t szA2 = wino2 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, a->Cout) : (size_t)M * a->Cout * 4;
     void* regA = w.take(szA1 > szA2 ? szA1 : szA2);
     float* xr = a->updown ? (float*)w.take((size_t)M * a->C1 * 4) : nullptr;
     float* regB = (float*)w.take((size_t)M * a->Cout * 4);

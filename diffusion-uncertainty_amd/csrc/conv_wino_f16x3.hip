@@ -8,9 +8,9 @@
 //
 // Three pieces:
 //   k_gn_apply_wino      GroupNorm * gamma + beta (+FiLM, SiLU, dropout mask, 2x resampling, virtual concat) -> the four V_f images
-//                        as f16x3 planes [f][N*(H/2)*W][C/32][hi 32 | lo 32] - one 128-byte line per (position, channel block),
-//                        so a K step of the conv consumes whole cache lines (the sliding window over y keeps every input
-//                        element read once)
+//                        as f16x3 images [f][tile of 128 positions][C/32][hi | lo][128][32]: the 16 KB the conv stages per
+//                        (tile, channel block, frequency) are contiguous in its LDS-image order (the sliding window over y keeps
+//                        every input element read once)
 //   k_pack_wino          OIHW fp32 weights -> U_f, per-output-row power-of-two scale, fp16 hi | lo planes in the tile order below
 //   k_wconv              LDS-DMA implicit GEMM on v_mfma_f32_16x16x32_f16 (the loop of conv_f16x3.hip's row-shift kernel): a
 //                        workgroup tile = 128 positions of the V images (whole image rows of W | 128 positions) x 128 output channels
@@ -31,7 +31,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WConvP {
-    const _Float16* V;       // [4 f][Mv][Cin / 32][hi 32 | lo 32]: one 128-byte line per (position, 32-channel block)
+    const _Float16* V;       // [4 f][ntm tiles of 128 positions][Cin / 32][hi | lo][128 positions][32 channels]
     const _Float16* B;       // packed weights [ntn][K / 32 steps][hi | lo][256 rows][32], then the row scales
     const float *bias, *res, *Cscale;
     float* C;
@@ -44,7 +44,8 @@ struct WConvP {
 #define WROWS 256
 #define WLD 32
 // Timing-only diagnostic builds (scripts/wconv_diag.py; WRONG results, never in the product library): WCONV_DIAG bit 0 drops the
-// per-step barrier, bit 1 the in-loop weight DMA, bit 2 the in-loop activation DMA, bit 3 the in-loop fragment reads.
+// per-step barrier, bit 1 the in-loop weight DMA, bit 2 the in-loop activation DMA, bit 3 the in-loop fragment reads; bit 4 reads the
+// activations of every tile from the first 32 tiles (prices the L2-miss path of the activation stream).
 #ifndef WCONV_DIAG
 #define WCONV_DIAG 0
 #endif
@@ -78,29 +79,29 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
     auto ra1 = ra0;
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
     const int b_lo = 256 * 32 * 2;                         // byte distance hi -> lo image inside a weight stage
-    const int a_lo = 64;                                   // byte distance hi -> lo halves inside a line
+    const int a_lo = 128 * 32 * 2;                         // byte distance hi -> lo image inside an activation stage block
     int grpA = 0;                                          // next activation group to request: channel block grpA >> 1, fi = grpA & 1
     unsigned vo0 = 0, vo1 = 0;
     bool prefetched = false;
     const int f_a = grp_w == 0 ? 1 : 0, f_b = grp_w == 0 ? 2 : 3;        // this wave's frequencies for fi = 0 / 1
 
+    const int ncb = p.Cin / 32;
     auto tile_geom = [&](int m0_, int tn_) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = 16 * ((2 * wave + j) & 7) + dl_row;             // position row of the tile this lane fills
-            const int m = min(m0_ + r, p.Mv - 1);
-            abase[j] = (unsigned)((long)(m - m0_) * p.Cin * 4 + 16 * dl_src);     // row = Cin / 32 lines of 128 B: [hi 32 | lo 32] halves
+            abase[j] = (unsigned)((16 * ((2 * wave + j) & 7) + dl_row) * 64 + 16 * dl_src);     // this lane's 16 bytes of the 128-row image
             boff[j] = (unsigned)((long)tn_ * (p.K / 32) * 32768 + (16 * (2 * wave + j) + dl_row) * 64 + 16 * dl_src);   // stage 0 of the column tile
         }
-        const long rem = ((long)p.Mv - m0_) * p.Cin * 4;                  // bytes from the rebased origin to the end of this frequency's image
-        const int rec = (int)(unsigned)(rem < 0xFFFFFFF0L ? rem : 0xFFFFFFF0L);   // num_records is an unsigned 32-bit field
-        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + ((long)f_a * p.Mv + m0_) * p.Cin * 2), 0, rec, 0x00020000);
-        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + ((long)f_b * p.Mv + m0_) * p.Cin * 2), 0, rec, 0x00020000);
+        // one tile of one frequency = ncb stage blocks of 16 KB ([hi | lo][128 positions][32 channels]), contiguous
+        const int rec = ncb * 16384;
+        const long tmi = (WCONV_DIAG & 16) ? (m0_ >> 7) & 31 : m0_ >> 7;   // (diagnostic: activations from a cache-resident set of tiles)
+        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (((long)f_a * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
+        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (((long)f_b * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
         grpA = 0;
     };
     bool fiA = false;                                     // frequency index of the group being requested (selects the descriptor)
     auto a_setup = [&]() {
-        const unsigned toff = (unsigned)((grpA >> 1) * 128);              // channel block cb: the cb-th 128-byte line of every row
+        const unsigned toff = (unsigned)((grpA >> 1) * 16384);            // channel block cb: the cb-th stage block of the tile
         vo0 = abase[0] + toff;
         vo1 = abase[1] + toff;
         fiA = (grpA & 1) != 0;
@@ -270,7 +271,6 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         using I2 = std::integral_constant<int, 2>;
         using BF = std::integral_constant<bool, false>;
         using BT = std::integral_constant<bool, true>;
-        const int ncb = nk / 6;
 #pragma nounroll
         for (int cbi = 0; cbi < ncb - 1; ++cbi) {
             step(I0{}, I0{}, BF{}, acc0); step(I0{}, I1{}, BF{}, acc0); step(I0{}, I2{}, BF{}, acc0);
@@ -468,7 +468,7 @@ extern "C" int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, in
     if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % 32 || Cout <= 0 || Cout % 4) return 0;
     if (H % 2 || W < 2 || W > 128 || (W & (W - 1))) return 0;
     const long Mv = (long)N * (H / 2) * W;
-    if (Mv >= (1L << 30) || (Mv + 128) * Cin * 4 >= 0xFFFFFFF0L) return 0;          // one frequency's image behind one 32-bit buffer range
+    if (Mv >= (1L << 30) || ((long)H * W) % 32) return 0;                           // (16-position groups of the writer stay inside one image)
     if ((size_t)wino_ntn(Cout) * 256 * 6 * Cin * 4 >= 0x7FFFFFF0ull) return 0;
     return ((long)H * W) % 128 == 0 ? 1 : 2;
 }
@@ -498,21 +498,29 @@ struct GnWinoP {
     const float *x1, *x2, *stats, *gamma, *beta, *film, *drop;
     _Float16* v;
     int C1, C2, N, H, W, G, act, resample;
-    long plane;              // Mv * C
+    int ntm;                 // position tiles of 128 per frequency image
     long film_ld;
     float oscale;
     int JC;                  // row pairs per chunk
 };
 
+// One wave = 16 consecutive positions of a row pair x one 32-channel block: lane -> (position lane >> 2, channels 8 (lane & 3) ..+7),
+// so a wave reads 16 whole 128-byte lines per row and writes, per frequency, the 1-KB piece [16 positions][32 channels] of the hi
+// image and of the lo image of the conv's stage block (tile, channel block) - exactly the pieces its LDS-DMA fetches.  Maps narrower
+// than 16 put 16 / W consecutive row pairs in a wave (then no row is shared between iterations and all four rows are re-read).
 __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
-    const int C = p.C1 + p.C2, O = C / 8, cpg = C / p.G;
+    const int C = p.C1 + p.C2, ncb = C / 32, cpg = C / p.G;
     const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
     const int P = Ho / 2;
-    const int nxb = (Wo * O + BLK - 1) / BLK;
-    const int n = blockIdx.y, jc = blockIdx.x / nxb, item = (blockIdx.x % nxb) * BLK + threadIdx.x;
-    if (item >= Wo * O) return;
-    const int xo = item / O, c = 8 * (item % O);
-    const bool oddq = (threadIdx.x >> 2) & 1;              // (Wo * O is a multiple of 8: a pair of quads is never split by the exit above)
+    const int JS = Wo >= 16 ? 1 : 16 / Wo;                 // row pairs covered by one 16-position group
+    const int npg = Wo >= 16 ? Wo / 16 : 1;                // position groups per row-pair row
+    const int nitems = npg * ncb, nxb = (nitems + 3) / 4;
+    const int n = blockIdx.y, jc = blockIdx.x / nxb, item = (blockIdx.x % nxb) * 4 + (threadIdx.x >> 6);
+    if (item >= nitems) return;
+    const int lane = threadIdx.x & 63, p16 = lane >> 2;
+    const int cbk = item % ncb, pg = item / ncb;
+    const int c = cbk * 32 + 8 * (lane & 3);
+    const int xo = Wo >= 16 ? pg * 16 + p16 : p16 % Wo, jo = Wo >= 16 ? 0 : p16 / Wo;
     const bool second = c >= p.C1;
     const float* src = second ? p.x2 : p.x1;
     const int cs = second ? p.C2 : p.C1, cq = second ? c - p.C1 : c;
@@ -573,26 +581,15 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
             h[j] = t;
             l[j] = (_Float16)(sv - (float)t);
         }
-        // line (m, c / 32) = [hi 32 | lo 32] halves, this lane's 16-byte piece k = (c & 31) / 8 of either half.  The four lanes of a
-        // line (a quad) would write it as two 64-byte halves in two instructions; instead quads pair up (lane ^ 4: the even quad hands
-        // over its lo pieces and takes the odd quad's hi pieces), so that each store instruction writes whole 128-byte lines.
-        const size_t lb = ((size_t)f * p.plane + m * C) * 2 + (size_t)(c >> 5) * 64 + (c & 31);
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 hu = __builtin_bit_cast(u32x4, h), lu = __builtin_bit_cast(u32x4, l);
-        const u32x4 give = oddq ? hu : lu;
-        u32x4 got;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) got[q] = (unsigned)__shfl_xor((int)give[q], 4);
-        const unsigned lb_lo = (unsigned)lb, lb_hi = (unsigned)(lb >> 32);
-        const size_t lbp = ((size_t)(unsigned)__shfl_xor((int)lb_hi, 4) << 32) | (unsigned)__shfl_xor((int)lb_lo, 4);
-        *(u32x4*)(p.v + (oddq ? lbp + 32 : lb)) = oddq ? got : hu;        // the even quad's line: its hi pieces | its lo pieces
-        *(u32x4*)(p.v + (oddq ? lb + 32 : lbp)) = oddq ? lu : got;        // the odd quad's line
+        // stage block (f, tile m / 128, channel block): [hi | lo][128 positions][32 channels]
+        _Float16* o = p.v + ((((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 2) * 4096 + (m & 127) * 32 + (c & 31);
+        *(h16x8*)o = h;
+        *(h16x8*)(o + 4096) = l;
     };
-    const int j0 = jc * p.JC, j1 = min(P, j0 + p.JC);
+    const int j0 = jc * p.JC + jo, j1 = min(P, (jc + 1) * p.JC);
     float dA[8], dB[8], dC[8], dD[8];
-    val(2 * j0 - 1, dA);
-    val(2 * j0, dB);
-    for (int j = j0; j < j1; ++j) {
+    if (j0 < j1) { val(2 * j0 - 1, dA); val(2 * j0, dB); }
+    for (int j = j0; j < j1; j += JS) {
         val(2 * j + 1, dC);
         val(2 * j + 2, dD);
         const size_t m = ((size_t)n * P + j) * Wo + xo;
@@ -609,13 +606,21 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = dB[q] - dD[q];
         put(3, m, v);
+        if (JS == 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { dA[q] = dC[q]; dB[q] = dD[q]; }
+            for (int q = 0; q < 8; ++q) { dA[q] = dC[q]; dB[q] = dD[q]; }
+        } else if (j + JS < j1) {
+            val(2 * (j + JS) - 1, dA);
+            val(2 * (j + JS), dB);
+        }
     }
 }
 
 // bytes of the V planes of a conv input [N][Ho][Wo][C] (Ho, Wo after the resampling): 4 frequencies x 2 planes x N*(Ho/2)*Wo*C halves
-extern "C" size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C) { return (size_t)16 * N * (Ho / 2) * Wo * C; }
+extern "C" size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C) {
+    const size_t Mv = (size_t)N * (Ho / 2) * Wo;
+    return (size_t)16 * ((Mv + 127) / 128 * 128) * C;                 // whole tiles of 128 positions
+}
 
 extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
@@ -630,15 +635,18 @@ extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const flo
     const int Ho = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wo = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
     DUA_REQUIRE(Ho >= 2 && Ho % 2 == 0, "dua_groupnorm_apply_wino_f16x3: the conv input needs an even number of rows (got %d)", Ho);
     if ((size_t)N * Ho * Wo == 0) return DUA_OK;
+    DUA_REQUIRE(C1 % 32 == 0 && Wo >= 2 && Wo <= 128 && (Wo & (Wo - 1)) == 0 && ((long)Ho * Wo) % 32 == 0,
+                "dua_groupnorm_apply_wino_f16x3: C1 %% 32 == 0, the conv input width a power of two <= 128 and H*W %% 32 == 0 are required");
     GnWinoP p{x1, x2, stats, gamma, beta, film, dropmask, (_Float16*)vplanes, C1, C2, N, H, W, G, act, resample, 0, film_ld ? film_ld : 2L * C, v_scale, 0};
     DUA_REQUIRE(p.film_ld >= 2L * C, "dua_groupnorm_apply_wino_f16x3: film_ld too small");
     const int P = Ho / 2;
-    p.plane = (long)N * P * Wo * C;
-    const int nxb = (Wo * (C / 8) + BLK - 1) / BLK;
+    p.ntm = (int)(((long)N * P * Wo + 127) / 128);
+    const int nxb = ((Wo >= 16 ? Wo / 16 : 1) * (C / 32) + 3) / 4;
     // Row pairs per workgroup chunk: 8 (two halo rows re-read per 16 = +12 % reads) keeps enough workgroups in flight on the large
     // maps (128^2 x 256 channels: 1.26 ms against 1.60 ms with one chunk per column; scripts/bench_gn_apply.py f16x3w)
     int JC = P < 8 ? P : 8;
     while ((long)N * nxb * ((P + JC - 1) / JC) < 1024 && JC > 4) JC = (JC + 1) / 2;
+    if (Wo < 16 && JC % (16 / Wo)) JC = (JC / (16 / Wo) + 1) * (16 / Wo);       // chunks hold whole 16-position groups
     p.JC = JC;
     hipLaunchKernelGGL(k_gn_apply_wino, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
     return dua_check_launch("dua_groupnorm_apply_wino_f16x3");

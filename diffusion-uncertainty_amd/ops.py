@@ -317,7 +317,8 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
         if split == "f16x3w":
             # Winograd F(2,3)-along-y operand of conv3x3 (csrc/conv_wino_f16x3.hip): the four V_f images as f16x3 planes of V * scale
             scale = 0.5 * F16X3_ACT_SCALE if split_scale is None else float(split_scale)
-            vbuf = torch.empty((4, N, Ho // 2, Wo, (C1 + C2) // 32, 2, 32), device=x1.device, dtype=torch.int16)   # [.., hi 32 | lo 32]
+            ntm = (N * (Ho // 2) * Wo + 127) // 128
+            vbuf = torch.empty((4, ntm, (C1 + C2) // 32, 2, 128, 32), device=x1.device, dtype=torch.int16)   # [f][tile][cb][hi | lo][128][32]
             check(_lib.lib().dua_groupnorm_apply_wino_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
                                                             _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
                                                             scale, _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f16x3")

@@ -306,8 +306,8 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  * precision: input rows d0..d3 = 2j-1 .. 2j+2 -> V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3; kernel rows g0..g2 ->
  * U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2; M_f = conv1x3(V_f, U_f); out row 2j = M0+M1+M2, row 2j+1 = M1-M2-M3.
  * dua_groupnorm_apply_wino_f16x3: dua_groupnorm_apply_split_f16x3 writing the four V_f images as f16x3 planes
- *   [f][N*(Ho/2)*Wo][C/32][hi 32 | lo 32] of V * v_scale - one 128-byte line per (position, 32-channel block) -
- *   (dua_f16x3_wino_act_bytes bytes; Ho, Wo = the conv's input size after `resample`);
+ *   [f][tile of 128 positions of N*(Ho/2)*Wo][C/32][hi | lo][128][32] of V * v_scale - 16 KB contiguous per (tile, 32-channel
+ *   block), the conv kernel's activation stage - (dua_f16x3_wino_act_bytes bytes; Ho, Wo = the conv's input size after `resample`);
  *   v_scale a power of two (|V| <= 2 max|activation|: the UNet uses act_scale / 2).
  * dua_pack_weight_f16x3_wino: OIHW fp32 weights -> U_f * 2^s as fp16 hi | lo images in the kernel's stage order
  *   ([column tile of 128][K step = (channel block, fi, dx)][hi | lo][group * 128 + channel][32]: 32 KB contiguous per step), then

@@ -4,7 +4,8 @@
     python scripts/wconv_diag.py --build            # here in the container: timing-only libraries in scripts/diag/build/
     python scripts/wconv_diag.py [--only 64x512x512,128x256x256]     # on the GPU box: one bench_conv_mix run per library
 
-The variants drop pieces of the loop (-DWCONV_DIAG bits: 1 barrier, 2 weight DMA, 4 activation DMA, 8 fragment reads) and produce
+The variants drop pieces of the loop (-DWCONV_DIAG bits: 1 barrier, 2 weight DMA, 4 activation DMA, 8 fragment reads; 16 = activations from a cache-resident
+set of tiles) and produce
 WRONG results; they exist only outside the product package."""
 import argparse
 import os
@@ -14,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "diffusion-uncertainty_amd")
 DIAG = os.path.join(ROOT, "scripts", "diag", "build")
-VARIANTS = (1, 2, 4, 6, 8, 15)
+VARIANTS = (1, 2, 4, 6, 8, 15, 16)
 
 
 def lib_of(v):

@@ -40,10 +40,12 @@ def v_reference(a):
 
 
 def decode_v(pl):
-    buf = pl.buf.cpu()                                       # [f][N][H/2][W][C/32][hi | lo][32]
+    buf = pl.buf.cpu()                                       # [f][tile][C/32][hi | lo][128 positions][32 channels]
+    N, H, W, C = pl.shape
     h = buf.view(torch.float16).double()
-    v = (h[..., 0, :] + h[..., 1, :]) / pl.scale
-    return v.reshape(*v.shape[:4], -1)
+    v = (h[:, :, :, 0] + h[:, :, :, 1]) / pl.scale          # [f][tile][cb][128][32]
+    v = v.permute(0, 1, 3, 2, 4).reshape(4, -1, C)[:, :N * (H // 2) * W]
+    return v.reshape(4, N, H // 2, W, C)
 
 
 def identity_stats(N, groups=32):
@@ -51,7 +53,7 @@ def identity_stats(N, groups=32):
 
 
 @pytest.mark.parametrize("N,H,W,C1,C2,resample,film,drop", [
-    (2, 16, 16, 64, 0, 0, False, False), (1, 32, 32, 32, 32, 0, True, False), (3, 8, 16, 96, 0, 0, True, True),
+    (2, 16, 16, 64, 0, 0, False, False), (1, 32, 32, 32, 32, 0, True, False), (3, 8, 16, 96, 0, 0, True, True), (5, 8, 8, 64, 32, 0, True, False), (3, 8, 4, 32, 0, 0, False, False),
     (2, 16, 16, 64, 0, 1, False, False), (2, 32, 32, 64, 0, -1, False, False), (1, 64, 64, 256, 0, 0, True, False),
     (2, 16, 16, 768, 512, 0, False, False)])
 def test_wino_writer_vs_torch(ops, N, H, W, C1, C2, resample, film, drop):
@@ -119,7 +121,7 @@ def test_wino_weight_pack(ops):
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (2, 8, 16, 96, 64), (1, 32, 32, 256, 256),
                                              (5, 16, 16, 128, 512), (3, 64, 64, 64, 256), (2, 128, 128, 32, 128), (4, 16, 8, 64, 36),
-                                             (130, 16, 16, 64, 64), (6, 8, 8, 96, 160), (3, 4, 4, 64, 64), (128, 8, 8, 128, 128)])
+                                             (130, 16, 16, 64, 64), (6, 8, 8, 96, 160), (3, 8, 4, 64, 64), (128, 8, 8, 128, 128)])
 def test_conv3x3_wino_vs_fp64(ops, N, H, W, Cin, Cout):
     """The whole Winograd path (writer -> packed weights -> kernel) against fp64, next to the direct f16x3 kernel and the exact fp32
     MFMA engine on the same problem: same bar as test_conv3x3_f16x3 (within 2x of the fp32 engine's error)."""
@@ -161,6 +163,7 @@ def test_conv3x3_wino_vs_fp64(ops, N, H, W, Cin, Cout):
 def test_conv3x3_wino_unsupported_shapes(ops):
     assert ops.conv3x3_wino_supported(2, 8, 8, 64, 64)              # small map: taken, without the column-sum output
     assert not ops.conv3x3_wino_supported(2, 15, 16, 64, 64)        # odd H
+    assert not ops.conv3x3_wino_supported(2, 4, 4, 64, 64)          # H*W % 32
     assert not ops.conv3x3_wino_supported(2, 16, 24, 64, 64)        # W not a power of two
     assert not ops.conv3x3_wino_supported(1, 256, 256, 128, 128)    # W > 128
     assert not ops.conv3x3_wino_supported(2, 16, 16, 48, 64)        # Cin % 32
