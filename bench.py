@@ -16,8 +16,9 @@ process per GPU, rank-sliced X_T, no data-path collective); the only collective 
 images at the end of each job.
 
 The headline precision is `f16x3`, the fp32-EQUIVALENT split (22 significant operand bits, fp32 accumulation; held by
-tests/test_gpu_models.py to the same end-to-end tolerances as the exact fp32 mode); `--precision fp32` runs the exact
-fp32 MFMA engine.  The narrower split modes (bf16x3 / f16f8 / f16f6) are reported under `other_precision_modes` only.
+tests/test_gpu_models.py to the same end-to-end tolerances as the exact fp32 mode; its 3x3 convs run in the Winograd F(2,3)-along-y
+form of csrc/conv_wino_f16x3.hip - 6 instead of 9 matrix-core taps per pixel at the same operand precision); `--precision fp32` runs
+the exact fp32 MFMA engine.  The narrower split modes (bf16x3 / f16f8 / f16f6) are reported under `other_precision_modes` only.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     - dominant kernel (implicit-GEMM conv3x3 of the selected precision mode): algorithmic FLOPs per launch / mean
@@ -63,9 +64,10 @@ MODES = {
     "f16f6": ("k_xconv_dma<NT, 2, true> (row-shift loop, fp16 hi*hi + both cross terms on one MXFP6 scaled MFMA per 32-deep K block)", 1.5,
               "f16f6 (fp16 hi + MXFP6 cross terms: ~14-15 significant bits)"),
 }
-PARITY_NOTE = ("full-size ADM-128 forward vs the reference CPU output (tests/test_gpu_models.py, tolerance 1e-3): max abs err "
-               "f16x3 5.7e-6, fp32 7.4e-6, bf16x3 3.1e-5, f16f8 5.3e-5, f16f6 6.8e-5; free-running full-size 10-step guided chain (G13): score err "
-               "f16x3 2.3e-4, fp32 2.4e-4, bf16x3 8.4e-4, f16f8 1.8e-3, f16f6 2.1e-3; percentile-0.9 mask agreement >= 99.99 % in every mode")
+PARITY_NOTE = ("full-size ADM-128 forward vs the reference CPU output (tests/test_gpu_models.py, tests/test_gpu_wino.py, tolerance 1e-3): max abs "
+               "err f16x3 5.2e-6 (3x3 convs in the Winograd form, the default; direct form 6.1e-6), fp32 7.4e-6, bf16x3 3.1e-5, f16f8 5.3e-5, "
+               "f16f6 6.8e-5; free-running full-size 10-step guided chain (G13): score err f16x3 2.0e-4, fp32 2.4e-4, bf16x3 8.4e-4, f16f8 1.8e-3, "
+               "f16f6 2.1e-3; percentile-0.9 mask agreement >= 99.99 % in every mode")
 
 
 def pmc_traffic(precision):

@@ -64,6 +64,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         unet.eval().to(device)
         unet.precision = args.precision
         unet.split_k = args.split_k == "on" or (args.split_k == "auto" and args.batch_size <= 32)
+        unet.winograd = args.winograd == "on"
         if args.hip_graph and args.scheduler_type != "mc_dropout":
             unet.enable_hip_graph()
         model = unet
@@ -140,6 +141,8 @@ def parse_args(argv=None):
     p.add_argument("--split-k", choices=["auto", "on", "off"], default="auto", dest="split_k",
                    help="f16x3: split the K range of conv / GEMM launches that cannot fill the 256 CUs (deterministic; results then depend on "
                         "the batch size at fp32-rounding level).  auto: on for batches of at most 32 images (2x on batch 4)")
+    p.add_argument("--winograd", choices=["on", "off"], default="on",
+                   help="f16x3: 3x3 convs in the Winograd F(2,3)-along-y form (6 instead of 9 matrix-core taps per pixel, same operand precision)")
     p.add_argument("--mc-group", type=int, default=1, dest="mc_group",
                    help="uncertainty_zigzag_centered: Monte-Carlo chains of a UC step per denoiser call (stacked batch, identical outputs; "
                         "helps U-ViT at batch 64: +4.6 %% with 5)")

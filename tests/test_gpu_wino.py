@@ -168,3 +168,32 @@ def test_conv3x3_wino_unsupported_shapes(ops):
     assert not ops.conv3x3_wino_supported(1, 256, 256, 128, 128)    # W > 128
     assert not ops.conv3x3_wino_supported(2, 16, 16, 48, 64)        # Cin % 32
     assert ops.conv3x3_wino_supported(128, 128, 128, 512, 256)
+
+
+def test_winograd_unet_vs_reference_and_direct(golden):
+    """Full-size ADM-64 / ADM-128 in f16x3 with the 3x3 convs in the Winograd form (the default) and in the direct form: both inside
+    the 1e-3 bar against the reference's own output (G5), within 3e-5 of each other, the Winograd run deterministic, and the block-level
+    C-ABI path bit-identical to the per-op composition with the Winograd operands."""
+    from conftest import T
+    from oracle import adm
+    from test_gpu_models import build_adm
+    for name, cfg in (("adm64", adm.ADM64), ("adm128", adm.ADM128)):
+        g = golden(f"g5_{name}_full")
+        m, _ = build_adm(dict(cfg), int(g["seed"]))
+        m.precision = "f16x3"
+        x, t, y = T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev)
+        assert m.winograd
+        w = m(x, t, y=y)
+        w2 = m(x, t, y=y)
+        m.use_block_abi = False
+        wop = m(x, t, y=y)
+        m.use_block_abi = True
+        m.winograd = False
+        d = m(x, t, y=y)
+        ew, ed = np.abs(w.cpu().numpy() - g["out"]).max(), np.abs(d.cpu().numpy() - g["out"]).max()
+        print(f"{name} f16x3: winograd err {ew:.3e}, direct err {ed:.3e}, |winograd - direct| {(w - d).abs().max().item():.3e}")
+        assert ew < 1e-3 and ed < 1e-3 and ew < 2 * ed + 2e-6
+        assert (w - d).abs().max().item() < 3e-5 and not torch.equal(w, d)
+        assert torch.equal(w, w2) and torch.equal(w, wop)
+        del m
+        torch.cuda.empty_cache()
