@@ -583,8 +583,9 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
         }
         // stage block (f, tile m / 128, channel block): [hi | lo][128 positions][32 channels]
         _Float16* o = p.v + ((((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 2) * 4096 + (m & 127) * 32 + (c & 31);
-        *(h16x8*)o = h;
-        *(h16x8*)(o + 4096) = l;
+        // written once, read by the next kernel: non-temporal stores (the small maps gain 25 - 35 % in this kernel, the job +0.6 %)
+        __builtin_nontemporal_store(h, (h16x8*)o);
+        __builtin_nontemporal_store(l, (h16x8*)(o + 4096));
     };
     const int j0 = jc * p.JC + jo, j1 = min(P, (jc + 1) * p.JC);
     float dA[8], dB[8], dC[8], dD[8];
