@@ -1,8 +1,8 @@
 // f16x3 implicit-GEMM 3x3 convolution / one-tap GEMM on the 16x16x32 fp16 matrix-core shape (gfx950).
 //
 // Operands are the f16x3 planes of include/dua_hip.h: activations [rows][Cin] as fp16 hi | fp16 lo of x * act_scale (written
-// by dua_groupnorm_apply_split_f16x3 / dua_attention_f16x3), weights [Npad128][K] hi | lo of w * 2^s with per-row 2^-s
-// (dua_pack_weight_f16x3; K ordered channel-block major, tap minor).  Product = lo*hi + hi*lo + hi*hi, fp32 accumulate, the
+// by dua_groupnorm_apply_split_f16x3 / dua_attention_f16x3), weights hi | lo of w * 2^s with per-row 2^-s, stage-contiguous
+// [row tile of 128][K step of 32][hi | lo][128][32] (dua_pack_weight_f16x3; K ordered channel-block major, tap minor).  Product = lo*hi + hi*lo + hi*hi, fp32 accumulate, the
 // epilogue multiplies by 2^-s / act_scale, adds bias / residual and leaves the next GroupNorm's column sums.
 //
 // Why a kernel of its own (k_xconv_dma<NT, 3> in mfma_bf16x3.hip is the same arithmetic on the 32x32x16 shape):
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
     auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
     auto ral = ra;
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
-    const int b_lo = (int)(p.b_plane * 2);                               // byte distance hi -> lo weight plane
+    const int b_lo = 8192;                                               // byte distance hi -> lo image inside a weight stage block
     int tap = 0, cb = 0;
     unsigned vo0 = 0, vo1 = 0;
     bool prefetched = false;
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
         cb = 0;
 #pragma unroll
         for (int j = 0; j < NT / 2; ++j)
-            boff[j] = (unsigned)(((long)(n0_ + 16 * ((NT / 2) * wave + j) + dl_row) * p.K + 8 * dl_src) * 2);
+        {   // stage-contiguous packing [row tile of 128][K step][hi | lo][128][32] (dua_pack_weight_f16x3)
+            const int r_ = n0_ + 16 * ((NT / 2) * wave + j) + dl_row;
+            boff[j] = (unsigned)(((long)(r_ >> 7) * (p.K / 32)) * 16384 + (r_ & 127) * 64 + 16 * dl_src);
+        }
     };
     // offsets of the next activation stage: per-tap form = the next (channel block, tap); RS = the next (channel block, dy)
     auto a_setup = [&]() {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
             if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, 0);
             if (i == 2 * j + 1) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, 0);
-                boff[j] += 64;
+                boff[j] += 16384;
             }
         }
     };

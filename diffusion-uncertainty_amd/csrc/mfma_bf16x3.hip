@@ -200,9 +200,15 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     if (!BSPLIT) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const long o = (long)(n0 + brow + 64 * j) * K + 8 * bch;              // planes are padded to 128 rows
-            pbh[j] = p.Bhi + o;
-            pbl[j] = p.Blo + o;
+            if (F16) {         // f16x3 weights: stage-contiguous packing (n0 is a multiple of 128: one row tile)
+                const long o = (long)(n0 >> 7) * (K / BK) * 8192 + (brow + 64 * j) * 32 + 8 * bch;
+                pbh[j] = p.Bhi + o;
+                pbl[j] = p.Bhi + o + 4096;
+            } else {
+                const long o = (long)(n0 + brow + 64 * j) * K + 8 * bch;          // planes are padded to 128 rows
+                pbh[j] = p.Bhi + o;
+                pbl[j] = p.Blo + o;
+            }
         }
     } else {
 #pragma unroll
@@ -230,7 +236,8 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         }
         if (!BSPLIT) {
             S.bh0 = *(const uint4*)pbh[0]; S.bh1 = *(const uint4*)pbh[1]; S.bl0 = *(const uint4*)pbl[0]; S.bl1 = *(const uint4*)pbl[1];
-            pbh[0] += BK; pbh[1] += BK; pbl[0] += BK; pbl[1] += BK;
+            constexpr int BSTEP = F16 ? 8192 : BK;                                // halves to the next K step
+            pbh[0] += BSTEP; pbh[1] += BSTEP; pbl[0] += BSTEP; pbl[1] += BSTEP;
         } else {
             S.bh0 = *(const uint4*)pbf[0]; S.bh1 = *(const uint4*)pbf[1]; S.bl0 = *(const uint4*)pbf[2]; S.bl1 = *(const uint4*)pbf[3];
             pbf[0] += BK; pbf[1] += BK; pbf[2] += BK; pbf[3] += BK;
@@ -666,10 +673,15 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #pragma unroll
     for (int j = 0; j < NT / 2; ++j) {
         bgrp[j] = ((NT / 2) * wave + j + brot) % (4 * NT);
-        boff[j] = (unsigned)(((long)(n0 + 16 * bgrp[j] + lrow) * p.K + 8 * csrc + (long)kb * BK) * 2);
+        if (FMT == 3) {        // f16x3: stage-contiguous packing [row tile of 128][K step][hi | lo][128][32]
+            const int r_ = n0 + 16 * bgrp[j] + lrow;
+            boff[j] = (unsigned)((((long)(r_ >> 7) * (p.K / BK) + kb) * 16384) + (r_ & 127) * 64 + 16 * csrc);
+        } else {
+            boff[j] = (unsigned)(((long)(n0 + 16 * bgrp[j] + lrow) * p.K + 8 * csrc + (long)kb * BK) * 2);
+        }
     }
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (p.dbg_norec & 2) ? 0 : (int)(2 * p.b_plane * 2), 0x00020000);
-    const int b_lo = (int)(p.b_plane * 2);                                   // byte distance hi -> lo weight plane
+    const int b_lo = FMT == 3 ? 8192 : (int)(p.b_plane * 2);                 // byte distance hi -> lo weight plane / image
     // The DMA pieces of a tile are issued one at a time so that the caller can spread them between MFMA groups
     // (an LDS-DMA issue holds the wave for ~60-180 cycles).
     unsigned vo0 = 0, vo1 = 0;
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             if (i == 2 * j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst, 16, boff[j], 0, 0, DUA_B_AUX);
             if (i == 2 * j + 1) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, dst + SB, 16, boff[j], b_lo, 0, DUA_B_AUX);
-                boff[j] += BK * 2;
+                boff[j] += FMT == 3 ? 16384 : BK * 2;
             }
         }
     };
@@ -1737,7 +1749,14 @@ __global__ void k_weight_row_scale_f16x3(const float* __restrict__ w, float* __r
         inv_scale[n] = __uint_as_float((unsigned)(127 - e) << 23);                           // 2^-e
     }
 }
-__global__ void k_split_weight_f16x3(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+// Stage-contiguous layout (round 3): [row tile of 128][K step of 32][hi | lo][128 rows][32] - the 16 KB a K step of a 128-row tile
+// stages are one block in LDS-image order, so every 1-KB LDS-DMA piece (16 rows x 64 B) reads eight whole 128-byte lines instead
+// of sixteen half lines of a row-major [N][K] plane.  Element (n, k) of plane pl:
+//   ((n / 128 * (K / 32) + k / 32) * 2 + pl) * 4096 + (n % 128) * 32 + k % 32     (halves)
+__device__ __forceinline__ size_t f16x3_staged_index(int n, int k, int K) {
+    return ((size_t)(n >> 7) * (K >> 5) + (k >> 5)) * 8192 + (size_t)(n & 127) * 32 + (k & 31);
+}
+__global__ void k_split_weight_f16x3(const float* __restrict__ w, _Float16* __restrict__ packed,
                                      const float* __restrict__ inv_scale, int N, int K, int Npad, int conv_cin) {
     size_t total = (size_t)Npad * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -1745,8 +1764,9 @@ __global__ void k_split_weight_f16x3(const float* __restrict__ w, _Float16* __re
         const float sc = 1.0f / inv_scale[n];                                                // exact: a power of two
         const float v = split_weight_src(w, n, k, N, K, conv_cin) * sc;
         const _Float16 h = (_Float16)v;
-        hi[i] = h;
-        lo[i] = (_Float16)(v - (float)h);
+        const size_t o = f16x3_staged_index(n, k, K);
+        packed[o] = h;
+        packed[o + 4096] = (_Float16)(v - (float)h);
     }
 }
 extern "C" size_t dua_f16x3_weight_bytes(int N, int K) { return 4 * dua_bf16x3_plane_elems(N, K) + 4 * (size_t)round_up(N, 256); }
@@ -1758,7 +1778,7 @@ extern "C" int dua_pack_weight_f16x3(const float* w, void* packed, int N, int K,
     _Float16* hi = (_Float16*)packed;
     float* inv_scale = (float*)(hi + 2 * plane);
     hipLaunchKernelGGL(k_weight_row_scale_f16x3, dim3(Nsc), 256, 0, as_stream(stream), w, inv_scale, N, K, Npad);
-    hipLaunchKernelGGL(k_split_weight_f16x3, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, hi + plane, inv_scale, N, K, Npad, conv_cin);
+    hipLaunchKernelGGL(k_split_weight_f16x3, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, inv_scale, N, K, Npad, conv_cin);
     return dua_check_launch("dua_pack_weight_f16x3");
 }
 extern "C" int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,

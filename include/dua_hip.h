@@ -286,7 +286,8 @@ int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float
  * (csrc/mfma_bf16x3.hip, FMT 3).  Activation planes ([rows][C], 2 bytes per element): plane 0 fp16(x * act_scale)
  * (saturating at +-65504), plane 1 fp16(x * act_scale - plane 0); act_scale is a power of two chosen by the caller (the
  * UNet uses 2^6: GroupNorm+SiLU outputs up to 1023 in magnitude are exact to 22 bits down to 2^-9).  Packed weights
- * (dua_f16x3_weight_bytes): plane 0 fp16(w * 2^s) [Npad128][K], plane 1 the fp16 remainder, then round_up(N, 256) floats
+ * (dua_f16x3_weight_bytes): fp16(w * 2^s) and the fp16 remainder, stage-contiguous - [row tile of 128][K step of 32][hi | lo]
+ * [128 rows][32]: the 16 KB a K step of a 128-row tile stages form one block in LDS-image order - then round_up(N, 256) floats
  * 2^-s with s per output row such that the row maximum lands in [2^14, 2^15). */
 size_t dua_f16x3_weight_bytes(int N, int K);
 int dua_pack_weight_f16x3(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
