@@ -39,22 +39,25 @@ def build(force=False, verbose=True):
 
 
 def build_select_variant(verbose=True):
-    """libdua_hip_select.so: the product sources with conv_f16x3.hip compiled -DDUA_RS_ZERO_SELECT=1 (the row-shift conv zeroes its
-    image-edge fragments by a register select instead of an out-of-range LDS read).  Test artefact (scripts/diag/build/, outside the
+    """libdua_hip_select.so: the product sources with conv_f16x3.hip and conv_wino_f16x3.hip compiled -DDUA_RS_ZERO_SELECT=1 (the
+    row-shift convs zero their image-edge fragments by a register select instead of an out-of-range LDS read).  Test artefact (scripts/diag/build/, outside the
     package): tests/test_gpu_ops.py compares the two forms bit for bit."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out_dir = os.path.join(os.path.dirname(PKG), "scripts", "diag", "build")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "libdua_hip_select.so")
-    src = os.path.join(HERE, "conv_f16x3.hip")
-    obj = os.path.join(out_dir, "conv_f16x3.select.o")
     hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "dconv.h"), os.path.join(os.path.dirname(PKG), "include", "dua_hip.h")]
-    if _stale(obj, [src] + hdrs):
-        cmd = [hipcc] + COMMON + ["-DDUA_RS_ZERO_SELECT=1", "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    objs = [os.path.join(HERE, s.replace(".hip", ".o")) if s != "conv_f16x3.hip" else obj for s, _ in SOURCES]
+    alt = {}
+    for name in ("conv_f16x3.hip", "conv_wino_f16x3.hip"):          # the two kernels with row-shifted fragment reads
+        src = os.path.join(HERE, name)
+        obj = os.path.join(out_dir, name.replace(".hip", ".select.o"))
+        if _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + COMMON + ["-DDUA_RS_ZERO_SELECT=1", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        alt[name] = obj
+    objs = [alt.get(s, os.path.join(HERE, s.replace(".hip", ".o"))) for s, _ in SOURCES]
     if _stale(out, objs):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
     return out

@@ -11,7 +11,8 @@
 //                        as f16x3 images [f][tile of 128 positions][C/32][hi | lo][128][32]: the 16 KB the conv stages per
 //                        (tile, channel block, frequency) are contiguous in its LDS-image order (the sliding window over y keeps
 //                        every input element read once)
-//   k_pack_wino          OIHW fp32 weights -> U_f, per-output-row power-of-two scale, fp16 hi | lo planes in the tile order below
+//   k_pack_wino          OIHW fp32 weights -> U_f, per-output-row power-of-two scale, fp16 hi | lo images, one contiguous 32 KB
+//                        block per (column tile, K step) in the order of the kernel's LDS weight stage
 //   k_wconv              LDS-DMA implicit GEMM on v_mfma_f32_16x16x32_f16 (the loop of conv_f16x3.hip's row-shift kernel): a
 //                        workgroup tile = 128 positions of the V images (whole image rows of W | 128 positions) x 128 output channels
 //                        x 4 frequencies = 65 536 accumulators.  Waves 0-3 hold f = 1, 2 and waves 4-7 f = 0, 3 of 64 positions x 64
@@ -152,14 +153,24 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         const int r_ = lr + dx;                                           // -1 .. 16
         return r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3));
     };
+    // The image-edge lanes take their dx = -1 / +1 fragments from an LDS address beyond the allocation (DS reads there return
+    // zeros); -DDUA_RS_ZERO_SELECT=1 builds the data-select form instead (the fragment is read from its in-range address and
+    // replaced by zeros in registers), compared bit for bit by tests/test_gpu_wino.py.
+#if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
+    constexpr bool ZSEL = true;
+#else
+    constexpr bool ZSEL = false;
+#endif
     const int zero_addr = OOBL + (lane & 1) * 16;
     const int ax0 = a_row0 + x_off(0);
     int axm[4], axp[4];
+    unsigned xedge = 0;                                    // bit i: position block i at x == 0; bit 4 + i: at x == W - 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int x_ = (ph * 64 + 16 * i + lr) & (p.W - 1);
-        axm[i] = x_ == 0 ? zero_addr : a_row0 + x_off(-1);
-        axp[i] = x_ == p.W - 1 ? zero_addr : a_row0 + x_off(1);
+        xedge |= (x_ == 0 ? 1u : 0u) << i | (x_ == p.W - 1 ? 1u : 0u) << (4 + i);
+        axm[i] = (!ZSEL && x_ == 0) ? zero_addr : a_row0 + x_off(-1);
+        axp[i] = (!ZSEL && x_ == p.W - 1) ? zero_addr : a_row0 + x_off(1);
     }
     const int aw0 = b_row0 + off_l, aw2 = aw0 + 2 * 2 * SB * 2;
 
@@ -184,7 +195,12 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         // with the image-edge lanes already pointed at the zero region; aw*: weight rows) plus an immediate (stage, plane, block)
         auto rd_x = [&](int sa, int pl, int i, int dx) -> h16x8 {
             const int a = dx < 0 ? axm[i] : (dx > 0 ? axp[i] : ax0);
-            return *(const h16x8*)(ldsb + a + (sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64));
+            const h16x8 v = *(const h16x8*)(ldsb + a + (sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64));
+            if (ZSEL && dx != 0) {
+                const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                return ((xedge >> (dx < 0 ? i : 4 + i)) & 1u) ? z : v;
+            }
+            return v;
         };
         auto rd_w = [&](int sb, int pl, int jj) -> h16x8 {
             return *(const h16x8*)(ldsb + (sb == 2 ? aw2 : aw0) + ((sb == 2 ? 0 : sb * 2 * SB * 2) + pl * SB * 2 + 16 * jj * 64));
