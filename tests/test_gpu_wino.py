@@ -237,7 +237,7 @@ def test_headline_job_variants_diverge_alike():
     the same Philox streams) in four arithmetic variants: exact fp32 MFMA, exact fp32 MFMA with the stand-alone GroupNorm statistics
     kernel (only the summation order of the statistics differs), f16x3 with direct 3x3 convs, f16x3 with the Winograd form (the
     headline).  A 50-step chain of a random-weight denoiser is chaotic at this length: ANY fp32-rounding-level difference grows by
-    three to five orders of magnitude (measured over four seeds, scratch run in DESIGN.md section 2: 7e-3 ... 0.44 on the score
+    three to five orders of magnitude (measured over four seeds, scripts/diag/chain_divergence.py, DESIGN.md section 2: 7e-3 ... 0.44 on the score
     between the two EXACT-fp32 variants), so no per-pixel bar can hold between two fp32-equivalent implementations over the full job -
     the parity bars are per call, teacher-forced and on the 10-step chains (test_gpu_models.py).  What this test pins is that the
     Winograd form is not an outlier: its distance from the exact mode is of the order of the distances between the other pairs."""
