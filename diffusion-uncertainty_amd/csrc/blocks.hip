@@ -17,15 +17,15 @@ struct ConvTimer {
     hipEvent_t a = nullptr;
     hipStream_t st;
     explicit ConvTimer(void* stream) : st(as_stream(stream)) {
-        if (g_prof && hipEventCreate(&a) == hipSuccess) hipEventRecord(a, st); else a = nullptr;
+        if (g_prof && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, st); else a = nullptr;
     }
     // flops: algorithmic (2*M*9*Cin*Cout); mfma_mult: matrix-core product FLOPs executed per algorithmic FLOP (direct f16x3: 3 fp16
     // products; Winograd form: 6 of 9 taps x 3 = 2; exact fp32 MFMA: 1)
     void done(double flops, double mfma_mult) {
         if (!a) return;
         hipEvent_t b;
-        if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return; }
-        hipEventRecord(b, st);
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        (void)hipEventRecord(b, st);
         g_recs.push_back({a, b, flops, flops * mfma_mult});
     }
 };
@@ -276,8 +276,8 @@ extern "C" int dua_conv_profile_collect(double* total_ms, double* total_flops, l
     for (ConvRec& r : g_recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; fl += r.flops; mf += r.mfma; ++n; }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_recs.clear();
     if (total_ms) *total_ms = ms;
