@@ -239,3 +239,28 @@ def test_precision_modes_pick_operand_formats():
     m.precision = "int8"
     with pytest.raises(AssertionError):
         _Ctx(m)
+
+
+def test_winograd_f23_along_y_identity():
+    """The algebra csrc/conv_wino_f16x3.hip implements, restated in fp64 torch: with V = (d0-d2, d1+d2, d2-d1, d1-d3) over the input rows
+    2j-1 .. 2j+2 (zero outside the image), U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) over the kernel rows and M_f = conv1x3(V_f, U_f) with
+    zero padding in x, the output rows are M0+M1+M2 (even) and M1-M2-M3 (odd) - exactly conv3x3 with padding 1; |V| <= 2 max|x|, which is
+    why the V planes carry half the activation planes' power-of-two scale."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    for (N, H, W, Cin, Cout) in [(2, 8, 8, 5, 7), (1, 6, 16, 3, 4), (3, 2, 4, 2, 2)]:
+        x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64)
+        ref = F.conv2d(x, w, padding=1)
+        xp = F.pad(x, (0, 0, 1, 1))
+        d0, d1, d2, d3 = xp[:, :, 0:H:2], xp[:, :, 1:H + 1:2], xp[:, :, 2:H + 2:2], xp[:, :, 3:H + 3:2]
+        V = [d0 - d2, d1 + d2, d2 - d1, d1 - d3]
+        g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
+        U = [g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2]
+        M = [F.conv2d(V[f], U[f][:, :, None, :], padding=(0, 1)) for f in range(4)]
+        out = torch.empty_like(ref)
+        out[:, :, 0::2] = M[0] + M[1] + M[2]
+        out[:, :, 1::2] = M[1] - M[2] - M[3]
+        assert (out - ref).abs().max().item() < 1e-12
+        assert max(v.abs().max().item() for v in V) <= 2 * x.abs().max().item() + 1e-12
