@@ -112,7 +112,7 @@ class ResBlock(TimestepBlock):
         Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
         cin = x.shape[3] + (0 if skip is None else skip.shape[3])
         h = ops.groupnorm_apply(x, st, gn1.weight, gn1.bias, x2=skip, act=1, resample=self.resample,
-                                split=ctx.conv_split(Wc, (N, Hc, Wc, cin, self.out_channels)))
+                                split=ctx.conv_split(Wc, (N, Hc, Wc, cin, self.out_channels) if x.shape[3] % 32 == 0 else None))
         if self.updown:
             x = ops.resample2x(x, self.resample)                                   # x_upd :243
         h = ctx.conv3x3(h, conv1, self.out_channels, colsum=True)      # epilogue leaves GroupNorm statistics for out_layers[0]
