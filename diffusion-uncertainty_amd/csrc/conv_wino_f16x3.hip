@@ -22,7 +22,7 @@
 //                        The epilogue exchanges P = M1 + M2 / M3 between partner waves through LDS, so the f = 1, 2 wave stores the
 //                        odd output row (M1 - M2) - M3 and the f = 0, 3 wave the even row M0 + P, with scale, bias, residual and the
 //                        next GroupNorm's column sums as in the direct kernels.
-// LDS image, swizzle, DMA piece shape and ring discipline are those of k_hconv<4, true> (conv_f16x3.hip).
+// LDS image, DMA piece shape and ring discipline are those of k_hconv<4, true> (conv_f16x3.hip); the chunk swizzle is its own.
 #include "common.h"
 #include <type_traits>
 
@@ -71,7 +71,11 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
     constexpr int OOBL = 0x40000;                          // LDS byte address beyond the allocation: DS reads there return zeros
     static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU");
     const int dl_row = lane >> 2;
-    const int dl_src = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    // LDS image: rows of 64 B, 16-byte chunk c of row r at chunk position c ^ (2 * ((r >> 2) & 1)).  For the lane groups of a
+    // ds_read_b128 (lane -> row (l & 15) + dx, chunk l >> 4) this is conflict-free for dx = -1, 0 AND +1 (exhaustive search over
+    // the 4-entry swizzle tables; the k_hconv swizzle c ^ ((-(r >> 2)) & 3) is conflict-free for dx = 0 only: its shifted reads
+    // were 23 % of this kernel's LDS cycles).  The DMA writes lane-linear pieces, so the swizzle is applied to the SOURCE chunk.
+    const int dl_src = (lane & 3) ^ (2 * ((lane >> 4) & 1));
     const int lr = lane & 15, lc = lane >> 4;
 
     // ---- DMA state
@@ -144,14 +148,14 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
     };
 
     const char* ldsb = reinterpret_cast<const char*>(lds);
-    const int off_l = lr * 64 + 16 * (lc ^ ((0 - (lr >> 2)) & 3));
+    const int off_l = lr * 64 + 16 * (lc ^ (2 * ((lr >> 2) & 1)));
     const int a_row0 = AOFF * 2 + wm * 64 * 64, b_row0 = BOFF * 2 + (grp_w * 128 + wn * 64) * 64;     // bytes, wave-uniform
     // Loop-invariant fragment addresses.  A tile is 128 consecutive positions starting at a multiple of 128 and W divides 128, so the x
     // coordinate of (position half, block i, lane row) - hence which lanes sit at the image's left / right edge - is the same for
     // every tile.  Row r + dx of the wave's 64 rows: the swizzle term depends on (lr + dx) only (16 i is a multiple of 4 rows * 4).
     auto x_off = [&](int dx) -> int {
         const int r_ = lr + dx;                                           // -1 .. 16
-        return r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3));
+        return r_ * 64 + 16 * (lc ^ (2 * (((r_ + 64) >> 2) & 1)));
     };
     // The image-edge lanes take their dx = -1 / +1 fragments from an LDS address beyond the allocation (DS reads there return
     // zeros); -DDUA_RS_ZERO_SELECT=1 builds the data-select form instead (the fragment is read from its in-range address and
