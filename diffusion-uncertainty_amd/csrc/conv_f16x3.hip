@@ -17,7 +17,8 @@
 //   * row-shift form (RS, image width divides 256 so a 256-row tile is whole image rows): ONE activation stage per (channel
 //     block, dy) serves the three dx taps; the taps read it at rows r-1, r, r+1 and the lanes at the image's left / right edge
 //     read zeros through an LDS address beyond the allocation.  L2 -> LDS activation traffic drops to a third.
-// LDS image: rows of 64 B (32 halves), 16-B chunk c of row r stored at chunk position c ^ ((-(r >> 2)) & 3): the four
+// LDS image: rows of 64 B (32 halves), 16-B chunk c of row r stored at chunk position c ^ (2 * ((r >> 2) & 1)) (round 3; conflict-free
+// for rows shifted by -1, 0 and +1 - the earlier c ^ ((-(r >> 2)) & 3) was for unshifted rows only: DESIGN.md section 6.8): the four
 // 16-lane groups of a ds_read_b128 (lane -> row l & 15, chunk l >> 4) land on 16 distinct 16-B slots.  The LDS-DMA writes
 // lane-linear 1-KB pieces (16 rows), so the swizzle is applied to each lane's SOURCE chunk.
 #include "common.h"
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
     constexpr int OOBL = 0x40000;
     static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU for every fragment offset");
     const int dl_row = lane >> 2;                                        // DMA: row of the 16-row piece this lane fills
-    const int dl_src = (lane & 3) ^ ((0 - (lane >> 4)) & 3);             // DMA: source chunk for this lane's LDS slot
+    const int dl_src = (lane & 3) ^ (2 * ((lane >> 4) & 1));             // DMA: source chunk for this lane's LDS slot
     const int lr = lane & 15, lc = lane >> 4;                            // fragment: row of the 16-row block, K chunk
 
     // ---- DMA state (lives across tiles: the next tile's first stages are requested before this tile's epilogue)
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
     };
 
     const char* ldsb = reinterpret_cast<const char*>(lds);
-    const int off_l = lr * 64 + 16 * (lc ^ ((0 - (lr >> 2)) & 3));        // this lane's fragment chunk inside a 16-row block
+    const int off_l = lr * 64 + 16 * (lc ^ (2 * ((lr >> 2) & 1)));        // this lane's fragment chunk inside a 16-row block
     const int a_row0 = AOFF * 2 + wm * 64 * 64, b_row0 = BOFF * 2 + wn * 32 * NT * 64;    // bytes, wave-uniform
 
     for (int ti = slot; ti < chunk_n; ti += nslot) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void k_hconv(DConvP p) {
             int o = off_l;
             if (RS) {
                 const int r_ = 16 * i + lr + dx;                                  // row inside the wave's 64 (may be -1 / 64: neighbour rows)
-                o = r_ * 64 + 16 * (lc ^ ((0 - ((r_ + 64) >> 2)) & 3)) - 16 * i * 64;
+                o = r_ * 64 + 16 * (lc ^ (2 * (((r_ + 64) >> 2) & 1))) - 16 * i * 64;
                 const bool edge = (dx < 0 && ((xedge >> i) & 1u)) || (dx > 0 && ((xedge >> (4 + i)) & 1u));
 #if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
                 const h16x8 v_ = *(const h16x8*)(ldsb + (a_row0 + sa * 2 * SA * 2 + pl * SA * 2 + 16 * i * 64) + o);
