@@ -55,7 +55,9 @@ MODES = {
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
               "with head dims <= 128 in this format, wider heads / embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
-    "fp32": ("k_tile<MODE_CONV> (fp32 MFMA implicit-GEMM conv3x3, v_mfma_f32_32x32x2_f32)", None, "f32"),
+    "fp32": ("k_wconv32 (csrc/conv_wino_f32.hip): exact-fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
+             "v_mfma_f32_16x16x4_f32 (6 instead of 9 taps per pixel, products and sums in fp32); in / out convs on the direct fp32 MFMA "
+             "kernel k_tile<MODE_CONV>", 1.0, "f32"),
     "bf16x3": ("k_xconv_dma<NT, 0> (LDS-DMA split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)", 3.0,
                "bf16x3 (fp32 operands split into 2 bf16 terms = 16 significant bits, 3 bf16 MFMA products, fp32 accumulate)"),
     "f16f8": ("k_xconv_dma<NT, 1> (fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms on one block-scaled "
@@ -140,8 +142,9 @@ class ConvProfile:
             r.update(executed_mfma_tflops=round(cs["mfma_tflops"], 1), executed_frac=round(cs["mfma_tflops"] / peak, 4),
                      executed_products_per_algorithmic_product=round(eff, 3),
                      note=f"achieved counts ALGORITHMIC fp32 FLOPs (2*N*H*W*9*Cin*Cout); the launches of this job execute {eff:.2f} "
-                          f"bf16-rate matrix-core products per algorithmic product ({mult:g} per tap in the direct kernels, 6 of 9 taps in the "
-                          f"Winograd form), so frac <= 1/{eff:.2f} against the 2.5 PF fp16/bf16 peak by construction")
+                          f"matrix-core products per algorithmic product ({mult:g} per tap in the direct kernels, 6 of 9 taps in the "
+                          f"Winograd form), so frac <= 1/{eff:.2f} against the {peak:g} TFLOP/s peak by construction"
+                          + (" (> 1 is possible and means fewer executed than algorithmic products; executed_frac is the pipe's share)" if eff < 1 else ""))
         return r
 
 

@@ -64,8 +64,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     // convolution's output (conv1's output is dead once the second GroupNorm has consumed it)
     // Winograd form of a 3x3 conv (csrc/conv_wino_f16x3.hip) where its packed weights are given and the shape allows: the GroupNorm
     // in front writes the four transformed images (8 bytes per element instead of 4)
-    const int wsup1 = (f16 && a->conv1_wino) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, C, a->Cout) : 0;
-    const int wsup2 = (f16 && a->conv2_wino) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
+    const int wsup1 = (a->conv1_wino && a->C1 % 32 == 0) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, C, a->Cout) : 0;
+    const int wsup2 = a->conv2_wino ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
     const bool wino1 = wsup1 != 0, wino2 = wsup2 != 0;          // (== 2: no column sums from that conv; the statistics kernel runs instead)
     const size_t szA1 = wino1 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, C) : (size_t)M * C * 4;             // (whole tiles of 128 positions)
     const size_t szA2 = wino2 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, a->Cout) : (size_t)M * a->Cout * 4;
@@ -83,7 +83,9 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     int rc;
     // in_layers: GroupNorm32 -> SiLU (-> 2x resampling of h, :238-243) -> conv3x3                       unet_openai.py:183-187
     if ((rc = gn_stats(a->x1, a->C1, a->x1_colsums, a->x2, a->C2, a->x2_colsums, a->N, a->H * a->W, G, gnws, stats1, stream))) return rc;
-    if (wino1) rc = dua_groupnorm_apply_wino_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
+    if (wino1 && !f16) rc = dua_groupnorm_apply_wino_f32(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1,
+                                                          a->updown, nullptr, h1, stream);
+    else if (wino1) rc = dua_groupnorm_apply_wino_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
                                                    nullptr, 0.5f * a->act_scale, h1, stream);
     else if (f16) rc = dua_groupnorm_apply_split_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
                                                   nullptr, a->act_scale, h1, stream);
@@ -93,15 +95,18 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     if (a->updown && (rc = dua_resample2x(a->x1, xr, a->N, a->H, a->W, a->C1, a->updown, stream))) return rc;          // x_upd :243
     {
         ConvTimer tm(stream);
-        if (wino1) rc = dua_conv3x3_f16x3_wino(h1, a->conv1_wino, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.5f * a->act_scale, stream);
+        if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
+        else if (wino1) rc = dua_conv3x3_f16x3_wino(h1, a->conv1_wino, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.5f * a->act_scale, stream);
         else if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
         else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
-        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, wino1 ? 2.0 : (f16 ? 3.0 : 1.0));
+        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, (f16 ? 3.0 : 1.0) * (wino1 ? 2.0 / 3.0 : 1.0));
     }
     if (rc) return rc;
     // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
     if ((rc = gn_stats(h2, a->Cout, cs2, nullptr, 0, nullptr, a->N, Ho * Wo, G, gnws, stats2, stream))) return rc;
-    if (wino2) rc = dua_groupnorm_apply_wino_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
+    if (wino2 && !f16) rc = dua_groupnorm_apply_wino_f32(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
+                                                          a->dropmask, h3, stream);
+    else if (wino2) rc = dua_groupnorm_apply_wino_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
                                                    a->dropmask, 0.5f * a->act_scale, h3, stream);
     else if (f16) rc = dua_groupnorm_apply_split_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
                                                   a->dropmask, a->act_scale, h3, stream);
@@ -128,10 +133,11 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
     DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0");
     ConvTimer tm(stream);
-    if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
+    if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
+    else if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
     else if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
     else rc = dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
-    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, wino2 ? 2.0 : (f16 ? 3.0 : 1.0));
+    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, (f16 ? 3.0 : 1.0) * (wino2 ? 2.0 / 3.0 : 1.0));
     return rc;
 }
 

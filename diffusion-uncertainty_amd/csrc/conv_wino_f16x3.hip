@@ -24,23 +24,12 @@
 //                        next GroupNorm's column sums as in the direct kernels.
 // LDS image, DMA piece shape and ring discipline are those of k_hconv<4, true> (conv_f16x3.hip); the chunk swizzle is its own.
 #include "common.h"
+#include "wconv.h"
 #include <type_traits>
 
 #define BLK 256
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct WConvP {
-    const _Float16* V;       // [4 f][ntm tiles of 128 positions][Cin / 32][hi | lo][128 positions][32 channels]
-    const _Float16* B;       // packed weights [ntn][K / 32 steps][hi | lo][256 rows][32], then the row scales
-    const float *bias, *res, *Cscale;
-    float* C;
-    float* colsum;
-    long b_plane;            // ntn * 256 * K
-    int Mv, N, Cin, K, H, W, ntm, ntn;
-    float out_scale;
-};
 
 #define WROWS 256
 #define WLD 32
@@ -100,8 +89,8 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         // one tile of one frequency = ncb stage blocks of 16 KB ([hi | lo][128 positions][32 channels]), contiguous
         const int rec = ncb * 16384;
         const long tmi = (WCONV_DIAG & 16) ? (m0_ >> 7) & 31 : m0_ >> 7;   // (diagnostic: activations from a cache-resident set of tiles)
-        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (((long)f_a * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
-        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.V + (((long)f_b * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
+        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.V + (((long)f_a * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
+        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.V + (((long)f_b * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
         grpA = 0;
     };
     bool fiA = false;                                     // frequency index of the group being requested (selects the descriptor)
@@ -308,105 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         }
 #undef WSB
 
-        // ---- epilogue.  Inverse transform across the partner waves (wave ^ 4: same positions and channels, other frequencies):
-        // the f = 1, 2 wave sends P = M1 + M2 and finishes the ODD output row (M1 - M2) - M3, the f = 0, 3 wave sends M3 and
-        // finishes the EVEN row M0 + P.  Two rounds of 8 KB per wave through activation stage 1 / weight stage 2.
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        char* ldsw = reinterpret_cast<char*>(lds);
-        auto slot_of = [&](int w) -> char* {
-            return ldsw + (w < 4 ? (AOFF + 1 * 2 * SA) * 2 + w * 8192 : (BOFF + 2 * 2 * SB) * 2 + (w - 4) * 8192);
-        };
-        char* mine = slot_of(wave);
-        char* theirs = slot_of(wave ^ 4);
-        const bool odd = grp_w == 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int jj = 2 * h + (k >> 2), i = k & 3;
-                const f32x4 v = odd ? acc0[jj][i] + acc1[jj][i] : acc1[jj][i];
-                *(f32x4*)(mine + k * 1024 + lane_e * 16) = v;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int jj = 2 * h + (k >> 2), i = k & 3;
-                const f32x4 r = *(const f32x4*)(theirs + k * 1024 + lane_e * 16);
-                acc0[jj][i] = odd ? (acc0[jj][i] - acc1[jj][i]) - r : acc0[jj][i] + r;
-            }
-            if (h == 0) __syncthreads();
-        }
-        // ---- stores: channel-block pairs (32 channels) of one 16-position block through a 16 x 144-byte patch (in the partner's
-        // slot, which only this wave still reads), so that residual reads and output stores move whole 128-byte rows
-        const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
-        const int pos0 = m0 + ph * 64;
-        char* pw = theirs;
-        const int pr_e = lane_e >> 3, pc_e = lane_e & 7;
-        const long oddoff = odd ? p.W : 0;
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-            const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
-            const bool cok = c < p.N;
-            float4 sq = *(const float4*)(p.Cscale + c);                      // (padded to the tile grid)
-            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && cok) bq = *(const float4*)(p.bias + c);
-            float4 rq[2], rn[2];
-            auto opix = [&](int i, int h) -> long {
-                const int pos = pos0 + 16 * i + 8 * h + pr_e;
-                return pos < p.Mv ? (long)pos + (pos & ~(p.W - 1)) + oddoff : -1L;
-            };
-            auto res_ld = [&](int i, float4 (&dst)[2]) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const long row = opix(i, h);
-                    dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.res && cok && row >= 0) dst[h] = *(const float4*)(p.res + row * p.N + c);
-                }
-            };
-            res_ld(0, rn);
-            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rq[0] = rn[0]; rq[1] = rn[1];
-                if (i < 3) res_ld(i + 1, rn);
-                *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc0[2 * jp][i];
-                *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc0[2 * jp + 1][i];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
-                    const long row = opix(i, h);
-                    float4 v;
-                    v.x = a[0] * sq.x + bq.x + rq[h].x;
-                    v.y = a[1] * sq.y + bq.y + rq[h].y;
-                    v.z = a[2] * sq.z + bq.z + rq[h].z;
-                    v.w = a[3] * sq.w + bq.w + rq[h].w;
-                    if (cok && row >= 0) {
-                        *(float4*)(p.C + row * p.N + c) = v;
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
-                    }
-                }
-            }
-            if (p.colsum) {
-                // The wave's 64 positions are 64 output pixels of ONE image (H*W % 128 == 0), every other row of a block of 128
-                // consecutive output pixels = two 64-pixel slots of the column-sum array; this wave fills the slot of its parity.
-                // The consumer (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
-                float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    t[u] += __shfl_xor(t[u], 8);
-                    t[u] += __shfl_xor(t[u], 16);
-                    t[u] += __shfl_xor(t[u], 32);
-                }
-                if (pr_e == 0 && cok && pos0 < p.Mv) {
-                    float* o = p.colsum + ((long)(pos0 >> 5) + (odd ? 1 : 0)) * 2 * p.N + c;
-                    *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
-                    *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
-                }
-            }
-        }
+        wconv_epilogue(p, acc0, acc1, reinterpret_cast<char*>(lds), wave, lane, m0, n0);
         // the next tile's fragment reads wait for its opening barrier; the patches above must be done before another wave's
         // exchange writes of the next tile land in them: that barrier orders them too (the writes come after the K loop)
     }
@@ -528,6 +419,7 @@ struct GnWinoP {
 // so a wave reads 16 whole 128-byte lines per row and writes, per frequency, the 1-KB piece [16 positions][32 channels] of the hi
 // image and of the lo image of the conv's stage block (tile, channel block) - exactly the pieces its LDS-DMA fetches.  Maps narrower
 // than 16 put 16 / W consecutive row pairs in a wave (then no row is shared between iterations and all four rows are re-read).
+template <bool F32>
 __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
     const int C = p.C1 + p.C2, ncb = C / 32, cpg = C / p.G;
     const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
@@ -593,6 +485,12 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
         }
     };
     auto put = [&](int f, size_t m, const float (&v)[8]) {
+        if (F32) {         // exact-fp32 operand of conv_wino_f32.hip: stage block (f, tile, channel block) = [128 positions][32 floats]
+            float* o = (float*)p.v + (((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 4096 + (m & 127) * 32 + (c & 31);
+            __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, (f32x4*)o);
+            __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, (f32x4*)(o + 4));
+            return;
+        }
         h16x8 h, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -643,9 +541,9 @@ extern "C" size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C) {
     return (size_t)16 * ((Mv + 127) / 128 * 128) * C;                 // whole tiles of 128 positions
 }
 
-extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                              const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
-                                              int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+static int gn_apply_wino_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                              const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                              int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream, bool f32) {
     const int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && vplanes, "dua_groupnorm_apply_wino_f16x3: null pointer");
     DUA_REQUIRE(C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % 32 == 0, "dua_groupnorm_apply_wino_f16x3: channel counts must be multiples of 8 (sum of 32)");
@@ -669,6 +567,19 @@ extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const flo
     while ((long)N * nxb * ((P + JC - 1) / JC) < 1024 && JC > 4) JC = (JC + 1) / 2;
     if (Wo < 16 && JC % (16 / Wo)) JC = (JC / (16 / Wo) + 1) * (16 / Wo);       // chunks hold whole 16-position groups
     p.JC = JC;
-    hipLaunchKernelGGL(k_gn_apply_wino, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
-    return dua_check_launch("dua_groupnorm_apply_wino_f16x3");
+    if (f32) hipLaunchKernelGGL(k_gn_apply_wino<true>, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(k_gn_apply_wino<false>, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
+    return dua_check_launch("dua_groupnorm_apply_wino");
+}
+extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                              const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                              int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+    return gn_apply_wino_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, v_scale, vplanes, stream, false);
+}
+// ... the four transformed images in fp32 (same stage-block layout with [128][32] floats per block, same byte count): the operand of
+// dua_conv3x3_f32_wino (conv_wino_f32.hip), the exact-fp32 mode
+extern "C" int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                            const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                            int act, int resample, const float* dropmask, void* vplanes, void* stream) {
+    return gn_apply_wino_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, 1.0f, vplanes, stream, true);
 }

@@ -99,8 +99,9 @@ class ResBlock(TimestepBlock):
             if not (drop.training and drop.p > 0 and self.updown):          # (a dropout mask on a resampling block: composed path)
                 Hb, Wb = (2 * H, 2 * W) if self.resample > 0 else ((H // 2, W // 2) if self.resample < 0 else (H, W))
                 cin = x.shape[3] + (0 if skip is None else skip.shape[3])
-                w1 = ctx.packed(conv1, "w3w") if ctx.wino_ok(N, Hb, Wb, cin, self.out_channels) else None
-                w2 = ctx.packed(conv2, "w3w") if ctx.wino_ok(N, Hb, Wb, self.out_channels, self.out_channels) else None
+                kw = "w3w" if ctx.model.precision == "f16x3" else "w3wf"
+                w1 = ctx.packed(conv1, kw) if ctx.wino_ok(N, Hb, Wb, cin, self.out_channels) else None
+                w2 = ctx.packed(conv2, kw) if ctx.wino_ok(N, Hb, Wb, self.out_channels, self.out_channels) else None
                 return ops.adm_resblock(x, skip, (gn1.weight, gn1.bias), ctx.packed(conv1, kind3), conv1.bias, ctx.film(self),
                                         (gn2.weight, gn2.bias), ctx.packed(conv2, kind3), conv2.bias,
                                         None if ident else ctx.packed(self.skip_connection, kind1),
@@ -224,7 +225,7 @@ class _Ctx:
 
     def wino_ok(self, N, H, W, cin, cout):
         """This 3x3 conv (input / output size H x W) runs in the Winograd F(2,3)-along-y form of the f16x3 kernel."""
-        return self.model.precision == "f16x3" and bool(getattr(self.model, "winograd", True)) and ops.conv3x3_wino_supported(N, H, W, cin, cout)
+        return self.model.precision in ("f16x3", "fp32") and bool(getattr(self.model, "winograd", True)) and ops.conv3x3_wino_supported(N, H, W, cin, cout)
 
     def conv_split(self, width, conv_shape=None):
         """Operand format the GroupNorm in front of a 3x3 conv of this output width writes (conv_shape = (N, H, W, Cin, Cout) lets
@@ -232,7 +233,7 @@ class _Ctx:
         if self.split_acts == "f16f6" and 256 % width != 0:
             return "f16f8"
         if conv_shape is not None and self.wino_ok(*conv_shape):
-            return "f16x3w"
+            return "f16x3w" if self.model.precision == "f16x3" else "f32w"
         return self.split_acts
 
     def packed(self, mod, kind):
@@ -254,6 +255,8 @@ class _Ctx:
                 cache[key] = ops.pack_weight_f16x3(mod.weight.detach().contiguous())
             elif kind == "w3w":
                 cache[key] = ops.pack_weight_f16x3_wino(mod.weight.detach().contiguous())
+            elif kind == "w3wf":
+                cache[key] = ops.pack_weight_f32_wino(mod.weight.detach().contiguous())
             elif kind == "qkvh":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16x3(wq), bq)
@@ -307,7 +310,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16f8": "w3f", "f16f6": "w3s", "f16x3": "w3h", "f16x3w": "w3w"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16f8": "w3f", "f16f6": "w3s", "f16x3": "w3h", "f16x3w": "w3w", "f32w": "w3wf"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -407,8 +410,9 @@ class UNetModel(nn.Module):
         # but the result then depends on the batch size at fp32-rounding level, so it is opt-in here: the Monte-Carlo chains of a
         # UC step stay bit-identical whether they run one by one or stacked)
         self.split_k = False
-        # f16x3: 3x3 convs in the Winograd F(2,3)-along-y form where the kernel takes the shape (csrc/conv_wino_f16x3.hip: 6 instead of
-        # 9 matrix-core taps per pixel at the same operand precision; results differ from the direct form at fp32-rounding level)
+        # f16x3 / fp32: 3x3 convs in the Winograd F(2,3)-along-y form where the kernel takes the shape (csrc/conv_wino_f16x3.hip,
+        # conv_wino_f32.hip: 6 instead of 9 matrix-core taps per pixel at the same operand precision; results differ from the direct
+        # form at fp32-rounding level)
         self.winograd = True
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).

@@ -314,6 +314,14 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
         buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
+        if split == "f32w":
+            # exact-fp32 Winograd operand (csrc/conv_wino_f32.hip): the four V_f images as floats, same stage-block layout
+            ntm = (N * (Ho // 2) * Wo + 127) // 128
+            vbuf = torch.empty((4, ntm, (C1 + C2) // 32, 128, 32), device=x1.device, dtype=torch.float32)
+            check(_lib.lib().dua_groupnorm_apply_wino_f32(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                                                          _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
+                                                          _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f32")
+            return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), "f32w", 1.0)
         if split == "f16x3w":
             # Winograd F(2,3)-along-y operand of conv3x3 (csrc/conv_wino_f16x3.hip): the four V_f images as f16x3 planes of V * scale
             scale = 0.5 * F16X3_ACT_SCALE if split_scale is None else float(split_scale)
@@ -569,6 +577,17 @@ def pack_weight_f16x3_wino(w):
     return packed
 
 
+def pack_weight_f32_wino(w):
+    """OIHW 3x3 conv weight -> the packed exact-fp32 Winograd weight of dua_conv3x3_f32_wino (U_f as floats in the kernel's stage order)."""
+    _req(w, name="w")
+    assert w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    L = _lib.lib()
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(L.dua_f32_wino_weight_bytes(cout, cin), device=w.device, dtype=torch.uint8)
+    check(L.dua_pack_weight_f32_wino(_p(w), _p(packed), cout, cin, _stream()), "dua_pack_weight_f32_wino")
+    return packed
+
+
 def conv3x3_wino_supported(N, H, W, cin, cout):
     """Shapes dua_conv3x3_f16x3_wino takes (H, W = the conv's input / output size)."""
     return bool(_lib.lib().dua_conv3x3_f16x3_wino_supported(int(N), int(H), int(W), int(cin), int(cout)))
@@ -632,7 +651,13 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if pre and x.fmt == "f16x3w":
+    if pre and x.fmt == "f32w":
+        assert not nchw_out, "the Winograd conv writes NHWC"
+        if (H * W) % 128:
+            ws = None
+        check(_lib.lib().dua_conv3x3_f32_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, _p(ws), _stream()),
+              "dua_conv3x3_f32_wino")
+    elif pre and x.fmt == "f16x3w":
         assert not nchw_out, "the Winograd conv writes NHWC"
         if (H * W) % 128:
             ws = None                                  # small maps: no column sums from the Winograd kernel
@@ -651,7 +676,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
                                             _p(ws), _stream()), "dua_conv3x3_bf16x3")
     if PROFILE is not None:
         e1.record()
-        PROFILE.record("conv3x3_wino" if (pre and x.fmt == "f16x3w") else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
+        PROFILE.record("conv3x3_wino" if (pre and x.fmt in ("f16x3w", "f32w")) else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
     return _attach_colsums(y, ws, H * W)
 
 

@@ -327,6 +327,16 @@ int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int
 int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, int Cout);
 int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
                            int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
+/* The same form in EXACT fp32 (csrc/conv_wino_f32.hip, v_mfma_f32_16x16x4_f32: products and sums in fp32 - the Winograd form of
+ * dua_conv3x3): the transformed images and the packed weights hold floats in the same stage-block layout (same byte counts:
+ * dua_f16x3_wino_act_bytes / dua_f32_wino_weight_bytes), shapes as dua_conv3x3_f16x3_wino_supported. */
+size_t dua_f32_wino_weight_bytes(int Cout, int Cin);
+int dua_pack_weight_f32_wino(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
+int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                 const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                 int resample, const float* dropmask, void* vplanes, void* stream);
+int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
+                         int N, int H, int W, int Cin, int Cout, float* colsum, void* stream);
 /* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
  * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */
 int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,
@@ -408,9 +418,10 @@ typedef struct {
     int precision; float act_scale, raw_scale;
     void* workspace; size_t workspace_bytes;
     float* y; float* y_colsums;          /* [N][Ho][Wo][Cout] */
-    const void *conv1_wino, *conv2_wino; /* DUA_PREC_F16X3, optional: the 3x3 weights also packed by dua_pack_weight_f16x3_wino; a conv whose
-                                            shape dua_conv3x3_f16x3_wino_supported accepts then runs in the Winograd form (conv*_packed
-                                            stays required: it serves every other shape) */
+    const void *conv1_wino, *conv2_wino; /* optional: the 3x3 weights also packed by dua_pack_weight_f16x3_wino (DUA_PREC_F16X3) /
+                                            dua_pack_weight_f32_wino (DUA_PREC_FP32); a conv whose shape dua_conv3x3_f16x3_wino_supported
+                                            accepts then runs in the Winograd form (conv*_packed stays required: it serves every other
+                                            shape) */
 } dua_resblock_args;
 /* ResBlock.forward, guided_diffusion/unet_openai.py:237-257 (use_scale_shift_norm, resblock_updown). */
 size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* args_host);

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--engine", type=int, default=1)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--fmt", default="bf16x3", choices=["bf16x3", "f16f8", "f16f6", "f16x3", "f16x3w"])
+    ap.add_argument("--fmt", default="bf16x3", choices=["bf16x3", "f16f8", "f16f6", "f16x3", "f16x3w", "f32w", "fp32"])
     ap.add_argument("--check", action="store_true", help="compare with an fp64 torch convolution (small shapes only)")
     ap.add_argument("--lib", default="", help="alternative libdua_hip build to load")
     ap.add_argument("--stagger", type=str, default="", help="phases,percent,min_tiles")
@@ -64,6 +64,15 @@ def main():
                 xs = ops.groupnorm_apply(x, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16x3")
                 planes = ops.pack_weight_f16x3(w)
                 hi = lo = buf = None
+            elif a.fmt in ("f32w", "fp32"):            # exact fp32: Winograd form (k_wconv32) / direct fp32 MFMA conv
+                st = torch.tensor([0.0, 1.0], device=dev).repeat(N * 32, 1).contiguous()
+                if a.fmt == "f32w" and ops.conv3x3_wino_supported(N, H, H, Cin, Cout):
+                    xs = ops.groupnorm_apply(x, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f32w")
+                    planes = ops.pack_weight_f32_wino(w)
+                else:
+                    xs = x.clone()
+                    planes = ops.pack_conv3x3_weight(w)
+                hi = lo = buf = None
             elif a.fmt == "f16x3w":
                 st = torch.tensor([0.0, 1.0], device=dev).repeat(N * 32, 1).contiguous()
                 if ops.conv3x3_wino_supported(N, H, H, Cin, Cout):
@@ -85,7 +94,8 @@ def main():
                 hi = lo = buf = None
             bias = torch.randn(Cout, device=dev)
             r = torch.randn(N, H, H, Cout, device=dev) if res else None
-            y = ops.conv3x3_bf16x3(xs, planes, bias, Cout, residual=r, colsum=True)
+            conv = ops.conv3x3_bf16x3 if isinstance(xs, ops.SplitPlanes) else ops.conv3x3
+            y = conv(xs, planes, bias, Cout, residual=r, colsum=True)
             torch.cuda.synchronize()
             if a.check:
                 ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
@@ -97,7 +107,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.reps):
-                ops.conv3x3_bf16x3(xs, planes, bias, Cout, residual=r, colsum=True)
+                conv(xs, planes, bias, Cout, residual=r, colsum=True)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.reps

@@ -274,3 +274,58 @@ def test_headline_job_variants_diverge_alike():
         assert torch.isfinite(r["score"]).all() and torch.isfinite(r["uncertainty"]).all() and (r["uncertainty"] >= 0).all()
     others = max(pairs["fp32b-fp32"][0], pairs["direct-fp32"][0])
     assert pairs["wino-fp32"][0] <= 10 * others + 1e-3, pairs
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (1, 32, 32, 256, 256), (3, 64, 64, 64, 256),
+                                             (2, 128, 128, 32, 128), (6, 8, 8, 96, 160), (130, 16, 16, 64, 64)])
+def test_conv3x3_wino_fp32_vs_fp64(ops, N, H, W, Cin, Cout):
+    """The exact-fp32 Winograd path (fp32 V images -> fp32 packed weights -> k_wconv32 on v_mfma_f32_16x16x4_f32) against fp64, next to
+    the direct fp32 MFMA conv on the same problem: within 2x of its error; V images equal the fp64 transform to fp32 rounding."""
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    w = w * torch.logspace(-3, 1, Cout).reshape(-1, 1, 1, 1)
+    x = x * torch.logspace(-4, 1.5, Cin).reshape(1, -1, 1, 1)
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    scale_out = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+    xd = nhwc(x).to(dev)
+    xv = ops.groupnorm_apply(xd, identity_stats(N), torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f32w")
+    assert xv.fmt == "f32w"
+    v = xv.buf.cpu().double().permute(0, 1, 3, 2, 4).reshape(4, -1, Cin)[:, :N * (H // 2) * W].reshape(4, N, H // 2, W, Cin)
+    vref = v_reference(nhwc(x).double())
+    assert (v - vref).abs().max().item() <= 2.0 ** -23 * vref.abs().max().item()
+    pk = ops.pack_weight_f32_wino(w.to(dev))
+    y = ops.conv3x3_bf16x3(xv, pk, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    y32 = ops.conv3x3(xd, ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err = ((nchw(y.cpu()).double() - ref).abs() / scale_out).max().item()
+    err32 = ((nchw(y32.cpu()).double() - ref).abs() / scale_out).max().item()
+    print(f"winograd fp32 rel err {err:.2e}  direct fp32-MFMA {err32:.2e}")
+    assert err < max(2 * err32, 2e-6), (err, err32)
+    if (H * W) % 128 == 0 and Cout % 32 == 0:
+        s1, s2 = ops.groupnorm_stats(y), ops.groupnorm_stats(y.clone())
+        np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    assert torch.equal(y, ops.conv3x3_bf16x3(xv, pk, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True))
+
+
+def test_winograd_unet_fp32_vs_reference_and_direct(golden):
+    """Full-size ADM-64 / ADM-128 in the exact fp32 mode with the 3x3 convs in the Winograd form (default) and in the direct form: both
+    inside the 1e-3 bar against the reference's own output (G5), within 3e-5 of each other; block-level path == per-op composition."""
+    from conftest import T
+    from oracle import adm
+    from test_gpu_models import build_adm
+    for name, cfg in (("adm64", adm.ADM64), ("adm128", adm.ADM128)):
+        g = golden(f"g5_{name}_full")
+        m, _ = build_adm(dict(cfg), int(g["seed"]))
+        assert m.precision == "fp32" and m.winograd
+        x, t, y = T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev)
+        w = m(x, t, y=y)
+        m.use_block_abi = False
+        wop = m(x, t, y=y)
+        m.use_block_abi = True
+        m.winograd = False
+        d = m(x, t, y=y)
+        ew, ed = np.abs(w.cpu().numpy() - g["out"]).max(), np.abs(d.cpu().numpy() - g["out"]).max()
+        print(f"{name} fp32: winograd err {ew:.3e}, direct err {ed:.3e}, |winograd - direct| {(w - d).abs().max().item():.3e}")
+        assert ew < 1e-3 and ed < 1e-3 and ew < 2 * ed + 2e-6
+        assert (w - d).abs().max().item() < 3e-5 and not torch.equal(w, d) and torch.equal(w, wop)
+        del m
+        torch.cuda.empty_cache()
