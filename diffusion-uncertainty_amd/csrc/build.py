@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
 
 
 def build_select_variant(verbose=True):
-    """libdua_hip_select.so: the product sources with conv_f16x3.hip and conv_wino_f16x3.hip compiled -DDUA_RS_ZERO_SELECT=1 (the
+    """libdua_hip_select.so: the product sources with conv_f16x3.hip, conv_wino_f16x3.hip and conv_wino_f32.hip compiled -DDUA_RS_ZERO_SELECT=1 (the
     row-shift convs zero their image-edge fragments by a register select instead of an out-of-range LDS read).  Test artefact (scripts/diag/build/, outside the
     package): tests/test_gpu_ops.py compares the two forms bit for bit."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -48,7 +48,7 @@ def build_select_variant(verbose=True):
     out = os.path.join(out_dir, "libdua_hip_select.so")
     hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "dconv.h"), os.path.join(HERE, "wconv.h"), os.path.join(os.path.dirname(PKG), "include", "dua_hip.h")]
     alt = {}
-    for name in ("conv_f16x3.hip", "conv_wino_f16x3.hip"):          # the two kernels with row-shifted fragment reads
+    for name in ("conv_f16x3.hip", "conv_wino_f16x3.hip", "conv_wino_f32.hip"):          # the kernels with row-shifted fragment reads
         src = os.path.join(HERE, name)
         obj = os.path.join(out_dir, name.replace(".hip", ".select.o"))
         if _stale(obj, [src] + hdrs):

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(512, 2) void k_wconv32(WConvP p) {
             // VALU slots to spare (128 MFMAs of 32 cycles per step), so the twelve addresses need not live in registers per block
             const bool edge = (xedge >> (dx < 0 ? i : 4 + i)) & 1u;
             const int d = dx + 1;
+#if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
+            const f32x8v v = rd8(ax[d][0], ax[d][1], off), z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // data-select form (test build)
+            return edge ? z : v;
+#else
             return rd8(edge ? zero_addr - off : ax[d][0], edge ? zero_addr - off : ax[d][1], off);
+#endif
         };
         auto rd_w = [&](int sb, int jj) -> f32x8v {
             const int off = (sb == 2 ? 0 : sb * ST * 4) + 16 * jj * 128;

@@ -229,6 +229,16 @@ def test_wino_zero_padding_forms_agree(ops):
         assert torch.equal(y0, y1), (N, H, W, Cin, Cout)
         ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
         assert (nchw(y0.cpu()).double() - ref).abs().max().item() < 2e-5
+        # the exact-fp32 kernel likewise
+        fn32 = A.dua_conv3x3_f32_wino
+        fn32.restype, fn32.argtypes = _lib.SIGNATURES["dua_conv3x3_f32_wino"]
+        xv32 = ops.groupnorm_apply(xd, identity_stats(N), torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f32w")
+        pk32 = ops.pack_weight_f32_wino(w.to(dev))
+        z0 = ops.conv3x3_bf16x3(xv32, pk32, bd, Cout)
+        z1 = torch.empty_like(z0)
+        rc = fn32(ctypes.c_void_p(xv32.buf.data_ptr()), ctypes.c_void_p(pk32.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None,
+                  ctypes.c_void_p(z1.data_ptr()), N, H, W, Cin, Cout, None, st)
+        assert rc == 0 and torch.equal(z0, z1), (N, H, W, Cin, Cout)
 
 
 def test_headline_job_variants_diverge_alike():
