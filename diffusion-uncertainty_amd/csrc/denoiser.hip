@@ -628,6 +628,31 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     return dua_check_launch("dua_groupnorm_apply");
 }
 
+// =================================== 3x3 conv with a handful of output channels ==================
+// conv3x3(x)[p][co] = sum over the 9 taps of T[p + offset(tap)][tap * cout + co], where T = x W_t^T is a plain one-tap GEMM over the
+// pixels with the 9 * cout tap columns as its N (the UNet's `out` conv, 256 -> 3 kept channels: the implicit-GEMM conv kernels would
+// compute a 128-column tile for it).  This kernel is the second half: it gathers the nine tap columns of the neighbour pixels (zero
+// outside the image), adds the bias and writes NCHW.  T rows of ldt floats; HBM-light (T is M x 28 floats for cout = 3).
+__global__ __launch_bounds__(BLK) void k_conv3x3_tap_gather(const float* __restrict__ T, int ldt, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int N, int H, int W, int cout) {
+    const size_t total = (size_t)N * cout * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), co = (int)((i / ((size_t)W * H)) % cout), n = (int)(i / ((size_t)W * H * cout));
+        float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) acc += T[(((size_t)n * H + yy) * W + xx) * ldt + t * cout + co];
+        }
+        out[i] = acc;
+    }
+}
+extern "C" int dua_conv3x3_tap_gather(const float* T, int ldt, const float* bias, float* out_nchw, int N, int H, int W, int cout, void* stream) {
+    DUA_REQUIRE(T && out_nchw && N > 0 && H > 0 && W > 0 && cout > 0 && ldt >= 9 * cout, "dua_conv3x3_tap_gather: T rows must hold 9 * cout columns");
+    hipLaunchKernelGGL(k_conv3x3_tap_gather, stream_grid((size_t)N * cout * H * W, BLK), BLK, 0, as_stream(stream), T, ldt, bias, out_nchw, N, H, W, cout);
+    return dua_check_launch("dua_conv3x3_tap_gather");
+}
+
 // =================================== latent-UNet (SD-1.5) helpers ===============================
 // x[n][p][c] += bias[n][c]  (ResnetBlock2D: hidden + time_emb_proj(silu(emb))[:, :, None, None]), in place
 __global__ __launch_bounds__(BLK) void k_add_channel_bias(float* __restrict__ x, const float* __restrict__ b, long bld, int N, int HW, int C) {

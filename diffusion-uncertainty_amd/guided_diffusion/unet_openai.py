@@ -414,6 +414,8 @@ class UNetModel(nn.Module):
         # conv_wino_f32.hip: 6 instead of 9 matrix-core taps per pixel at the same operand precision; results differ from the direct
         # form at fp32-rounding level)
         self.winograd = True
+        # fp32 / f16x3: the few-channel `out` conv as one-tap GEMM + tap gather (see _forward_body)
+        self.out_conv_taps = True
         # mc_dropout: masks come from the CPU generator in ResBlock execution order by default (parity with the
         # reference CPU path); set to a device generator for speed (see schedulers_uncertainty/noise.py).
         self.dropout_mask_source = host_dropout_mask
@@ -479,7 +481,7 @@ class UNetModel(nn.Module):
         t = timesteps.to(torch.int64).contiguous()
         yy = y.to(torch.int64).contiguous() if y is not None else None
         key = (tuple(x.shape), self.precision, out_channels_keep, self.use_block_abi, self.fuse_gn_stats, ops.ATTENTION_MODE, y is not None,
-               bool(self.split_k), bool(getattr(self, "winograd", True)))
+               bool(self.split_k), bool(getattr(self, "winograd", True)), bool(getattr(self, "out_conv_taps", True)))
         entry = graphs.get(key)
         if entry is None:
             self._forward_impl(x, t, yy, out_channels_keep)            # eager once: packs the weights, warms the allocator
@@ -526,8 +528,25 @@ class UNetModel(nn.Module):
             h = module.run(ctx, h, hs.pop(), name=f"output_blocks.{i}")
         gn, conv = self.out[0], self.out[2]
         st = ops.groupnorm_stats(h)
-        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split=ctx.conv_split(h.shape[2]))
         keep = self.out_channels if out_channels_keep is None else out_channels_keep
+        if self.precision in ("fp32", "f16x3") and keep <= 8 and h.shape[3] % 32 == 0 and bool(getattr(self, "out_conv_taps", True)):
+            # the out conv (:616) keeps 3 - 6 channels: nine tap columns per channel from ONE one-tap GEMM over the pixels, then a
+            # gather of the neighbours' columns (ops.conv3x3_tap_gather) - the implicit-GEMM conv kernels would compute a 128-column
+            # tile for it (2.8 ms of a 170 ms forward at batch 128)
+            N_, H_, W_, C_ = h.shape
+            key = (id(conv), "taps", keep, self.precision)
+            if key not in self._packed:
+                wt = ops.tap_column_weight(conv.weight.detach(), keep)
+                self._packed[key] = (ops.pack_weight_f16x3(wt) if self.precision == "f16x3" else wt, wt.shape[0])
+            wt, ncol = self._packed[key]
+            if self.precision == "f16x3":
+                hp = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split="f16x3")
+                T = ops.gemm_bf16x3_presplit(hp, wt, ncol)
+            else:
+                hp = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1)
+                T = ops.gemm(hp.view(N_ * H_ * W_, C_), wt)
+            return ops.conv3x3_tap_gather(T, conv.bias.detach()[:keep].contiguous(), N_, H_, W_, keep)
+        h = ops.groupnorm_apply(h, st, gn.weight, gn.bias, act=1, split=ctx.conv_split(h.shape[2]))
         return ctx.conv3x3(h, conv, keep, nchw_out=True)
 
 

@@ -577,6 +577,26 @@ def pack_weight_f16x3_wino(w):
     return packed
 
 
+def tap_column_weight(w, keep):
+    """OIHW 3x3 conv weight -> the [N][Cin] matrix of its tap columns for conv3x3_small_cout: row (tap * keep + co) = w[co, :, tap]
+    for the first `keep` output channels, zero rows up to a multiple of 32."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3 and 0 < keep <= cout
+    rows = w[:keep].reshape(keep, cin, 9).permute(2, 0, 1).reshape(9 * keep, cin)
+    n = (9 * keep + 31) // 32 * 32
+    wt = torch.zeros((n, cin), device=w.device, dtype=torch.float32)
+    wt[:9 * keep] = rows
+    return wt.contiguous()
+
+
+def conv3x3_tap_gather(T, bias, N, H, W, cout):
+    """Second half of the small-Cout 3x3 conv: T [N*H*W, >= 9*cout] tap columns -> NCHW [N, cout, H, W] (+ bias)."""
+    _req(T, name="T")
+    out = torch.empty((N, cout, H, W), device=T.device, dtype=torch.float32)
+    check(_lib.lib().dua_conv3x3_tap_gather(_p(T), T.shape[1], _p(bias), _p(out), N, H, W, cout, _stream()), "dua_conv3x3_tap_gather")
+    return out
+
+
 def pack_weight_f32_wino(w):
     """OIHW 3x3 conv weight -> the packed exact-fp32 Winograd weight of dua_conv3x3_f32_wino (U_f as floats in the kernel's stage order)."""
     _req(w, name="w")

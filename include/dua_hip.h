@@ -318,6 +318,11 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  *   dua_groupnorm_stats_from_colsums folds, are exact).  Shapes: dua_conv3x3_f16x3_wino_supported returns 1 for H even, W a power
  *   of two <= 128, Cin % 32 == 0, Cout % 4 == 0, H*W % 128 == 0, and 2 for the same with a smaller map (colsum must then be NULL);
  *   0 = not taken, the conv goes through dua_conv3x3_f16x3_presplit. */
+/* 3x3 convolution with a handful of output channels (the UNet's `out` conv, unet_openai.py:616: 256 -> 6, of which traits.py:18 keeps 3)
+ * as a one-tap GEMM plus a gather: T[M][ldt] = x W_t^T with W_t row (tap * cout + co) = w[co][:][tap] (any GEMM entry point of this
+ * header, N = 9 * cout padded to its granularity), then out[n][co][y][x] = bias[co] + sum_tap T[pixel + offset(tap)][tap * cout + co]
+ * (zero outside the image), NCHW.  The implicit-GEMM kernels would spend a 128-column tile on it. */
+int dua_conv3x3_tap_gather(const float* T, int ldt, const float* bias, float* out_nchw, int N, int H, int W, int cout, void* stream);
 size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C);
 size_t dua_f16x3_wino_weight_bytes(int Cout, int Cin);
 int dua_pack_weight_f16x3_wino(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);

@@ -339,3 +339,22 @@ def test_winograd_unet_fp32_vs_reference_and_direct(golden):
         assert (w - d).abs().max().item() < 3e-5 and not torch.equal(w, d) and torch.equal(w, wop)
         del m
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,keep,cout", [(2, 16, 16, 64, 3, 6), (1, 8, 24, 32, 6, 6), (3, 32, 32, 256, 3, 6), (2, 5, 7, 32, 1, 4)])
+def test_small_cout_conv_as_tap_gemm(ops, N, H, W, Cin, keep, cout):
+    """The UNet's `out` conv (256 -> 6, 3 kept) as ONE one-tap GEMM over the pixels (nine tap columns per kept channel) plus the tap
+    gather, in fp32 and in f16x3: against fp64 conv2d, held to the direct fp32 conv kernel's error on the same problem."""
+    x, w, b = rnd(60, N, Cin, H, W), rnd(61, cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(62, cout) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)[:, :keep]
+    xd = nhwc(x).to(dev)
+    wt = ops.tap_column_weight(w.to(dev), keep)
+    assert wt.shape == ((9 * keep + 31) // 32 * 32, Cin)
+    bk = b[:keep].contiguous().to(dev)
+    y32 = ops.conv3x3_tap_gather(ops.gemm(xd.view(-1, Cin), wt), bk, N, H, W, keep)
+    xs = ops.groupnorm_apply(xd, identity_stats(N), torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16x3")
+    y16 = ops.conv3x3_tap_gather(ops.gemm_bf16x3_presplit(xs, ops.pack_weight_f16x3(wt), wt.shape[0]), bk, N, H, W, keep)
+    yd = ops.conv3x3(xd, ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), keep, nchw_out=True)
+    e32, e16, ed = [(t.cpu().double() - ref).abs().max().item() for t in (y32, y16, yd)]
+    print(f"small-Cout conv: tap GEMM fp32 {e32:.2e}, f16x3 {e16:.2e}, direct fp32 conv {ed:.2e}")
+    assert y32.shape == (N, keep, H, W) and e32 < max(2 * ed, 2e-6) and e16 < max(2 * ed, 2e-6)
