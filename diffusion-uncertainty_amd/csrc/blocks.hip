@@ -70,7 +70,9 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     const size_t szA1 = wino1 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, C) : (size_t)M * C * 4;             // (whole tiles of 128 positions)
     const size_t szA2 = wino2 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, a->Cout) : (size_t)M * a->Cout * 4;
     void* regA = w.take(szA1 > szA2 ? szA1 : szA2);
-    float* xr = a->updown ? (float*)w.take((size_t)M * a->C1 * 4) : nullptr;
+    // the resampled identity skip x_upd (:243): the Winograd conv2 reads x through the resampling in its epilogue; the other forms take a copy
+    const bool fuse_xr = a->updown && wino2;
+    float* xr = (a->updown && !fuse_xr) ? (float*)w.take((size_t)M * a->C1 * 4) : nullptr;
     float* regB = (float*)w.take((size_t)M * a->Cout * 4);
     float* cs2 = (colsum2 && wsup1 != 2) ? (float*)w.take(colsum_floats(M, a->Cout) * 4) : nullptr;
     float* stats2 = (float*)w.take((size_t)a->N * G * 2 * 4);
@@ -92,11 +94,11 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     else rc = dua_groupnorm_apply(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown, nullptr,
                                   (float*)h1, stream);
     if (rc) return rc;
-    if (a->updown && (rc = dua_resample2x(a->x1, xr, a->N, a->H, a->W, a->C1, a->updown, stream))) return rc;          // x_upd :243
+    if (xr && (rc = dua_resample2x(a->x1, xr, a->N, a->H, a->W, a->C1, a->updown, stream))) return rc;          // x_upd :243
     {
         ConvTimer tm(stream);
-        if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
-        else if (wino1) rc = dua_conv3x3_f16x3_wino(h1, a->conv1_wino, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.5f * a->act_scale, stream);
+        if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
+        else if (wino1) rc = dua_conv3x3_f16x3_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.5f * a->act_scale, stream);
         else if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
         else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
         tm.done(2.0 * (double)M * 9.0 * C * a->Cout, (f16 ? 3.0 : 1.0) * (wino1 ? 2.0 / 3.0 : 1.0));
@@ -113,7 +115,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     else rc = dua_groupnorm_apply(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0, a->dropmask,
                                   (float*)h3, stream);
     if (rc) return rc;
-    const float* xin = a->updown ? xr : a->x1;
+    const float* xin = xr ? xr : a->x1;
+    const int rmode = fuse_xr ? a->updown : 0;
     const float* resid = xin;                                                                                  // identity skip :223-226
     if (a->skip_packed) {                                                                                      // 1x1 convolution over [x | skip]
         if (f16) {
@@ -133,8 +136,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
     DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0");
     ConvTimer tm(stream);
-    if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
-    else if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
+    if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
+    else if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
     else if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
     else rc = dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
     tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, (f16 ? 3.0 : 1.0) * (wino2 ? 2.0 / 3.0 : 1.0));

@@ -384,16 +384,17 @@ extern "C" int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, in
     return ((long)H * W) % 128 == 0 ? 1 : 2;
 }
 
-extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
+extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                                       int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
     DUA_REQUIRE(vplanes && packed && y, "dua_conv3x3_f16x3_wino: null pointer");
+    DUA_REQUIRE(res_resample >= -1 && res_resample <= 1 && (res_resample <= 0 || W >= 2), "dua_conv3x3_f16x3_wino: res_resample must be -1, 0 or +1");
     DUA_REQUIRE(v_scale > 0.f, "dua_conv3x3_f16x3_wino: v_scale must be positive");
     const int sup = dua_conv3x3_f16x3_wino_supported(N, H, W, Cin, Cout);
     DUA_REQUIRE(sup, "dua_conv3x3_f16x3_wino: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (H even, W a power of two <= 128, "
                 "Cin %% 32 == 0, Cout %% 4 == 0)", N, H, W, Cin, Cout);
     DUA_REQUIRE(!colsum || sup == 1, "dua_conv3x3_f16x3_wino: the column-sum output needs H*W %% 128 == 0 (got %d x %d)", H, W);
     WConvP p{};
-    p.V = (const _Float16*)vplanes; p.B = (const _Float16*)packed; p.bias = bias; p.res = residual; p.C = y; p.colsum = colsum;
+    p.V = (const _Float16*)vplanes; p.B = (const _Float16*)packed; p.bias = bias; p.res = residual; p.res_mode = residual ? res_resample : 0; p.C = y; p.colsum = colsum;
     p.Mv = N * (H / 2) * W; p.N = Cout; p.Cin = Cin; p.K = 6 * Cin; p.H = H; p.W = W;
     p.ntm = (p.Mv + 127) / 128; p.ntn = wino_ntn(Cout);
     p.b_plane = (long)p.ntn * 256 * p.K;

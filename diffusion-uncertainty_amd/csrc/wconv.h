@@ -15,6 +15,9 @@ struct WConvP {
     long b_plane;            // ntn * 256 * K
     int Mv, N, Cin, K, H, W, ntm, ntn;
     float out_scale;
+    int res_mode;            // 0: res is [N][H][W][Cout]; +1: res is [N][H/2][W/2][Cout], read through nearest-neighbour 2x upsampling;
+                             // -1: res is [N][2H][2W][Cout], read through 2x2 average pooling (the resampled identity skip of an ADM
+                             // up / down block, unet_openai.py:238-243, without materialising it)
 };
 
 
@@ -76,7 +79,22 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
             for (int h = 0; h < 2; ++h) {
                 const long row = opix(i, h);
                 dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.res && cok && row >= 0) dst[h] = *(const float4*)(p.res + row * p.N + c);
+                if (!(p.res && cok && row >= 0)) continue;
+                if (p.res_mode == 0) {
+                    dst[h] = *(const float4*)(p.res + row * p.N + c);
+                    continue;
+                }
+                const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
+                if (p.res_mode > 0) {
+                    const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
+                    dst[h] = *(const float4*)(p.res + src * p.N + c);
+                } else {                                                  // same order of additions as k_resample2x (denoiser.hip)
+                    const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
+                    const float4 a = *(const float4*)(p.res + src * p.N + c), b = *(const float4*)(p.res + (src + 1) * p.N + c);
+                    const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
+                    dst[h] = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
+                                         (a.w + b.w + d.w + e.w) * 0.25f);
+                }
             }
         };
         res_ld(0, rn);

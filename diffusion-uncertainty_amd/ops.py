@@ -659,14 +659,20 @@ def planes_f16f6_reference(x):
     return SplitPlanes(buf, (N, H, W, C), "f16f6")
 
 
-def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=False):
-    """Split-operand 3x3 convolution; a SplitPlanes input selects the kernel by its format (the weight must be packed to match)."""
+def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=False, res_resample=0):
+    """Split-operand 3x3 convolution; a SplitPlanes input selects the kernel by its format (the weight must be packed to match).
+    res_resample (Winograd formats only): +1 / -1 = `residual` is the half / double resolution map, added through nearest 2x upsampling /
+    2x2 average pooling."""
     pre = isinstance(x, SplitPlanes)
     if not pre:
         _req(x, name="x")
     N, H, W, Cin = x.shape
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
     ws = _colsum_ws(N * H * W, cout, x.device, colsum and not nchw_out)
+    assert res_resample == 0 or (pre and x.fmt in ("f16x3w", "f32w") and residual is not None), "res_resample is a Winograd-conv option"
+    if res_resample:
+        rs = (N, H // 2, W // 2, cout) if res_resample > 0 else (N, 2 * H, 2 * W, cout)
+        assert tuple(residual.shape) == rs and residual.is_contiguous() and residual.dtype == torch.float32, f"residual must be fp32 {rs}"
     e0 = e1 = None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -675,13 +681,14 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
         assert not nchw_out, "the Winograd conv writes NHWC"
         if (H * W) % 128:
             ws = None
-        check(_lib.lib().dua_conv3x3_f32_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, _p(ws), _stream()),
+        check(_lib.lib().dua_conv3x3_f32_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws), _stream()),
               "dua_conv3x3_f32_wino")
     elif pre and x.fmt == "f16x3w":
         assert not nchw_out, "the Winograd conv writes NHWC"
         if (H * W) % 128:
             ws = None                                  # small maps: no column sums from the Winograd kernel
-        check(_lib.lib().dua_conv3x3_f16x3_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, _p(ws), x.scale,
+        check(_lib.lib().dua_conv3x3_f16x3_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws),
+                                                x.scale,
                                                 _stream()), "dua_conv3x3_f16x3_wino")
     elif pre and x.fmt == "f16x3":
         check(_lib.lib().dua_conv3x3_f16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),

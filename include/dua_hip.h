@@ -317,7 +317,10 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  *   that a 64-pixel slot holds the sums of every other row of a 128-pixel block (the per-image totals, which is what
  *   dua_groupnorm_stats_from_colsums folds, are exact).  Shapes: dua_conv3x3_f16x3_wino_supported returns 1 for H even, W a power
  *   of two <= 128, Cin % 32 == 0, Cout % 4 == 0, H*W % 128 == 0, and 2 for the same with a smaller map (colsum must then be NULL);
- *   0 = not taken, the conv goes through dua_conv3x3_f16x3_presplit. */
+ *   0 = not taken, the conv goes through dua_conv3x3_f16x3_presplit.  res_resample: 0 = residual is [N][H][W][Cout]; +1 = residual is
+ *   [N][H/2][W/2][Cout] and is added through nearest-neighbour 2x upsampling, -1 = residual is [N][2H][2W][Cout] and is added through
+ *   2x2 average pooling - the resampled identity skip of an ADM up / down block (unet_openai.py:238-243) read in place, bit-identical
+ *   to dua_resample2x followed by res_resample = 0. */
 /* 3x3 convolution with a handful of output channels (the UNet's `out` conv, unet_openai.py:616: 256 -> 6, of which traits.py:18 keeps 3)
  * as a one-tap GEMM plus a gather: T[M][ldt] = x W_t^T with W_t row (tap * cout + co) = w[co][:][tap] (any GEMM entry point of this
  * header, N = 9 * cout padded to its granularity), then out[n][co][y][x] = bias[co] + sum_tap T[pixel + offset(tap)][tap * cout + co]
@@ -330,7 +333,7 @@ int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int
                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                    int resample, const float* dropmask, float v_scale, void* vplanes, void* stream);
 int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, int Cout);
-int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
+int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                            int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
 /* The same form in EXACT fp32 (csrc/conv_wino_f32.hip, v_mfma_f32_16x16x4_f32: products and sums in fp32 - the Winograd form of
  * dua_conv3x3): the transformed images and the packed weights hold floats in the same stage-block layout (same byte counts:
@@ -340,7 +343,7 @@ int dua_pack_weight_f32_wino(const float* w_oihw, void* packed, int Cout, int Ci
 int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                                  const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                  int resample, const float* dropmask, void* vplanes, void* stream);
-int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, float* y,
+int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                          int N, int H, int W, int Cin, int Cout, float* colsum, void* stream);
 /* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
  * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */

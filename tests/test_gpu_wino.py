@@ -223,7 +223,7 @@ def test_wino_zero_padding_forms_agree(ops):
         y0 = ops.conv3x3_bf16x3(xv, packed, bd, Cout)
         y1 = torch.empty_like(y0)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = fn(ctypes.c_void_p(xv.buf.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None,
+        rc = fn(ctypes.c_void_p(xv.buf.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None, 0,
                 ctypes.c_void_p(y1.data_ptr()), N, H, W, Cin, Cout, None, xv.scale, st)
         assert rc == 0
         assert torch.equal(y0, y1), (N, H, W, Cin, Cout)
@@ -236,9 +236,30 @@ def test_wino_zero_padding_forms_agree(ops):
         pk32 = ops.pack_weight_f32_wino(w.to(dev))
         z0 = ops.conv3x3_bf16x3(xv32, pk32, bd, Cout)
         z1 = torch.empty_like(z0)
-        rc = fn32(ctypes.c_void_p(xv32.buf.data_ptr()), ctypes.c_void_p(pk32.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None,
+        rc = fn32(ctypes.c_void_p(xv32.buf.data_ptr()), ctypes.c_void_p(pk32.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None, 0,
                   ctypes.c_void_p(z1.data_ptr()), N, H, W, Cin, Cout, None, st)
         assert rc == 0 and torch.equal(z0, z1), (N, H, W, Cin, Cout)
+
+
+def test_wino_resampled_residual_in_epilogue(ops):
+    """The identity skip of an ADM up / down block (unet_openai.py:238-243: x_upd = nearest 2x upsampling / 2x2 average pooling of x)
+    read through the resampling in the conv's epilogue (res_resample = +1 / -1) must be bit-identical to dua_resample2x followed by
+    the plain residual add, in both Winograd kernels, including a map smaller than one tile and a non-power-of-two height."""
+    for (N, H, W, Cin, Cout) in [(4, 32, 32, 64, 128), (3, 8, 4, 32, 64), (2, 24, 16, 32, 96), (5, 16, 16, 64, 256)]:
+        x, w, b = rnd(60, N, Cin, H, W), rnd(61, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(62, Cout) * 0.1
+        xd, bd = nhwc(x).to(dev), b.to(dev)
+        for fmt, pack in (("f16x3w", ops.pack_weight_f16x3_wino), ("f32w", ops.pack_weight_f32_wino)):
+            xv = ops.groupnorm_apply(xd, identity_stats(N), torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split=fmt)
+            packed = pack(w.to(dev))
+            for mode, rshape in ((1, (N, H // 2, W // 2, Cout)), (-1, (N, 2 * H, 2 * W, Cout))):
+                r = torch.randn(rshape, generator=torch.Generator().manual_seed(63 + mode)).to(dev)
+                rr = ops.resample2x(r, mode)
+                assert tuple(rr.shape) == (N, H, W, Cout)
+                y0 = ops.conv3x3_bf16x3(xv, packed, bd, Cout, residual=rr)
+                y1 = ops.conv3x3_bf16x3(xv, packed, bd, Cout, residual=r, res_resample=mode)
+                assert torch.equal(y0, y1), (fmt, mode, N, H, W, Cin, Cout)
+                ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + nchw(rr.cpu()).double()
+                assert (nchw(y1.cpu()).double() - ref).abs().max().item() < 2e-5
 
 
 def test_headline_job_variants_diverge_alike():
