@@ -420,7 +420,10 @@ struct GnWinoP {
 // so a wave reads 16 whole 128-byte lines per row and writes, per frequency, the 1-KB piece [16 positions][32 channels] of the hi
 // image and of the lo image of the conv's stage block (tile, channel block) - exactly the pieces its LDS-DMA fetches.  Maps narrower
 // than 16 put 16 / W consecutive row pairs in a wave (then no row is shared between iterations and all four rows are re-read).
-template <bool F32>
+// STREAM (maps at least 16 wide, no pooling, no dropout mask - every conv of the sampling jobs but the down blocks' first): the two new
+// rows of the NEXT row pair are requested before this pair's eight stores go out, so a wave always has 64 bytes per lane of loads in
+// flight behind its stores instead of waiting for one row at a time.  Same arithmetic, same bits.
+template <bool F32, bool STREAM>
 __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
     const int C = p.C1 + p.C2, ncb = C / 32, cpg = C / p.G;
     const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
@@ -437,20 +440,34 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
     const bool second = c >= p.C1;
     const float* src = second ? p.x2 : p.x1;
     const int cs = second ? p.C2 : p.C1, cq = second ? c - p.C1 : c;
+    // per-channel scale and offset of the thread's 8 channels; every operand is requested before the first use (one latency, not eight)
     float ca[8], cb[8];
+    {
+        const float4 g0 = *(const float4*)(p.gamma + c), g1 = *(const float4*)(p.gamma + c + 4);
+        const float4 b0 = *(const float4*)(p.beta + c), b1 = *(const float4*)(p.beta + c + 4);
+        float2 st[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int ch = c + j;
-        const float2 st = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + ch / cpg));
-        float a = st.y * p.gamma[ch];
-        float b = p.beta[ch] - st.x * a;
+        for (int j = 0; j < 8; ++j) st[j] = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + (c + j) / cpg));
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, h0 = s0, h1 = s0;
         if (p.film) {
-            const float sc = 1.0f + p.film[(size_t)n * p.film_ld + ch];
-            a *= sc;
-            b = b * sc + p.film[(size_t)n * p.film_ld + C + ch];
+            const float* fr = p.film + (size_t)n * p.film_ld + c;
+            s0 = *(const float4*)fr; s1 = *(const float4*)(fr + 4);
+            h0 = *(const float4*)(fr + C); h1 = *(const float4*)(fr + C + 4);
         }
-        ca[j] = a;
-        cb[j] = b;
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float fs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, fh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = st[j].y * g[j];
+            float b = bt[j] - st[j].x * a;
+            if (p.film) {
+                const float sc = 1.0f + fs[j];
+                a *= sc;
+                b = b * sc + fh[j];
+            }
+            ca[j] = a;
+            cb[j] = b;
+        }
     }
     const size_t img_in = (size_t)n * p.H * p.W;
     auto xf = [&](size_t pix, float (&r)[8]) {
@@ -508,6 +525,54 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
     };
     const int j0 = jc * p.JC + jo, j1 = min(P, (jc + 1) * p.JC);
     float dA[8], dB[8], dC[8], dD[8];
+    if constexpr (STREAM) {
+        if (j0 >= j1) return;
+        struct Raw { float4 a, b; };
+        auto ld = [&](int yo) -> Raw {                                   // (rows outside the image: any valid address, zeroed in `fin`)
+            const int yc = min(max(yo, 0), Ho - 1);
+            const size_t pix = img_in + (p.resample > 0 ? (size_t)(yc >> 1) * p.W + (xo >> 1) : (size_t)yc * p.W + xo);
+            return Raw{*(const float4*)(src + pix * cs + cq), *(const float4*)(src + pix * cs + cq + 4)};
+        };
+        auto fin = [&](const Raw& w, int yo, float (&r)[8]) {
+            const float v[8] = {w.a.x, w.a.y, w.a.z, w.a.w, w.b.x, w.b.y, w.b.z, w.b.w};
+            const bool in = yo >= 0 && yo < Ho;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float t = v[q] * ca[q] + cb[q];
+                if (p.act == 1) t = silu_f(t);
+                r[q] = in ? t : 0.f;
+            }
+        };
+        Raw rA = ld(2 * j0 - 1), rB = ld(2 * j0), rC = ld(2 * j0 + 1), rD = ld(2 * j0 + 2);
+        fin(rA, 2 * j0 - 1, dA);
+        fin(rB, 2 * j0, dB);
+        auto pair = [&](int j) {
+            fin(rC, 2 * j + 1, dC);
+            fin(rD, 2 * j + 2, dD);
+            if (j + 1 < j1) { rC = ld(2 * j + 3); rD = ld(2 * j + 4); }
+            const size_t m = ((size_t)n * P + j) * Wo + xo;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = dA[q] - dC[q];
+            put(0, m, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = dB[q] + dC[q];
+            put(1, m, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = dC[q] - dB[q];
+            put(2, m, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = dB[q] - dD[q];
+            put(3, m, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dA[q] = dC[q]; dB[q] = dD[q]; }
+        };
+        // the first pair stands outside the loop so that both ways into the loop body carry the same queue (four loads, then eight
+        // stores): the wait in front of `fin` then leaves the stores in flight
+        pair(j0);
+        for (int j = j0 + 1; j < j1; ++j) pair(j);
+        return;
+    }
     if (j0 < j1) { val(2 * j0 - 1, dA); val(2 * j0, dB); }
     for (int j = j0; j < j1; j += JS) {
         val(2 * j + 1, dC);
@@ -559,6 +624,8 @@ static int gn_apply_wino_impl(const float* x1, int C1, const float* x2, int C2, 
                 "dua_groupnorm_apply_wino_f16x3: C1 %% 32 == 0, the conv input width a power of two <= 128 and H*W %% 32 == 0 are required");
     GnWinoP p{x1, x2, stats, gamma, beta, film, dropmask, (_Float16*)vplanes, C1, C2, N, H, W, G, act, resample, 0, film_ld ? film_ld : 2L * C, v_scale, 0};
     DUA_REQUIRE(p.film_ld >= 2L * C, "dua_groupnorm_apply_wino_f16x3: film_ld too small");
+    DUA_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)film) & 15) == 0 && (!film || p.film_ld % 4 == 0),
+                "dua_groupnorm_apply_wino_f16x3: gamma, beta and the FiLM rows must be 16-byte aligned");
     const int P = Ho / 2;
     p.ntm = (int)(((long)N * P * Wo + 127) / 128);
     const int nxb = ((Wo >= 16 ? Wo / 16 : 1) * (C / 32) + 3) / 4;
@@ -568,8 +635,12 @@ static int gn_apply_wino_impl(const float* x1, int C1, const float* x2, int C2, 
     while ((long)N * nxb * ((P + JC - 1) / JC) < 1024 && JC > 4) JC = (JC + 1) / 2;
     if (Wo < 16 && JC % (16 / Wo)) JC = (JC / (16 / Wo) + 1) * (16 / Wo);       // chunks hold whole 16-position groups
     p.JC = JC;
-    if (f32) hipLaunchKernelGGL(k_gn_apply_wino<true>, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(k_gn_apply_wino<false>, dim3(nxb * ((P + JC - 1) / JC), N), BLK, 0, as_stream(stream), p);
+    const dim3 grid(nxb * ((P + JC - 1) / JC), N);
+    const bool strm = resample >= 0 && !dropmask && Wo >= 16;
+    if (f32 && strm) hipLaunchKernelGGL((k_gn_apply_wino<true, true>), grid, BLK, 0, as_stream(stream), p);
+    else if (f32) hipLaunchKernelGGL((k_gn_apply_wino<true, false>), grid, BLK, 0, as_stream(stream), p);
+    else if (strm) hipLaunchKernelGGL((k_gn_apply_wino<false, true>), grid, BLK, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_gn_apply_wino<false, false>), grid, BLK, 0, as_stream(stream), p);
     return dua_check_launch("dua_groupnorm_apply_wino");
 }
 extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
