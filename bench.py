@@ -54,7 +54,7 @@ MODES = {
               "8x8 level and the in / out convs on the direct kernels k_xconv_dma<NT, 3> / k_hconv<NT, RS>", 3.0,
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
-              "with head dims <= 128 in this format, wider heads / embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
+              "(head dims <= 256) in this format, embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
     "fp32": ("k_wconv32 (csrc/conv_wino_f32.hip): exact-fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
              "v_mfma_f32_16x16x4_f32 (6 instead of 9 taps per pixel, products and sums in fp32); in / out convs on the direct fp32 MFMA "
              "kernel k_tile<MODE_CONV>", 1.0, "f32"),

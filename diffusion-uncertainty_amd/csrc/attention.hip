@@ -221,24 +221,35 @@ __device__ __forceinline__ V8 tr_pair(const E* a, const E* b) {
     return r;
 }
 
+// Heads wider than 128 channels (CT16 > 8: ADM-128's 16^2 / 8^2 levels, 192 / 256 channels per head): the query halves (up to 128
+// registers) and the output tile (up to 128) leave no room for two waves per SIMD, so the kernel is built for ONE workgroup of four
+// waves per CU with the 512-register budget (the K / V tiles then live in dynamic LDS: 55 - 71 KB), and the logit chain runs on two
+// accumulators so that a wave alone on its SIMD does not wait for its own previous MFMA.
 template <int CT16 /* 16-channel steps: ceil(ch/16) */, int QW, bool F16 = false>
-__global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
+__global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(AttnP p) {
     typedef typename AT<F16>::e el;
     typedef typename AT<F16>::v8 abf16x8;
     typedef typename AT<F16>::v4 abf16x4;
+    constexpr bool WIDE = CT16 > 8;
     constexpr int CHP = CT16 * 16, CT32 = (CHP + 31) / 32;
     constexpr int KP = CHP + 8;          // K tile row pitch (bf16): 16-byte reads of 16 consecutive rows hit distinct banks
     // V tile row-major [key][channel] like K, read TRANSPOSED by ds_read_b64_tr_b16 (a 16-lane group fetches a 4-key x 16-channel block
     // and every lane receives its channel's 4 keys): the staging writes are 8-byte row writes instead of 2-byte column writes, which
     // were 16-way bank-conflicted (80 % of the LDS cycles of this kernel were conflict cycles).  Row pitch = 32 or 96 (mod 128)
     // elements: the 4 key rows of a block then start 16 dwords apart (mod 64) and a 32-lane half covers all 64 banks once.
-    constexpr int VPR = CT32 * 32 <= 32 ? 32 : (CT32 * 32 <= 96 ? 96 : 160);
-    __shared__ __attribute__((aligned(16))) el Kh[32 * KP], Kl[32 * KP], Vh[32 * VPR], Vl[32 * VPR];
-    // Wide heads (>= 112 channels): the lo halves of the wave's queries live in LDS (lane-private 16-byte slots, re-read once per
+    constexpr int VPR = CT32 * 32 <= 32 ? 32 : (CT32 * 32 <= 96 ? 96 : (CT32 * 32 <= 160 ? 160 : (CT32 * 32 <= 224 ? 224 : 288)));
+    __shared__ __attribute__((aligned(16))) el Kh_s[WIDE ? 8 : 32 * KP], Kl_s[WIDE ? 8 : 32 * KP], Vh_s[WIDE ? 8 : 32 * VPR], Vl_s[WIDE ? 8 : 32 * VPR];
+    // Heads of 112 - 128 channels: the lo halves of the wave's queries live in LDS (lane-private 16-byte slots, re-read once per
     // key tile and step) instead of 32 registers - with them the kernel spilled (40 - 300 bytes of scratch per lane)
-    constexpr bool QL_LDS = CT16 >= 7;
+    // (256-channel heads too: with them in registers the 512-register kernel spilled 232 bytes per lane)
+    constexpr bool QL_LDS = (CT16 >= 7 && !WIDE) || CT16 > 12;
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds_raw_[];
-    el* const qlds = reinterpret_cast<el*>(qlds_raw_);
+    el* const dyn = reinterpret_cast<el*>(qlds_raw_);
+    el* const Kh = WIDE ? dyn : Kh_s;
+    el* const Kl = WIDE ? dyn + 32 * KP : Kl_s;
+    el* const Vh = WIDE ? dyn + 64 * KP : Vh_s;
+    el* const Vl = WIDE ? dyn + 64 * KP + 32 * VPR : Vl_s;
+    el* const qlds = WIDE ? dyn + 64 * KP + 64 * VPR : dyn;
     const int ch = p.ch, C = p.heads * ch, T = p.T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, kh = lane >> 5;
@@ -336,16 +347,26 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
         DUA_ATTNX_FETCH(kt + 1)
 
         // ---- S^T tile: keys on rows, this wave's 32 queries on columns (scale folded into Q)
-        f32x16 s;
+        f32x16 s, s_b;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; s_b[r] = 0.f; }
 #pragma unroll
         for (int c = 0; c < CT16; ++c) {
             const abf16x8 ah = *(const abf16x8*)(Kh + lr * KP + 16 * c + 8 * kh), al = *(const abf16x8*)(Kl + lr * KP + 16 * c + 8 * kh);
             const abf16x8 qlc = QL_LDS ? *(const abf16x8*)(qlds + ((wave * CT16 + c) * 64 + lane) * 8) : ql[QL_LDS ? 0 : c];
-            s = amfma(al, qh[c], s);
-            s = amfma(ah, qlc, s);
-            s = amfma(ah, qh[c], s);
+            if (WIDE && (c & 1)) {
+                s_b = amfma(al, qh[c], s_b);
+                s_b = amfma(ah, qlc, s_b);
+                s_b = amfma(ah, qh[c], s_b);
+            } else {
+                s = amfma(al, qh[c], s);
+                s = amfma(ah, qlc, s);
+                s = amfma(ah, qh[c], s);
+            }
+        }
+        if (WIDE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += s_b[r];
         }
         // ---- online softmax (query = lane; this lane holds keys (r&3) + 8(r>>2) + 4kh of the tile)
         float mloc = -INFINITY;
@@ -419,7 +440,10 @@ __global__ __launch_bounds__(64 * QW, 2) void k_flash_attn_x(AttnP p) {
 template <int CT16, int QW, bool F16 = false>
 static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
     dim3 grid((p.T + QW * 32 - 1) / (QW * 32), B * p.heads);
-    constexpr size_t qlds = CT16 >= 7 ? (size_t)QW * CT16 * 64 * 16 : 0;        // lo halves of the queries (wide heads)
+    constexpr int CHP_ = CT16 * 16, CT32_ = (CHP_ + 31) / 32, VPR_ = CT32_ * 32 <= 160 ? 160 : (CT32_ * 32 <= 224 ? 224 : 288);
+    // heads of 112 - 128 channels: the lo halves of the queries; wider heads: the K / V tiles (hi and lo)
+    constexpr size_t qlds = CT16 > 8 ? (size_t)(64 * (CHP_ + 8) + 64 * VPR_) * 2 + (CT16 > 12 ? (size_t)QW * CT16 * 64 * 16 : 0)
+                                     : (CT16 >= 7 ? (size_t)QW * CT16 * 64 * 16 : 0);
     if (qlds) {
         static bool raised = false;            // (per instantiation; static + dynamic LDS exceeds the 64 KB default)
         if (!raised) {
@@ -439,7 +463,7 @@ static int attention_x_launch(const AttnP& p, int B, void* stream, bool f16 = fa
 extern "C" int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float planes_scale, int B, int T, int heads, int ch,
                                    float scale, void* stream) {
     DUA_REQUIRE(qkv && (out || out_planes) && B > 0 && T > 0 && heads > 0, "dua_attention_f16x3: bad arguments");
-    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_attention_f16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
+    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 256, "dua_attention_f16x3: head dim must be a multiple of 4 in [8, 256] (got %d)", ch);
     DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_f16x3: B*heads must be <= 65535");
     DUA_REQUIRE(!out_planes || planes_scale > 0.f, "dua_attention_f16x3: planes_scale must be positive");
     AttnP p{qkv, out, T, heads, ch, scale, out_planes, (long)B * T * heads * ch, planes_scale};
@@ -450,7 +474,7 @@ extern "C" int dua_attention_f16x3(const float* qkv, float* out, void* out_plane
 extern "C" int dua_cross_attention_f16x3(const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, void* out_planes,
                                          float planes_scale, int B, int Tq, int Tk, int heads, int ch, float scale, void* stream) {
     DUA_REQUIRE(q && k && v && (out || out_planes) && B > 0 && Tq > 0 && Tk > 0 && heads > 0, "dua_cross_attention_f16x3: bad arguments");
-    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_cross_attention_f16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
+    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 256, "dua_cross_attention_f16x3: head dim must be a multiple of 4 in [8, 256] (got %d)", ch);
     DUA_REQUIRE(ldq >= (long)heads * ch && ldkv >= (long)heads * ch && ldq % 4 == 0 && ldkv % 4 == 0 && ldkv * 32 < (1L << 31),
                 "dua_cross_attention_f16x3: row strides must cover heads*ch and be multiples of 4");
     DUA_REQUIRE(((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0), "dua_cross_attention_f16x3: operands must be 16-byte aligned");
@@ -487,6 +511,8 @@ static int attention_x_launch(const AttnP& p, int B, void* stream, bool f16) {
 #define ATTNX_CASE(CTV) \
     case CTV: return f16 ? (three ? launch_attn_x<CTV, 3, true>(p, B, s) : small ? launch_attn_x<CTV, 2, true>(p, B, s) : launch_attn_x<CTV, 4, true>(p, B, s)) \
                          : (three ? launch_attn_x<CTV, 3>(p, B, s) : small ? launch_attn_x<CTV, 2>(p, B, s) : launch_attn_x<CTV, 4>(p, B, s));
+    if (f16 && ch > 128 && ch <= 256)            // wide heads (f16x3 only): 128 queries per workgroup, one workgroup per CU
+        return ch <= 192 ? launch_attn_x<12, 4, true>(p, B, s) : launch_attn_x<16, 4, true>(p, B, s);
     switch ((ch + 15) / 16) {
         ATTNX_CASE(1) ATTNX_CASE(2) ATTNX_CASE(3) ATTNX_CASE(4) ATTNX_CASE(5) ATTNX_CASE(6) ATTNX_CASE(7) ATTNX_CASE(8)
     }

@@ -266,7 +266,7 @@ int check_attnblock(const dua_attnblock_args* a) {
     DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3, "dua_adm_attnblock_fwd: precision must be DUA_PREC_FP32 or DUA_PREC_F16X3");
     DUA_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->C % 32 == 0 && a->heads > 0 && a->C % a->heads == 0, "dua_adm_attnblock_fwd: bad shape");
     const int ch = a->C / a->heads;
-    DUA_REQUIRE(a->precision == DUA_PREC_F16X3 ? (ch % 4 == 0 && ch >= 8 && ch <= 128) : (ch % 8 == 0 && ch <= 128),
+    DUA_REQUIRE(a->precision == DUA_PREC_F16X3 ? (ch % 4 == 0 && ch >= 8 && ch <= 256) : (ch % 8 == 0 && ch <= 128),
                 "dua_adm_attnblock_fwd: head dim %d is outside the fused attention kernels of this precision", ch);
     DUA_REQUIRE(a->precision != DUA_PREC_F16X3 || (a->act_scale > 0.f && a->raw_scale > 0.f), "dua_adm_attnblock_fwd: f16x3 needs positive scales");
     return DUA_OK;

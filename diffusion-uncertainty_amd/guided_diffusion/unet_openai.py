@@ -172,7 +172,8 @@ class AttentionBlock(nn.Module):
         N, H, W, C = x.shape
         T = H * W
         ch = C // self.num_heads
-        if ctx.block_abi and C % 32 == 0 and ch <= 128 and ch % 8 == 0 and ctx.model.presplit_qkv and ops.ATTENTION_MODE == "auto":
+        chmax = 256 if ctx.model.precision == "f16x3" else 128          # (fp32 flash kernel: the GEMM pair is faster above 128)
+        if ctx.block_abi and C % 32 == 0 and ch <= chmax and ch % 8 == 0 and ctx.model.presplit_qkv and ops.ATTENTION_MODE == "auto":
             f16 = ctx.model.precision == "f16x3"
             qk, bq = ctx.packed(self, "qkvh" if f16 else "qkv")
             return ops.adm_attnblock(x, self.num_heads, (self.norm.weight, self.norm.bias), qk, bq,
@@ -214,7 +215,7 @@ class _Ctx:
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
         # (False | True = bf16x3 planes | "f16f8" planes | "f16f6" planes: 3x3 convs whose width divides 256 only)
         # "f16x3" (fp32-equivalent): 3x3 convs and qkv on fp16 hi / lo planes written by the GroupNorm kernels, 1x1 skip / proj_out
-        # with the raw fp32 operand split on the fly (same 22-bit split), attention (head dims <= 128) on the split flash kernel in the same format
+        # with the raw fp32 operand split on the fly (same 22-bit split), attention (head dims <= 256) on the split flash kernel in the same format
         assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6", "f16x3"), model.precision
         self.split_mode = model.precision not in ("fp32", "f16x3")          # on-the-fly bf16 split of raw fp32 operands
         self.presplit = model.precision != "fp32"

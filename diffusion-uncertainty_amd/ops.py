@@ -394,7 +394,7 @@ def pick_even(x):
 def attention(q, k, v, heads, precision="fp32", planes_out=False):
     """Multi-head attention with separate operands (cross-attention): q [B, Tq, C], k / v [B, Tk, C], heads of C/heads
     channels, softmax(q k^T / sqrt(ch)) v -> [B, Tq, C].  fp32: MFMA products with the logits in HBM (the SD-1.5 shapes
-    are small: Tk = 77 for the text context).  precision="f16x3" (head dims <= 128): the split flash kernel in ONE launch,
+    are small: Tk = 77 for the text context).  precision="f16x3" (head dims <= 256): the split flash kernel in ONE launch,
     optionally with the result as f16x3 planes [B*Tq, C] (operand of the presplit to_out GEMM)."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):
         _req(t, name=nm)
@@ -402,7 +402,7 @@ def attention(q, k, v, heads, precision="fp32", planes_out=False):
     Tk = k.shape[1]
     ch = C // heads
     assert k.shape == (B, Tk, C) and v.shape == (B, Tk, C) and C % heads == 0 and ch % 4 == 0 and B * heads <= 65535
-    if precision == "f16x3" and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
+    if precision == "f16x3" and 8 <= ch <= 256 and ATTENTION_MODE in ("auto", "fused_x"):
         if planes_out and C % 32 == 0:
             buf = torch.empty((2, B * Tq, C), device=q.device, dtype=torch.int16)
             check(_lib.lib().dua_cross_attention_f16x3(_p(q), C, _p(k), _p(v), C, None, _p(buf), F16X3_RAW_SCALE, B, Tq, Tk, heads, ch,
@@ -962,7 +962,7 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32", planes_out=False):
     assert qkv.shape == (B * T, 3 * C)
     assert B * heads <= 65535
     if precision == "f16x3":
-        if ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):      # the split flash kernel on fp16 hi / lo halves
+        if ch % 4 == 0 and 8 <= ch <= 256 and ATTENTION_MODE in ("auto", "fused_x"):      # the split flash kernel on fp16 hi / lo halves
             if planes_out and C % 32 == 0:
                 buf = torch.empty((2, B * T, C), device=qkv.device, dtype=torch.int16)
                 check(_lib.lib().dua_attention_f16x3(_p(qkv), None, _p(buf), F16X3_RAW_SCALE, B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()),
@@ -972,7 +972,7 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32", planes_out=False):
             check(_lib.lib().dua_attention_f16x3(_p(qkv), _p(out), None, 0.0, B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()),
                   "dua_attention_f16x3")
             return out
-        precision = "fp32"                       # wide heads (ADM-128's 16^2 / 8^2 levels): the exact fp32 paths
+        precision = "fp32"                       # heads wider than 256 / forced GEMM mode: the exact fp32 paths
     if precision == "bf16x3" and ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
         if planes_out and C % 32 == 0:       # result straight in the operand format of the presplit proj GEMM
             buf = torch.empty((2, B * T, C), device=qkv.device, dtype=torch.int16)
@@ -1115,7 +1115,7 @@ def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, c
 
 
 def adm_attnblock(x, heads, gn, qkv_packed, qkv_b, proj_packed, proj_b, precision="fp32", want_colsum=True):
-    """One ADM AttentionBlock forward through dua_adm_attnblock_fwd (unet_openai.py:300-306), head dims <= 128."""
+    """One ADM AttentionBlock forward through dua_adm_attnblock_fwd (unet_openai.py:300-306), head dims <= 128 (f16x3: <= 256)."""
     _req(x, name="x")
     N, H, W, C = x.shape
     y = torch.empty_like(x)

@@ -360,7 +360,8 @@ int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, 
                    const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                    int act_out, float alpha, float* colsum, float act_scale, void* stream);
 /* Fused attention (dua_attention) with both products on the f16x3 split: q, k, P and v scaled by powers of two and split
- * into fp16 hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2^-22 per product), softmax in fp32.  Head dims <= 128.
+ * into fp16 hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2^-22 per product), softmax in fp32.  Head dims <= 256 (above 128: a
+ * 512-register build of the same kernel, one workgroup of 128 queries per CU - ADM-128's 192- and 256-channel heads).
  * out_planes != NULL: the result is written as f16x3 planes of out * planes_scale ([B*T][heads*ch] hi | lo), the operand of
  * dua_gemm_f16x3_presplit (proj_out, unet_openai.py:295); otherwise fp32 `out`. */
 int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float planes_scale, int B, int T, int heads, int ch,
@@ -445,8 +446,8 @@ typedef struct {
     void* workspace; size_t workspace_bytes;
     float* y; float* y_colsums;          /* x + proj_out(attention(qkv(norm(x))))   :300-306 */
 } dua_attnblock_args;
-/* AttentionBlock.forward, unet_openai.py:300-306, on the fused attention kernels: head dims <= 128 (multiple of 8 in fp32, of 4 in
- * f16x3); wider heads are composed from dua_gemm / dua_softmax_rows by the caller. */
+/* AttentionBlock.forward, unet_openai.py:300-306, on the fused attention kernels: head dims <= 128 (multiple of 8) in fp32, <= 256
+ * (multiple of 4) in f16x3; wider heads are composed from dua_gemm / dua_softmax_rows by the caller. */
 size_t dua_adm_attnblock_workspace_bytes(const dua_attnblock_args* args_host);
 typedef struct {
     const float* x; const float* skip;   /* tokens [B*L][D]; skip = the long-skip tokens of an out-block or NULL   uvit.py:116-117 */
