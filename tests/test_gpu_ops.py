@@ -653,9 +653,11 @@ def test_conv3x3_f16x3_split_k(ops, N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 128, 32, 0), (200, 72, 64, 0), (5, 2048, 256, 0), (300, 96, 64, 32), (64, 16, 1152, 0),
-                                        (4096, 256, 512, 256)])
+                                        (4096, 256, 512, 256), (33000, 256, 256, 256), (36000, 136, 64, 0), (70000, 128, 96, 32),
+                                        (16384, 1024, 1024, 768)])
 def test_gemm_f16x3(ops, M, N, K1, K2):
-    """1x1 skip / proj_out GEMM with the raw fp32 operand split into fp16 hi + lo on the fly: held to the exact fp32 engine's error."""
+    """1x1 skip / proj_out GEMM with the raw fp32 operand split into fp16 hi + lo on the fly: held to the exact fp32 engine's error.
+    The column sums left for the next GroupNorm are checked against the output itself (ragged last 64-row block included)."""
     a1 = rnd(40, M, K1) * torch.logspace(-3, 2, K1)             # residual-stream-like dynamic range
     a2 = rnd(41, M, K2) * 3 if K2 else None
     w, b, res = rnd(42, N, K1 + K2) / math.sqrt(K1 + K2) * torch.logspace(-2, 1, N).reshape(-1, 1), rnd(43, N) * 0.1, rnd(44, M, N)
@@ -668,6 +670,15 @@ def test_gemm_f16x3(ops, M, N, K1, K2):
     e, e32 = ((c.cpu().double() - ref).abs() / sc).max().item(), ((c32.cpu().double() - ref).abs() / sc).max().item()
     print(f"gemm f16x3 rel err {e:.2e}  fp32-MFMA rel err {e32:.2e}")
     assert e < max(2 * e32, 2e-6), (e, e32)
+    ws = getattr(c, "_dua_colsums_rows", None)
+    if ws is not None:
+        nb = (M + 63) // 64
+        pad = torch.zeros(nb * 64, N, dtype=torch.float64)
+        pad[:M] = c.cpu().double()
+        blk = pad.reshape(nb, 64, N)
+        w2 = ws.cpu().double().reshape(nb, 2, N)
+        assert ((w2[:, 0] - blk.sum(1)).abs().max() / blk.abs().sum(1).max()).item() < 1e-5
+        assert ((w2[:, 1] - (blk * blk).sum(1)).abs().max() / (blk * blk).sum(1).max()).item() < 1e-5
     # out-of-range operands: hi saturates at 65504 / scale and lo carries the remainder - finite and close, never inf
     big = a1.clone()
     big[0, 0] = 6000.0                                           # * 16 = 96000 > 65504
