@@ -220,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             constexpr bool more = (!LAST || DXI < 2) && !(WCONV_DIAG & 8);
             constexpr int sa_n = FI ^ 1, sb_n = (DXI + 2) % 3;
             constexpr int sa_r = DXI == 2 ? (FI ^ 1) : FI, sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;   // the NEXT step's fragments
+            const bool idle_ = (WCONV_DIAG & 32) && FI == 1 && wave < 4;       // (diagnostic: the f = 2 products skipped, as if V2 == 0)
             if (preA) { a_setup(); fiA = FI == 0; }
             auto early_piece = [&](int q) {
                 if (q < NBP) { if (preB && !(WCONV_DIAG & 2)) dma_b(sb_n, q); }
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xl[i], A[jj][i], 0, 0, 0);
+                    if (!idle_) A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xl[i], A[jj][i], 0, 0, 0);
                     WSB();
                     const int m_ = jj * 4 + i;
                     if ((m_ & 1) == 0) early_piece(m_ >> 1);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xh[i], A[jj][i], 0, 0, 0);
+                    if (!idle_) A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xh[i], A[jj][i], 0, 0, 0);
                     WSB();
                     if (jj == 0 && more) { xl[i] = rd_x(sa_r, 1, i, dxn); WSB(); }
                 }
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[jj], xh[i], A[jj][i], 0, 0, 0);
+                    if (!idle_) A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[jj], xh[i], A[jj][i], 0, 0, 0);
                     WSB();
                     if (jj == 3 && more) { xh[i] = rd_x(sa_r, 0, i, dxn); WSB(); }
                 }
