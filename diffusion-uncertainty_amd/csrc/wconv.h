@@ -37,6 +37,50 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
     char* mine = slot_of(wave);
     char* theirs = slot_of(wave ^ 4);
     const bool odd = grp_w == 0;
+    // the epilogue's first global operands (column scales, bias, the first residual rows of both channel-block pairs) are requested
+    // BEFORE the exchange: its two barriers would otherwise stand between the tile's last MFMA and the first of three dependent
+    // load latencies per pair
+    const int pr_e = lane_e >> 3, pc_e = lane_e & 7;
+    const int pos0 = m0 + ph * 64;
+    const long oddoff = odd ? p.W : 0;
+    auto opix = [&](int i, int h) -> long {
+        const int pos = pos0 + 16 * i + 8 * h + pr_e;
+        return pos < p.Mv ? (long)pos + (pos & ~(p.W - 1)) + oddoff : -1L;
+    };
+    float4 sq_[2], bq_[2], rn_[2][2];
+    auto res_ld = [&](int jp, int i, float4 (&dst)[2]) {
+        const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
+        const bool cok = c < p.N;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long row = opix(i, h);
+            dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(p.res && cok && row >= 0)) continue;
+            if (p.res_mode == 0) {
+                dst[h] = *(const float4*)(p.res + row * p.N + c);
+                continue;
+            }
+            const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
+            if (p.res_mode > 0) {
+                const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
+                dst[h] = *(const float4*)(p.res + src * p.N + c);
+            } else {                                                  // same order of additions as k_resample2x (denoiser.hip)
+                const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
+                const float4 a = *(const float4*)(p.res + src * p.N + c), b = *(const float4*)(p.res + (src + 1) * p.N + c);
+                const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
+                dst[h] = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
+                                     (a.w + b.w + d.w + e.w) * 0.25f);
+            }
+        }
+    };
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+        const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
+        sq_[jp] = *(const float4*)(p.Cscale + c);                        // (padded to the tile grid)
+        bq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && c < p.N) bq_[jp] = *(const float4*)(p.bias + c);
+        res_ld(jp, 0, rn_[jp]);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -57,52 +101,20 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
     // ---- stores: channel-block pairs (32 channels) of one 16-position block through a 16 x 144-byte patch (in the partner's
     // slot, which only this wave still reads), so that residual reads and output stores move whole 128-byte rows
     const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
-    const int pos0 = m0 + ph * 64;
     char* pw = theirs;
-    const int pr_e = lane_e >> 3, pc_e = lane_e & 7;
-    const long oddoff = odd ? p.W : 0;
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
         const bool cok = c < p.N;
-        float4 sq = *(const float4*)(p.Cscale + c);                      // (padded to the tile grid)
+        float4 sq = sq_[jp];
         sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && cok) bq = *(const float4*)(p.bias + c);
-        float4 rq[2], rn[2];
-        auto opix = [&](int i, int h) -> long {
-            const int pos = pos0 + 16 * i + 8 * h + pr_e;
-            return pos < p.Mv ? (long)pos + (pos & ~(p.W - 1)) + oddoff : -1L;
-        };
-        auto res_ld = [&](int i, float4 (&dst)[2]) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long row = opix(i, h);
-                dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(p.res && cok && row >= 0)) continue;
-                if (p.res_mode == 0) {
-                    dst[h] = *(const float4*)(p.res + row * p.N + c);
-                    continue;
-                }
-                const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
-                if (p.res_mode > 0) {
-                    const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
-                    dst[h] = *(const float4*)(p.res + src * p.N + c);
-                } else {                                                  // same order of additions as k_resample2x (denoiser.hip)
-                    const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
-                    const float4 a = *(const float4*)(p.res + src * p.N + c), b = *(const float4*)(p.res + (src + 1) * p.N + c);
-                    const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
-                    dst[h] = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
-                                         (a.w + b.w + d.w + e.w) * 0.25f);
-                }
-            }
-        };
-        res_ld(0, rn);
+        const float4 bq = bq_[jp];
+        float4 rq[2], rn[2] = {rn_[jp][0], rn_[jp][1]};
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             rq[0] = rn[0]; rq[1] = rn[1];
-            if (i < 3) res_ld(i + 1, rn);
+            if (i < 3) res_ld(jp, i + 1, rn);
             *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc0[2 * jp][i];
             *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc0[2 * jp + 1][i];
 #pragma unroll
