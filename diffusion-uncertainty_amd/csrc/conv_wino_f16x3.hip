@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
             tile_geom(m0, tn);
             issue_prologue();
         }
+        const bool after_epilogue = prefetched;       // this tile's first stages were requested before the previous tile's epilogue
         prefetched = false;
 
         f32x4 acc0[4][4], acc1[4][4];                // [channel block][position block] of fi = 0 / 1
@@ -200,7 +201,11 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the first stages have landed; behind them in the (in-order) queue are only the previous epilogue's operations, of which the
+        // last WCONV_EPILOGUE_STORES - output stores - may stay in flight
+        static_assert(WCONV_EPILOGUE_STORES == 16, "the immediate below");
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xl[i] = rd_x(0, 1, i, -1); xh[i] = rd_x(0, 0, i, -1); }
@@ -298,6 +303,14 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
         }
 #undef WSB
 
+        if (WCONV_DIAG & 64) {                       // (diagnostic: no epilogue - the accumulators are kept alive by a store that never happens)
+            float t_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t_ += acc0[j][i][0] + acc0[j][i][1] + acc0[j][i][2] + acc0[j][i][3] + acc1[j][i][0] + acc1[j][i][1] + acc1[j][i][2] + acc1[j][i][3];
+            if (t_ == 1.2345e-30f) p.C[0] = t_;
+        } else
         wconv_epilogue(p, acc0, acc1, reinterpret_cast<char*>(lds), wave, lane, m0, n0);
         // the next tile's fragment reads wait for its opening barrier; the patches above must be done before another wave's
         // exchange writes of the next tile land in them: that barrier orders them too (the writes come after the K loop)

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv32(WConvP p) {
             tile_geom(m0, tn);
             issue_prologue();
         }
+        const bool after_epilogue = prefetched;       // this tile's first stages were requested before the previous tile's epilogue
         prefetched = false;
 
         f32x4 acc0[4][4], acc1[4][4];
@@ -161,7 +162,11 @@ __global__ __launch_bounds__(512, 2) void k_wconv32(WConvP p) {
         };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the first stages have landed; behind them in the (in-order) queue are only the previous epilogue's operations, of which the
+        // last WCONV_EPILOGUE_STORES - output stores - may stay in flight
+        static_assert(WCONV_EPILOGUE_STORES == 16, "the immediate below");
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = rd_x(0, i, -1);

@@ -6,6 +6,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#define WCONV_EPILOGUE_STORES 16     // output stores wconv_epilogue always issues (2 channel-block pairs x 4 position blocks x 2 half blocks)
+
 struct WConvP {
     const void* V;           // [4 f][ntm tiles of 128 positions][Cin / 32] stage blocks of 16 KB: [hi | lo][128][32] halves or [128][32] floats
     const void* B;           // packed weights [ntn][K / 32 steps] stage blocks of 32 KB ([hi | lo][256][32] halves or [256][32] floats), then the row scales
@@ -47,7 +49,7 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
         const int pos = pos0 + 16 * i + 8 * h + pr_e;
         return pos < p.Mv ? (long)pos + (pos & ~(p.W - 1)) + oddoff : -1L;
     };
-    float4 sq_[2], bq_[2], rn_[2][2];
+    float4 sq_[2], bq_[2], rn_[2][4][2];
     auto res_ld = [&](int jp, int i, float4 (&dst)[2]) {
         const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
         const bool cok = c < p.N;
@@ -79,8 +81,17 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
         sq_[jp] = *(const float4*)(p.Cscale + c);                        // (padded to the tile grid)
         bq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias && c < p.N) bq_[jp] = *(const float4*)(p.bias + c);
-        res_ld(jp, 0, rn_[jp]);
+        if (jp == 0) {                                                   // (the second pair's rows after the exchange, into the registers it frees)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res_ld(0, i, rn_[0][i]);
+        }
     }
+    // The output stores are buffer stores that ALWAYS issue (lanes outside the tensor get an out-of-range offset, which the buffer unit
+    // drops): the kernels count on WCONV_EPILOGUE_STORES vector-memory operations behind the next tile's prologue DMA, so that their
+    // tile-start wait can leave that many operations - these stores - in flight instead of draining the queue (vmcnt retires in order)
+    const long cpix0 = 2L * m0;                                          // the tile's 128 positions are output pixels 2 m0 .. 2 m0 + 255
+    const long crem = (2L * p.Mv - cpix0) * p.N * 4;
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -103,18 +114,18 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
     const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
     char* pw = theirs;
 #pragma unroll
+    for (int i = 0; i < 4; ++i) res_ld(1, i, rn_[1][i]);
+#pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
         const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
         const bool cok = c < p.N;
         float4 sq = sq_[jp];
         sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
         const float4 bq = bq_[jp];
-        float4 rq[2], rn[2] = {rn_[jp][0], rn_[jp][1]};
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rq[0] = rn[0]; rq[1] = rn[1];
-            if (i < 3) res_ld(jp, i + 1, rn);
+            const float4 (&rq)[2] = rn_[jp][i];
             *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc0[2 * jp][i];
             *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc0[2 * jp + 1][i];
 #pragma unroll
@@ -126,8 +137,11 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
                 v.y = a[1] * sq.y + bq.y + rq[h].y;
                 v.z = a[2] * sq.z + bq.z + rq[h].z;
                 v.w = a[3] * sq.w + bq.w + rq[h].w;
-                if (cok && row >= 0) {
-                    *(float4*)(p.C + row * p.N + c) = v;
+                const bool ok = cok && row >= 0;
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                if (ok) {
                     cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
                     cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
                 }

@@ -5,7 +5,7 @@
     python scripts/wconv_diag.py [--only 64x512x512,128x256x256]     # on the GPU box: one bench_conv_mix run per library
 
 The variants drop pieces of the loop (-DWCONV_DIAG bits: 1 barrier, 2 weight DMA, 4 activation DMA, 8 fragment reads; 16 = activations from a cache-resident
-set of tiles, 32 = the f = 2 products skipped by their waves, as for an all-zero V2) and produce
+set of tiles, 32 = the f = 2 products skipped by their waves, as for an all-zero V2; 64 = no epilogue) and produce
 WRONG results; they exist only outside the product package."""
 import argparse
 import os
@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "diffusion-uncertainty_amd")
 DIAG = os.path.join(ROOT, "scripts", "diag", "build")
-VARIANTS = (1, 2, 4, 6, 8, 15, 16, 32)
+VARIANTS = (1, 2, 4, 6, 8, 15, 16, 32, 64)
 
 
 def lib_of(v):
