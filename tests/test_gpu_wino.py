@@ -121,7 +121,10 @@ def test_wino_weight_pack(ops):
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (2, 8, 16, 96, 64), (1, 32, 32, 256, 256),
                                              (5, 16, 16, 128, 512), (3, 64, 64, 64, 256), (2, 128, 128, 32, 128), (4, 16, 8, 64, 36),
-                                             (130, 16, 16, 64, 64), (6, 8, 8, 96, 160), (3, 8, 4, 64, 64), (128, 8, 8, 128, 128)])
+                                             (130, 16, 16, 64, 64), (6, 8, 8, 96, 160), (3, 8, 4, 64, 64), (128, 8, 8, 128, 128),
+                                             # 514 tiles on 256 workgroups with a ragged last row tile and a half-empty column tile: every
+                                             # workgroup runs the tile-after-epilogue path (counted wait, always-issued stores) with masked lanes
+                                             (513, 16, 8, 32, 192)])
 def test_conv3x3_wino_vs_fp64(ops, N, H, W, Cin, Cout):
     """The whole Winograd path (writer -> packed weights -> kernel) against fp64, next to the direct f16x3 kernel and the exact fp32
     MFMA engine on the same problem: same bar as test_conv3x3_f16x3 (within 2x of the fp32 engine's error)."""
@@ -245,7 +248,7 @@ def test_wino_resampled_residual_in_epilogue(ops):
     """The identity skip of an ADM up / down block (unet_openai.py:238-243: x_upd = nearest 2x upsampling / 2x2 average pooling of x)
     read through the resampling in the conv's epilogue (res_resample = +1 / -1) must be bit-identical to dua_resample2x followed by
     the plain residual add, in both Winograd kernels, including a map smaller than one tile and a non-power-of-two height."""
-    for (N, H, W, Cin, Cout) in [(4, 32, 32, 64, 128), (3, 8, 4, 32, 64), (2, 24, 16, 32, 96), (5, 16, 16, 64, 256)]:
+    for (N, H, W, Cin, Cout) in [(4, 32, 32, 64, 128), (3, 8, 4, 32, 64), (2, 24, 16, 32, 96), (5, 16, 16, 64, 256), (300, 16, 16, 32, 160)]:
         x, w, b = rnd(60, N, Cin, H, W), rnd(61, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(62, Cout) * 0.1
         xd, bd = nhwc(x).to(dev), b.to(dev)
         for fmt, pack in (("f16x3w", ops.pack_weight_f16x3_wino), ("f32w", ops.pack_weight_f32_wino)):
@@ -308,7 +311,7 @@ def test_headline_job_variants_diverge_alike():
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (1, 32, 32, 256, 256), (3, 64, 64, 64, 256),
-                                             (2, 128, 128, 32, 128), (6, 8, 8, 96, 160), (130, 16, 16, 64, 64)])
+                                             (2, 128, 128, 32, 128), (6, 8, 8, 96, 160), (130, 16, 16, 64, 64), (513, 16, 8, 32, 192)])
 def test_conv3x3_wino_fp32_vs_fp64(ops, N, H, W, Cin, Cout):
     """The exact-fp32 Winograd path (fp32 V images -> fp32 packed weights -> k_wconv32 on v_mfma_f32_16x16x4_f32) against fp64, next to
     the direct fp32 MFMA conv on the same problem: within 2x of its error; V images equal the fp64 transform to fp32 rounding."""
