@@ -1,0 +1,27 @@
+// Parameter block of the f16x3 one-tap GEMM kernel (gemm_f16x3.hip: k_hgemm, k_hgemm_reduce).
+#pragma once
+#include "common.h"
+
+struct HGemmP {
+    const _Float16 *A1, *A2;     // activation planes [hi | lo][M][K1] / [M][K2] (the lo plane a*_plane elements behind the hi plane); A2 optional (K concat)
+    long a1_plane, a2_plane;
+    const _Float16* B;           // dua_pack_weight_f16x3: [N / 128 row tiles][K / 32 steps][hi | lo][128][32], then the per-row 2^-s
+    long b_bytes;                // bytes of the packed planes (hi and lo)
+    const float *Cscale, *bias, *res;
+    float* C;                    // EPI 0: fp32 [M][N] = act(acc * Cscale * out_scale + bias) + res
+    _Float16* Cplanes;           // EPI 1: f16x3 planes [hi | lo][M][N] of act(acc * Cscale * out_scale + bias) * split_scale
+    _Float16* Cextra;            // EPI 0, optional: additionally the f16x3 planes of the fp32 result * split_scale (operand of a later presplit GEMM)
+    float* colsum;               // optional [ceil(M / 64)][2][N] column sums / sums of squares per 64-row block
+    int M, N, K1, K2, ntm, ntn;
+    int act_out;                 // 2 = GELU
+    float out_scale, split_scale;
+    // Work list of the persistent grid: items [0, n_full) are whole tiles (tile id = tm * ntn + tn).  The remaining tail_tiles tiles are
+    // cut into K-step units, tail_u consecutive units per workgroup (stream-K): a workgroup's range touches at most two tiles, each
+    // partial result goes to kpart[2 * cu + j] in accumulator layout and k_hgemm_reduce folds the parts of a tile in workgroup order.
+    int n_full, tail_tiles, tail_u;
+    float* kpart;
+};
+
+int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what);
+void dua_hgemm_set_workspace(void* ws, size_t bytes);
+int dua_hgemm_enabled();

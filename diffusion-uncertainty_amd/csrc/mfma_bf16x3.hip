@@ -14,6 +14,7 @@
 // chunk column) then land on 16 distinct 16-byte slots and the 8-lane groups of ds_write_b128 (2 rows x 4 chunks) on 8.
 #include "common.h"
 #include "dconv.h"
+#include "hgemm.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -1507,6 +1508,7 @@ extern "C" int dua_set_splitk_workspace(void* ws, size_t bytes) {
     DUA_REQUIRE((ws == nullptr) == (bytes == 0) && ((uintptr_t)ws & 15) == 0, "dua_set_splitk_workspace: a 16-byte aligned buffer, or (NULL, 0) to switch split-K off");
     dua_splitk_ws = (float*)ws;
     dua_splitk_ws_bytes = bytes;
+    dua_hgemm_set_workspace(ws, bytes);          // the stream-K tail of the one-tap GEMM kernel (gemm_f16x3.hip) shares the buffer
     return DUA_OK;
 }
 // One workgroup per (64-row block, 64-column block): C = sum_s part[s] (index order) + bias (+ residual), and the block's column
@@ -1798,6 +1800,16 @@ static int gemm_presplit_impl(const void* aplanes, const void* planes, const flo
     DUA_REQUIRE(!Csplit || fmt == 0 || N % 32 == 0, "dua_gemm_f16f8_presplit: a split output needs N %% 32 == 0");
     size_t plane = dua_bf16x3_plane_elems(N, K);
     DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm presplit: operand too large");
+    if (fmt == 3 && dua_hgemm_enabled() && (!Csplit || N % 32 == 0) && (size_t)M * K * 2 < 0xFFFFFFF0ull) {
+        // the one-tap GEMM kernel of gemm_f16x3.hip (16x16x32 MFMA shape, static rings, 256 / 192 / 128-column tiles, stream-K tail)
+        HGemmP h{};
+        h.A1 = (const _Float16*)aplanes; h.a1_plane = (long)M * K; h.K1 = K; h.K2 = 0;
+        h.B = (const _Float16*)planes; h.b_bytes = (long)(4 * plane);
+        h.Cscale = (const float*)((const __bf16*)planes + 2 * plane); h.bias = bias; h.res = residual; h.C = C;
+        h.Cplanes = (_Float16*)Csplit; h.colsum = colsum; h.M = M; h.N = N; h.act_out = act_out;
+        h.out_scale = 1.0f / act_scale; h.split_scale = split_scale;
+        return dua_launch_hgemm(h, as_stream(stream), "dua_gemm presplit (hgemm)");
+    }
     DConvP d{};
     d.A = (const __bf16*)aplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = C;
     d.a_plane = (long)M * K; d.b_plane = (long)plane;
@@ -1822,6 +1834,26 @@ extern "C" int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, 
                                        int M, int N, int K, int act_out, float* colsum, float act_scale, void* stream) {
     DUA_REQUIRE(act_scale > 0.f, "dua_gemm_f16x3_presplit: act_scale must be positive");
     return gemm_presplit_impl(aplanes, packed, bias, residual, C, nullptr, M, N, K, act_out, colsum, 3, stream, act_scale);
+}
+// ... with the A operand concatenated along K from two plane sets, and optionally the f16x3 planes of the result beside it
+extern "C" int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void* a2planes, int K2, const void* packed, const float* bias,
+                                        const float* residual, float* C, void* extra_planes, int M, int N, int act_out, float* colsum,
+                                        float act_scale, float split_scale, void* stream) {
+    DUA_REQUIRE(a1planes && packed && C && M > 0 && N > 0 && K1 >= BK && K1 % BK == 0 && K2 >= 0 && K2 % BK == 0,
+                "dua_gemm_f16x3_presplit2: K1 and K2 must be multiples of 32 (got %d, %d)", K1, K2);
+    DUA_REQUIRE((K2 == 0) == (a2planes == nullptr), "dua_gemm_f16x3_presplit2: a2planes / K2 mismatch");
+    DUA_REQUIRE(N % 4 == 0 && act_scale > 0.f && (!extra_planes || split_scale > 0.f), "dua_gemm_f16x3_presplit2: N %% 4 == 0 and positive scales are required");
+    const int K = K1 + K2;
+    const size_t plane = dua_bf16x3_plane_elems(N, K);
+    DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)M * (K1 > K2 ? K1 : K2) * 2 < 0xFFFFFFF0ull, "dua_gemm_f16x3_presplit2: operand too large");
+    HGemmP h{};
+    h.A1 = (const _Float16*)a1planes; h.a1_plane = (long)M * K1; h.K1 = K1;
+    h.A2 = (const _Float16*)a2planes; h.a2_plane = (long)M * K2; h.K2 = K2;
+    h.B = (const _Float16*)packed; h.b_bytes = (long)(4 * plane);
+    h.Cscale = (const float*)((const __bf16*)packed + 2 * plane); h.bias = bias; h.res = residual; h.C = C;
+    h.Cextra = (_Float16*)extra_planes; h.colsum = colsum; h.M = M; h.N = N; h.act_out = act_out;
+    h.out_scale = 1.0f / act_scale; h.split_scale = split_scale;
+    return dua_launch_hgemm(h, as_stream(stream), "dua_gemm_f16x3_presplit2");
 }
 // ... with the result written as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM (U-ViT fc1 -> GELU -> fc2)
 extern "C" int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,

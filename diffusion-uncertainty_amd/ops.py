@@ -444,7 +444,8 @@ F16X3_RAW_SCALE = 16.0
 
 
 # Split-K workspace of the f16x3 LDS-DMA launches (dua_set_splitk_workspace): S * M * N floats with S * tiles <= 256, i.e. at most
-# 256 tiles of 256 x 128 floats = 32 MiB.  One buffer per device, kept for the life of the process (captured HIP graphs hold its address).
+# 256 tiles of 256 x 128 floats = 32 MiB; the stream-K tail of the one-tap GEMM kernel (csrc/gemm_f16x3.hip) keeps up to two partial tiles
+# of 256 x 256 floats per workgroup = 128 MiB.  One buffer per device, kept for the life of the process (captured HIP graphs hold its address).
 _SPLITK_WS = {}
 _SPLITK_ON = False
 
@@ -458,7 +459,7 @@ def set_split_k(on, device=None):
         dev = torch.device(device if device is not None else "cuda")
         key = dev.index if dev.index is not None else torch.cuda.current_device()
         if key not in _SPLITK_WS:
-            _SPLITK_WS[key] = torch.empty(40 << 20, device=dev, dtype=torch.uint8)
+            _SPLITK_WS[key] = torch.empty(130 << 20, device=dev, dtype=torch.uint8)
         ws = _SPLITK_WS[key]
         check(_lib.lib().dua_set_splitk_workspace(_p(ws), ws.numel()), "dua_set_splitk_workspace")
     else:
@@ -777,6 +778,26 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
     check(_lib.lib().dua_gemm_bf16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), None, M, n_out, K, int(act_out), None,
                                               _stream()), "dua_gemm_bf16x3_presplit")
     return c
+
+
+def gemm_f16x3_presplit2(a1, a2, packed, n_out, bias=None, residual=None, act_out=0, colsum=False, planes_out=False):
+    """[a1 | a2] @ W^T with both operands given as f16x3 SplitPlanes (a2 may be None): the 1x1 skip convolution / U-ViT skip_linear on
+    a virtual concatenation.  planes_out: additionally return the f16x3 planes of the fp32 result (scale F16X3_RAW_SCALE)."""
+    assert a1.fmt == "f16x3" and (a2 is None or (a2.fmt == "f16x3" and a2.scale == a1.scale))
+    K1 = a1.shape[-1]
+    K2 = 0 if a2 is None else a2.shape[-1]
+    M = 1
+    for d in a1.shape[:-1]:
+        M *= d
+    c = torch.empty((M, n_out), device=a1.device, dtype=torch.float32)
+    ws = _colsum_ws(M, n_out, a1.device, colsum)
+    if ws is not None:
+        c._dua_colsums_rows = ws
+    xp = torch.empty((2, M, n_out), device=a1.device, dtype=torch.int16) if planes_out else None
+    check(_lib.lib().dua_gemm_f16x3_presplit2(_p(a1.buf), K1, _p(a2.buf) if a2 is not None else None, K2, _p(packed), _p(bias), _p(residual),
+                                              _p(c), _p(xp), M, n_out, int(act_out), _p(ws), a1.scale, F16X3_RAW_SCALE, _stream()),
+          "dua_gemm_f16x3_presplit2")
+    return (c, SplitPlanes(xp, (M, n_out), "f16x3", F16X3_RAW_SCALE)) if planes_out else c
 
 
 def gemm_raw(**kw):

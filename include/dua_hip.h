@@ -345,6 +345,17 @@ int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float* x2, int C
                                  int resample, const float* dropmask, void* vplanes, void* stream);
 int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                          int N, int H, int W, int Cin, int Cout, float* colsum, void* stream);
+/* dua_gemm_f16x3_presplit with the A operand concatenated along K from TWO plane sets (rows [M][K1] and [M][K2], each K % 32 == 0):
+ * the 1x1 skip convolution of an ADM output block on torch.cat([h, hs.pop()]) (unet_openai.py:219-223,662) and U-ViT's
+ * skip_linear(cat([x, skip])) (uvit/uvit.py:116-117) without materialising the concatenation.  a2planes may be NULL (K2 = 0).
+ * extra_planes != NULL: the fp32 result is ALSO written as f16x3 planes of C * split_scale ([M][N] hi | lo). */
+int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void* a2planes, int K2, const void* packed, const float* bias,
+                             const float* residual, float* C, void* extra_planes, int M, int N, int act_out, float* colsum,
+                             float act_scale, float split_scale, void* stream);
+/* A/B switches of the one-tap f16x3 GEMM kernel behind the presplit entry points (csrc/gemm_f16x3.hip; correct kernels only, process-global):
+ * nt = 0 picks the tile width per shape (default), 2 / 3 / 4 force 128 / 192 / 256 columns, -1 sends the calls to the previous engine
+ * (k_xconv_dma<NT, 3> / k_hconv<NT, false>); streamk = 0 runs whole tiles only even when dua_set_splitk_workspace registered a buffer. */
+int dua_set_hgemm_mode(int nt, int streamk);
 /* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
  * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */
 int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,
@@ -489,6 +500,9 @@ int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C
 /* Split-K for the f16x3 LDS-DMA conv / presplit GEMM launches that cannot fill the chip (fewer than 128 tiles of 256 rows: small
  * batches, e.g. SD's CFG batch of 2): with a workspace registered, such a launch runs every tile as up to 16 K parts on separate
  * workgroups and a second kernel folds the parts in index order (deterministic) and applies bias / residual / statistics.
+ * The one-tap GEMM kernel (csrc/gemm_f16x3.hip) uses the same buffer for its stream-K tail: the tiles of the last, partly filled round
+ * are cut into K-step units spread evenly over the 256 workgroups (needs 2 * 256 tiles of 256 x 256 floats = 128 MiB; a smaller buffer
+ * leaves that kernel on whole tiles).
  * Results differ from the single-pass kernel by fp32 summation order only; the choice depends on the row count, so outputs are no
  * longer bit-identical across batch sizes while it is on.  Process-global, one stream at a time; (NULL, 0) switches it off (default). */
 int dua_set_splitk_workspace(void* ws, size_t bytes);

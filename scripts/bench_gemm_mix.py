@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-shape micro-benchmark of the f16x3 one-tap GEMMs (presplit LDS-DMA form and on-the-fly-split form).
+
+    python scripts/bench_gemm_mix.py [--set uvit64|uvit320|adm] [--engine 1] [--reps 5] [--splitk]
+
+Shapes: the linears of one U-ViT-H/2 block at batch 64 / 320 (BASELINE configs[2]: 258 tokens per image; uvit/uvit.py:54-120,
+timm.py:96-111) and the 1x1 skip convs / qkv / proj_out GEMMs of one ADM-128 forward at batch 128 (unet_openai.py:219-223,287,295).
+Prints per shape the mean launch time and the algorithmic TFLOP/s (2*M*N*K), then the FLOP-weighted mix.  Random operands."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def uvit_shapes(B):
+    M = B * 258
+    # (name, M, K1, K2, N, kind, count per forward); kind: p = presplit, g = presplit + GELU -> planes, r = presplit + residual, s = on-the-fly split
+    return [("qkv", M, 1152, 0, 3456, "p", 29), ("proj", M, 1152, 0, 1152, "r", 29), ("fc1", M, 1152, 0, 4608, "g", 29),
+            ("fc2", M, 4608, 0, 1152, "r", 29), ("skip", M, 1152, 1152, 1152, "s", 14)]
+
+
+def adm_shapes(B=128):
+    sk = [(128, 256, 256, 256, 3), (64, 512, 256, 256, 1), (64, 256, 256, 256, 2), (32, 768, 512, 512, 1), (32, 512, 512, 512, 1),
+          (32, 512, 256, 512, 1), (32, 256, 0, 512, 1), (16, 1024, 768, 768, 1), (16, 768, 768, 768, 1), (16, 768, 512, 768, 1), (16, 512, 0, 768, 1),
+          (8, 1024, 1024, 1024, 2), (8, 1024, 768, 1024, 1), (8, 768, 0, 1024, 1)]
+    out = [(f"skip{H}", B * H * H, c1, c2, n, "s", cnt) for H, c1, c2, n, cnt in sk]
+    for H, C, cnt in ((32, 512, 5), (16, 768, 5), (8, 1024, 6)):
+        out.append((f"qkv{H}", B * H * H, C, 0, 3 * C, "p", cnt))
+        out.append((f"proj{H}", B * H * H, C, 0, C, "r", cnt))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--set", default="uvit64")
+    ap.add_argument("--engine", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--splitk", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--hg", default="", help="dua_set_hgemm_mode: nt[,streamk]  (nt -1 = previous engine, 0 = auto, 2 / 3 / 4)")
+    a = ap.parse_args()
+    from diffusion_uncertainty_amd import _lib, ops
+    _lib.lib().dua_set_dma_conv(a.engine)
+    if a.hg:
+        v = [int(t) for t in a.hg.split(",")]
+        assert _lib.lib().dua_set_hgemm_mode(v[0], v[1] if len(v) > 1 else 1) == 0
+    dev = torch.device("cuda")
+    if a.splitk:
+        ops.set_split_k(True, dev)
+    shapes = {"uvit64": uvit_shapes(64), "uvit320": uvit_shapes(320), "adm": adm_shapes()}[a.set]
+    tf, tt = 0.0, 0.0
+    for name, M, K1, K2, N, kind, cnt in shapes:
+        if a.only and name not in a.only.split(","):
+            continue
+        K = K1 + K2
+        w = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev)
+        pk = ops.pack_weight_f16x3(w)
+        res = torch.randn(M, N, device=dev) if kind == "r" else None
+        if kind == "s":
+            a1 = torch.randn(M, K1, device=dev)
+            a2 = torch.randn(M, K2, device=dev) if K2 else None
+            fn = lambda: ops.gemm_f16x3(a1, pk, N, bias=b, a2=a2, colsum=(a.set == "adm"))  # noqa: E731
+        else:
+            x = torch.randn(M, K, device=dev) * ops.F16X3_ACT_SCALE
+            hi = x.half()
+            pl = ops.SplitPlanes(torch.stack([hi, (x - hi.float()).half()]).contiguous().view(torch.int16), (M, K), "f16x3", ops.F16X3_ACT_SCALE)
+            del x, hi
+            if kind == "g":
+                fn = lambda: ops.gemm_bf16x3_presplit(pl, pk, N, bias=b, act_out=2, split_out=True)  # noqa: E731
+            else:
+                fn = lambda: ops.gemm_bf16x3_presplit(pl, pk, N, bias=b, residual=res, colsum=(a.set == "adm" and kind == "r"))  # noqa: E731
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.reps
+        fl = 2.0 * M * N * K
+        print(f"{name:8s} M={M:8d} K={K1}+{K2} N={N:5d} [{kind}] x{cnt:2d}: {ms:8.3f} ms  {fl / ms / 1e9:6.1f} TF", flush=True)
+        tf += cnt * fl
+        tt += cnt * ms
+    print(f"mix ({a.set}, engine {a.engine}, hgemm mode '{a.hg}'{', split-K' if a.splitk else ''}): {tt:.2f} ms per forward, {tf / tt / 1e9:.1f} TF algorithmic")
+
+
+if __name__ == "__main__":
+    main()
