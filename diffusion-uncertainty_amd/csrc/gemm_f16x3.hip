@@ -30,15 +30,42 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define HG_ROWS 256
+// Timing-only diagnostic builds (scripts/hgemm_diag.py; WRONG results, never in the product library): HG_DIAG bit 0 drops the epilogue,
+// bit 1 its output stores (dropped by the buffer unit), bit 2 the prefetch of the next item's first stages, bit 3 the GELU.
+#ifndef HG_DIAG
+#define HG_DIAG 0
+#endif
 #define HG_TAIL_WAIT 8               // vector-memory operations an epilogue ALWAYS issues after the next item's prologue DMA (stores)
 
-__device__ __forceinline__ float hg_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// Exact GELU v * Phi(v) (uvit/timm.py:96-111, nn.GELU) without the two-branch erff: with x = |v| / sqrt(2), erfc(x) = exp(-x g(x)) and g a
+// degree-8 polynomial on [0, 4] (least-squares fit weighted by the sensitivity of erfc; beyond 4 erfc < 2e-8), so Phi(v) = erfc(x) / 2 for
+// v < 0 - no cancellation on the negative side, unlike 0.5 (1 + erf) - and 1 - erfc(x) / 2 otherwise.  Against fp64 over [-12, 12]:
+// max abs error 3.9e-7 (the fp32 erf formula: 4.5e-7), i.e. half an ulp of the result's magnitude; ~18 VALU operations, no divergence.
+__device__ __forceinline__ float hg_gelu(float v) {
+    if (HG_DIAG & 8) return v;
+    const float x = fminf(fabsf(v) * 0.70710678118654752f, 4.0f);
+    float g = -8.056373400e-06f;
+    g = fmaf(g, x, 1.061473860e-04f);
+    g = fmaf(g, x, -5.884277713e-04f);
+    g = fmaf(g, x, 1.577756018e-03f);
+    g = fmaf(g, x, -5.995723508e-05f);
+    g = fmaf(g, x, -1.921636361e-02f);
+    g = fmaf(g, x, 1.027989408e-01f);
+    g = fmaf(g, x, 6.366161475e-01f);
+    g = fmaf(g, x, 1.128379331e+00f);
+    const float he = 0.5f * __builtin_amdgcn_exp2f(x * g * -1.4426950408889634f);
+    return v * (v < 0.f ? he : 1.0f - he);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Epilogue of one 256 x (64 NT) tile from the accumulator layout acc[channel block][row block]: lane = channels 4 (lane >> 4) .. + 3 of row
-// lane & 15.  Channel-block pairs (32 channels) of one 16-row block go through a 16 x 144-byte LDS patch of the wave so that residual
-// reads and output stores move whole 128-byte rows.  Every store is a buffer store that ALWAYS issues (lanes outside the tensor get an
-// out-of-range offset, which the buffer unit drops): at least HG_TAIL_WAIT of them follow the next item's prologue DMA in the queue.
+// Epilogues of one 256 x (64 NT) tile from the accumulator layout acc[channel block][row block]: lane = channels 4 (lane >> 4) .. + 3 of row
+// lane & 15.  Every output store is a buffer store that ALWAYS issues (lanes outside the tensor get an out-of-range offset, which the
+// buffer unit drops): at least HG_TAIL_WAIT of them follow the next item's prologue DMA in the queue.
+//
+// Patch form: channel-block pairs (32 channels) of one 16-row block go through a 16 x 128-byte LDS patch of the wave (two patches,
+// alternating, 16-B chunk c of row r at chunk position c ^ ((r >> 1) & 7): conflict-free for the accumulator-layout writes and for both
+// row-major read shapes), so that residual reads and output stores move whole 128-byte rows; the write of slot t + 2 and the read of slot
+// t + 1 are in the LDS queue while slot t is computed and stored.
 template <int NT, int EPI>
 __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 * NT][4], char* pw, int wave, int lane, int m0, int n0) {
     static_assert(8 * NT >= HG_TAIL_WAIT, "the item-start wait counts on this many stores");
@@ -48,6 +75,13 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
     const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
     const int row0 = m0 + wm * 64;
     const unsigned OOB = 0xFFFFFFF0u;
+    constexpr int T = 4 * NT;                                    // slots (pair jp = t >> 2, row block i = t & 3)
+    const int wr_off = lr_e * 128, wr_sw = (lr_e >> 1) & 7;
+    auto patch_put = [&](int t) {
+        char* b = pw + (t & 1) * 2048 + wr_off;
+        *(f32x4*)(b + 16 * (lc_e ^ wr_sw)) = acc[2 * (t >> 2)][t & 3];
+        *(f32x4*)(b + 16 * ((4 + lc_e) ^ wr_sw)) = acc[2 * (t >> 2) + 1][t & 3];
+    };
     if constexpr (EPI == 0) {
         const long crem = ((long)p.M - m0) * p.N * 4;
         const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long)m0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
@@ -56,79 +90,99 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         const auto rxh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cextra + (long)m0 * p.N), 0, xrec, 0x00020000);
         const auto rxl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cextra + (long)p.M * p.N + (long)m0 * p.N), 0, xrec, 0x00020000);
         const int pr_e = lane_e >> 3, pc_e = lane_e & 7;         // row-major side: row of the half block, 16-B chunk of the 128-B row
+        // every global operand of the epilogue is requested up front (column scales, bias, the first residual rows): one exposed
+        // latency instead of two per pair; the residual rows of slot t + 2 are requested while slot t is stored
+        float4 sq_[NT], bq_[NT], rres[3][2];
+        auto res_ld = [&](int t, float4 (&dst)[2]) {
+            const int c = n0 + wn * 32 * NT + 32 * (t >> 2) + 4 * pc_e;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = row0 + 16 * (t & 3) + 8 * h + pr_e;
+                dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res && c < p.N && row < p.M) dst[h] = *(const float4*)(p.res + (long)row * p.N + c);
+            }
+        };
 #pragma unroll
         for (int jp = 0; jp < NT; ++jp) {
             const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
+            sq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bq_[jp] = sq_[jp];
+            if (c < p.N) {
+                sq_[jp] = *(const float4*)(p.Cscale + c);
+                if (p.bias) bq_[jp] = *(const float4*)(p.bias + c);
+            }
+        }
+        res_ld(0, rres[0]);
+        res_ld(1, rres[1]);
+        patch_put(0);
+        patch_put(1);
+        f32x4 pa[2][2];
+        auto patch_get = [&](int t, f32x4 (&d)[2]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * h + pr_e;
+                d[h] = *(const f32x4*)(pw + (t & 1) * 2048 + r * 128 + 16 * (pc_e ^ ((r >> 1) & 7)));
+            }
+        };
+        patch_get(0, pa[0]);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int jp = t >> 2, i = t & 3;
+            const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
             const bool cok = c < p.N;
-            float4 sq = make_float4(0.f, 0.f, 0.f, 0.f), bq = sq;
-            if (cok) {
-                sq = *(const float4*)(p.Cscale + c);
-                sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-                if (p.bias) bq = *(const float4*)(p.bias + c);
-            }
-            float4 rq[2], rn[2];
-            auto res_ld = [&](int i, float4 (&dst)[2]) {
+            if (t + 1 < T) patch_get(t + 1, pa[(t + 1) & 1]);
+            if (t + 2 < T) res_ld(t + 2, rres[(t + 2) % 3]);
+            float4 sq = sq_[jp];
+            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+            const float4 bq = bq_[jp];
+            const float4 (&rq)[2] = rres[t % 3];
+            if (i == 0) { cs = make_float4(0.f, 0.f, 0.f, 0.f); cq2 = cs; }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = row0 + 16 * i + 8 * h + pr_e;
-                    dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.res && cok && row < p.M) dst[h] = *(const float4*)(p.res + (long)row * p.N + c);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 a = pa[t & 1][h];
+                const int row = row0 + 16 * i + 8 * h + pr_e;
+                float4 v;
+                v.x = a[0] * sq.x + bq.x; v.y = a[1] * sq.y + bq.y; v.z = a[2] * sq.z + bq.z; v.w = a[3] * sq.w + bq.w;
+                if (p.act_out == 2) { v.x = hg_gelu(v.x); v.y = hg_gelu(v.y); v.z = hg_gelu(v.z); v.w = hg_gelu(v.w); }
+                v.x += rq[h].x; v.y += rq[h].y; v.z += rq[h].z; v.w += rq[h].w;
+                const bool ok = cok && row < p.M;
+                const u32x4 vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (ok && !(HG_DIAG & 2)) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
+                if (p.Cextra) {               // the same values as f16x3 planes (operand of a later presplit GEMM)
+                    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const float f[4] = {v.x * p.split_scale, v.y * p.split_scale, v.z * p.split_scale, v.w * p.split_scale};
+                    f16x4_t hh, ll;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float sv = fminf(fmaxf(f[q], -65504.f), 65504.f);
+                        const _Float16 t16 = (_Float16)sv;
+                        hh[q] = t16;
+                        ll[q] = (_Float16)(sv - (float)t16);
+                    }
+                    const unsigned xo = ok ? (unsigned)(((long)(row - m0) * p.N + c) * 2) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rxh, xo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rxl, xo, 0, 0);
                 }
-            };
-            res_ld(0, rn);
-            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rq[0] = rn[0]; rq[1] = rn[1];
-                if (i < 3) res_ld(i + 1, rn);
-                *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc[2 * jp][i];
-                *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc[2 * jp + 1][i];
-                // (same-wave LDS write -> read: in-order LDS queue, no barrier)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
-                    const int row = row0 + 16 * i + 8 * h + pr_e;
-                    float4 v;
-                    v.x = a[0] * sq.x + bq.x; v.y = a[1] * sq.y + bq.y; v.z = a[2] * sq.z + bq.z; v.w = a[3] * sq.w + bq.w;
-                    if (p.act_out == 2) { v.x = hg_gelu(v.x); v.y = hg_gelu(v.y); v.z = hg_gelu(v.z); v.w = hg_gelu(v.w); }
-                    v.x += rq[h].x; v.y += rq[h].y; v.z += rq[h].z; v.w += rq[h].w;
-                    const bool ok = cok && row < p.M;
-                    const u32x4 vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
-                    if (p.Cextra) {               // the same values as f16x3 planes (operand of a later presplit GEMM)
-                        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        const float f[4] = {v.x * p.split_scale, v.y * p.split_scale, v.z * p.split_scale, v.w * p.split_scale};
-                        f16x4_t hh, ll;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float sv = fminf(fmaxf(f[q], -65504.f), 65504.f);
-                            const _Float16 t = (_Float16)sv;
-                            hh[q] = t;
-                            ll[q] = (_Float16)(sv - (float)t);
-                        }
-                        const unsigned xo = ok ? (unsigned)(((long)(row - m0) * p.N + c) * 2) : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rxh, xo, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rxl, xo, 0, 0);
-                    }
-                    if (ok) {
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
-                    }
+                if (ok) {
+                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                    cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
                 }
             }
-            if (p.colsum) {      // GroupNorm statistics of the next layer: fold the 8 row lanes that share these channels
-                float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+            if (t + 2 < T) patch_put(t + 2);     // (its patch was read for slot t: the LDS queue is in order)
+            if (i == 3 && p.colsum) {            // GroupNorm statistics of the next layer: fold the 8 row lanes that share these channels
+                float u_[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    t[u] += __shfl_xor(t[u], 8);
-                    t[u] += __shfl_xor(t[u], 16);
-                    t[u] += __shfl_xor(t[u], 32);
+                    u_[u] += __shfl_xor(u_[u], 8);
+                    u_[u] += __shfl_xor(u_[u], 16);
+                    u_[u] += __shfl_xor(u_[u], 32);
                 }
                 if (pr_e == 0 && cok && row0 < p.M) {
                     float* o = p.colsum + (long)(row0 >> 6) * 2 * p.N + c;
-                    *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
-                    *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
+                    *(float4*)o = make_float4(u_[0], u_[1], u_[2], u_[3]);
+                    *(float4*)(o + p.N) = make_float4(u_[4], u_[5], u_[6], u_[7]);
                 }
             }
         }
@@ -139,43 +193,128 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         const auto rch = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cplanes + (long)m0 * p.N), 0, crec, 0x00020000);
         const auto rcl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cplanes + (long)p.M * p.N + (long)m0 * p.N), 0, crec, 0x00020000);
         const int r16 = lane_e >> 2, ch8 = lane_e & 3;
+        float4 s0_[NT], s1_[NT], b0_[NT], b1_[NT];               // requested up front: one exposed latency for all pairs
 #pragma unroll
         for (int jp = 0; jp < NT; ++jp) {
             const int c = n0 + wn * 32 * NT + 32 * jp + 8 * ch8;
-            const bool cok = c < p.N;
-            float sq[8], bq[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { sq[q] = 0.f; bq[q] = 0.f; }
-            if (cok) {
-                const float4 s0 = *(const float4*)(p.Cscale + c), s1 = *(const float4*)(p.Cscale + c + 4);
-                sq[0] = s0.x; sq[1] = s0.y; sq[2] = s0.z; sq[3] = s0.w; sq[4] = s1.x; sq[5] = s1.y; sq[6] = s1.z; sq[7] = s1.w;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sq[q] *= p.out_scale;
-                if (p.bias) {
-                    const float4 b0 = *(const float4*)(p.bias + c), b1 = *(const float4*)(p.bias + c + 4);
-                    bq[0] = b0.x; bq[1] = b0.y; bq[2] = b0.z; bq[3] = b0.w; bq[4] = b1.x; bq[5] = b1.y; bq[6] = b1.z; bq[7] = b1.w;
-                }
+            s0_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s1_[jp] = s0_[jp]; b0_[jp] = s0_[jp]; b1_[jp] = s0_[jp];
+            if (c < p.N) {
+                s0_[jp] = *(const float4*)(p.Cscale + c); s1_[jp] = *(const float4*)(p.Cscale + c + 4);
+                if (p.bias) { b0_[jp] = *(const float4*)(p.bias + c); b1_[jp] = *(const float4*)(p.bias + c + 4); }
             }
+        }
+        patch_put(0);
+        patch_put(1);
+        f32x4 pa[2][2];
+        const int rd_sw = (r16 >> 1) & 7;
+        auto patch_get = [&](int t, f32x4 (&d)[2]) {
+            const char* b = pw + (t & 1) * 2048 + r16 * 128;
+            d[0] = *(const f32x4*)(b + 16 * ((2 * ch8) ^ rd_sw));
+            d[1] = *(const f32x4*)(b + 16 * ((2 * ch8 + 1) ^ rd_sw));
+        };
+        patch_get(0, pa[0]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc[2 * jp][i];
-                *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc[2 * jp + 1][i];
-                const f32x4 a0 = *(const f32x4*)(pw + r16 * 144 + 32 * ch8), a1 = *(const f32x4*)(pw + r16 * 144 + 32 * ch8 + 16);
-                const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const int row = row0 + 16 * i + r16;
-                h16x8 hh, ll;
+        for (int t = 0; t < T; ++t) {
+            const int jp = t >> 2, i = t & 3;
+            const int c = n0 + wn * 32 * NT + 32 * jp + 8 * ch8;
+            const bool cok = c < p.N;
+            if (t + 1 < T) patch_get(t + 1, pa[(t + 1) & 1]);
+            const float4 s0 = s0_[jp], s1 = s1_[jp], b0 = b0_[jp], b1 = b1_[jp];
+            const float sq[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float bq[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const f32x4 a0 = pa[t & 1][0], a1 = pa[t & 1][1];
+            const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const int row = row0 + 16 * i + r16;
+            h16x8 hh, ll;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float v = a[q] * sq[q] + bq[q];
-                    if (p.act_out == 2) v = hg_gelu(v);
-                    const float sv = fminf(fmaxf(v * p.split_scale, -65504.f), 65504.f);
-                    const _Float16 t = (_Float16)sv;
-                    hh[q] = t;
-                    ll[q] = (_Float16)(sv - (float)t);
-                }
-                const unsigned o = (cok && row < p.M) ? (unsigned)(((long)(row - m0) * p.N + c) * 2) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh), rch, o, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll), rcl, o, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                float v = a[q] * (sq[q] * p.out_scale) + bq[q];
+                if (p.act_out == 2) v = hg_gelu(v);
+                const float sv = fminf(fmaxf(v * p.split_scale, -65504.f), 65504.f);
+                const _Float16 t16 = (_Float16)sv;
+                hh[q] = t16;
+                ll[q] = (_Float16)(sv - (float)t16);
+            }
+            const unsigned o = (cok && row < p.M && !(HG_DIAG & 2)) ? (unsigned)(((long)(row - m0) * p.N + c) * 2) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hh), rch, o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ll), rcl, o, 0, 0);
+            if (t + 2 < T) patch_put(t + 2);
+        }
+    }
+}
+
+// Direct form (fp32 output, no planes beside it): straight from the accumulators, no LDS.  A store instruction then covers 16 rows x 64 B
+// (the four lanes that share a row hold 4 x 16 B of consecutive channels; the other half of each 128-byte line follows in the next
+// instruction).  Fewer bytes per request than the patch form's whole lines, but no transposition and no dependent LDS round trip per
+// slot: the better trade for the short K loops of one-tap GEMMs (measured: scripts/hgemm_diag.py).
+template <int NT>
+__device__ __forceinline__ void hgemm_epilogue_direct(const HGemmP& p, f32x4 (&acc)[2 * NT][4], int wave, int lane, int m0, int n0) {
+    constexpr int NB = 2 * NT;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
+    const int row0 = m0 + wm * 64, c0 = n0 + wn * 32 * NT + 4 * lc_e;
+    const unsigned OOB = 0xFFFFFFF0u;
+    const long crem = ((long)p.M - m0) * p.N * 4;
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long)m0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
+    // channel block j: its column scales / bias and the residual of its four row blocks are requested while block j - 1 is stored
+    float4 sb[2][2], rres[2][4];
+    auto blk_ld = [&](int j, float4 (&sbd)[2], float4 (&dst)[4]) {
+        const int c = c0 + 16 * j;
+        sbd[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sbd[1] = sbd[0];
+        if (c < p.N) {
+            sbd[0] = *(const float4*)(p.Cscale + c);
+            if (p.bias) sbd[1] = *(const float4*)(p.bias + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 16 * i + lr_e;
+            dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.res && c < p.N && row < p.M) dst[i] = *(const float4*)(p.res + (long)row * p.N + c);
+        }
+    };
+    blk_ld(0, sb[0], rres[0]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j + 1 < NB) blk_ld(j + 1, sb[(j + 1) & 1], rres[(j + 1) & 1]);
+        const int c = c0 + 16 * j;
+        float4 sq = sb[j & 1][0];
+        sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+        const float4 bq = sb[j & 1][1];
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 16 * i + lr_e;
+            const bool ok = c < p.N && row < p.M;
+            const f32x4 a = acc[j][i];
+            const float4 rq = rres[j & 1][i];
+            float4 v;
+            v.x = a[0] * sq.x + bq.x; v.y = a[1] * sq.y + bq.y; v.z = a[2] * sq.z + bq.z; v.w = a[3] * sq.w + bq.w;
+            if (p.act_out == 2) { v.x = hg_gelu(v.x); v.y = hg_gelu(v.y); v.z = hg_gelu(v.z); v.w = hg_gelu(v.w); }
+            v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w;
+            const u32x4 vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (ok && !(HG_DIAG & 2)) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
+            if (ok) {
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+            }
+        }
+        if (p.colsum) {          // fold the 16 row lanes that share these channels
+            float u_[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                u_[u] += __shfl_xor(u_[u], 1);
+                u_[u] += __shfl_xor(u_[u], 2);
+                u_[u] += __shfl_xor(u_[u], 4);
+                u_[u] += __shfl_xor(u_[u], 8);
+            }
+            if (lr_e == 0 && c < p.N && row0 < p.M) {
+                float* o = p.colsum + (long)(row0 >> 6) * 2 * p.N + c;
+                *(float4*)o = make_float4(u_[0], u_[1], u_[2], u_[3]);
+                *(float4*)(o + p.N) = make_float4(u_[4], u_[5], u_[6], u_[7]);
             }
         }
     }
@@ -203,28 +342,24 @@ __global__ __launch_bounds__(512, 2) void k_hgemm(HGemmP p) {
     const int cq = p.n_full >> 3, cr = p.n_full & 7;
     const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
     const int n_head = slot < chunk_n ? (chunk_n - slot + nslot - 1) / nslot : 0;
-    // stream-K tail: workgroup cu owns the K-step units [cu * tail_u, (cu + 1) * tail_u) of the tail tiles (at most two tiles)
+    // stream-K part of the work list: the K-step units of the tiles [n_full, n_full + tail_tiles) are cut into tail_p contiguous ranges,
+    // workgroup cu < tail_p owns [cu * U / tail_p, (cu + 1) * U / tail_p): a partial first tile, whole tiles, a partial last tile
     const int cu = xcd * (gridDim.x >> 3) + slot;
     const long U = (long)p.tail_tiles * nk;
-    const long u0 = (long)cu * p.tail_u, u1 = u0 + p.tail_u < U ? u0 + p.tail_u : U;
-    int n_seg = 0, seg_tile = 0, seg_k0 = 0, seg_k1 = 0, seg2_k1 = 0;
-    if (p.tail_tiles > 0 && u0 < u1) {
-        seg_tile = (int)(u0 / nk);
-        seg_k0 = (int)(u0 - (long)seg_tile * nk);
-        const long e = u1 - (long)seg_tile * nk;
-        seg_k1 = e < nk ? (int)e : nk;
-        n_seg = 1;
-        if (e > nk) { seg2_k1 = (int)(e - nk); n_seg = 2; }
-    }
+    long u0 = 0, u1 = 0;
+    if (p.tail_tiles > 0 && cu < p.tail_p) { u0 = ((long)cu * U) / p.tail_p; u1 = ((long)(cu + 1) * U) / p.tail_p; }
+    const int seg_first = (int)(u0 / nk), seg_k0 = (int)(u0 - (long)seg_first * nk);
+    const int seg_last = u1 > u0 ? (int)((u1 - 1) / nk) : seg_first - 1, seg_k1 = (int)(u1 - (long)seg_last * nk);
+    const int n_seg = seg_last - seg_first + 1;
     const int n_items = n_head + n_seg;
     // item idx -> (tile id, K range, workspace slot or -1 for a whole tile with the real epilogue)
     auto get_item = [&](int idx, int& tile, int& k0, int& k1, int& part) {
         if (idx < n_head) { tile = chunk0 + slot + idx * nslot; k0 = 0; k1 = nk; part = -1; return; }
         const int j = idx - n_head;
-        tile = p.n_full + seg_tile + j;
+        tile = p.n_full + seg_first + j;
         k0 = j == 0 ? seg_k0 : 0;
-        k1 = j == 0 ? seg_k1 : seg2_k1;
-        part = (k0 == 0 && k1 == nk) ? -1 : 2 * cu + j;
+        k1 = j == n_seg - 1 ? seg_k1 : nk;
+        part = (k0 == 0 && k1 == nk) ? -1 : 2 * cu + (j == 0 ? 0 : 1);
     };
 
     const int dl_row = lane >> 2;
@@ -449,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void k_hgemm(HGemmP p) {
 #undef GSB
         // the last barrier of the item has retired every LDS read: request the first stages of the next item now (activation slots
         // 0, 1 and weight slots 0, 1); their latency runs under the epilogue, whose patches live in activation slot 2
-        if (it + 1 < n_items) {
+        if (it + 1 < n_items && !(HG_DIAG & 4)) {
             get_item(it + 1, tile, k0, k1, part);
             item_geom((tile / p.ntn) * HG_ROWS, (tile % p.ntn) * 64 * NT, k0);
             issue_prologue(k1 - k0);
@@ -462,8 +597,17 @@ __global__ __launch_bounds__(512, 2) void k_hgemm(HGemmP p) {
             for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *(f32x4*)(dst + (j * 4 + i) * 256) = acc[j][i];
+        } else if (HG_DIAG & 1) {                            // (diagnostic: no epilogue - the accumulators are kept alive by a store that never happens)
+            float t_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t_ += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+            if (t_ == 1.2345e-30f) p.C[0] = t_;
+        } else if (EPI == 0 && p.direct_epi) {
+            hgemm_epilogue_direct<NT>(p, acc, wave, lane, m0, n0);
         } else {
-            hgemm_epilogue<NT, EPI>(p, acc, lds + 2 * ABY + wave * (16 * 144), wave, lane, m0, n0);
+            hgemm_epilogue<NT, EPI>(p, acc, lds + 2 * ABY + wave * 4096, wave, lane, m0, n0);
         }
         // the patches must be done before another wave's DMA of the next item's third stage lands in activation slot 2: that piece is
         // requested after the next item's opening barrier
@@ -476,11 +620,13 @@ template <int NT, int EPI>
 __global__ __launch_bounds__(512) void k_hgemm_reduce(HGemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NB = 2 * NT;
-    __shared__ __attribute__((aligned(16))) char patch[8 * 16 * 144];
+    __shared__ __attribute__((aligned(16))) char patch[8 * 4096];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int t = blockIdx.x, nk = (p.K1 + p.K2) / 32;
+    const long U = (long)p.tail_tiles * nk, P = p.tail_p;
     const long ulo = (long)t * nk, uhi = ulo + nk;
-    const int c_lo = (int)(ulo / p.tail_u), c_hi = (int)((uhi - 1) / p.tail_u);
+    // range c holds unit x  <=>  floor(c U / P) <= x < floor((c + 1) U / P)  <=>  c = floor(((x + 1) P - 1) / U)
+    const int c_lo = (int)(((ulo + 1) * P - 1) / U), c_hi = (int)((uhi * P - 1) / U);
     if (c_lo == c_hi) return;                                // one workgroup ran the whole tile (and its epilogue)
     f32x4 acc[NB][4];
 #pragma unroll
@@ -488,7 +634,7 @@ __global__ __launch_bounds__(512) void k_hgemm_reduce(HGemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int c = c_lo; c <= c_hi; ++c) {
-        const int first = (int)(((long)c * p.tail_u) / nk);
+        const int first = (int)((((long)c * U) / P) / nk);      // the first tile of range c: its part sits in slot 2 c, any other in 2 c + 1
         const int part = 2 * c + (t != first ? 1 : 0);
         const float* src = p.kpart + (long)part * (HG_ROWS * 64 * NT) + (long)wave * (NB * 4 * 256) + lane * 4;
 #pragma unroll
@@ -497,22 +643,28 @@ __global__ __launch_bounds__(512) void k_hgemm_reduce(HGemmP p) {
             for (int i = 0; i < 4; ++i) acc[j][i] += *(const f32x4*)(src + (j * 4 + i) * 256);
     }
     const int tile = p.n_full + t;
-    hgemm_epilogue<NT, EPI>(p, acc, patch + wave * (16 * 144), wave, lane, (tile / p.ntn) * HG_ROWS, (tile % p.ntn) * 64 * NT);
+    const int m0 = (tile / p.ntn) * HG_ROWS, n0 = (tile % p.ntn) * 64 * NT;
+    if (EPI == 0 && p.direct_epi) hgemm_epilogue_direct<NT>(p, acc, wave, lane, m0, n0);
+    else hgemm_epilogue<NT, EPI>(p, acc, patch + wave * 4096, wave, lane, m0, n0);
 #endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 static float* hg_ws = nullptr;
 static size_t hg_ws_bytes = 0;
-static int hg_force_nt = 0, hg_streamk = 1;
+static int hg_sk_whole = -1;              // stream-K over the whole launch: -1 = per shape, 0 = tail only, 1 = always
+static int hg_force_nt = 0, hg_streamk = 1, hg_direct = -1;     // hg_direct: -1 = per shape, 0 = patch epilogue, 1 = direct epilogue
 void dua_hgemm_set_workspace(void* ws, size_t bytes) { hg_ws = (float*)ws; hg_ws_bytes = bytes; }
 // A/B switches (process-global, correct kernels only): nt = 0 picks the tile width per shape, 2 / 3 / 4 forces 128 / 192 / 256 columns,
-// -1 sends the presplit GEMMs back to the previous engine (k_xconv_dma<NT, 3> / k_hconv<NT, false>); streamk = 0 runs whole tiles only
+// -1 sends the presplit GEMMs back to the previous engine (k_xconv_dma<NT, 3> / k_hconv<NT, false>); streamk bit 0 = 0 runs whole tiles
+// only, bits 1-2 pick the fp32 epilogue (0 per shape, 2 patch, 4 direct)
 int dua_hgemm_enabled() { return hg_force_nt >= 0; }
 extern "C" int dua_set_hgemm_mode(int nt, int streamk) {
     DUA_REQUIRE(nt == -1 || nt == 0 || (nt >= 2 && nt <= 4), "dua_set_hgemm_mode: nt must be -1 (previous engine), 0, 2, 3 or 4");
     hg_force_nt = nt;
-    hg_streamk = streamk != 0;
+    hg_streamk = (streamk & 1) != 0;
+    hg_direct = (streamk & 6) == 2 ? 0 : ((streamk & 6) == 4 ? 1 : -1);          // bits 1-2 of `streamk`: 2 = patch epilogue, 4 = direct epilogue
+    hg_sk_whole = (streamk & 24) == 8 ? 0 : ((streamk & 24) == 16 ? 1 : -1);      // bits 3-4: 8 = stream-K on the tail round only, 16 = on the whole launch
     return DUA_OK;
 }
 
@@ -520,10 +672,10 @@ template <int NT>
 static void hg_launch(const HGemmP& p, int grid, bool planes, hipStream_t st) {
     if (planes) {
         hipLaunchKernelGGL((k_hgemm<NT, 1>), dim3(grid), 512, 0, st, p);
-        if (p.tail_tiles > 0) hipLaunchKernelGGL((k_hgemm_reduce<NT, 1>), dim3(p.tail_tiles), 512, 0, st, p);
+        if (p.tail_tiles > 0 && p.tail_p > 1) hipLaunchKernelGGL((k_hgemm_reduce<NT, 1>), dim3(p.tail_tiles), 512, 0, st, p);
     } else {
         hipLaunchKernelGGL((k_hgemm<NT, 0>), dim3(grid), 512, 0, st, p);
-        if (p.tail_tiles > 0) hipLaunchKernelGGL((k_hgemm_reduce<NT, 0>), dim3(p.tail_tiles), 512, 0, st, p);
+        if (p.tail_tiles > 0 && p.tail_p > 1) hipLaunchKernelGGL((k_hgemm_reduce<NT, 0>), dim3(p.tail_tiles), 512, 0, st, p);
     }
 }
 
@@ -531,38 +683,43 @@ int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what) {
     const int nk = (p.K1 + p.K2) / 32;
     p.ntm = (p.M + HG_ROWS - 1) / HG_ROWS;
     const bool ws_ok = hg_streamk && hg_ws != nullptr;
-    // Tile width: the widest tile wastes the least L2 -> LDS traffic per MFMA, a width that divides N wastes no columns; without the
-    // stream-K workspace the occupancy of the last round of tiles counts too.
+    // Tile width: estimated launch time = rounds of tiles on 256 CUs x (K steps + ~8 steps of per-tile overhead) x tile width / loop
+    // efficiency of that width (the widest tile moves the least L2 -> LDS traffic per MFMA; measured steady rates 256 : 192 : 128 columns
+    // = 1 : 0.95 : 0.85, scripts/diag/hgemm_sweep.py); columns beyond N are wasted work of the last column tile.
     int nt = hg_force_nt;
     if (!nt) {
-        double best = -1.0;
+        double best = 1e300;
         for (int c = 4; c >= 2; --c) {
             const int w = 64 * c, tn = (p.N + w - 1) / w;
             const long tiles = (long)p.ntm * tn;
-            double sc = (double)p.N / ((double)tn * w) * (c == 4 ? 1.0 : (c == 3 ? 0.95 : 0.85));
-            if (!ws_ok || nk < 16) sc *= (double)tiles / (double)((tiles + 255) / 256 * 256);
-            if (sc > best) { best = sc; nt = c; }
+            const double t = (double)((tiles + 255) / 256) * (nk + 8) * c / (c == 4 ? 1.0 : (c == 3 ? 0.95 : 0.85));
+            if (t < best) { best = t; nt = c; }
         }
     }
     p.ntn = (p.N + 64 * nt - 1) / (64 * nt);
     const int ntiles = p.ntm * p.ntn;
-    p.n_full = ntiles; p.tail_tiles = 0; p.tail_u = 1; p.kpart = nullptr;
+    p.n_full = ntiles; p.tail_tiles = 0; p.tail_p = 1; p.kpart = nullptr;
     int grid = ntiles < 256 ? ntiles : 256;
-    if (ws_ok && nk >= 16 && ntiles % 256 != 0) {
+    const size_t need = (size_t)2 * 256 * HG_ROWS * 64 * nt * sizeof(float);
+    if (ws_ok && nk >= 16 && need <= hg_ws_bytes) {
+        // Stream-K.  Default: launches that fill at most 3/8 of the chip (up to 96 tiles: small batches - SD's CFG batch of 2, ADM-64
+        // at batch 4); measured on U-ViT-H/2's shapes (scripts/diag/hgemm_sweep.py), neither the tail round alone (585 or 390 tiles on
+        // 256 CUs: the part dumps and the fold kernel cost more than the idle half round) nor the whole launch (workgroups out of phase
+        // spread their HBM-bound epilogue bursts, but stop sharing the weight stream in their XCD's L2: -22 % in the K loop) pays above
+        // that; both stay selectable (dua_set_hgemm_mode) for A/B runs.
         const int rem = ntiles % 256;
-        const long U = (long)rem * nk;
-        long P = U / 12;
-        if (P > 256) P = 256;
-        if (P < rem) P = rem;
-        const int u = (int)((U + P - 1) / P);
-        const size_t need = (size_t)2 * 256 * HG_ROWS * 64 * nt * sizeof(float);
-        // worth it when the last round would leave at least ~15 % of the chip idle
-        if (rem <= 216 && u <= nk && need <= hg_ws_bytes) {
-            p.n_full = ntiles - rem; p.tail_tiles = rem; p.tail_u = u; p.kpart = hg_ws;
+        const int tail = hg_sk_whole == 1 ? ntiles : (hg_sk_whole == 0 ? (rem <= 216 ? rem : 0) : (ntiles <= 96 ? ntiles : 0));
+        if (tail > 0) {
+            const long U = (long)tail * nk;
+            long P = U / 12;
+            if (P > 256) P = 256;
+            if (P < 1) P = 1;
+            p.n_full = ntiles - tail; p.tail_tiles = tail; p.tail_p = (int)P; p.kpart = hg_ws;
             grid = 256;
         }
     }
     const bool planes = p.Cplanes != nullptr;
+    p.direct_epi = (!planes && !p.Cextra && hg_direct == 1) ? 1 : 0;
     if (nt == 4) hg_launch<4>(p, grid, planes, st);
     else if (nt == 3) hg_launch<3>(p, grid, planes, st);
     else hg_launch<2>(p, grid, planes, st);

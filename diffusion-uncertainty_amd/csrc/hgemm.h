@@ -14,11 +14,13 @@ struct HGemmP {
     float* colsum;               // optional [ceil(M / 64)][2][N] column sums / sums of squares per 64-row block
     int M, N, K1, K2, ntm, ntn;
     int act_out;                 // 2 = GELU
+    int direct_epi;              // EPI 0: stores straight from the accumulator layout (no LDS transposition); set by dua_launch_hgemm
     float out_scale, split_scale;
-    // Work list of the persistent grid: items [0, n_full) are whole tiles (tile id = tm * ntn + tn).  The remaining tail_tiles tiles are
-    // cut into K-step units, tail_u consecutive units per workgroup (stream-K): a workgroup's range touches at most two tiles, each
-    // partial result goes to kpart[2 * cu + j] in accumulator layout and k_hgemm_reduce folds the parts of a tile in workgroup order.
-    int n_full, tail_tiles, tail_u;
+    // Work list of the persistent grid: items [0, n_full) are whole tiles (tile id = tm * ntn + tn).  The K-step units of the remaining
+    // tail_tiles tiles are cut into tail_p contiguous ranges (stream-K), range c = [c U / tail_p, (c + 1) U / tail_p) owned by workgroup c:
+    // a partial first tile (result to kpart[2 c]), whole tiles (real epilogue), a partial last tile (kpart[2 c + 1]), all in accumulator
+    // layout; k_hgemm_reduce folds the parts of a tile in workgroup order.
+    int n_full, tail_tiles, tail_p;
     float* kpart;
 };
 
