@@ -30,3 +30,14 @@ def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(seconds, device):
+    """The wall time of every rank, in rank order (list of floats; a one-element list without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(seconds)]
+    w = dist.get_world_size()
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    out = torch.empty(w, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.tolist()]
