@@ -44,20 +44,25 @@ FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table (fp32-
 BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md chip table (dense bf16 / fp16 MFMA)
 STEP_TIMESTEPS = 5                       # one bench step = 5 DDIM timesteps
 MC_GROUP = 1                             # set from --mc-group
-PRECISIONS = ["f16x3", "fp32", "bf16x3", "f16f8", "f16f6"]
+PRECISIONS = ["f16x3", "fp32", "f16w", "bf16x3", "f16f8", "f16f6"]
 
 # per precision mode: (kernel description, MFMA products executed per algorithmic product at the bf16 rate, dtype string)
 MODES = {
     "f16x3": ("k_wconv (csrc/conv_wino_f16x3.hip): LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
               "v_mfma_f32_16x16x32_f16 - four 1x3 row convolutions per two output rows (6 instead of 9 taps per pixel) on fp16 hi / lo "
-              "planes of the transformed, scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs per product, fp32 accumulate; the "
-              "8x8 level and the in / out convs on the direct kernels k_xconv_dma<NT, 3> / k_hconv<NT, RS>", 3.0,
+              "planes of the transformed, scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs per product, fp32 accumulate; every "
+              "ResBlock conv of the forward (70 of 72 conv3x3, the 8x8 level included); the input conv runs on the fp32 MFMA kernel and the "
+              "3-of-6-channel output conv as a one-tap GEMM + tap gather", 3.0,
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
               "(head dims <= 256) in this format, embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
     "fp32": ("k_wconv32 (csrc/conv_wino_f32.hip): exact-fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
              "v_mfma_f32_16x16x4_f32 (6 instead of 9 taps per pixel, products and sums in fp32); in / out convs on the direct fp32 MFMA "
              "kernel k_tile<MODE_CONV>", 1.0, "f32"),
+    "f16w": ("k_wconv1 (csrc/conv_wino_f16x3.hip): the Winograd F(2,3)-along-y LDS-DMA conv3x3 with ONE fp16 MFMA per tap on the hi images "
+             "of the transformed operands (fp16 x fp16 products, fp32 accumulate; half the DMA pieces and a third of the MFMAs of k_wconv)", 1.0,
+             "f16w (3x3 convs of the ResBlocks: fp16 operands, one product per tap, fp32 accumulation - the arithmetic class of the "
+             "reference's own GPU path under torch.autocast(fp16); everything else as f16x3.  NOT a parity mode: 11-bit operands)"),
     "bf16x3": ("k_xconv_dma<NT, 0> (LDS-DMA split-bf16 implicit-GEMM conv3x3, 3 x v_mfma_f32_32x32x16_bf16 per product)", 3.0,
                "bf16x3 (fp32 operands split into 2 bf16 terms = 16 significant bits, 3 bf16 MFMA products, fp32 accumulate)"),
     "f16f8": ("k_xconv_dma<NT, 1> (fp16 hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms on one block-scaled "
@@ -391,7 +396,9 @@ def parse_args(argv=None):
     ap.add_argument("--faithful-zigzag", action="store_true", help="execute the dead num_zigzag-1 forwards too")
     ap.add_argument("--mc-group", type=int, default=1, help="Monte-Carlo chains of a UC step per denoiser call (stacked batch)")
     ap.add_argument("--precision", choices=PRECISIONS, default="f16x3")
-    ap.add_argument("--secondary", default="fp32,f16f6", help="comma list of precision modes run for ONE job each after the headline (N=1 only)")
+    ap.add_argument("--secondary", default="fp32,f16w", help="comma list of precision modes run for ONE job each after the headline (N=1 only)")
+    ap.add_argument("--winograd", default="on", choices=["on", "off"],
+                    help="off: every 3x3 conv on the direct kernels (k_tile<MODE_CONV> in fp32, k_xconv_dma / k_hconv in f16x3) - the round-2 baselines")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the one-job runs of BASELINE configs[2] (U-ViT) and configs[4] (SD) at N=1")
@@ -487,6 +494,7 @@ def main(argv=None):
     from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
 
     model, base, sd = build_model(dev)
+    model.winograd = a.winograd == "on"
     # synthetic inputs exactly as scripts/generate_diffusion_starting_data.py:27-49, sharded by rank like the script (:51)
     g = torch.Generator().manual_seed(49394 + 1)         # dataset index k = 1 (imagenet128), SURVEY 8(d)
     X_all = torch.randn(a.batch * world, 3, 128, 128, generator=g)
@@ -496,11 +504,22 @@ def main(argv=None):
 
     ranks_seen = [world]
 
-    def job(n_steps, start, num, seed, M=None, faithful=None):
+    class PlainDDIM:
+        """The scheduler's plain DDIM steps behind an object that is NOT a SchedulerUncertaintyMixin: what the reference times as
+        `time_normal` (measure_times_imagenet.py:109-118 builds a diffusers DDIMScheduler from the same config; the driver then collects
+        no uncertainty maps).  The wrapped scheduler's window is empty, so every step() is the plain update (k_ddim_step)."""
+
+        def __init__(self, inner):
+            self._inner = inner
+
+        def __getattr__(self, name):
+            return getattr(self._inner, name)
+
+    def job(n_steps, start, num, seed, M=None, faithful=None, plain=False):
         s = make_scheduler(model, base, a.M if M is None else M, start, num, a.num_zigzag, seed,
                            a.faithful_zigzag if faithful is None else faithful)
         s.set_timesteps(n_steps)
-        r = gen(X_T, y, a.batch, dev, model, s)
+        r = gen(X_T, y, a.batch, dev, model, PlainDDIM(s) if plain else s)
         g_all = gather_images(r["gen_images"].to(dev))     # RCCL over xGMI: the only collective of the path
         assert g_all.shape[0] == world and g_all.shape[1] == a.batch, (tuple(g_all.shape), world, a.batch)
         ranks_seen[0] = min(ranks_seen[0], int(g_all.shape[0]))
@@ -551,7 +570,7 @@ def main(argv=None):
         def adm_leg(name, start, num, M, faithful, ref_fwd, note):
             sync()
             t0 = time.perf_counter()
-            uc = job(a.generation_steps, start, num, 77, M=M, faithful=faithful)
+            uc = job(a.generation_steps, start, num, 77, M=M, faithful=faithful, plain=(num == 0))
             sync()
             dt_ = time.perf_counter() - t0
             fwd = a.generation_steps + uc
@@ -601,7 +620,7 @@ def main(argv=None):
                        "zigzag_mode": "faithful (all forwards executed)" if a.faithful_zigzag else
                                       "skip_dead_zigzag (outputs identical; noise draws still consumed)",
                        "executed_forwards_per_image": fwd_per_img, "reference_forwards_per_image": ref_fwd,
-                       "noise": "device Philox (dua_randn)", "precision": a.precision, "parity": PARITY_NOTE,
+                       "noise": "device Philox (dua_randn)", "precision": a.precision, "winograd_convs": a.winograd, "parity": PARITY_NOTE,
                        "warmup_pass": f"{STEP_TIMESTEPS}-timestep job, last timestep in the UC window"},
             "end_to_end_tflops": round(exec_flops / dt / 1e12, 2),
             "value_at_reference_forward_count": round(images / dt * fwd_per_img / ref_fwd, 4),

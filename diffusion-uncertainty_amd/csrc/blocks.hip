@@ -56,7 +56,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     const int C = a->C1 + a->C2, G = 32;
     const int Ho = a->updown < 0 ? a->H / 2 : (a->updown > 0 ? 2 * a->H : a->H), Wo = a->updown < 0 ? a->W / 2 : (a->updown > 0 ? 2 * a->W : a->W);
     const long M = (long)a->N * Ho * Wo;
-    const bool f16 = a->precision == DUA_PREC_F16X3, colsum2 = a->Cout % 4 == 0;
+    const bool single = a->precision == DUA_PREC_F16W;                 // one fp16 product per tap in the Winograd-form convs
+    const bool f16 = a->precision == DUA_PREC_F16X3 || single, colsum2 = a->Cout % 4 == 0;
     float* stats1 = (float*)w.take((size_t)a->N * G * 2 * 4);
     float* gnws = (float*)w.take(dua_groupnorm_ws_floats(a->N, a->H * a->W > Ho * Wo ? a->H * a->W : Ho * Wo, C > a->Cout ? C : a->Cout, G) * 4);
     // two activation-sized regions, reused like the per-op composition's freed tensors (a smaller live footprint keeps more of
@@ -87,8 +88,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     if ((rc = gn_stats(a->x1, a->C1, a->x1_colsums, a->x2, a->C2, a->x2_colsums, a->N, a->H * a->W, G, gnws, stats1, stream))) return rc;
     if (wino1 && !f16) rc = dua_groupnorm_apply_wino_f32(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1,
                                                           a->updown, nullptr, h1, stream);
-    else if (wino1) rc = dua_groupnorm_apply_wino_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
-                                                   nullptr, 0.5f * a->act_scale, h1, stream);
+    else if (wino1) rc = (single ? dua_groupnorm_apply_wino_f16w : dua_groupnorm_apply_wino_f16x3)(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w,
+                                                   a->gn1_b, nullptr, 0, 1, a->updown, nullptr, 0.5f * a->act_scale, h1, stream);
     else if (f16) rc = dua_groupnorm_apply_split_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
                                                   nullptr, a->act_scale, h1, stream);
     else rc = dua_groupnorm_apply(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown, nullptr,
@@ -98,18 +99,19 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     {
         ConvTimer tm(stream);
         if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
-        else if (wino1) rc = dua_conv3x3_f16x3_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.5f * a->act_scale, stream);
+        else if (wino1) rc = (single ? dua_conv3x3_f16w_wino : dua_conv3x3_f16x3_wino)(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2,
+                                                                                       0.5f * a->act_scale, stream);
         else if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
         else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
-        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, (f16 ? 3.0 : 1.0) * (wino1 ? 2.0 / 3.0 : 1.0));
+        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, (f16 ? ((single && wino1) ? 1.0 : 3.0) : 1.0) * (wino1 ? 2.0 / 3.0 : 1.0));
     }
     if (rc) return rc;
     // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
     if ((rc = gn_stats(h2, a->Cout, cs2, nullptr, 0, nullptr, a->N, Ho * Wo, G, gnws, stats2, stream))) return rc;
     if (wino2 && !f16) rc = dua_groupnorm_apply_wino_f32(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
                                                           a->dropmask, h3, stream);
-    else if (wino2) rc = dua_groupnorm_apply_wino_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
-                                                   a->dropmask, 0.5f * a->act_scale, h3, stream);
+    else if (wino2) rc = (single ? dua_groupnorm_apply_wino_f16w : dua_groupnorm_apply_wino_f16x3)(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b,
+                                                   a->film, a->film_ld, 1, 0, a->dropmask, 0.5f * a->act_scale, h3, stream);
     else if (f16) rc = dua_groupnorm_apply_split_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
                                                   a->dropmask, a->act_scale, h3, stream);
     else rc = dua_groupnorm_apply(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0, a->dropmask,
@@ -137,10 +139,11 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0");
     ConvTimer tm(stream);
     if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
-    else if (wino2) rc = dua_conv3x3_f16x3_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.5f * a->act_scale, stream);
+    else if (wino2) rc = (single ? dua_conv3x3_f16w_wino : dua_conv3x3_f16x3_wino)(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs,
+                                                                                   0.5f * a->act_scale, stream);
     else if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
     else rc = dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
-    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, (f16 ? 3.0 : 1.0) * (wino2 ? 2.0 / 3.0 : 1.0));
+    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, (f16 ? ((single && wino2) ? 1.0 : 3.0) : 1.0) * (wino2 ? 2.0 / 3.0 : 1.0));
     return rc;
 }
 
@@ -250,14 +253,15 @@ int check_uvitblock(const dua_uvitblock_args* a) {
 int check_resblock(const dua_resblock_args* a) {
     DUA_REQUIRE(a && a->x1 && a->y && a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_packed && a->conv2_packed && a->film,
                 "dua_adm_resblock_fwd: null pointer");
-    DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3, "dua_adm_resblock_fwd: precision must be DUA_PREC_FP32 or DUA_PREC_F16X3");
+    DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3 || a->precision == DUA_PREC_F16W,
+                "dua_adm_resblock_fwd: precision must be DUA_PREC_FP32, DUA_PREC_F16X3 or DUA_PREC_F16W");
     DUA_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->C1 > 0 && a->C2 >= 0 && a->Cout > 0 && (a->C1 + a->C2) % 32 == 0 && a->Cout % 32 == 0,
                 "dua_adm_resblock_fwd: channel counts must be positive multiples of 32 (GroupNorm32)");
     DUA_REQUIRE((a->C2 == 0) == (a->x2 == nullptr), "dua_adm_resblock_fwd: x2 / C2 mismatch");
     DUA_REQUIRE(a->updown >= -1 && a->updown <= 1 && (a->updown == 0 || (a->C2 == 0 && !a->skip_packed && !a->dropmask)),
                 "dua_adm_resblock_fwd: a resampling block takes one source, an identity skip and no dropout mask");
     DUA_REQUIRE(a->skip_packed || a->C1 + a->C2 == a->Cout, "dua_adm_resblock_fwd: a channel-changing block needs the 1x1 skip weights");
-    DUA_REQUIRE(a->precision != DUA_PREC_F16X3 || (a->act_scale > 0.f && a->raw_scale > 0.f && a->C1 % 32 == 0), "dua_adm_resblock_fwd: f16x3 needs positive scales and C1 %% 32 == 0");
+    DUA_REQUIRE(a->precision == DUA_PREC_FP32 || (a->act_scale > 0.f && a->raw_scale > 0.f && a->C1 % 32 == 0), "dua_adm_resblock_fwd: f16x3 needs positive scales and C1 %% 32 == 0");
     return DUA_OK;
 }
 

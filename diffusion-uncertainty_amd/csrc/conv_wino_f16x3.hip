@@ -318,6 +318,218 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_wconv1: the same convolution with ONE fp16 product per tap (precision mode "f16w": fp16 operands, fp32 accumulation - the arithmetic
+// of the reference's own GPU path, torch.autocast fp16, scripts/generate_dataset_score_uncertainty_imagenet.py:83; GroupNorm and
+// softmax stay fp32 as nn.py:17-19).  Same tile, rings, stage blocks and epilogue as k_wconv; only the hi images of the activation and
+// weight stages are fetched and multiplied (half the DMA pieces, a third of the MFMAs).  A step is then 16 MFMAs per wave, too short to
+// hide a fragment read behind a later phase, so the fragments are double-buffered in registers: right after the barrier that publishes
+// stage s + 1 the wave requests that stage's fragments into the other set and then issues the 16 MFMAs of stage s from this one.
+// NOT a parity mode (11-bit operands); reported by bench.py under other_precision_modes only.
+__global__ __launch_bounds__(512, 2) void k_wconv1(WConvP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int RA = 2, RB = 3;
+    constexpr int SA = WROWS * WLD, SB = WROWS * WLD;
+    constexpr int BOFF = 0, AOFF = RB * 2 * SB;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[RA * 2 * SA + RB * 2 * SB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp_w = wave >> 2, ph = wm & 1;
+    const int ntiles = p.ntm * p.ntn;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
+    constexpr int OOBL = 0x40000;
+    const int dl_row = lane >> 2;
+    const int dl_src = (lane & 3) ^ (2 * ((lane >> 4) & 1));
+    const int lr = lane & 15, lc = lane >> 4;
+
+    unsigned abase[2] = {0, 0}, boff[2] = {0, 0};
+    auto ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, 0, 0x00020000);
+    auto ra1 = ra0;
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
+    int grpA = 0;
+    unsigned vo0 = 0, vo1 = 0;
+    bool prefetched = false;
+    const int f_a = grp_w == 0 ? 1 : 0, f_b = grp_w == 0 ? 2 : 3;
+    const int ncb = p.Cin / 32;
+    auto tile_geom = [&](int m0_, int tn_) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            abase[j] = (unsigned)((16 * ((2 * wave + j) & 7) + dl_row) * 64 + 16 * dl_src);
+            boff[j] = (unsigned)((long)tn_ * (p.K / 32) * 32768 + (16 * (2 * wave + j) + dl_row) * 64 + 16 * dl_src);
+        }
+        const int rec = ncb * 16384;
+        const long tmi = m0_ >> 7;
+        ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.V + (((long)f_a * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
+        ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)p.V + (((long)f_b * p.ntm + tmi) * ncb) * 8192), 0, rec, 0x00020000);
+        grpA = 0;
+    };
+    bool fiA = false;
+    auto a_setup = [&]() {
+        const unsigned toff = (unsigned)((grpA >> 1) * 16384);
+        vo0 = abase[0] + toff;
+        vo1 = abase[1] + toff;
+        fiA = (grpA & 1) != 0;
+        ++grpA;
+    };
+    auto dma_a = [&](int sa, int j) {                      // hi piece of this wave's row group j = 0, 1
+        _Float16* st = lds + AOFF + sa * 2 * SA;
+        const auto r = fiA ? ra1 : ra0;
+        if (j == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, st + (16 * (2 * wave)) * WLD, 16, vo0, 0, 0, 0);
+        if (j == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, st + (16 * (2 * wave + 1)) * WLD, 16, vo1, 0, 0, 0);
+    };
+    auto dma_b = [&](int sb, int j) {                      // hi piece of this wave's weight row group j = 0, 1; advances to the next K step
+        _Float16* st = lds + BOFF + sb * 2 * SB;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            if (jj == j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + (16 * (2 * wave + jj)) * WLD, 16, boff[jj], 0, 0, 0);
+                boff[jj] += 32768;
+            }
+    };
+    auto issue_prologue = [&]() {          // A(group 0) B(0) B(1)
+        a_setup();
+        dma_a(0, 0); dma_a(0, 1);
+        dma_b(0, 0); dma_b(0, 1);
+        dma_b(1, 0); dma_b(1, 1);
+    };
+
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const int off_l = lr * 64 + 16 * (lc ^ (2 * ((lr >> 2) & 1)));
+    const int a_row0 = AOFF * 2 + wm * 64 * 64, b_row0 = BOFF * 2 + (grp_w * 128 + wn * 64) * 64;
+    auto x_off = [&](int dx) -> int {
+        const int r_ = lr + dx;
+        return r_ * 64 + 16 * (lc ^ (2 * (((r_ + 64) >> 2) & 1)));
+    };
+#if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
+    constexpr bool ZSEL = true;
+#else
+    constexpr bool ZSEL = false;
+#endif
+    const int zero_addr = OOBL + (lane & 1) * 16;
+    const int ax0 = a_row0 + x_off(0);
+    int axm[4], axp[4];
+    unsigned xedge = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x_ = (ph * 64 + 16 * i + lr) & (p.W - 1);
+        xedge |= (x_ == 0 ? 1u : 0u) << i | (x_ == p.W - 1 ? 1u : 0u) << (4 + i);
+        axm[i] = (!ZSEL && x_ == 0) ? zero_addr : a_row0 + x_off(-1);
+        axp[i] = (!ZSEL && x_ == p.W - 1) ? zero_addr : a_row0 + x_off(1);
+    }
+    const int aw0 = b_row0 + off_l, aw2 = aw0 + 2 * 2 * SB * 2;
+
+    for (int ti = slot; ti < chunk_n; ti += nslot) {
+        const int lid = chunk0 + ti;
+        const int tn = lid % p.ntn, tm = lid / p.ntn;
+        const int m0 = tm * 128, n0 = tn * 128;
+        if (!prefetched) {
+            tile_geom(m0, tn);
+            issue_prologue();
+        }
+        const bool after_epilogue = prefetched;
+        prefetched = false;
+
+        f32x4 acc0[4][4], acc1[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc0[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        h16x8 xA[4], wA[4], xB[4], wB[4];            // two fragment sets, alternating between steps
+        auto rd_x = [&](int sa, int i, int dx) -> h16x8 {
+            const int a = dx < 0 ? axm[i] : (dx > 0 ? axp[i] : ax0);
+            const h16x8 v = *(const h16x8*)(ldsb + a + (sa * 2 * SA * 2 + 16 * i * 64));
+            if (ZSEL && dx != 0) {
+                const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                return ((xedge >> (dx < 0 ? i : 4 + i)) & 1u) ? z : v;
+            }
+            return v;
+        };
+        auto rd_w = [&](int sb, int jj) -> h16x8 {
+            return *(const h16x8*)(ldsb + (sb == 2 ? aw2 : aw0) + ((sb == 2 ? 0 : sb * 2 * SB * 2) + 16 * jj * 64));
+        };
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+        static_assert(WCONV_EPILOGUE_STORES == 16, "the immediate below");
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xA[i] = rd_x(0, i, -1);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) wA[jj] = rd_w(0, jj);
+        WSB();
+
+        // One K step = (channel block, fi, dx): the DMA pieces of later stages, the barrier that publishes the next stage, that stage's
+        // fragments into the OTHER register set, then this step's 16 MFMAs (they also cover the barrier of the next step)
+        auto step = [&](auto fi_c, auto dxi_c, auto last_c, f32x4 (&A)[4][4], h16x8 (&XC)[4], h16x8 (&WC)[4], h16x8 (&XN)[4], h16x8 (&WN)[4])
+                        __attribute__((always_inline)) {
+            constexpr int FI = decltype(fi_c)::value, DXI = decltype(dxi_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            constexpr bool preA = !LAST && DXI == 0;
+            constexpr bool pieceA = !LAST && DXI < 2;                           // one activation piece in each of the group's first two steps
+            constexpr bool preB = !LAST || DXI == 0;
+            constexpr bool more = !LAST || DXI < 2;
+            constexpr int sa_n = FI ^ 1, sb_n = (DXI + 2) % 3;
+            constexpr int sa_r = DXI == 2 ? (FI ^ 1) : FI, sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;
+            if (preA) { a_setup(); fiA = FI == 0; }
+            WSB();
+            if (preB) { dma_b(sb_n, 0); dma_b(sb_n, 1); }
+            if (pieceA) dma_a(sa_n, DXI);
+            WSB();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                // in issue order: [B(s+1) x2, A x1] of the previous step, [B(s+2) x2, A x1] of this one.  B(s+1) must have landed; the
+                // group's last step also needs both activation pieces
+                constexpr int keep = LAST ? (preB ? 2 : 0) : (DXI == 0 ? 3 : (DXI == 1 ? 4 : 2));
+                if (keep == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (keep == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            WSB();
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) XN[i] = rd_x(sa_r, i, dxn);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) WN[jj] = rd_w(sb_r, jj);
+            }
+            WSB();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A[jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WC[jj], XC[i], A[jj][i], 0, 0, 0);
+                    WSB();
+                }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using BF = std::integral_constant<bool, false>;
+        using BT = std::integral_constant<bool, true>;
+        // six steps per channel block: the fragment sets alternate A B A B A B, so every channel block starts on set A
+#pragma nounroll
+        for (int cbi = 0; cbi < ncb - 1; ++cbi) {
+            step(I0{}, I0{}, BF{}, acc0, xA, wA, xB, wB); step(I0{}, I1{}, BF{}, acc0, xB, wB, xA, wA); step(I0{}, I2{}, BF{}, acc0, xA, wA, xB, wB);
+            step(I1{}, I0{}, BF{}, acc1, xB, wB, xA, wA); step(I1{}, I1{}, BF{}, acc1, xA, wA, xB, wB); step(I1{}, I2{}, BF{}, acc1, xB, wB, xA, wA);
+        }
+        step(I0{}, I0{}, BF{}, acc0, xA, wA, xB, wB); step(I0{}, I1{}, BF{}, acc0, xB, wB, xA, wA); step(I0{}, I2{}, BF{}, acc0, xA, wA, xB, wB);
+        step(I1{}, I0{}, BT{}, acc1, xB, wB, xA, wA); step(I1{}, I1{}, BT{}, acc1, xA, wA, xB, wB); step(I1{}, I2{}, BT{}, acc1, xB, wB, xA, wA);
+        if (ti + nslot < chunk_n) {
+            const int nl = chunk0 + ti + nslot;
+            tile_geom((nl / p.ntn) * 128, nl % p.ntn);
+            issue_prologue();
+            prefetched = true;
+        }
+#undef WSB
+        wconv_epilogue(p, acc0, acc1, reinterpret_cast<char*>(lds), wave, lane, m0, n0);
+    }
+#endif
+}
+
 // =================================== weight packer ===========================================
 // frequency of (group, fi): group 0 (waves 0-3) holds f = 1, 2; group 1 holds f = 0, 3
 __device__ __forceinline__ double wino_u(const float* __restrict__ w, int cout, int ci, int dx, int f, int Cin) {
@@ -398,8 +610,8 @@ extern "C" int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, in
     return ((long)H * W) % 128 == 0 ? 1 : 2;
 }
 
-extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
-                                      int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
+static int conv3x3_wino_impl(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                             int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream, bool single) {
     DUA_REQUIRE(vplanes && packed && y, "dua_conv3x3_f16x3_wino: null pointer");
     DUA_REQUIRE(res_resample >= -1 && res_resample <= 1 && (res_resample <= 0 || W >= 2), "dua_conv3x3_f16x3_wino: res_resample must be -1, 0 or +1");
     DUA_REQUIRE(v_scale > 0.f, "dua_conv3x3_f16x3_wino: v_scale must be positive");
@@ -415,8 +627,18 @@ extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, c
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
     p.out_scale = 1.0f / v_scale;
     const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(k_wconv, dim3(grid), 512, 0, as_stream(stream), p);
+    if (single) hipLaunchKernelGGL(k_wconv1, dim3(grid), 512, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(k_wconv, dim3(grid), 512, 0, as_stream(stream), p);
     return dua_check_launch("dua_conv3x3_f16x3_wino");
+}
+extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                                      int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
+    return conv3x3_wino_impl(vplanes, packed, bias, residual, res_resample, y, N, H, W, Cin, Cout, colsum, v_scale, stream, false);
+}
+// ... with one fp16 product per tap (mode "f16w"): reads only the hi images of the planes and of the packed weights
+extern "C" int dua_conv3x3_f16w_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                                     int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
+    return conv3x3_wino_impl(vplanes, packed, bias, residual, res_resample, y, N, H, W, Cin, Cout, colsum, v_scale, stream, true);
 }
 
 // =================================== GroupNorm apply -> V planes ===========================================
@@ -437,7 +659,7 @@ struct GnWinoP {
 // STREAM (maps at least 16 wide, no pooling, no dropout mask - every conv of the sampling jobs but the down blocks' first): the two new
 // rows of the NEXT row pair are requested before this pair's eight stores go out, so a wave always has 64 bytes per lane of loads in
 // flight behind its stores instead of waiting for one row at a time.  Same arithmetic, same bits.
-template <bool F32, bool STREAM>
+template <bool F32, bool STREAM, bool HI_ONLY = false>
 __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
     const int C = p.C1 + p.C2, ncb = C / 32, cpg = C / p.G;
     const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
@@ -535,7 +757,7 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
         _Float16* o = p.v + ((((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 2) * 4096 + (m & 127) * 32 + (c & 31);
         // written once, read by the next kernel: non-temporal stores (the small maps gain 25 - 35 % in this kernel, the job +0.6 %)
         __builtin_nontemporal_store(h, (h16x8*)o);
-        __builtin_nontemporal_store(l, (h16x8*)(o + 4096));
+        if (!HI_ONLY) __builtin_nontemporal_store(l, (h16x8*)(o + 4096));     // (mode "f16w": the conv reads the hi images only)
     };
     const int j0 = jc * p.JC + jo, j1 = min(P, (jc + 1) * p.JC);
     float dA[8], dB[8], dC[8], dD[8];
@@ -623,7 +845,7 @@ extern "C" size_t dua_f16x3_wino_act_bytes(int N, int Ho, int Wo, int C) {
 
 static int gn_apply_wino_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
-                              int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream, bool f32) {
+                              int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream, bool f32, bool hi_only = false) {
     const int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && vplanes, "dua_groupnorm_apply_wino_f16x3: null pointer");
     DUA_REQUIRE(C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % 32 == 0, "dua_groupnorm_apply_wino_f16x3: channel counts must be multiples of 8 (sum of 32)");
@@ -651,7 +873,9 @@ static int gn_apply_wino_impl(const float* x1, int C1, const float* x2, int C2, 
     p.JC = JC;
     const dim3 grid(nxb * ((P + JC - 1) / JC), N);
     const bool strm = resample >= 0 && !dropmask && Wo >= 16;
-    if (f32 && strm) hipLaunchKernelGGL((k_gn_apply_wino<true, true>), grid, BLK, 0, as_stream(stream), p);
+    if (hi_only && strm) hipLaunchKernelGGL((k_gn_apply_wino<false, true, true>), grid, BLK, 0, as_stream(stream), p);
+    else if (hi_only) hipLaunchKernelGGL((k_gn_apply_wino<false, false, true>), grid, BLK, 0, as_stream(stream), p);
+    else if (f32 && strm) hipLaunchKernelGGL((k_gn_apply_wino<true, true>), grid, BLK, 0, as_stream(stream), p);
     else if (f32) hipLaunchKernelGGL((k_gn_apply_wino<true, false>), grid, BLK, 0, as_stream(stream), p);
     else if (strm) hipLaunchKernelGGL((k_gn_apply_wino<false, true>), grid, BLK, 0, as_stream(stream), p);
     else hipLaunchKernelGGL((k_gn_apply_wino<false, false>), grid, BLK, 0, as_stream(stream), p);
@@ -661,6 +885,12 @@ extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const flo
                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
                                               int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
     return gn_apply_wino_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, v_scale, vplanes, stream, false);
+}
+// ... the hi images only (mode "f16w", operand of dua_conv3x3_f16w_wino): same layout, the lo halves of the stage blocks are not written
+extern "C" int dua_groupnorm_apply_wino_f16w(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                             const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                             int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+    return gn_apply_wino_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, v_scale, vplanes, stream, false, true);
 }
 // ... the four transformed images in fp32 (same stage-block layout with [128][32] floats per block, same byte count): the operand of
 // dua_conv3x3_f32_wino (conv_wino_f32.hip), the exact-fp32 mode

@@ -322,15 +322,18 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
                                                           _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
                                                           _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f32")
             return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), "f32w", 1.0)
-        if split == "f16x3w":
+        if split in ("f16x3w", "f16w"):
             # Winograd F(2,3)-along-y operand of conv3x3 (csrc/conv_wino_f16x3.hip): the four V_f images as f16x3 planes of V * scale
+            # ("f16w": only the hi images are written - the operand of the single-product conv, mode "f16w")
             scale = 0.5 * F16X3_ACT_SCALE if split_scale is None else float(split_scale)
             ntm = (N * (Ho // 2) * Wo + 127) // 128
             vbuf = torch.empty((4, ntm, (C1 + C2) // 32, 2, 128, 32), device=x1.device, dtype=torch.int16)   # [f][tile][cb][hi | lo][128][32]
-            check(_lib.lib().dua_groupnorm_apply_wino_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
-                                                            _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
-                                                            scale, _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f16x3")
-            return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), "f16x3w", scale)
+            fn = _lib.lib().dua_groupnorm_apply_wino_f16w if split == "f16w" else _lib.lib().dua_groupnorm_apply_wino_f16x3
+            if split == "f16w":
+                vbuf.zero_()                       # (the lo halves stay unwritten: defined contents for tests that decode the buffer)
+            check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film), _film_ld(film, N, C1 + C2), int(act),
+                     int(resample), _p(dropmask), scale, _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f16x3")
+            return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), split, scale)
         if fmt == "f16x3":
             scale = F16X3_ACT_SCALE if split_scale is None else float(split_scale)
             check(_lib.lib().dua_groupnorm_apply_split_f16x3(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
@@ -670,7 +673,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
     N, H, W, Cin = x.shape
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
     ws = _colsum_ws(N * H * W, cout, x.device, colsum and not nchw_out)
-    assert res_resample == 0 or (pre and x.fmt in ("f16x3w", "f32w") and residual is not None), "res_resample is a Winograd-conv option"
+    assert res_resample == 0 or (pre and x.fmt in ("f16x3w", "f16w", "f32w") and residual is not None), "res_resample is a Winograd-conv option"
     if res_resample:
         rs = (N, H // 2, W // 2, cout) if res_resample > 0 else (N, 2 * H, 2 * W, cout)
         assert tuple(residual.shape) == rs and residual.is_contiguous() and residual.dtype == torch.float32, f"residual must be fp32 {rs}"
@@ -684,13 +687,13 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
             ws = None
         check(_lib.lib().dua_conv3x3_f32_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws), _stream()),
               "dua_conv3x3_f32_wino")
-    elif pre and x.fmt == "f16x3w":
+    elif pre and x.fmt in ("f16x3w", "f16w"):
         assert not nchw_out, "the Winograd conv writes NHWC"
         if (H * W) % 128:
             ws = None                                  # small maps: no column sums from the Winograd kernel
-        check(_lib.lib().dua_conv3x3_f16x3_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws),
-                                                x.scale,
-                                                _stream()), "dua_conv3x3_f16x3_wino")
+        fn = _lib.lib().dua_conv3x3_f16w_wino if x.fmt == "f16w" else _lib.lib().dua_conv3x3_f16x3_wino
+        check(fn(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws), x.scale, _stream()),
+              "dua_conv3x3_f16x3_wino")
     elif pre and x.fmt == "f16x3":
         check(_lib.lib().dua_conv3x3_f16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
                                                     _p(ws), x.scale, _stream()), "dua_conv3x3_f16x3_presplit")
@@ -704,7 +707,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
                                             _p(ws), _stream()), "dua_conv3x3_bf16x3")
     if PROFILE is not None:
         e1.record()
-        PROFILE.record("conv3x3_wino" if (pre and x.fmt in ("f16x3w", "f32w")) else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
+        PROFILE.record("conv3x3_wino" if (pre and x.fmt in ("f16x3w", "f16w", "f32w")) else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
     return _attach_colsums(y, ws, H * W)
 
 
@@ -1094,7 +1097,7 @@ def unpatchify(tok, B, L, extras, C, P):
 
 
 # ------------------------------------------------------------------ block-level entry points
-PRECISION_CODE = {"fp32": 0, "f16x3": 3}
+PRECISION_CODE = {"fp32": 0, "f16x3": 3, "f16w": 4}          # "f16w": dua_adm_resblock_fwd only (DUA_PREC_F16W)
 
 
 def _cs(t):

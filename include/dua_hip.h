@@ -335,6 +335,14 @@ int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int
 int dua_conv3x3_f16x3_wino_supported(int N, int H, int W, int Cin, int Cout);
 int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                            int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
+/* Mode "f16w": the Winograd form with one fp16 product per tap.  The writer stores only the hi images of the stage blocks (4 bytes
+ * written per input element instead of 8), the conv fetches and multiplies only the hi images of the planes and of the packed weights
+ * (same buffers, same packing: dua_f16x3_wino_act_bytes / dua_pack_weight_f16x3_wino). */
+int dua_groupnorm_apply_wino_f16w(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                  const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                  int resample, const float* dropmask, float v_scale, void* vplanes, void* stream);
+int dua_conv3x3_f16w_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                          int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
 /* The same form in EXACT fp32 (csrc/conv_wino_f32.hip, v_mfma_f32_16x16x4_f32: products and sums in fp32 - the Winograd form of
  * dua_conv3x3): the transformed images and the packed weights hold floats in the same stage-block layout (same byte counts:
  * dua_f16x3_wino_act_bytes / dua_f32_wino_weight_bytes), shapes as dua_conv3x3_f16x3_wino_supported. */
@@ -424,6 +432,10 @@ int dua_transpose_batched(const float* in, float* out, int R, int Cc, long ld_in
  * NULL; y_colsums (optional, [ceil(N*H*W/64)][2][Cout] floats) receives those of the block's output. */
 #define DUA_PREC_FP32 0
 #define DUA_PREC_F16X3 3
+/* dua_adm_resblock_fwd only: DUA_PREC_F16X3 with ONE fp16 product per tap in the Winograd-form 3x3 convs (conv*_wino given and the shape
+ * supported) - fp16 operands, fp32 accumulation: the arithmetic of the reference's own GPU path (torch.autocast fp16, script :83); every
+ * other operation as DUA_PREC_F16X3.  Not a parity mode (11-bit operands): mode "f16w" of the Python host, reported beside the headline. */
+#define DUA_PREC_F16W 4
 typedef struct {
     const float* x1; int C1;             /* input; (x2, C2) = the skip half of the channel concat of unet_openai.py:662, or (NULL, 0) */
     const float* x2; int C2;

@@ -163,6 +163,99 @@ def test_conv3x3_wino_vs_fp64(ops, N, H, W, Cin, Cout):
     assert torch.equal(y, y1)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 64, 96), (3, 64, 64, 64, 256), (130, 16, 16, 64, 64), (513, 16, 8, 32, 192), (128, 8, 8, 128, 128)])
+def test_conv3x3_f16w_single_product(ops, N, H, W, Cin, Cout):
+    """Mode "f16w" (csrc/conv_wino_f16x3.hip k_wconv1): the Winograd conv with ONE fp16 product per tap on the hi images only.
+    (a) operands that are exactly representable in the hi planes (small dyadic rationals): the lo halves are zero, so the single-product
+    kernel must equal the three-product kernel BIT FOR BIT (same hi*hi products in the same order) and fp64 to fp32-accumulation level;
+    (b) random operands: an 11-bit-operand error (fp16 autocast class), far above f16x3's and far below a wrong-tap error."""
+    assert ops.conv3x3_wino_supported(N, H, W, Cin, Cout)
+    g = torch.Generator().manual_seed(7)
+    st = identity_stats(N)
+    one, zero = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    # (a) exact operands
+    x = torch.randint(-64, 65, (N, Cin, H, W), generator=g).float() / 16.0
+    w = (2 * torch.randint(-16, 17, (Cout, Cin, 3, 3), generator=g)).float() / 64.0
+    b, res = rnd(31, Cout), rnd(32, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    xd = nhwc(x).to(dev)
+    wp = ops.pack_weight_f16x3_wino(w.to(dev))
+    v1 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16w")
+    v3 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3w")
+    hi1 = v1.buf.view(torch.float16)[:, :, :, 0]
+    assert torch.equal(hi1, v3.buf.view(torch.float16)[:, :, :, 0])                 # the same hi images
+    assert (v3.buf.view(torch.float16)[:, :, :, 1] == 0).all()                      # ... and nothing left for the lo images
+    y1 = ops.conv3x3_bf16x3(v1, wp, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    y3 = ops.conv3x3_bf16x3(v3, wp, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    assert torch.equal(y1, y3)
+    e = ((nchw(y1.cpu()).double() - ref).abs().max() / ref.abs().max()).item()
+    assert e < 2e-6, e
+    if (H * W) % 128 == 0:
+        assert torch.equal(y1._dua_colsums, y3._dua_colsums)
+    # (b) random operands
+    x, w = rnd(33, N, Cin, H, W), rnd(34, Cout, Cin, 3, 3) / math.sqrt(9 * Cin)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    xd = nhwc(x).to(dev)
+    wp = ops.pack_weight_f16x3_wino(w.to(dev))
+    y1 = ops.conv3x3_bf16x3(ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16w"), wp, None, Cout)
+    y3 = ops.conv3x3_bf16x3(ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3w"), wp, None, Cout)
+    sc = ref.abs().max()
+    e1, e3 = ((nchw(y1.cpu()).double() - ref).abs().max() / sc).item(), ((nchw(y3.cpu()).double() - ref).abs().max() / sc).item()
+    print(f"f16w rel err {e1:.2e} (f16x3 {e3:.2e})")
+    assert 10 * e3 < e1 < 2e-3, (e1, e3)
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout", [(128, 128, 256, 256), (128, 64, 512, 512)])
+def test_headline_geometry_writer_wconv(ops, N, H, Cin, Cout):
+    """The geometry of the headline job itself (BASELINE configs[1]: batch 128 at 128^2 x 256 channels = 2^21 positions, 8.6 GB of V
+    planes, 32 768 tiles on 256 persistent workgroups; and 64^2 x 512): GroupNorm + FiLM + SiLU writer -> k_wconv with a residual and
+    the column sums, against the direct f16x3 kernel on planes written from the same input (every tile index, descriptor rebase and
+    persistent-loop path of the full-size launch), and against fp64 on sampled images.  Shapes of init_model.py:21 at --batch-size 128
+    (readme.md:116)."""
+    torch.cuda.empty_cache()
+    W = H
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(N, H, W, Cin, device=dev, generator=g)
+    x += 0.5 * torch.randn(N, 1, 1, Cin, device=dev, generator=g)                   # per-image channel offsets: statistics that differ per image
+    gamma, beta = torch.randn(Cin, device=dev, generator=g), 0.3 * torch.randn(Cin, device=dev, generator=g)
+    film = 0.5 * torch.randn(N, 2 * Cin, device=dev, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) / math.sqrt(9 * Cin)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    res = torch.randn(N, H, W, Cout, device=dev, generator=g)
+    st = ops.groupnorm_stats(x)
+    xv = ops.groupnorm_apply(x, st, gamma, beta, film=film, act=1, split="f16x3w")
+    yw = ops.conv3x3_bf16x3(xv, ops.pack_weight_f16x3_wino(w), b, Cout, residual=res, colsum=True)
+    del xv
+    xs = ops.groupnorm_apply(x, st, gamma, beta, film=film, act=1, split="f16x3")
+    yd = ops.conv3x3_bf16x3(xs, ops.pack_weight_f16x3(w), b, Cout, residual=res, colsum=True)
+    del xs
+    scale = yd.abs().max().item()
+    dmax = 0.0
+    for i in range(0, N, 16):                                                        # chunked: keeps the temporaries small
+        dmax = max(dmax, (yw[i:i + 16] - yd[i:i + 16]).abs().max().item())
+    print(f"N={N} {H}^2 {Cin}->{Cout}: max |winograd - direct| = {dmax:.3e} (output scale {scale:.2f})")
+    assert dmax < 3e-5 * max(1.0, scale)
+    # the next GroupNorm's statistics from the epilogue's column sums: both kernels, every image
+    s_w, s_d = ops.groupnorm_stats(yw), ops.groupnorm_stats(yd)
+    s_ref = ops.groupnorm_stats(yd.clone())                                          # (a clone carries no column sums: the statistics kernel)
+    np.testing.assert_allclose(s_w.cpu().numpy(), s_ref.cpu().numpy(), rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(s_d.cpu().numpy(), s_ref.cpu().numpy(), rtol=3e-4, atol=3e-5)
+    # fp64 on sampled images (first, last, and two in the middle whose tiles sit behind a few thousand others)
+    stc = st.cpu().double().reshape(N, 32, 2)
+    for i in (0, 41, 86, N - 1):
+        xi = x[i].cpu().double().permute(2, 0, 1)[None]                               # [1, C, H, W]
+        mean, rstd = stc[i, :, 0].repeat_interleave(Cin // 32), stc[i, :, 1].repeat_interleave(Cin // 32)
+        a = (xi - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1) * gamma.cpu().double().view(1, -1, 1, 1) + beta.cpu().double().view(1, -1, 1, 1)
+        fi = film[i].cpu().double()
+        a = F.silu(a * (1 + fi[:Cin]).view(1, -1, 1, 1) + fi[Cin:].view(1, -1, 1, 1))
+        ref = F.conv2d(a, w.cpu().double(), b.cpu().double(), padding=1) + res[i].cpu().double().permute(2, 0, 1)[None]
+        e = (yw[i].cpu().double().permute(2, 0, 1)[None] - ref).abs().max().item()
+        print(f"  image {i}: max |winograd - fp64| = {e:.3e}")
+        assert e < 2e-5 * max(1.0, ref.abs().max().item()), (i, e)
+    del x, yw, yd, res
+    torch.cuda.empty_cache()
+
+
 def test_conv3x3_wino_unsupported_shapes(ops):
     assert ops.conv3x3_wino_supported(2, 8, 8, 64, 64)              # small map: taken, without the column-sum output
     assert not ops.conv3x3_wino_supported(2, 15, 16, 64, 64)        # odd H
