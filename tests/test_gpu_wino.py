@@ -182,9 +182,7 @@ def test_conv3x3_f16w_single_product(ops, N, H, W, Cin, Cout):
     wp = ops.pack_weight_f16x3_wino(w.to(dev))
     v1 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16w")
     v3 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3w")
-    hi1 = v1.buf.view(torch.float16)[:, :, :, 0]
-    assert torch.equal(hi1, v3.buf.view(torch.float16)[:, :, :, 0])                 # the same hi images
-    assert (v3.buf.view(torch.float16)[:, :, :, 1] == 0).all()                      # ... and nothing left for the lo images
+    assert torch.equal(decode_v(v1), decode_v(v3))          # the same hi images, and nothing left for the lo images (valid positions)
     y1 = ops.conv3x3_bf16x3(v1, wp, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
     y3 = ops.conv3x3_bf16x3(v3, wp, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
     assert torch.equal(y1, y3)
