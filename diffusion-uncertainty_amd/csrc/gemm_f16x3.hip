@@ -147,9 +147,11 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
                 if (p.act_out == 2) { v.x = hg_gelu(v.x); v.y = hg_gelu(v.y); v.z = hg_gelu(v.z); v.w = hg_gelu(v.w); }
                 v.x += rq[h].x; v.y += rq[h].y; v.z += rq[h].z; v.w += rq[h].w;
                 const bool ok = cok && row < p.M;
+                const bool xcol = p.Cextra && c >= p.extra_from;              // (uniform per 32-column pair: extra_from % 32 == 0)
                 const u32x4 vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (ok && !(HG_DIAG & 2)) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
-                if (p.Cextra) {               // the same values as f16x3 planes (operand of a later presplit GEMM)
+                if (!(xcol && p.extra_only))
+                    __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (ok && !(HG_DIAG & 2)) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
+                if (xcol) {                   // the same values as f16x3 planes (operand of a later presplit GEMM / the attention kernel)
                     typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     const float f[4] = {v.x * p.split_scale, v.y * p.split_scale, v.z * p.split_scale, v.w * p.split_scale};

@@ -11,6 +11,7 @@ struct HGemmP {
     float* C;                    // EPI 0: fp32 [M][N] = act(acc * Cscale * out_scale + bias) + res
     _Float16* Cplanes;           // EPI 1: f16x3 planes [hi | lo][M][N] of act(acc * Cscale * out_scale + bias) * split_scale
     _Float16* Cextra;            // EPI 0, optional: additionally the f16x3 planes of the fp32 result * split_scale (operand of a later presplit GEMM)
+    int extra_from, extra_only;  // ... for the columns >= extra_from (a multiple of 32) only; extra_only: those columns are NOT written to C
     float* colsum;               // optional [ceil(M / 64)][2][N] column sums / sums of squares per 64-row block
     int M, N, K1, K2, ntm, ntn;
     int act_out;                 // 2 = GELU

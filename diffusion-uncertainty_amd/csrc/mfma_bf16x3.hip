@@ -1837,12 +1837,14 @@ extern "C" int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, 
 }
 // ... with the A operand concatenated along K from two plane sets, and optionally the f16x3 planes of the result beside it
 extern "C" int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void* a2planes, int K2, const void* packed, const float* bias,
-                                        const float* residual, float* C, void* extra_planes, int M, int N, int act_out, float* colsum,
-                                        float act_scale, float split_scale, void* stream) {
+                                        const float* residual, float* C, void* extra_planes, int extra_from, int extra_only, int M, int N,
+                                        int act_out, float* colsum, float act_scale, float split_scale, void* stream) {
     DUA_REQUIRE(a1planes && packed && C && M > 0 && N > 0 && K1 >= BK && K1 % BK == 0 && K2 >= 0 && K2 % BK == 0,
                 "dua_gemm_f16x3_presplit2: K1 and K2 must be multiples of 32 (got %d, %d)", K1, K2);
     DUA_REQUIRE((K2 == 0) == (a2planes == nullptr), "dua_gemm_f16x3_presplit2: a2planes / K2 mismatch");
     DUA_REQUIRE(N % 4 == 0 && act_scale > 0.f && (!extra_planes || split_scale > 0.f), "dua_gemm_f16x3_presplit2: N %% 4 == 0 and positive scales are required");
+    DUA_REQUIRE(!extra_planes || (extra_from >= 0 && extra_from % 32 == 0 && (!extra_only || (!colsum && !residual))),
+                "dua_gemm_f16x3_presplit2: extra_from must be a multiple of 32; extra_only excludes colsum / residual");
     const int K = K1 + K2;
     const size_t plane = dua_bf16x3_plane_elems(N, K);
     DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)M * (K1 > K2 ? K1 : K2) * 2 < 0xFFFFFFF0ull, "dua_gemm_f16x3_presplit2: operand too large");
@@ -1851,7 +1853,7 @@ extern "C" int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void
     h.A2 = (const _Float16*)a2planes; h.a2_plane = (long)M * K2; h.K2 = K2;
     h.B = (const _Float16*)packed; h.b_bytes = (long)(4 * plane);
     h.Cscale = (const float*)((const __bf16*)packed + 2 * plane); h.bias = bias; h.res = residual; h.C = C;
-    h.Cextra = (_Float16*)extra_planes; h.colsum = colsum; h.M = M; h.N = N; h.act_out = act_out;
+    h.Cextra = (_Float16*)extra_planes; h.extra_from = extra_from; h.extra_only = extra_only; h.colsum = colsum; h.M = M; h.N = N; h.act_out = act_out;
     h.out_scale = 1.0f / act_scale; h.split_scale = split_scale;
     return dua_launch_hgemm(h, as_stream(stream), "dua_gemm_f16x3_presplit2");
 }

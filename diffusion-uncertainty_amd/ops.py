@@ -783,7 +783,8 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
     return c
 
 
-def gemm_f16x3_presplit2(a1, a2, packed, n_out, bias=None, residual=None, act_out=0, colsum=False, planes_out=False):
+def gemm_f16x3_presplit2(a1, a2, packed, n_out, bias=None, residual=None, act_out=0, colsum=False, planes_out=False, extra_from=0,
+                         extra_only=False):
     """[a1 | a2] @ W^T with both operands given as f16x3 SplitPlanes (a2 may be None): the 1x1 skip convolution / U-ViT skip_linear on
     a virtual concatenation.  planes_out: additionally return the f16x3 planes of the fp32 result (scale F16X3_RAW_SCALE)."""
     assert a1.fmt == "f16x3" and (a2 is None or (a2.fmt == "f16x3" and a2.scale == a1.scale))
@@ -798,7 +799,8 @@ def gemm_f16x3_presplit2(a1, a2, packed, n_out, bias=None, residual=None, act_ou
         c._dua_colsums_rows = ws
     xp = torch.empty((2, M, n_out), device=a1.device, dtype=torch.int16) if planes_out else None
     check(_lib.lib().dua_gemm_f16x3_presplit2(_p(a1.buf), K1, _p(a2.buf) if a2 is not None else None, K2, _p(packed), _p(bias), _p(residual),
-                                              _p(c), _p(xp), M, n_out, int(act_out), _p(ws), a1.scale, F16X3_RAW_SCALE, _stream()),
+                                              _p(c), _p(xp), int(extra_from), int(bool(extra_only)), M, n_out, int(act_out), _p(ws), a1.scale,
+                                              F16X3_RAW_SCALE, _stream()),
           "dua_gemm_f16x3_presplit2")
     return (c, SplitPlanes(xp, (M, n_out), "f16x3", F16X3_RAW_SCALE)) if planes_out else c
 
