@@ -136,7 +136,6 @@ SIGNATURES = {
     "dua_conv3x3_f32_wino": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dua_gemm_f16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _F, _P]),
     "dua_attention_f16x3": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _F, _P]),
-    "dua_attention_f16x3_kv": (_I, [_P, _P, _L, _P, _P, _F, _I, _I, _I, _I, _F, _P]),
     "dua_cross_attention_f16x3": (_I, [_P, _L, _P, _P, _L, _P, _P, _F, _I, _I, _I, _I, _I, _F, _P]),
     "dua_adm_resblock_workspace_bytes": (_Z, [_c.POINTER(ResBlockArgs)]),
     "dua_adm_resblock_fwd": (_I, [_c.POINTER(ResBlockArgs), _P]),

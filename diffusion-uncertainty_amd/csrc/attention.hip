@@ -31,11 +31,6 @@ struct AttnP {
     const float *k, *v;
     long ldq, ldkv;
     int Tk;
-    // f16x3 kernel, self-attention only: keys / values as f16x3 planes of the packed rows ([B*T][3C] fp16 hi, the lo plane kv_plane_elems
-    // behind) at the scale of the kernel's key / value tiles (DUA_AX_SK = DUA_AX_SV = 16), written by the qkv GEMM's epilogue
-    // (dua_gemm_f16x3_presplit2 with extra_from = C): the staging of a tile is then a copy, no conversion per query workgroup
-    const void* kv_planes;
-    long kv_plane_elems;
 };
 
 template <int CT /* 32-channel tiles: ceil(ch/32) */, int QW /* waves (32 queries each) per workgroup */>
@@ -314,10 +309,6 @@ __global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(Attn
         krow[j] = live ? r : (1 << 30);
     }
     float4 kr[NL], vr[NL];
-    // (planes input: kr[j] = {k hi (4 halves), k lo}, vr[j] = {v hi, v lo} as raw 8-byte pairs)
-    const bool kvp = F16 && p.kv_planes != nullptr;
-    const _Float16* kph = (const _Float16*)p.kv_planes + (long)b * T * 3 * C + C + h * ch;
-    const _Float16* kpl = kph + p.kv_plane_elems;
 #define DUA_ATTNX_FETCH(KT)                                                                                          \
     {                                                                                                                \
         const long adv = (long)(KT) * 32 * ldk;                                                                      \
@@ -325,12 +316,7 @@ __global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(Attn
             const bool ok = (KT) * 32 + krow[j] < Tk;                                                                \
             kr[j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
             vr[j] = kr[j];                                                                                           \
-            if (ok && kvp) {                                                                                         \
-                const float2 a_ = *(const float2*)(kph + adv + goff[j]), b_ = *(const float2*)(kpl + adv + goff[j]);  \
-                const float2 c_ = *(const float2*)(kph + C + adv + goff[j]), d_ = *(const float2*)(kpl + C + adv + goff[j]); \
-                kr[j] = make_float4(a_.x, a_.y, b_.x, b_.y);                                                         \
-                vr[j] = make_float4(c_.x, c_.y, d_.x, d_.y);                                                         \
-            } else if (ok) {                                                                                         \
+            if (ok) {                                                                                                \
                 kr[j] = *(const float4*)(kbase + adv + goff[j]);                                                     \
                 vr[j] = *(const float4*)(vbase + adv + goff[j]);                                                     \
             }                                                                                                        \
@@ -345,15 +331,6 @@ __global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(Attn
         for (int j = 0; j < NL; ++j)
             if (krow[j] < 32) {
                 const int r = krow[j], c = kcol[j];
-                if (kvp) {                    // planes input: the tile's hi / lo halves as they lie
-                    typedef float f2_ __attribute__((ext_vector_type(2)));
-                    const f2_ kh2 = {kr[j].x, kr[j].y}, kl2 = {kr[j].z, kr[j].w}, vh2 = {vr[j].x, vr[j].y}, vl2 = {vr[j].z, vr[j].w};
-                    *(f2_*)(Kh + r * KP + c) = kh2;
-                    *(f2_*)(Kl + r * KP + c) = kl2;
-                    *(f2_*)(Vh + r * VPR + c) = vh2;
-                    *(f2_*)(Vl + r * VPR + c) = vl2;
-                    continue;
-                }
                 const float kf[4] = {kr[j].x, kr[j].y, kr[j].z, kr[j].w}, vf[4] = {vr[j].x, vr[j].y, vr[j].z, vr[j].w};
                 abf16x4 a_, b_;
 #pragma unroll
@@ -480,19 +457,6 @@ static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
 }
 
 static int attention_x_launch(const AttnP& p, int B, void* stream, bool f16 = false);
-
-/* dua_attention_f16x3 with the keys / values taken from f16x3 planes of the packed qkv rows (kv_planes: [B*T][3*heads*ch] fp16 hi, the lo
- * plane kv_plane_elems elements behind; scale 16), q still from the fp32 rows: bit-identical to dua_attention_f16x3 on the same values. */
-extern "C" int dua_attention_f16x3_kv(const float* qkv, const void* kv_planes, long kv_plane_elems, float* out, void* out_planes,
-                                      float planes_scale, int B, int T, int heads, int ch, float scale, void* stream) {
-    DUA_REQUIRE(qkv && kv_planes && (out || out_planes) && B > 0 && T > 0 && heads > 0, "dua_attention_f16x3_kv: bad arguments");
-    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 256, "dua_attention_f16x3_kv: head dim must be a multiple of 4 in [8, 256] (got %d)", ch);
-    DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_f16x3_kv: B*heads must be <= 65535");
-    DUA_REQUIRE(!out_planes || planes_scale > 0.f, "dua_attention_f16x3_kv: planes_scale must be positive");
-    AttnP p{qkv, out, T, heads, ch, scale, out_planes, (long)B * T * heads * ch, planes_scale};
-    p.kv_planes = kv_planes; p.kv_plane_elems = kv_plane_elems;
-    return attention_x_launch(p, B, stream, true);
-}
 
 /* The fused attention on the fp32-equivalent split (f16x3): fp32 output, or f16x3 planes of out * planes_scale (operand of
  * dua_gemm_f16x3_presplit: proj_out) when out_planes != NULL. */

@@ -156,9 +156,6 @@ int attnblock_run(const dua_attnblock_args* a, Carver& w, void* stream) {
     void* xn = w.take((size_t)M * C * 4);
     float* qkv = (float*)w.take((size_t)M * 3 * C * 4);
     void* att = w.take((size_t)M * C * 4);
-    // f16x3: the k | v thirds of the qkv projection leave its epilogue as f16x3 planes (scale 16 = the scale of the attention kernel's key /
-    // value tiles) instead of fp32: the kernel stages them as they lie instead of converting every key tile in every query workgroup
-    void* qkvp = f16 ? w.take((size_t)M * 3 * C * 4) : nullptr;
     if (w.dry) return DUA_OK;
     DUA_REQUIRE(w.used <= w.cap && a->workspace, "dua_adm_attnblock_fwd: workspace of %zu bytes needed, %zu given", w.used, w.cap);
     int rc;
@@ -168,9 +165,8 @@ int attnblock_run(const dua_attnblock_args* a, Carver& w, void* stream) {
     if (f16) {
         if ((rc = dua_groupnorm_apply_split_f16x3(a->x, C, nullptr, 0, a->N, a->H, a->W, G, stats, a->gn_w, a->gn_b, nullptr, 0, 0, 0, nullptr,
                                                   a->act_scale, xn, stream))) return rc;
-        if ((rc = dua_gemm_f16x3_presplit2(xn, C, nullptr, 0, a->qkv_packed, a->qkv_b, nullptr, qkv, qkvp, C, 1, (int)M, 3 * C, 0, nullptr, a->act_scale,
-                                           16.0f, stream))) return rc;                                                                                   // qkv :301
-        if ((rc = dua_attention_f16x3_kv(qkv, qkvp, (long)M * 3 * C, nullptr, att, a->raw_scale, a->N, T, a->heads, ch, scale, stream))) return rc;     // :302
+        if ((rc = dua_gemm_f16x3_presplit(xn, a->qkv_packed, a->qkv_b, nullptr, qkv, (int)M, 3 * C, C, 0, nullptr, a->act_scale, stream))) return rc;   // qkv :301
+        if ((rc = dua_attention_f16x3(qkv, nullptr, att, a->raw_scale, a->N, T, a->heads, ch, scale, stream))) return rc;                               // :302
         return dua_gemm_f16x3_presplit(att, a->proj_packed, a->proj_b, a->x, a->y, (int)M, C, C, 0, ycs, a->raw_scale, stream);                         // proj_out + x :303-306
     }
     if ((rc = dua_groupnorm_apply(a->x, C, nullptr, 0, a->N, a->H, a->W, G, stats, a->gn_w, a->gn_b, nullptr, 0, 0, 0, nullptr, (float*)xn, stream))) return rc;
@@ -195,7 +191,6 @@ int uvitblock_run(const dua_uvitblock_args* a, Carver& w, void* stream) {
     void* hn = w.take((size_t)M * D * 4);                                               // LayerNorm output (fp32 or planes), both norms
     float* qkv = (float*)w.take((size_t)M * 3 * D * 4);
     void* att = w.take((size_t)M * D * 4);
-    void* qkvp = f16 ? w.take((size_t)M * 3 * D * 4) : nullptr;                         // k | v thirds of qkv as f16x3 planes (see attnblock_run)
     float* x2 = (float*)w.take((size_t)M * D * 4);                                      // x + proj(attention)
     void* hid = w.take((size_t)M * Hd * 4);                                             // gelu(fc1) (fp32 or planes)
     if (w.dry) return DUA_OK;
@@ -220,9 +215,8 @@ int uvitblock_run(const dua_uvitblock_args* a, Carver& w, void* stream) {
     }
     if (f16) {
         if ((rc = dua_layernorm_split_f16x3(x, a->norm1_w, a->norm1_b, hn, M, D, a->eps, a->act_scale, stream))) return rc;        // :118 norm1
-        if ((rc = dua_gemm_f16x3_presplit2(hn, D, nullptr, 0, a->qkv_packed, a->qkv_b, nullptr, qkv, qkvp, D, 1, (int)M, 3 * D, 0, nullptr, a->act_scale,
-                                           16.0f, stream))) return rc;
-        if ((rc = dua_attention_f16x3_kv(qkv, qkvp, (long)M * 3 * D, nullptr, att, a->raw_scale, a->B, a->L, a->heads, ch, scale, stream))) return rc;   // :69-73
+        if ((rc = dua_gemm_f16x3_presplit(hn, a->qkv_packed, a->qkv_b, nullptr, qkv, (int)M, 3 * D, D, 0, nullptr, a->act_scale, stream))) return rc;
+        if ((rc = dua_attention_f16x3(qkv, nullptr, att, a->raw_scale, a->B, a->L, a->heads, ch, scale, stream))) return rc;        // :69-73
         if ((rc = dua_gemm_f16x3_presplit(att, a->proj_packed, a->proj_b, x, x2, (int)M, D, D, 0, nullptr, a->raw_scale, stream))) return rc;
         if ((rc = dua_layernorm_split_f16x3(x2, a->norm2_w, a->norm2_b, hn, M, D, a->eps, a->act_scale, stream))) return rc;       // :119 norm2
         if ((rc = dua_gemm_f16x3_presplit_planes(hn, a->fc1_packed, a->fc1_b, hid, (int)M, Hd, D, 2, a->act_scale, a->raw_scale, stream))) return rc;

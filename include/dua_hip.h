@@ -358,7 +358,7 @@ int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* b
  * skip_linear(cat([x, skip])) (uvit/uvit.py:116-117) without materialising the concatenation.  a2planes may be NULL (K2 = 0).
  * extra_planes != NULL: the columns >= extra_from (a multiple of 32) of the fp32 result are ALSO written as f16x3 planes of C * split_scale
  * ([M][N] hi | lo; columns below extra_from stay unwritten there); extra_only != 0: those columns are written as planes ONLY (not to C) -
- * the k | v thirds of a qkv projection, handed to dua_attention_f16x3_kv in the operand format of its key / value tiles. */
+ * (tried for the k | v thirds of a qkv projection handed to the attention kernel as planes: slower end to end, profiles/LOG.md). */
 int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void* a2planes, int K2, const void* packed, const float* bias,
                              const float* residual, float* C, void* extra_planes, int extra_from, int extra_only, int M, int N, int act_out,
                              float* colsum, float act_scale, float split_scale, void* stream);
@@ -389,11 +389,6 @@ int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, 
  * dua_gemm_f16x3_presplit (proj_out, unet_openai.py:295); otherwise fp32 `out`. */
 int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float planes_scale, int B, int T, int heads, int ch,
                         float scale, void* stream);
-/* ... with the keys / values taken from f16x3 planes of the packed rows ([B*T][3*heads*ch] fp16 hi, the lo plane kv_plane_elems elements
- * behind, scale 16: written by dua_gemm_f16x3_presplit2 with extra_from = heads*ch); q from the fp32 rows.  The staging of a key / value
- * tile is then a copy instead of a conversion repeated by every query workgroup; bit-identical to dua_attention_f16x3. */
-int dua_attention_f16x3_kv(const float* qkv, const void* kv_planes, long kv_plane_elems, float* out, void* out_planes, float planes_scale,
-                           int B, int T, int heads, int ch, float scale, void* stream);
 /* ... with keys / values from their own tensors (cross-attention, diffusers Attention with encoder_hidden_states): q rows
  * [B*Tq][ldq], k / v rows [B*Tk][ldkv], head h at column h*ch of each; Tk any (77 text tokens). */
 int dua_cross_attention_f16x3(const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, void* out_planes,
