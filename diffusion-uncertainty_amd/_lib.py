@@ -88,6 +88,8 @@ SIGNATURES = {
     "dua_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _P]),
     "dua_gemm": (_I, [_c.POINTER(GemmArgs), _P]),
     "dua_softmax_rows": (_I, [_P, _L, _I, _L, _P]),
+    "dua_range_check": (_I, [_I]),
+    "dua_range_check_read": (_I, [_c.POINTER(_c.c_ulonglong), _c.POINTER(_c.c_ulonglong), _I]),
     "dua_set_splitk_workspace": (_I, [_P, _Z]),
     "dua_groupnorm_bwd": (_I, [_P, _I, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "dua_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P]),

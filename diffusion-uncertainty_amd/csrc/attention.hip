@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(Attn
                         const float f[4] = {w.x * p.planes_scale, w.y * p.planes_scale, w.z * p.planes_scale, w.w * p.planes_scale};
                         af16x4 hh, ll;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { _Float16 x_, y_; asplit(f[u], x_, y_); hh[u] = x_; ll[u] = y_; }
+                        for (int u = 0; u < 4; ++u) { _Float16 x_, y_; if (unsigned long long* rc_ = dua_range_ctr()) dua_range_note(rc_, f[u]); asplit(f[u], x_, y_); hh[u] = x_; ll[u] = y_; }
                         *(af16x4*)((_Float16*)p.out_planes + ro + c) = hh;
                         *(af16x4*)((_Float16*)p.out_planes + p.plane_elems + ro + c) = ll;
                     } else if (p.out_planes) dua_store_f16f8_quad(p.out_planes, p.plane_elems, ro + c, w);
@@ -552,3 +552,5 @@ extern "C" int dua_attention(const float* qkv, float* out, int B, int T, int hea
     dua_set_error("dua_attention: unsupported head dim %d", ch);
     return DUA_EINVAL;
 }
+
+DUA_RANGE_TU(attention)

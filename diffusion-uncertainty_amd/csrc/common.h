@@ -60,11 +60,38 @@ __device__ __forceinline__ void dua_store_f16f8_quad(void* planes, long plane_el
     *(int*)(x8 + 32) = hi8;
 }
 
+
+// ---- f16x3 range check (debug facility, off by default): with dua_range_check(1) every kernel that WRITES f16x3 operands (the GroupNorm /
+// LayerNorm / GELU / attention plane writers, the Winograd V writer, the on-the-fly split of raw operands) counts the operands whose scaled
+// magnitude leaves fp16's range (|s| > 65504: hi saturates and the pair carries fewer than 22 bits - counter 0) and those below fp16's
+// smallest normal (0 < |s| < 2^-14: hi is subnormal; the pair is still exact to 2^-25 / scale absolutely - counter 1).  Each translation
+// unit holds its own copy of the device pointer (static: no relocatable device code needed); dua_range_check sets them all.
+static __device__ unsigned long long* dua_range_dev = nullptr;
+// (kernels load the pointer ONCE - dua_range_ctr() - and test it per group of operands: one uniform branch when the check is off)
+__device__ __forceinline__ unsigned long long* dua_range_ctr() {
+#ifdef DUA_NO_RANGE_CHECK                                             // (A/B build: prices the check in the plane writers)
+    return nullptr;
+#else
+    return dua_range_dev;
+#endif
+}
+__device__ __forceinline__ void dua_range_note(unsigned long long* c, float s) {            // s = operand * plane scale, BEFORE the clamp
+    const float a = fabsf(s);
+    if (a > 65504.f) atomicAdd(c, 1ull);
+    else if (a > 0.f && a < 6.103515625e-05f) atomicAdd(c + 1, 1ull);
+}
+#define DUA_RANGE_TU(NAME)                                                                                      \
+    void dua_range_set_##NAME(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(dua_range_dev), &p, sizeof(p)); }
+
 // Four consecutive columns of one row as f16x3 planes: plane 0 fp16(x * scale) (saturating), plane 1 the fp16 remainder.
 __device__ __forceinline__ void dua_store_f16x3_quad(void* planes, long plane_elems, long o, float4 w, float scale) {
     typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
     const float f[4] = {w.x * scale, w.y * scale, w.z * scale, w.w * scale};
     f16x4_t h, l;
+    if (unsigned long long* rc_ = dua_range_ctr()) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dua_range_note(rc_, f[j]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float sv = fminf(fmaxf(f[j], -65504.f), 65504.f);

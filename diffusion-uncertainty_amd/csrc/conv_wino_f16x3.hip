@@ -738,6 +738,7 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
             for (int j = 0; j < 8; ++j) r[j] = (a[j] + b[j] + d[j] + e[j]) * 0.25f;
         }
     };
+    unsigned long long* const rctr = dua_range_ctr();          // f16x3 range check (debug facility; nullptr when off)
     auto put = [&](int f, size_t m, const float (&v)[8]) {
         if (F32) {         // exact-fp32 operand of conv_wino_f32.hip: stage block (f, tile, channel block) = [128 positions][32 floats]
             float* o = (float*)p.v + (((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 4096 + (m & 127) * 32 + (c & 31);
@@ -746,6 +747,10 @@ __global__ __launch_bounds__(BLK) void k_gn_apply_wino(GnWinoP p) {
             return;
         }
         h16x8 h, l;
+        if (rctr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dua_range_note(rctr, v[j] * p.oscale);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sv = fminf(fmaxf(v[j] * p.oscale, -65504.f), 65504.f);
@@ -899,3 +904,5 @@ extern "C" int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float
                                             int act, int resample, const float* dropmask, void* vplanes, void* stream) {
     return gn_apply_wino_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, 1.0f, vplanes, stream, true);
 }
+
+DUA_RANGE_TU(conv_wino)

@@ -266,6 +266,10 @@ __device__ __forceinline__ void gn_store(const GnApplyP& p, size_t off, float4 v
         typedef _Float16 gn_f16x4 __attribute__((ext_vector_type(4)));
         const float f[4] = {v.x, v.y, v.z, v.w};
         gn_f16x4 h, l;
+        if (unsigned long long* rc_ = dua_range_ctr()) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dua_range_note(rc_, f[j] * p.oscale);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float sv = fminf(fmaxf(f[j] * p.oscale, -65504.f), 65504.f);
@@ -425,6 +429,10 @@ __device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const f
         *(unsigned long long*)(blk + 32) = oh;
     } else if (p.split == 4) {
         gn_f16x8 h, l;
+        if (unsigned long long* rc_ = dua_range_ctr()) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dua_range_note(rc_, f[j] * p.oscale);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sv = fminf(fmaxf(f[j] * p.oscale, -65504.f), 65504.f);
@@ -853,6 +861,7 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
             const float o = (v[j] - mean) * rstd * ga[c] + be[c];
             if (!split) y[row * (long)D + c] = o;
             else if (split == 4) {           // f16x3 planes: fp16 hi | fp16 lo of o * oscale
+                if (unsigned long long* rc_ = dua_range_ctr()) dua_range_note(rc_, o * oscale);
                 const float sv = fminf(fmaxf(o * oscale, -65504.f), 65504.f);
                 const _Float16 h = (_Float16)sv;
                 ((_Float16*)y)[row * (long)D + c] = h;
@@ -1091,4 +1100,40 @@ extern "C" int dua_transpose_batched(const float* in, float* out, int R, int Cc,
     hipLaunchKernelGGL(k_transpose, dim3((Cc + 31) / 32, (R + 31) / 32, batch), BLK, 0, as_stream(stream), in, out, R, Cc, ld_in, ld_out,
                        sIn, sIni, sOut, sOuti, batch_inner);
     return dua_check_launch("dua_transpose_batched");
+}
+
+DUA_RANGE_TU(denoiser)
+
+// ---- f16x3 range check: host side (see common.h).  Process-global debug facility; dua_range_check_read synchronises the device.
+void dua_range_set_conv_wino(unsigned long long*);
+void dua_range_set_xtile(unsigned long long*);
+void dua_range_set_hgemm(unsigned long long*);
+void dua_range_set_attention(unsigned long long*);
+static unsigned long long* g_range_buf = nullptr;
+static int g_range_on = 0;
+static void range_set_all(unsigned long long* p) {
+    dua_range_set_denoiser(p); dua_range_set_conv_wino(p); dua_range_set_xtile(p); dua_range_set_hgemm(p); dua_range_set_attention(p);
+}
+extern "C" int dua_range_check(int on) {
+    const int was = g_range_on;
+    if (on && !g_range_buf) {
+        if (hipMalloc((void**)&g_range_buf, 2 * sizeof(unsigned long long)) != hipSuccess) { dua_set_error("dua_range_check: hipMalloc failed"); return DUA_EHIP; }
+    }
+    if (on) (void)hipMemset(g_range_buf, 0, 2 * sizeof(unsigned long long));
+    (void)hipDeviceSynchronize();
+    range_set_all(on ? g_range_buf : nullptr);
+    g_range_on = on != 0;
+    return was;
+}
+extern "C" int dua_range_check_read(unsigned long long* saturated, unsigned long long* subnormal, int reset) {
+    DUA_REQUIRE(g_range_buf != nullptr, "dua_range_check_read: dua_range_check(1) first");
+    unsigned long long h[2] = {0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, g_range_buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) {
+        dua_set_error("dua_range_check_read: device error");
+        return DUA_EHIP;
+    }
+    if (saturated) *saturated = h[0];
+    if (subnormal) *subnormal = h[1];
+    if (reset) (void)hipMemset(g_range_buf, 0, sizeof(h));
+    return DUA_OK;
 }

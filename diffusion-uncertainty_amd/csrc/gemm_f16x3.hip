@@ -158,6 +158,7 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
                     f16x4_t hh, ll;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if (unsigned long long* rc_ = dua_range_ctr()) dua_range_note(rc_, f[q]);
                         const float sv = fminf(fmaxf(f[q], -65504.f), 65504.f);
                         const _Float16 t16 = (_Float16)sv;
                         hh[q] = t16;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
             for (int q = 0; q < 8; ++q) {
                 float v = a[q] * (sq[q] * p.out_scale) + bq[q];
                 if (p.act_out == 2) v = hg_gelu(v);
+                if (unsigned long long* rc_ = dua_range_ctr()) dua_range_note(rc_, v * p.split_scale);
                 const float sv = fminf(fmaxf(v * p.split_scale, -65504.f), 65504.f);
                 const _Float16 t16 = (_Float16)sv;
                 hh[q] = t16;
@@ -727,3 +729,5 @@ int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what) {
     else hg_launch<2>(p, grid, planes, st);
     return dua_check_launch(what);
 }
+
+DUA_RANGE_TU(hgemm)

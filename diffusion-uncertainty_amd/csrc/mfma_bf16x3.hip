@@ -73,6 +73,10 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split4h(float4 v, float sc, h16x4& hi, h16x4& lo) {
     float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    if (unsigned long long* rc_ = dua_range_ctr()) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dua_range_note(rc_, f[j]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const _Float16 h = (_Float16)fminf(fmaxf(f[j], -65504.f), 65504.f);
@@ -1915,3 +1919,5 @@ extern "C" int dua_gemm_nt_bf16x3_batched(const float* A, long lda, long sA, lon
     p.sA = sA; p.sAi = sAi; p.sB = sB; p.sBi = sBi; p.sC = sC; p.sCi = sCi; p.batch_inner = batch_inner; p.alpha = alpha;
     return launch_x<XMODE_GEMM, false, false, true>(p, as_stream(stream), batch);
 }
+
+DUA_RANGE_TU(xtile)

@@ -471,6 +471,18 @@ def set_split_k(on, device=None):
     return prev
 
 
+def range_check(on):
+    """Switch the f16x3 range counters on / off (dua_range_check); returns the previous setting."""
+    return bool(_lib.lib().dua_range_check(1 if on else 0))
+
+
+def range_check_read(reset=True):
+    """(saturated, subnormal) operand counts since the counters were switched on / last reset (synchronises the device)."""
+    a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    check(_lib.lib().dua_range_check_read(ctypes.byref(a), ctypes.byref(b), 1 if reset else 0), "dua_range_check_read")
+    return int(a.value), int(b.value)
+
+
 # Optional per-launch timing hook used by bench.py: an object with .record(kind, flops, start_evt, end_evt).
 PROFILE = None
 

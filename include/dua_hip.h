@@ -513,6 +513,18 @@ int dua_uvit_assemble(const float* patches, const float* time_tok, const float* 
  * 'B (h w) (p1 p2 C) -> B C (h p1) (w p2)' (uvit.py:46-51,228-229). */
 int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C, int P, void* stream);
 
+/* f16x3 range check (debug facility, off by default; process-global, synchronises the device when switched or read).  While on, every
+ * kernel that WRITES f16x3 operands - the GroupNorm / LayerNorm / GELU / attention plane writers, the Winograd V writer, the on-the-fly
+ * split of raw residual-stream operands in dua_gemm_f16x3 - counts, per operand, (a) saturated: |x * plane scale| > 65504, the fp16 hi half
+ * clamps and the hi + lo pair no longer carries 22 bits of x: the "fp32-equivalent" claim does not hold for that operand; (b) subnormal:
+ * 0 < |x * plane scale| < 2^-14, hi is an fp16 subnormal - harmless (the pair stays exact to 2^-25 / scale absolutely), reported for
+ * completeness.  The plane scales are static (64 for GroupNorm / SiLU / LayerNorm outputs: |x| <= 1023; 16 for raw-stream operands, GELU
+ * and attention outputs: |x| <= 4094; 32 for the Winograd images): a non-zero saturation count on real checkpoints says the activations
+ * exceed those bounds and the run should use precision "fp32" (INTEGRATION.md section 4).  dua_range_check returns the previous setting
+ * and zeroes the counters when switched on; dua_range_check_read copies them out (reset != 0 zeroes them). */
+int dua_range_check(int on);
+int dua_range_check_read(unsigned long long* saturated, unsigned long long* subnormal, int reset);
+
 /* Split-K for the f16x3 LDS-DMA conv / presplit GEMM launches that cannot fill the chip (fewer than 128 tiles of 256 rows: small
  * batches, e.g. SD's CFG batch of 2): with a workspace registered, such a launch runs every tile as up to 16 K parts on separate
  * workgroups and a second kernel folds the parts in index order (deterministic) and applies bias / residual / statistics.

@@ -91,6 +91,9 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         uc_scheduler.mc_group = args.mc_group
     uc_scheduler.set_timesteps(args.generation_steps)
     import time
+    if args.check_range:
+        from diffusion_uncertainty_amd import ops as _ops
+        _ops.range_check(True)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     if args.model_type == "unet":
@@ -99,6 +102,11 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         results = generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(X_T, y, args.batch_size, model, uc_scheduler, device)
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    if args.check_range:
+        sat, sub = _ops.range_check_read()
+        _ops.range_check(False)
+        print(f"[rank {gpu_idx}] f16x3 range check: {sat} operand(s) beyond fp16's range after scaling (hi half saturated), {sub} below its "
+              f"smallest normal (harmless)" + ("" if sat == 0 else " - the fp32-equivalent claim does NOT hold for this run: use --precision fp32"))
     if args.measure_time:
         print(f"[rank {gpu_idx}] {X_T.shape[0]} images in {elapsed:.2f} s -> {X_T.shape[0] / elapsed:.3f} images/s "
               f"({uc_scheduler.denoiser_calls} UC forwards + {args.generation_steps} main forwards per batch)")
@@ -146,7 +154,10 @@ def parse_args(argv=None):
     p.add_argument("--mc-group", type=int, default=1, dest="mc_group",
                    help="uncertainty_zigzag_centered: Monte-Carlo chains of a UC step per denoiser call (stacked batch, identical outputs; "
                         "helps U-ViT at batch 64: +4.6 %% with 5)")
-    p.add_argument("--precision", choices=["f16x3", "fp32", "f16f6", "f16f8", "bf16x3"], default="f16x3",
+    p.add_argument("--check-range", action="store_true", dest="check_range",
+                   help="f16x3: count the operands that leave fp16's range after their static power-of-two scale (dua_range_check); "
+                        "a non-zero saturation count means the run is not fp32-equivalent")
+    p.add_argument("--precision", choices=["f16x3", "fp32", "f16w", "f16f6", "f16f8", "bf16x3"], default="f16x3",
                    help="f16x3 (default): the fp32-equivalent split - trajectories match the reference CPU path like the exact fp32 mode's; "
                         "fp32: exact fp32 MFMA; bf16x3 / f16f8 / f16f6: narrower throughput modes (16 / ~15 / ~14-15 operand bits)")
     p.add_argument("--noise", choices=["host", "device"], default="host", help="host: CPU-generator noise tape in the reference's draw order")
