@@ -289,6 +289,7 @@ def other_config_uvit(dev, a):
     from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
     uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
     ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
+    uvit.skip_planes = os.environ.get("DUA_UVIT_SKIP_PLANES", "1") != "0"        # (A/B switch for scripts/diag/uvit_job.py)
     uvit.split_k = bool(getattr(a, "uvit_split_k", True))     # tail rows of under-filled GEMM rounds split along K (deterministic)
     uvit.precision, ae.precision = "f16x3", "f16x3"           # the fp32-equivalent split for the U-ViT and the VAE decode (once per batch)
     model = UViTAE(uvit, ae).to(dev)

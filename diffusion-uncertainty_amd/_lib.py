@@ -44,7 +44,7 @@ class UViTBlockArgs(_c.Structure):
                 ("skip_packed", _P), ("skip_b", _P), ("norm1_w", _P), ("norm1_b", _P), ("norm2_w", _P), ("norm2_b", _P), ("eps", _F),
                 ("qkv_packed", _P), ("qkv_b", _P), ("proj_packed", _P), ("proj_b", _P), ("fc1_packed", _P), ("fc1_b", _P),
                 ("fc2_packed", _P), ("fc2_b", _P), ("precision", _I), ("act_scale", _F), ("raw_scale", _F),
-                ("workspace", _P), ("workspace_bytes", _Z), ("y", _P)]
+                ("workspace", _P), ("workspace_bytes", _Z), ("y", _P), ("x_planes", _P), ("skip_planes", _P), ("y_planes", _P)]
 
 
 # name -> (restype, argtypes); every symbol include/dua_hip.h declares

@@ -207,8 +207,11 @@ int uvitblock_run(const dua_uvitblock_args* a, Carver& w, void* stream) {
     };
     const float* x = a->x;
     if (a->skip_packed) {                                                                               // uvit.py:116-117
-        if (f16) rc = dua_gemm_f16x3(a->x, D, D, a->skip, D, D, a->skip_packed, a->skip_b, nullptr, D, x1, D, (int)M, D, 0, 0, 1.0f, nullptr,
-                                     a->raw_scale, stream);
+        if (f16 && a->x_planes && a->skip_planes)                                                       // both operands exist as planes: presplit two-source GEMM
+            rc = dua_gemm_f16x3_presplit2(a->x_planes, D, a->skip_planes, D, a->skip_packed, a->skip_b, nullptr, x1, nullptr, 0, 0, (int)M, D, 0, nullptr,
+                                          a->raw_scale, a->raw_scale, stream);
+        else if (f16) rc = dua_gemm_f16x3(a->x, D, D, a->skip, D, D, a->skip_packed, a->skip_b, nullptr, D, x1, D, (int)M, D, 0, 0, 1.0f, nullptr,
+                                          a->raw_scale, stream);
         else rc = gemm32(a->x, D, a->skip, D, a->skip_packed, a->skip_b, nullptr, x1, D, 0);
         if (rc) return rc;
         x = x1;
@@ -220,6 +223,9 @@ int uvitblock_run(const dua_uvitblock_args* a, Carver& w, void* stream) {
         if ((rc = dua_gemm_f16x3_presplit(att, a->proj_packed, a->proj_b, x, x2, (int)M, D, D, 0, nullptr, a->raw_scale, stream))) return rc;
         if ((rc = dua_layernorm_split_f16x3(x2, a->norm2_w, a->norm2_b, hn, M, D, a->eps, a->act_scale, stream))) return rc;       // :119 norm2
         if ((rc = dua_gemm_f16x3_presplit_planes(hn, a->fc1_packed, a->fc1_b, hid, (int)M, Hd, D, 2, a->act_scale, a->raw_scale, stream))) return rc;
+        if (a->y_planes)
+            return dua_gemm_f16x3_presplit2(hid, Hd, nullptr, 0, a->fc2_packed, a->fc2_b, x2, a->y, a->y_planes, 0, 0, (int)M, D, 0, nullptr, a->raw_scale,
+                                            a->raw_scale, stream);
         return dua_gemm_f16x3_presplit(hid, a->fc2_packed, a->fc2_b, x2, a->y, (int)M, D, Hd, 0, nullptr, a->raw_scale, stream);
     }
     if ((rc = dua_layernorm(x, a->norm1_w, a->norm1_b, (float*)hn, M, D, a->eps, stream))) return rc;

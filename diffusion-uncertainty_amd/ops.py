@@ -1173,14 +1173,21 @@ def adm_attnblock(x, heads, gn, qkv_packed, qkv_b, proj_packed, proj_b, precisio
     return _attach_colsums(y, ws_y, H * W)
 
 
-def uvit_block(x, skip, B, L, heads, w, precision="fp32", eps=1e-5):
+def uvit_block(x, skip, B, L, heads, w, precision="fp32", eps=1e-5, want_planes=False):
     """One U-ViT block through dua_uvit_block_fwd (uvit/uvit.py:95-120).  x / skip: [B*L, D] fp32; w: dict of device tensors
     (skip_w, skip_b | None, norm1_w, norm1_b, norm2_w, norm2_b, qkv_w, qkv_b | None, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b),
-    the *_w entries packed for `precision`."""
+    the *_w entries packed for `precision`.  f16x3: tensors produced with want_planes carry their f16x3 planes (`_dua_planes`); when both x and
+    skip carry them, skip_linear runs on the presplit two-source GEMM."""
     _req(x, name="x")
     M, D = x.shape
     hidden = int(w["hidden"])
     y = torch.empty_like(x)
+    f16 = precision == "f16x3"
+    xp = getattr(x, "_dua_planes", None) if (f16 and skip is not None) else None
+    sp = getattr(skip, "_dua_planes", None) if (f16 and skip is not None) else None
+    if xp is None or sp is None:
+        xp = sp = None
+    yp = torch.empty((2, M, D), device=x.device, dtype=torch.int16) if (f16 and want_planes) else None
     ptr = lambda t: (t.data_ptr() if t is not None else None)     # noqa: E731
     a = UViTBlockArgs(x=x.data_ptr(), skip=ptr(skip), B=B, L=L, D=D, heads=int(heads), hidden=hidden,
                       skip_packed=ptr(w.get("skip_w")) if skip is not None else None, skip_b=ptr(w.get("skip_b")) if skip is not None else None,
@@ -1188,7 +1195,7 @@ def uvit_block(x, skip, B, L, heads, w, precision="fp32", eps=1e-5):
                       qkv_packed=ptr(w["qkv_w"]), qkv_b=ptr(w.get("qkv_b")), proj_packed=ptr(w["proj_w"]), proj_b=ptr(w.get("proj_b")),
                       fc1_packed=ptr(w["fc1_w"]), fc1_b=ptr(w.get("fc1_b")), fc2_packed=ptr(w["fc2_w"]), fc2_b=ptr(w.get("fc2_b")),
                       precision=PRECISION_CODE[precision], act_scale=F16X3_ACT_SCALE, raw_scale=F16X3_RAW_SCALE,
-                      workspace=None, workspace_bytes=0, y=y.data_ptr())
+                      workspace=None, workspace_bytes=0, y=y.data_ptr(), x_planes=ptr(xp), skip_planes=ptr(sp), y_planes=ptr(yp))
     Lb = _lib.lib()
     nbytes = Lb.dua_uvit_block_workspace_bytes(ctypes.byref(a))
     if nbytes == 0:
@@ -1196,4 +1203,6 @@ def uvit_block(x, skip, B, L, heads, w, precision="fp32", eps=1e-5):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     check(Lb.dua_uvit_block_fwd(ctypes.byref(a), _stream()), "dua_uvit_block_fwd")
+    if yp is not None:
+        y._dua_planes = yp
     return y

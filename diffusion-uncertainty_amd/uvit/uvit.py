@@ -62,7 +62,7 @@ class Block(nn.Module):
             cache[key] = d
         return cache[key]
 
-    def run(self, lin, x, B, L, skip=None, precision="fp32", block_cache=None):
+    def run(self, lin, x, B, L, skip=None, precision="fp32", block_cache=None, want_planes=False):
         """x, skip: [B*L, D]; lin(a, linear_module, **kw) is the model's precision-aware GEMM."""
         D = x.shape[1]
         ch = D // self.attn.num_heads
@@ -70,9 +70,18 @@ class Block(nn.Module):
                 ch % 8 == 0 and ch <= 128 and ops.ATTENTION_MODE == "auto"):
             # the whole block as ONE C-ABI call (dua_uvit_block_fwd: the same kernels in the same order, bit-identical)
             return ops.uvit_block(x, skip if self.skip_linear is not None else None, B, L, self.attn.num_heads,
-                                  self.packed(block_cache, precision), precision=precision, eps=self.norm1.eps)
+                                  self.packed(block_cache, precision), precision=precision, eps=self.norm1.eps, want_planes=want_planes)
         if self.skip_linear is not None:
-            x = lin(x, self.skip_linear, a2=skip)                                                  # :116-117
+            xp, sp = getattr(x, "_dua_planes", None), getattr(skip, "_dua_planes", None)
+            if precision == "f16x3" and xp is not None and sp is not None:       # both operands exist as planes: presplit two-source GEMM
+                key = (id(self.skip_linear), "f16x3")
+                cache = block_cache if block_cache is not None else lin.__self__._planes          # (the model's packed-weight cache)
+                if key not in cache:
+                    cache[key] = ops.pack_weight_f16x3(self.skip_linear.weight.detach().contiguous())
+                pl = lambda b: ops.SplitPlanes(b, tuple(x.shape), "f16x3", ops.F16X3_RAW_SCALE)      # noqa: E731
+                x = ops.gemm_f16x3_presplit2(pl(xp), pl(sp), cache[key], D, bias=self.skip_linear.bias)
+            else:
+                x = lin(x, self.skip_linear, a2=skip)                                              # :116-117
         # split modes: LayerNorm / GELU outputs go out in the operand format of the LDS-DMA GEMMs (bf16 planes or f16f8 planes)
         # ("f16x3": the fp32-equivalent split, fp16 hi / lo planes)
         fast = (precision if precision in ("f16f8", "f16x3") else precision == "bf16x3") if D % 32 == 0 else False
@@ -84,6 +93,14 @@ class Block(nn.Module):
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, split=fast)
         h = lin(h, self.mlp.fc1, act_out=2, split_out=bool(fast))                                  # fc1 + GELU
+        if want_planes and precision == "f16x3" and isinstance(h, ops.SplitPlanes):
+            key = (id(self.mlp.fc2), "f16x3")
+            cache = block_cache if block_cache is not None else lin.__self__._planes          # (the model's packed-weight cache)
+            if key not in cache:
+                cache[key] = ops.pack_weight_f16x3(self.mlp.fc2.weight.detach().contiguous())
+            y, yp = ops.gemm_f16x3_presplit2(h, None, cache[key], D, bias=self.mlp.fc2.bias, residual=x, planes_out=True)
+            y._dua_planes = yp.buf
+            return y
         return lin(h, self.mlp.fc2, residual=x)                                                    # :119
 
 
@@ -131,6 +148,7 @@ class UViT(nn.Module):
         # mostly idle (N = 1152 projections at batch 64: 585 tiles on 256 CUs) run their tail rows split along K.  Opt-in: results
         # then depend on the batch size at fp32-rounding level
         self.split_k = False
+        self.skip_planes = True          # f16x3: block outputs that feed a skip_linear also leave the fc2 epilogue as f16x3 planes (A/B switch)
         self._planes = {}
 
     def _apply(self, fn, *a, **k):
@@ -201,12 +219,16 @@ class UViT(nn.Module):
         h = h.view(B * T, D)
         skips = []
         bc = self._planes if self.use_block_abi else None
+        # f16x3: a block whose output is the x or the long skip of a skip_linear also leaves it as f16x3 planes (the epilogue of fc2 writes
+        # them beside the fp32 tokens), so that skip_linear(cat([x, skip])) runs on the presplit two-source GEMM
+        wp = self.precision == "f16x3" and self.skip_planes and bool(self.out_blocks) and self.out_blocks[0].skip_linear is not None
         for blk in self.in_blocks:
-            h = blk.run(self._lin, h, B, T, precision=self.precision, block_cache=bc)
+            h = blk.run(self._lin, h, B, T, precision=self.precision, block_cache=bc, want_planes=wp)
             skips.append(h)
-        h = self.mid_block.run(self._lin, h, B, T, precision=self.precision, block_cache=bc)
-        for blk in self.out_blocks:
-            h = blk.run(self._lin, h, B, T, skips.pop(), precision=self.precision, block_cache=bc)
+        h = self.mid_block.run(self._lin, h, B, T, precision=self.precision, block_cache=bc, want_planes=wp)
+        for i, blk in enumerate(self.out_blocks):
+            h = blk.run(self._lin, h, B, T, skips.pop(), precision=self.precision, block_cache=bc,
+                        want_planes=wp and i + 1 < len(self.out_blocks))
         h = ops.layernorm(h, self.norm.weight, self.norm.bias, self.norm.eps)
         h = self._lin(h, self.decoder_pred)                                                # [B*T, P*P*C]
         return ops.unpatchify(h, B, L, self.extras, C, P)                                  # :228-229

@@ -488,6 +488,11 @@ typedef struct {
     int precision; float act_scale, raw_scale;
     void* workspace; size_t workspace_bytes;
     float* y;
+    /* DUA_PREC_F16X3, optional (all may be NULL): the f16x3 planes ([B*L][D] fp16 hi | lo of the tokens * raw_scale) of x and of skip -
+     * with both given, skip_linear runs on the presplit two-source GEMM (dua_gemm_f16x3_presplit2) instead of splitting the fp32 rows on
+     * the fly - and y_planes: the same planes of this block's output, written beside y by the epilogue of fc2 (for the block that will
+     * take y as its x or as its long skip). */
+    const void* x_planes; const void* skip_planes; void* y_planes;
 } dua_uvitblock_args;
 /* uvit_block_fwd: Block.forward of uvit/uvit.py:95-120 (skip_linear(cat) -> x + attn(norm1 x) -> x + mlp(norm2 x)), fp32 or f16x3;
  * weights as stored ([N][K], fp32) or packed by dua_pack_weight_f16x3; head dims multiple of 8, <= 128. */
