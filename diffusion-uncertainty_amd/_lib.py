@@ -100,7 +100,6 @@ SIGNATURES = {
     "dua_mc_var_grad": (_I, [_P, _P, _I, _Z, _F, _P]),
     "dua_attention": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dua_attention_bf16x3": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
-    "dua_attention_bf16x3_planes": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "dua_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_timestep_embedding": (_I, [_P, _P, _I, _I, _P]),
     "dua_embedding_add": (_I, [_P, _P, _P, _P, _I, _I, _P]),
@@ -109,13 +108,6 @@ SIGNATURES = {
     "dua_conv3x3_bf16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_conv3x3_bf16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_groupnorm_apply_split": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
-    "dua_f16f8_weight_bytes": (_Z, [_I, _I]),
-    "dua_pack_weight_f16f8": (_I, [_P, _P, _I, _I, _I, _P]),
-    "dua_groupnorm_apply_split_f16f8": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
-    "dua_conv3x3_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "dua_groupnorm_apply_split_f16f6": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
-    "dua_pack_weight_f16f6": (_I, [_P, _P, _I, _I, _I, _P]),
-    "dua_conv3x3_f16f6_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "dua_f16x3_weight_bytes": (_Z, [_I, _I]),
     "dua_pack_weight_f16x3": (_I, [_P, _P, _I, _I, _I, _P]),
     "dua_groupnorm_apply_split_f16x3": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _F, _P, _P]),
@@ -149,8 +141,6 @@ SIGNATURES = {
     "dua_uvit_block_fwd": (_I, [_c.POINTER(UViTBlockArgs), _P]),
     "dua_conv_profile": (_I, [_I]),
     "dua_conv_profile_collect": (_I, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.POINTER(_c.c_double)]),
-    "dua_gemm_f16f8_presplit": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "dua_layernorm_split_f16f8": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "dua_set_dma_conv": (_I, [_I]),
     "dua_set_gn_apply_wide": (_I, [_I]),
     "dua_set_conv_stagger": (_I, [_I, _I, _I]),

@@ -23,7 +23,7 @@ struct AttnP {
     float* out;
     int T, heads, ch;
     float scale;
-    void* out_planes;        // split kernel only: write the result as f16f8 planes [B*T][C] (operand of the presplit proj GEMM)
+    void* out_planes;        // f16x3 kernel only: write the result as f16x3 planes [B*T][C] (operand of the presplit proj GEMM)
     long plane_elems;
     float planes_scale;      // f16x3 kernel: out_planes holds fp16 hi | fp16 lo of out * planes_scale
     // split kernels only: keys / values from their own tensors (cross-attention).  k == NULL: the packed (q | k | v) rows above.
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * QW) void k_flash_attn(AttnP p) {
 }
 
 // ================================================================================================================
-// Split-bf16 form of the same kernel (precision modes bf16x3 / f16f8 of the models): both products run as
+// Split-bf16 form of the same kernel (precision mode bf16x3 of the models): both products run as
 // hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (2^-17 per product), 16 channels / 16 keys per instruction instead
 // of 2, i.e. 96 instead of 512 matrix-core cycles per 32x32x16 block of the exact-fp32 form.
 //   S^T = K . Q^T : A = K tile (LDS, bf16 hi | lo planes, key rows, channel-contiguous), B = this wave's 32 queries, kept in
@@ -430,8 +430,7 @@ __global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(Attn
                         for (int u = 0; u < 4; ++u) { _Float16 x_, y_; if (unsigned long long* rc_ = dua_range_ctr()) dua_range_note(rc_, f[u]); asplit(f[u], x_, y_); hh[u] = x_; ll[u] = y_; }
                         *(af16x4*)((_Float16*)p.out_planes + ro + c) = hh;
                         *(af16x4*)((_Float16*)p.out_planes + p.plane_elems + ro + c) = ll;
-                    } else if (p.out_planes) dua_store_f16f8_quad(p.out_planes, p.plane_elems, ro + c, w);
-                    else *(float4*)(p.out + ro + c) = w;
+                    } else *(float4*)(p.out + ro + c) = w;
                 }
             }
     }
@@ -489,16 +488,6 @@ extern "C" int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, 
     DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128, "dua_attention_bf16x3: head dim must be a multiple of 4 in [8, 128] (got %d)", ch);
     DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_bf16x3: B*heads must be <= 65535");
     AttnP p{qkv, out, T, heads, ch, scale, nullptr, 0};
-    return attention_x_launch(p, B, stream);
-}
-
-/* Same, with the result written as f16f8 planes [B*T][heads*ch] (needs heads*ch % 32 == 0): the next GEMM (attention proj_out /
- * proj) then runs on the presplit LDS-DMA kernel without a conversion pass. */
-extern "C" int dua_attention_bf16x3_planes(const float* qkv, void* out_planes, int B, int T, int heads, int ch, float scale, void* stream) {
-    DUA_REQUIRE(qkv && out_planes && B > 0 && T > 0 && heads > 0, "dua_attention_bf16x3_planes: bad arguments");
-    DUA_REQUIRE(ch >= 8 && ch % 4 == 0 && ch <= 128 && (heads * ch) % 32 == 0, "dua_attention_bf16x3_planes: ch %% 4 == 0, ch <= 128, heads*ch %% 32 == 0");
-    DUA_REQUIRE((long)B * heads <= 65535, "dua_attention_bf16x3_planes: B*heads must be <= 65535");
-    AttnP p{qkv, nullptr, T, heads, ch, scale, out_planes, (long)B * T * heads * ch};
     return attention_x_launch(p, B, stream);
 }
 

@@ -14,7 +14,6 @@ struct DConvP {
     int ntaps;               // 9 = 3x3 convolution, 1 = plain GEMM over rows (1x1 convolution / linear layer)
     int act_out;             // 2 = GELU on the output (U-ViT fc1)
     __bf16* Csplit;          // optional: write the output as split bf16 planes (hi | lo, [M][N] each) instead of fp32 C
-    const signed char* Bscale;  // FMT 1 (f16f8): per weight row r, w_hi8 = fp8(w * 2^Bscale[r]), w_lo8 = fp8(w_lo * 2^(Bscale[r] + 12))
     int stagger_phases;      // > 1: workgroup start-up stagger (see k_xconv_dma); stagger_sleeps = s_sleep(127) per phase step
     int stagger_sleeps;
     const float* Cscale;     // FMT 3 (f16x3): per weight row 2^-s (the planes hold w * 2^s), padded to the tile grid

@@ -228,8 +228,7 @@ struct GnApplyP {
     const float *x1, *x2, *stats, *gamma, *beta, *film, *drop;
     float* y;
     int C1, C2, N, H, W, G, act, resample;
-    int split;               // 1: y is two bf16 planes (hi | lo) of the output shape, for the bf16x3 conv
-                             // 2: f16f8 planes: fp16 hi | per 32-channel block [32 x fp8(lo * 2^12) | 32 x fp8(x)]
+    int split;               // 1: y is two bf16 planes (hi | lo) of the output shape, for the bf16x3 conv; 4: f16x3 planes (below)
     long plane;              // elements per plane
     long film_ld;            // row stride of film in floats (>= 2*C)
     float oscale;            // split == 4 (f16x3): planes hold fp16 hi | fp16 lo of y * oscale (a power of two)
@@ -241,26 +240,6 @@ typedef __bf16 gn_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gn_store(const GnApplyP& p, size_t off, float4 v) {
     if (!p.split) {
         *(float4*)(p.y + off) = v;
-    } else if (p.split == 2) {
-        // C % 32 == 0, so the 32-channel block and the position inside it follow from the element offset alone
-        typedef _Float16 gn_f16x4 __attribute__((ext_vector_type(4)));
-        float f[4] = {v.x, v.y, v.z, v.w}, l[4], c8[4];
-        gn_f16x4 h;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const _Float16 t = (_Float16)f[j];
-            h[j] = t;
-            l[j] = fminf(fmaxf((f[j] - (float)t) * 4096.0f, -448.f), 448.f);
-            c8[j] = fminf(fmaxf(f[j], -448.f), 448.f);
-        }
-        *(gn_f16x4*)((_Float16*)p.y + off) = h;
-        unsigned char* x8 = (unsigned char*)((_Float16*)p.y + p.plane) + (off >> 5) * 64 + (off & 31);
-        int lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false);
-        lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo8, true);
-        int hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], 0, false);
-        hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], hi8, true);
-        *(int*)x8 = lo8;
-        *(int*)(x8 + 32) = hi8;
     } else if (p.split == 4) {
         // f16x3 planes: hi = fp16(s), lo = fp16(s - hi) of s = y * oscale (saturated to the fp16 range): 22 significant bits
         typedef _Float16 gn_f16x4 __attribute__((ext_vector_type(4)));
@@ -385,48 +364,13 @@ __global__ __launch_bounds__(BLK) void k_gn_apply(GnApplyP p, int chunk_px) {
 }
 
 // ---- 8 channels per lane: every plane is written 16 B per lane (two float4 for the fp32 output).  Used when both
-// sources have a multiple of 8 channels (f16f8: of 32, so that the lane pair 2i / 2i+1 sits in one 32-channel block).
-// f16f8 plane 1 holds per 32-channel block [32 x lo8 | 32 x hi8]: a lane owns 8 B of each half, so lane pairs swap one
-// half (even lane: the 16 lo8 bytes of both, odd lane: the 16 hi8 bytes) and store 16 contiguous bytes.
+// sources have a multiple of 8 channels.
 typedef __bf16 gn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 gn_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const float (&f)[8], int lane_odd) {
     if (!p.split) {
         *(float4*)(p.y + off) = make_float4(f[0], f[1], f[2], f[3]);
         *(float4*)(p.y + off + 4) = make_float4(f[4], f[5], f[6], f[7]);
-    } else if (p.split == 3) {
-        // f16f6 planes: plane 0 fp16; plane 1 per 32-channel block [24 B e2m3(lo) | exp | 7 pad | 24 B e2m3(x) | exp | 7 pad].
-        // The four lanes of a block (8 channels each) agree on the block exponents (two butterfly steps), encode their 8 values
-        // of each term as 48 bits, and pass bits along so that lanes 0-2 each store 8 aligned bytes of the 24-byte stream and
-        // lane 3 the exponent byte.
-        gn_f16x8 h;
-        float l[8], ml = 0.f, mh = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const _Float16 t = (_Float16)f[j];
-            h[j] = t;
-            l[j] = f[j] - (float)t;
-            ml = fmaxf(ml, fabsf(l[j]));
-            mh = fmaxf(mh, fabsf(f[j]));
-        }
-        *(gn_f16x8*)((_Float16*)p.y + off) = h;
-        ml = fmaxf(ml, __shfl_xor(ml, 1)); ml = fmaxf(ml, __shfl_xor(ml, 2));
-        mh = fmaxf(mh, __shfl_xor(mh, 1)); mh = fmaxf(mh, __shfl_xor(mh, 2));
-        const int ebl = (int)((__float_as_uint(ml) >> 23) & 0xff), ebh = (int)((__float_as_uint(mh) >> 23) & 0xff);
-        const int sbl = ebl > 2 ? ebl - 2 : 0, sbh = ebh > 2 ? ebh - 2 : 0;
-        unsigned long long pl = 0, ph = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            pl |= (unsigned long long)dua_e2m3_code(l[j], sbl) << (6 * j);
-            ph |= (unsigned long long)dua_e2m3_code(f[j], sbh) << (6 * j);
-        }
-        const unsigned long long nl = __shfl_down(pl, 1), nh = __shfl_down(ph, 1);
-        const int q = (int)((off >> 3) & 3);                              // this lane's octet inside the 32-channel block
-        const unsigned long long ol = q == 3 ? (unsigned long long)sbl : (pl >> (16 * q)) | (nl << (48 - 16 * q));
-        const unsigned long long oh = q == 3 ? (unsigned long long)sbh : (ph >> (16 * q)) | (nh << (48 - 16 * q));
-        unsigned char* blk = (unsigned char*)((_Float16*)p.y + p.plane) + (off >> 5) * 64 + 8 * q;
-        *(unsigned long long*)blk = ol;
-        *(unsigned long long*)(blk + 32) = oh;
     } else if (p.split == 4) {
         gn_f16x8 h, l;
         if (unsigned long long* rc_ = dua_range_ctr()) {
@@ -454,29 +398,6 @@ __device__ __forceinline__ void gn_store8(const GnApplyP& p, size_t off, const f
         __bf16* hi = (__bf16*)p.y + off;
         *(gn_bf16x8*)hi = h;
         *(gn_bf16x8*)(hi + p.plane) = l;
-    } else {
-        gn_f16x8 h;
-        float l[8], c8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const _Float16 t = (_Float16)f[j];
-            h[j] = t;
-            l[j] = fminf(fmaxf((f[j] - (float)t) * 4096.0f, -448.f), 448.f);
-            c8[j] = fminf(fmaxf(f[j], -448.f), 448.f);
-        }
-        *(gn_f16x8*)((_Float16*)p.y + off) = h;
-        int lo0 = __builtin_amdgcn_cvt_pk_fp8_f32(l[0], l[1], 0, false), lo1 = __builtin_amdgcn_cvt_pk_fp8_f32(l[4], l[5], 0, false);
-        lo0 = __builtin_amdgcn_cvt_pk_fp8_f32(l[2], l[3], lo0, true);
-        lo1 = __builtin_amdgcn_cvt_pk_fp8_f32(l[6], l[7], lo1, true);
-        int hi0 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], 0, false), hi1 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[4], c8[5], 0, false);
-        hi0 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], hi0, true);
-        hi1 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[6], c8[7], hi1, true);
-        // even lane keeps its lo8 and receives the partner's lo8; odd lane keeps hi8 and receives the partner's hi8
-        const int give0 = lane_odd ? lo0 : hi0, give1 = lane_odd ? lo1 : hi1;
-        const int got0 = __shfl_xor(give0, 1), got1 = __shfl_xor(give1, 1);
-        const size_t eoff = off & ~(size_t)15;                       // element offset of the pair's 16 channels
-        unsigned char* x8 = (unsigned char*)((_Float16*)p.y + p.plane) + (eoff >> 5) * 64 + (eoff & 31) + (lane_odd ? 32 : 0);
-        *(int4*)x8 = lane_odd ? make_int4(got0, got1, hi0, hi1) : make_int4(lo0, lo1, got0, got1);
     }
 }
 
@@ -571,19 +492,7 @@ extern "C" int dua_groupnorm_apply_split(const float* x1, int C1, const float* x
     return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 1, stream);
 }
 
-extern "C" int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                                               int resample, const float* dropmask, void* yplanes, void* stream) {
-    DUA_REQUIRE((C1 + C2) % 32 == 0, "dua_groupnorm_apply_split_f16f8: channels must be a multiple of 32");
-    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 2, stream);
-}
 
-extern "C" int dua_groupnorm_apply_split_f16f6(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                                               int resample, const float* dropmask, void* yplanes, void* stream) {
-    DUA_REQUIRE((C1 + C2) % 32 == 0 && C1 % 32 == 0 && (C1 + C2) / 8 <= BLK, "dua_groupnorm_apply_split_f16f6: channel counts must be multiples of 32, at most 2048");
-    return gn_apply_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, (float*)yplanes, 3, stream);
-}
 
 // "f16x3" planes (fp16 hi | fp16 lo of y * act_scale, act_scale a power of two): operand of dua_conv3x3_f16x3_presplit /
 // dua_gemm_f16x3_presplit, which undo the scale in their epilogue.
@@ -627,9 +536,9 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     gn_chunking(N, Ho * Wo, &cp, &nc);
     // the 16-byte-store kernel wins on the large maps (+11 % at 128^2, +5 % at 64^2) and loses on the small ones, where its
     // fewer, fatter lanes leave part of a workgroup idle
-    const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && (split != 2 || (C1 % 16 == 0 && C2 % 16 == 0)) &&
+    const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && 
                       (long)Ho * Wo >= 4096 && BLK % (C / 8) == 0;
-    if ((wide && gn_apply_wide) || split == 3) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
+    if (wide && gn_apply_wide) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= 2 * BLK) hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else hipLaunchKernelGGL(k_gn_apply<3>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);    // SD-1.5 up blocks: 1280 + 1280
@@ -866,13 +775,6 @@ __global__ __launch_bounds__(BLK) void k_layernorm(const float* __restrict__ x, 
                 const _Float16 h = (_Float16)sv;
                 ((_Float16*)y)[row * (long)D + c] = h;
                 ((_Float16*)y)[rows * (long)D + row * (long)D + c] = (_Float16)(sv - (float)h);
-            } else if (split == 2) {           // f16f8 planes: fp16 hi | per 32-column block [32 x e4m3(lo * 2^12) | 32 x e4m3(o)]
-                const _Float16 h = (_Float16)o;
-                ((_Float16*)y)[row * (long)D + c] = h;
-                unsigned char* x8 = (unsigned char*)((_Float16*)y + rows * (long)D) + (row * (long)D + (c & ~31)) * 2 + (c & 31);
-                const float l = fminf(fmaxf((o - (float)h) * 4096.0f, -448.f), 448.f), g = fminf(fmaxf(o, -448.f), 448.f);
-                x8[0] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(l, 0.f, 0, false) & 0xff);
-                x8[32] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(g, 0.f, 0, false) & 0xff);
             } else {
                 __bf16* hi = (__bf16*)y;
                 const __bf16 h = (__bf16)o;
@@ -917,7 +819,6 @@ __global__ __launch_bounds__(BLK) void k_layernorm4(const float* __restrict__ x,
                                          (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
             const long off = row * (long)D + c;
             if (!split) *(float4*)(y + off) = o;
-            else if (split == 2) dua_store_f16f8_quad(y, rows * (long)D, off, o);
             else if (split == 4) dua_store_f16x3_quad(y, rows * (long)D, off, o, oscale);
             else {
                 typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
@@ -958,11 +859,6 @@ extern "C" int dua_layernorm(const float* x, const float* gamma, const float* be
 extern "C" int dua_layernorm_split(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                                    void* stream) {
     return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 1, stream);
-}
-extern "C" int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
-                                         void* stream) {
-    DUA_REQUIRE(D % 32 == 0, "dua_layernorm_split_f16f8: D must be a multiple of 32");
-    return layernorm_impl(x, gamma, beta, (float*)yplanes, rows, D, eps, 2, stream);
 }
 
 extern "C" int dua_layernorm_split_f16x3(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,

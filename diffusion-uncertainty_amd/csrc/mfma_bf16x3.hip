@@ -477,9 +477,7 @@ __device__ __forceinline__ void dconv_row_out(const DConvP& p, float4 w, const f
     if (ACT == 2) { w.x = gelu_x(w.x); w.y = gelu_x(w.y); w.z = gelu_x(w.z); w.w = gelu_x(w.w); }
     if (RES) { w.x += q.x; w.y += q.y; w.z += q.z; w.w += q.w; }
     if (SPLIT) {               // the consumer is another split-operand GEMM: hand it the operand format directly
-        if (FMT == 1) {
-            dua_store_f16f8_quad(p.Csplit, (long)p.M * p.N, o, w);
-        } else if (FMT == 3) {
+        if (FMT == 3) {
             dua_store_f16x3_quad(p.Csplit, (long)p.M * p.N, o, w, p.split_scale);
         } else {
             bf16x4 hi, lo;
@@ -540,29 +538,18 @@ extern "C" int dua_debug_tile_times(unsigned long long* host) {
 
 // FMT selects the operand format of the two planes (same bytes, same DMA):
 //   0 "bf16x3": plane 0 = bf16 hi, plane 1 = bf16 lo; product = hi*hi + hi*lo + lo*hi, three v_mfma_f32_32x32x16_bf16 per 16 k.
-//   1 "f16f8":  plane 0 = fp16 hi; plane 1 = per 32-k block [32 x fp8 lo*2^12 | 32 x fp8 hi] (activations) resp.
-//               [32 x fp8 w*2^s | 32 x fp8 w_lo*2^(s+12)] (weights, s per output row).  hi*hi runs on v_mfma_f32_32x32x16_f16;
-//               BOTH cross terms of a 32-k block run as ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4: its k-block 0
-//               (lanes 0-31) holds a_lo8 x w_hi8 with E8M0 scales 2^-12, 2^-s, its k-block 1 (lanes 32-63) a_hi8 x w_lo8 with
-//               scales 1, 2^-(s+12).  The cross terms are 2^-11 of the product and fp8 keeps 2^-4 of them: 2^-15 per
-//               product, like the bf16 split, at 2/3 of its matrix-core cycles (128 instead of 192 per 32x32x32 block).
-//   RS ("row shift", f16f8 3x3 convolutions whose image width divides 256): ONE activation stage per (channel block, dy) serves
-//   the three dx taps.  The 256-row tile is whole image rows, so the pixel a dx = -1 / +1 tap reads outside the tile is always
-//   outside the image (zero): the taps read the same LDS stage at rows r-1, r, r+1 and zero the lanes at the image's left /
-//   right edge in registers.  Activation traffic L2 -> LDS drops to a third (the taps of a stage used to be re-fetched from L2:
-//   92 % L2 hits but 8 TB/s through the L2s, the limiter of the f16f8 K loop next to the matrix cores).
+//   3 "f16x3":  fp16 hi | lo of the power-of-two-scaled operand, the same loop on v_mfma_f32_32x32x16_f16 (see dua_hip.h).
+// (Round 4 removed formats 1 "f16f8" and 2 "f16f6" - fp16 hi + block-scaled fp8 / MXFP6 cross terms - together with their K loops and
+// the row-shift form RS they alone used: narrower than the parity modes, and since the Winograd form of the 3x3 convs no longer
+// faster than f16x3.  RS is kept as a template parameter that must be false.)
 template <int NT, int FMT, bool RS = false, bool KS = false /* split-K work items (DConvP::ksplit): its own instantiation, so that the
                                                                single-pass kernels compile exactly as they did without it */>
 __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins have no host-side type: the host pass only needs the stub
     constexpr int DBN = 64 * NT;
     // Ring depths (stages) of the activation / weight operand.  With the 256x256 tile the 160 KB of LDS hold five 32 KB
-    // stages: the bf16x3 loop (matrix-core bound) keeps the activations two tiles ahead; the f16f8 loop is bound by the
-    // WEIGHT stream - every workgroup of the chip asks for the same 32 KB tile at the same time, and the activation
-    // stream has pushed it out of the 4 MB L2s since the previous M tile, so it comes from the Infinity Cache - and
-    // keeps the weights two tiles ahead instead (measured per 72-step tile: weight stream 36k cycles exposed, activation
-    // stream 7k).
-    constexpr bool BDEEP = (NT == 4 && FMT == 1) || RS;
+    // stages: the loop (matrix-core bound) keeps the activations two tiles ahead.
+    constexpr bool BDEEP = RS;
     constexpr int RA = BDEEP ? 2 : 3, RB = NT == 2 || BDEEP ? 3 : 2;
     constexpr int SA = DBM * LDH;                    // bf16 elements per A plane of a stage
     constexpr int SB = DBN * LDH;
@@ -750,8 +737,9 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, kh = lane >> 5;
-  if constexpr (FMT == 0 || FMT == 3) {
-    static_assert(!RS, "the row-shift loop is built for the f16f8 / f16f6 formats");
+  {
+    static_assert(FMT == 0 || FMT == 3, "operand formats: 0 = split bf16 planes, 3 = f16x3 planes");
+    static_assert(!RS, "the row-shift loop of the removed f16f8 / f16f6 formats");
     typedef typename frag8<FMT == 3>::type bf16x8;      // FMT 3: the same loop on fp16 planes (v_mfma_f32_32x32x16_f16)
     // Fragment registers of ONE half step (16 of the 32 K columns of a stage); they are refilled in place while the
     // MFMA group that no longer needs them is executing, so the matrix pipe always has a full group queued when the
@@ -845,330 +833,6 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
 #undef SBAR
 #undef DWAIT_TILE
 
-  } else {
-    // ---------------- f16f8: fp16 hi*hi + one block-scaled fp8 MFMA for both cross terms ----------------
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    typedef int i32x8 __attribute__((ext_vector_type(8)));
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    f16x8 ah[2][2], bh[2][NT];          // [k16 half][tile]
-    i32x8 ax[2], bx[NT];
-    // Four lane-varying LDS byte offsets serve every fragment read: the A and the B side differ by a wave-uniform amount
-    // (kept in SGPRs), tiles by an immediate.  hi plane: chunk 2s + kh of the row; cross plane: chunks 2kh, 2kh + 1.
-    const int sw_ = (lr >> 2) & 3;
-    const int o_h0 = (lr * LDH + 8 * ((0 + kh) ^ sw_)) * 2, o_h1 = (lr * LDH + 8 * ((2 + kh) ^ sw_)) * 2;
-    const int o_x0 = (lr * LDH + 8 * ((2 * kh) ^ sw_)) * 2, o_x1 = (lr * LDH + 8 * ((2 * kh + 1) ^ sw_)) * 2;
-    const int a_row0 = wm * 64 * LDH * 2, b_row0 = (BOFF + wn * 32 * NT * LDH) * 2;      // bytes, wave-uniform
-    const char* ldsb = reinterpret_cast<const char*>(lds);
-    const int sca = kh ? 127 : 115;                                                  // E8M0: 2^0 (a_hi8) / 2^-12 (a_lo8 * 2^12)
-    int scbp = 0;                                                                    // the NT column-tile scales, one byte each
-    auto load_scales = [&]() {       // called AFTER the prologue DMA has been issued: its latency then runs under that of the DMA
-        if (FMT == 2) return;        // (MXFP6: block exponents travel with the operands)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            scbp |= ((127 - (int)p.Bscale[n0 + wn * 32 * NT + 32 * j + lr] - (kh ? 12 : 0)) & 0xff) << (8 * j);
-    };
-    // ---- single operations; the step below lays them out one by one (every ds_read / DMA sits between two MFMAs)
-    auto rd_ah = [&](int st, int s_, int i_) {
-        ah[s_][i_] = *(const f16x8*)(ldsb + (st * 2 * SA * 2 + a_row0 + 32 * i_ * LDH * 2) + (s_ ? o_h1 : o_h0));
-    };
-    auto rd_bh = [&](int st, int s_, int j_) {
-        bh[s_][j_] = *(const f16x8*)(ldsb + (st * 2 * SB * 2 + b_row0 + 32 * j_ * LDH * 2) + (s_ ? o_h1 : o_h0));
-    };
-    auto rd_x = [&](int uni) -> i32x8 {
-        const i32x4 u0_ = *(const i32x4*)(ldsb + uni + o_x0), u1_ = *(const i32x4*)(ldsb + uni + o_x1);
-        return (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
-    };
-    auto rd_ax = [&](int st, int i_) { ax[i_] = rd_x((st * 2 * SA + SA) * 2 + a_row0 + 32 * i_ * LDH * 2); };
-    auto rd_bx = [&](int st, int j_) { bx[j_] = rd_x((st * 2 * SB + SB) * 2 + b_row0 + 32 * j_ * LDH * 2); };
-#define SBAR() __builtin_amdgcn_sched_barrier(0)
-  if constexpr (RS) {
-    // ================= row-shift loop: one activation stage per (channel block, dy), three dx steps on it =================
-    constexpr int NM = 2 * NT;
-    const int a_stage0 = AOFF * 2 + a_row0;                                            // bytes
-    // lane offset (bytes) of chunk c of the fragment row shifted by dx; the swizzle follows the ACTUAL LDS row
-    // Every lane-derived offset of the loop is recomputed per step from the lane id (a handful of VALU operations):
-    // the accumulators and fragments take 224 of the 256 registers, and a loop-invariant offset that ends up in scratch
-    // costs a vmcnt(0) at its reload, i.e. the whole DMA pipeline.
-    auto loff = [&](int lr_, int dx, int c) -> int {
-        const int r_ = lr_ + dx;
-        return (r_ * LDH + 8 * (c ^ ((r_ >> 2) & 3))) * 2;
-    };
-    // image-edge lanes: bit i = row block i sits at x == 0, bit 2 + i = at x == W - 1
-    // (kept in bits 4..7 of the lane word that already holds the y-edge bits of the DMA rows)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int x_ = (m0 + wm * 64 + 32 * i + lr) & (p.W - 1);          // W divides 256: a power of two
-        rsy |= (x_ == 0 ? 1u : 0u) << (4 + i);
-        rsy |= (x_ == p.W - 1 ? 1u : 0u) << (6 + i);
-    }
-    asm volatile("" : "+v"(rsy));
-    // Edge lanes read ZEROS instead of their shifted row: their fragment address is replaced by one beyond the workgroup's
-    // LDS allocation (out-of-range DS reads return 0), four address selects per step instead of 32 data selects that would
-    // sit between the ds_reads and the MFMAs that consume them (measured: 29k of 220k cycles per tile).
-    constexpr int OOBL = 0x40000;
-    static_assert(OOBL >= 160 * 1024 + 256 * 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU for every fragment offset");
-    auto edge = [&](int dx, int i) -> bool { return (dx < 0 && ((rsy >> (4 + i)) & 1u)) || (dx > 0 && ((rsy >> (6 + i)) & 1u)); };
-    auto wait_vm = [&](int n) {        // counted wait with a run-time choice among the few counts that occur
-        if (n >= NT + 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT + 4) : "memory");
-        else if (n >= 4 && NT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (n >= NT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    const int ngroups = nk / 3;
-    // prologue: stage of group 0 (already requested by the previous tile's epilogue unless this is the first tile), weight
-    // tiles 0 and 1.  Every tile starts on activation stage 1: the epilogue patches cover the weight ring and stage 0 only.
-    if (!a_prefetched) {
-        dma_setup();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma_a(1, i);
-    }
-    a_prefetched = false;
-    issue_b(0);
-    if (nk > 1) issue_b(1);
-    load_scales();
-    wait_vm(nk > 1 ? NT : 0);
-    __builtin_amdgcn_s_barrier();
-    DUA_STAMP(1)
-    int sa = 1, sb = 0, dxi = 0, grp = 0;
-    bool a_inflight = false;
-    {
-        const int oh0 = loff(lr, -1, kh);
-        const int oha[2] = {edge(-1, 0) ? OOBL : oh0, edge(-1, 1) ? OOBL : oh0};
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) {
-#pragma unroll
-            for (int i_ = 0; i_ < 2; ++i_) ah[s_][i_] = *(const f16x8*)(ldsb + (a_stage0 + 2 * SA * 2 + 32 * i_ * LDH * 2) + (s_ ? oha[i_] ^ 32 : oha[i_]));
-#pragma unroll
-            for (int j_ = 0; j_ < NT; ++j_) rd_bh(0, s_, j_);
-        }
-    }
-    SBAR();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int dxc = dxi - 1;
-        int sbn = sb + 2;
-        if (sbn >= RB) sbn -= RB;
-        const bool preB = kt + 2 < nk;
-        const bool issueA = dxi == 0 && grp + 1 < ngroups;
-        if (issueA) dma_setup();
-        auto dma_piece = [&](int piece) {          // issue order of a step: weight pieces first, then the next activation stage
-            if (DUA_DIAG & 2) return;
-            if (piece < NT) { if (preB) dma_b(sbn, piece); }
-            else if (piece < NT + 4) { if (issueA) dma_a(sa ^ 1, piece - NT); }
-        };
-        int lane_k = lane;
-        asm volatile("" : "+v"(lane_k));                 // keeps the derived values below inside the step
-        const int lr_k = lane_k & 31, kh_k = lane_k >> 5;
-        const int ob_h = loff(lr_k, 0, kh_k), ob_x = loff(lr_k, 0, 2 * kh_k);      // weight side: chunk kh (s = 1: ^ 32), chunk 2kh (^ 16)
-        const int sca_k = kh_k ? 127 : 115;
-        auto rd_bh_k = [&](int st, int s_, int j_) {
-            bh[s_][j_] = *(const f16x8*)(ldsb + (st * 2 * SB * 2 + b_row0 + 32 * j_ * LDH * 2) + (s_ ? ob_h ^ 32 : ob_h));
-        };
-        auto rd_bx_k = [&](int st, int j_) {
-            const char* b_ = ldsb + ((st * 2 * SB + SB) * 2 + b_row0 + 32 * j_ * LDH * 2);
-            const i32x4 u0_ = *(const i32x4*)(b_ + ob_x), u1_ = *(const i32x4*)(b_ + (ob_x ^ 16));
-            bx[j_] = (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
-        };
-        const int ox0 = loff(lr_k, dxc, 2 * kh_k);                      // chunk 2kh + 1 sits at ox0 ^ 16
-        const int oxa[2] = {edge(dxc, 0) ? OOBL : ox0, edge(dxc, 1) ? OOBL : ox0};
-        const int a_st = a_stage0 + sa * 2 * SA * 2;
-        SBAR();
-        // ---- hi*hi, k 0..15: cross fragments of this step (rows shifted by dx), first DMA pieces
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) {
-            const int i_ = m_ / NT, j_ = m_ % NT;
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i_], bh[0][j_], acc[i_][j_], 0, 0, 0);
-            SBAR();
-            if (m_ < 2) {
-                if (!(DUA_DIAG & 4)) {
-                const char* a_ = ldsb + (a_st + SA * 2 + 32 * m_ * LDH * 2);
-                const i32x4 u0_ = *(const i32x4*)(a_ + oxa[m_]), u1_ = *(const i32x4*)(a_ + (oxa[m_] ^ 16));
-                ax[m_] = (i32x8){u0_[0], u0_[1], u0_[2], u0_[3], u1_[0], u1_[1], u1_[2], u1_[3]};
-                }
-            } else if (m_ - 2 < NT) { if (!(DUA_DIAG & 4)) rd_bx_k(sb, m_ - 2); }
-            else dma_piece(m_ - 2 - NT);                                   // NT = 4: gaps 6, 7 -> pieces 0, 1
-            SBAR();
-        }
-        // ---- hi*hi, k 16..31: the remaining DMA pieces
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) {
-            const int i_ = m_ / NT, j_ = m_ % NT;
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i_], bh[1][j_], acc[i_][j_], 0, 0, 0);
-            SBAR();
-            if (NT == 4) { if (m_ < 6) dma_piece(2 + m_); }
-            else if (m_ < 2) { dma_piece(2 * m_); dma_piece(2 * m_ + 1); }
-            else dma_piece(2 + m_);
-            SBAR();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // what may stay in flight: the weight tile two steps ahead, and the next activation stage until its group starts
-        if (issueA) a_inflight = true;
-        wait_vm((preB ? NT : 0) + ((a_inflight && dxi != 2) ? 4 : 0));
-        if (!(DUA_DIAG & 1)) __builtin_amdgcn_s_barrier();
-        if (++sb == RB) sb = 0;
-        int dxn = dxc + 1;                          // dx of the next step, and the stage it reads
-        if (dxi == 2) { sa ^= 1; dxn = -1; dxi = 0; ++grp; a_inflight = false; } else ++dxi;
-        SBAR();
-        const int oh0 = loff(lr_k, dxn, kh_k);                          // chunk 2 + kh sits at oh0 ^ 32
-        const int oha[2] = {edge(dxn, 0) ? OOBL : oh0, edge(dxn, 1) ? OOBL : oh0};
-        const int a_sn = a_stage0 + sa * 2 * SA * 2;
-        SBAR();
-        // ---- cross terms of this step (registers); between them the hi fragments of the next step
-        auto rd_hi = [&](int r_) {
-            if (DUA_DIAG & 4) return;
-            const int s_ = r_ / (2 + NT), q_ = r_ % (2 + NT);
-            if (q_ == 0) ah[s_][0] = *(const f16x8*)(ldsb + a_sn + (s_ ? oha[0] ^ 32 : oha[0]));
-            else if (q_ <= NT) rd_bh_k(sb, s_, q_ - 1);
-            else ah[s_][1] = *(const f16x8*)(ldsb + (a_sn + 32 * LDH * 2) + (s_ ? oha[1] ^ 32 : oha[1]));
-        };
-        constexpr int NR = 4 + 2 * NT, NDBL = NR - NM;
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) {
-            const int i_ = m_ / NT, j_ = m_ % NT;
-            if (FMT == 2)     // MXFP6 (e2m3) cross terms: the E8M0 block exponent of each lane's 32-k block rides in dword 6 of its operand
-                acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 2, 2, 0, ax[i_][6], 0, bx[j_][6]);
-            else
-                acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 0, 0, 0, sca_k, 0, scbp >> (8 * j_));
-            SBAR();
-            if (m_ < NDBL) { rd_hi(2 * m_); rd_hi(2 * m_ + 1); }
-            else rd_hi(2 * NDBL + (m_ - NDBL));
-            SBAR();
-        }
-    }
-  } else {
-    constexpr int KEEP = NT == 4 ? 4 : 6;
-#define DWAIT_TILE(more) \
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    constexpr int NM = 2 * NT;                       // MFMAs per group (wave tile 64 x 32*NT)
-    constexpr int NPIECE = NT == 4 ? 8 : 6;          // DMA pieces per step: NT=4 [B0..B3 A0..A3], NT=2 [A0..A3 B0 B1]
-    issue_a(0);
-    issue_b(0);
-    if (nk > 1) {
-        if (!BDEEP) issue_a(1);
-        if (NT == 2 || BDEEP) issue_b(1);
-    }
-    load_scales();
-    DWAIT_TILE(nk > 1)
-    __builtin_amdgcn_s_barrier();
-    DUA_STAMP(1)
-    int sa = 0, sb = 0;
-#pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-        rd_ah(0, s_, 0); rd_ah(0, s_, 1);
-#pragma unroll
-        for (int j_ = 0; j_ < NT; ++j_) rd_bh(0, s_, j_);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // Per K step:  [hi*hi k 0..15 | hi*hi k 16..31]  wait + barrier  [cross MFMA].  The cross fragments of the step are read
-    // between the hi*hi MFMAs, the hi fragments of the NEXT stage between the cross MFMAs (after the barrier that publishes
-    // it), the DMA pieces of the tiles ahead between the hi*hi MFMAs: at most two ds_read_b128 or one DMA piece per MFMA
-    // gap, never a burst of reads that would hold the matrix pipe of the wave.
-    for (int kt = 0; kt < nk; ++kt) {
-        constexpr int AA = BDEEP ? 1 : 2, BA = NT == 4 && !BDEEP ? 1 : 2;      // tiles ahead of the step being multiplied
-        int sa2 = sa + AA;
-        if (sa2 >= RA) sa2 -= RA;
-        int sbn = sb + BA;
-        if (sbn >= RB) sbn -= RB;
-        const bool preA = kt + AA < nk, preB = kt + BA < nk;
-        if (preA) dma_setup();
-        // piece order of a step = issue order = vmcnt order: the operand that is only ONE tile ahead goes first, so that the
-        // counted wait at the end of the step can leave the 4 (NT = 4) / 6 (NT = 2) pieces of the far tile in flight
-        auto dma_piece = [&](int piece) {
-            if (NT == 4 && !BDEEP) {
-                if (piece < 4) { if (preB) dma_b(sbn, piece); }
-                else if (piece < 8) { if (preA) dma_a(sa2, piece - 4); }
-            } else {
-                if (piece < 4) { if (preA) dma_a(sa2, piece); }
-                else if (piece < 4 + NT) { if (preB) dma_b(sbn, piece - 4); }
-            }
-        };
-        SBAR();
-        // hi fragments in consumption order: ah[s][0], bh[s][0..NT-1], ah[s][1] for s = 0, 1
-        auto rd_hi = [&](int st_a, int st_b, int r_) {
-            const int s_ = r_ / (2 + NT), q_ = r_ % (2 + NT);
-            if (q_ == 0) rd_ah(st_a, s_, 0);
-            else if (q_ <= NT) rd_bh(st_b, s_, q_ - 1);
-            else rd_ah(st_a, s_, 1);
-        };
-        constexpr int NR = 4 + 2 * NT;
-#ifndef DUA_SCHED
-#define DUA_SCHED 2      // 1 = grouped reads / DMA bursts, 2 = one read or DMA piece per MFMA gap (+1 % on the ADM-128 mix)
-#endif
-#if DUA_SCHED == 1
-        // ---- grouped schedule: [cross reads | hi*hi 0 | DMA | hi*hi 1 | DMA] wait + barrier [next hi reads | cross MFMA]
-        rd_ax(sa, 0); rd_ax(sa, 1);
-#pragma unroll
-        for (int j_ = 0; j_ < NT; ++j_) rd_bx(sb, j_);
-        SBAR();
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_)
-            acc[m_ / NT][m_ % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][m_ / NT], bh[0][m_ % NT], acc[m_ / NT][m_ % NT], 0, 0, 0);
-        SBAR();
-#pragma unroll
-        for (int u_ = 0; u_ < NPIECE / 2; ++u_) dma_piece(u_);
-        SBAR();
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_)
-            acc[m_ / NT][m_ % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][m_ / NT], bh[1][m_ % NT], acc[m_ / NT][m_ % NT], 0, 0, 0);
-        SBAR();
-#pragma unroll
-        for (int u_ = NPIECE / 2; u_ < NPIECE; ++u_) dma_piece(u_);
-        SBAR();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        DWAIT_TILE(BDEEP ? preB : preA)
-        __builtin_amdgcn_s_barrier();
-        if (++sa == RA) sa = 0;
-        if (++sb == RB) sb = 0;
-        SBAR();
-#pragma unroll
-        for (int r_ = 0; r_ < NR; ++r_) rd_hi(sa, sb, r_);
-        SBAR();
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_)
-            acc[m_ / NT][m_ % NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[m_ / NT], bx[m_ % NT], acc[m_ / NT][m_ % NT], 0, 0, 0, sca, 0, scbp >> (8 * (m_ % NT)));
-        SBAR();
-#else
-        // ---- interleaved schedule: one read / DMA piece per MFMA gap
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) {
-            const int i_ = m_ / NT, j_ = m_ % NT;
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i_], bh[0][j_], acc[i_][j_], 0, 0, 0);
-            SBAR();
-            if (m_ < 2) rd_ax(sa, m_);
-            else if (m_ - 2 < NT) rd_bx(sb, m_ - 2);
-            else dma_piece(m_ - 2 - NT);                                   // NT = 4: gaps 6, 7 -> pieces 0, 1
-            SBAR();
-        }
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) {
-            const int i_ = m_ / NT, j_ = m_ % NT;
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i_], bh[1][j_], acc[i_][j_], 0, 0, 0);
-            SBAR();
-            if (NT == 4) { if (m_ < 6) dma_piece(2 + m_); }
-            else if (m_ < 2) { dma_piece(2 * m_); dma_piece(2 * m_ + 1); }
-            else dma_piece(2 + m_);
-            SBAR();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        DWAIT_TILE(BDEEP ? preB : preA)
-        __builtin_amdgcn_s_barrier();
-        if (++sa == RA) sa = 0;
-        if (++sb == RB) sb = 0;
-        SBAR();
-        constexpr int NDBL = NR - NM;                   // gaps m < NDBL carry two reads, the rest one
-#pragma unroll
-        for (int m_ = 0; m_ < NM; ++m_) {
-            const int i_ = m_ / NT, j_ = m_ % NT;
-            acc[i_][j_] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ax[i_], bx[j_], acc[i_][j_], 0, 0, 0, sca, 0, scbp >> (8 * j_));
-            SBAR();
-            if (m_ < NDBL) { rd_hi(sa, sb, 2 * m_); rd_hi(sa, sb, 2 * m_ + 1); }
-            else rd_hi(sa, sb, 2 * NDBL + (m_ - NDBL));
-            SBAR();
-        }
-#endif
-    }
-#undef DWAIT_TILE
-  }
-#undef SBAR
   }
     DUA_STAMP(2)
     // The K loop's last barrier has retired every read of the stages: the row-shift loop requests the first activation stage
@@ -1303,9 +967,7 @@ __global__ __launch_bounds__(512, 2) void k_xconv_dma(DConvP p) {
                         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                     }
                     if (p.Csplit) {        // the consumer is another split-operand GEMM: hand it the operand format directly
-                        if (FMT == 1) {
-                            dua_store_f16f8_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v);
-                        } else if (FMT == 3) {
+                        if (FMT == 3) {
                             dua_store_f16x3_quad(p.Csplit, (long)p.M * p.N, (long)row * p.N + colq, v, p.split_scale);
                         } else {
                             bf16x4 hi, lo;
@@ -1389,48 +1051,7 @@ __global__ void k_split_weight(const float* __restrict__ w, __bf16* __restrict__
     }
 }
 
-// f16f8 weight format: plane 0 = fp16(w); plane 1 = per (row, 32-k block) 64 bytes [32 x fp8(w * 2^s) | 32 x fp8((w - fp16(w)) * 2^(s+12))]
-// with s = 7 - floor(log2(max |row|)) (the row maximum lands in [128, 256), below the e4m3 maximum 448); s per row in `scale`.
-__device__ __forceinline__ unsigned char to_fp8(float v) {
-    v = fminf(fmaxf(v, -448.f), 448.f);
-    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
-}
-__global__ void k_weight_row_scale(const float* __restrict__ w, signed char* __restrict__ scale, int N, int K, int Npad) {
-    const int n = blockIdx.x;              // one workgroup per padded row (the K order does not matter for the maximum)
-    float m = 0.f;
-    if (n < N)
-        for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, fabsf(w[(size_t)n * K + k]));
-    __shared__ float red[256];
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int e = 0;
-        if (red[0] > 0.f) e = 7 - (int)floorf(log2f(red[0]));
-        scale[n] = (signed char)max(-60, min(60, e));
-    }
-}
-__global__ void k_split_weight_f16f8(const float* __restrict__ w, _Float16* __restrict__ hi, unsigned char* __restrict__ x8,
-                                     const signed char* __restrict__ scale, int N, int K, int Npad, int conv_cin) {
-    size_t total = (size_t)Npad * K;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int n = (int)(i / K), k = (int)(i % K);
-        float v = split_weight_src(w, n, k, N, K, conv_cin);
-        _Float16 h = (_Float16)v;
-        hi[i] = h;
-        const float sc = exp2f((float)scale[n]);
-        unsigned char* o = x8 + ((size_t)n * K + (k & ~31)) * 2 + (k & 31);
-        o[0] = to_fp8(v * sc);
-        o[32] = to_fp8((v - (float)h) * sc * 4096.f);
-    }
-}
-
 extern "C" size_t dua_bf16x3_plane_elems(int N, int K) { return (size_t)round_up(N, BN) * K; }
-// bytes of a packed f16f8 weight: two planes of Npad x K 2-byte elements + Npad row-scale bytes (padded to 16)
-extern "C" size_t dua_f16f8_weight_bytes(int N, int K) { return 4 * dua_bf16x3_plane_elems(N, K) + (size_t)round_up(round_up(N, BN), 16); }
 
 extern "C" int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K, int conv_cin, void* stream) {
     DUA_REQUIRE(w && planes && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_bf16x3: K must be a positive multiple of 32 (got %d)", K);
@@ -1442,18 +1063,6 @@ extern "C" int dua_pack_weight_bf16x3(const float* w, void* planes, int N, int K
     return dua_check_launch("dua_pack_weight_bf16x3");
 }
 
-extern "C" int dua_pack_weight_f16f8(const float* w, void* packed, int N, int K, int conv_cin, void* stream) {
-    DUA_REQUIRE(w && packed && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_f16f8: K must be a positive multiple of 32 (got %d)", K);
-    DUA_REQUIRE(conv_cin == 0 || (K == 9 * conv_cin && conv_cin % BK == 0), "dua_pack_weight_f16f8: conv K must be 9*Cin, Cin %% 32 == 0");
-    int Npad = round_up(N, BN);
-    size_t plane = (size_t)Npad * K;
-    _Float16* hi = (_Float16*)packed;
-    unsigned char* x8 = (unsigned char*)(hi + plane);
-    signed char* scale = (signed char*)(x8 + 2 * plane);
-    hipLaunchKernelGGL(k_weight_row_scale, dim3(Npad), 256, 0, as_stream(stream), w, scale, N, K, Npad);
-    hipLaunchKernelGGL(k_split_weight_f16f8, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, x8, scale, N, K, Npad, conv_cin);
-    return dua_check_launch("dua_pack_weight_f16f8");
-}
 
 extern "C" int dua_conv3x3_bf16x3(const float* x, const void* planes, const float* bias, const float* residual, float* y, int N,
                                   int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
@@ -1629,15 +1238,9 @@ static int launch_dconv(DConvP& d, int fmt, hipStream_t st, const char* what) {
         }
         if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 3>), dim3(grid), 512, 0, st, d);
         else hipLaunchKernelGGL((k_xconv_dma<2, 3>), dim3(grid), 512, 0, st, d);
-    } else if (fmt == 2) {                                                        // MXFP6 cross terms: row-shift convolutions only
-        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 2, true>), dim3(grid), 512, 0, st, d);
-        else hipLaunchKernelGGL((k_xconv_dma<2, 2, true>), dim3(grid), 512, 0, st, d);
-    } else if (d.ntaps == 9 && 256 % d.W == 0 && dua_dma_conv_enabled != 6) {     // row-shift form (6: A/B switch to the per-tap form)
-        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 1, true>), dim3(grid), 512, 0, st, d);
-        else hipLaunchKernelGGL((k_xconv_dma<2, 1, true>), dim3(grid), 512, 0, st, d);
     } else {
-        if (wide) hipLaunchKernelGGL((k_xconv_dma<4, 1>), dim3(grid), 512, 0, st, d);
-        else hipLaunchKernelGGL((k_xconv_dma<2, 1>), dim3(grid), 512, 0, st, d);
+        dua_set_error("%s: unknown operand format %d", what, fmt);
+        return DUA_EINVAL;
     }
     return dua_check_launch(what);
 }
@@ -1651,15 +1254,13 @@ static int conv3x3_presplit_impl(const void* xplanes, const void* planes, const 
     size_t plane = dua_bf16x3_plane_elems(Cout, 9 * Cin);
     const size_t a_plane = (size_t)N * H * W * Cin;
     const bool dma_ok = 4 * plane < 0x7FFFFFF0ull && (size_t)(2 * W + 260) * Cin * 2 < 0x7FFFFFF0ull;
-    if (fmt >= 1) DUA_REQUIRE(dma_ok, "dua_conv3x3_f16f8_presplit: operand too large for the LDS-DMA kernel");
-    if (fmt == 2) DUA_REQUIRE(256 % W == 0, "dua_conv3x3_f16f6_presplit: the image width must divide 256 (got %d)", W);
+    if (fmt >= 1) DUA_REQUIRE(dma_ok, "dua_conv3x3 presplit: operand too large for the LDS-DMA kernel");
     if ((dua_dma_conv_enabled != 0 || fmt >= 1) && dma_ok) {
         DConvP d{};
         d.A = (const __bf16*)xplanes; d.B = (const __bf16*)planes; d.bias = bias; d.res = residual; d.C = y;
         d.a_plane = (long)a_plane; d.b_plane = (long)plane;
         d.M = N * H * W; d.N = Cout; d.K = 9 * Cin; d.H = H; d.W = W; d.Cin = Cin; d.nchw_out = nchw_out; d.colsum = colsum;
         d.ntaps = 9;
-        d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
         d.Cscale = (const float*)((const __bf16*)planes + 2 * plane);
         d.out_scale = 1.0f / act_scale;
         return launch_dconv(d, fmt, as_stream(stream), "dua_conv3x3 presplit (dma)");
@@ -1675,61 +1276,6 @@ static int conv3x3_presplit_impl(const void* xplanes, const void* planes, const 
 extern "C" int dua_conv3x3_bf16x3_presplit(const void* xplanes, const void* planes, const float* bias, const float* residual,
                                            float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
     return conv3x3_presplit_impl(xplanes, planes, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 0, stream);
-}
-extern "C" int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,
-                                          float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
-    return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 1, stream);
-}
-extern "C" int dua_conv3x3_f16f6_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual,
-                                          float* y, int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream) {
-    return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 2, stream);
-}
-
-// ---- f16f6 weight format: plane 0 = fp16(w) [Npad128][K]; plane 1 per (row, 32-k block) 64 bytes:
-//   [32 x e2m3(w * 2^-Ew) (24 B)][E8M0 byte 127 + Ew][7 B pad][32 x e2m3((w - fp16 w) * 2^-El) (24 B)][127 + El][7 B pad]
-// (activation planes: the same block with the low part first - see dua_hip.h).  Block exponent: biased exponent of the block
-// maximum minus two, i.e. the maximum lands in [4, 8) of the e2m3 range [0, 7.5] (a maximum above 7.75 rounds to the 7.5 clamp).
-__global__ void k_split_weight_f16f6(const float* __restrict__ w, _Float16* __restrict__ hi, unsigned char* __restrict__ x6,
-                                     int N, int K, int Npad, int conv_cin) {
-    // one thread per (row, 32-k block)
-    const size_t nblk = (size_t)Npad * (K / 32);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i / (K / 32)), kb = (int)(i % (K / 32)) * 32;
-        float v[32], l[32], mw = 0.f, ml = 0.f;
-        for (int j = 0; j < 32; ++j) {
-            v[j] = split_weight_src(w, n, kb + j, N, K, conv_cin);
-            const _Float16 h = (_Float16)v[j];
-            hi[(size_t)n * K + kb + j] = h;
-            l[j] = v[j] - (float)h;
-            mw = fmaxf(mw, fabsf(v[j]));
-            ml = fmaxf(ml, fabsf(l[j]));
-        }
-        unsigned char* o = x6 + ((size_t)n * K + kb) * 2;
-        for (int t = 0; t < 2; ++t) {
-            const float* src = t == 0 ? v : l;
-            const int eb = (int)((__float_as_uint(t == 0 ? mw : ml) >> 23) & 0xff);
-            const int sb = eb > 2 ? eb - 2 : 0;
-            unsigned long long bits[3] = {0, 0, 0};                               // 192-bit stream, element j at bits [6j, 6j + 6)
-            for (int j = 0; j < 32; ++j) {
-                const unsigned long long c = dua_e2m3_code(src[j], sb);
-                const int bp = 6 * j;
-                bits[bp >> 6] |= c << (bp & 63);
-                if ((bp & 63) > 58) bits[(bp >> 6) + 1] |= c >> (64 - (bp & 63));
-            }
-            for (int q = 0; q < 3; ++q) *(unsigned long long*)(o + 32 * t + 8 * q) = bits[q];
-            *(unsigned long long*)(o + 32 * t + 24) = (unsigned long long)sb;
-        }
-    }
-}
-extern "C" int dua_pack_weight_f16f6(const float* w, void* packed, int N, int K, int conv_cin, void* stream) {
-    DUA_REQUIRE(w && packed && N > 0 && K > 0 && K % BK == 0, "dua_pack_weight_f16f6: K must be a positive multiple of 32 (got %d)", K);
-    DUA_REQUIRE(conv_cin == 0 || (K == 9 * conv_cin && conv_cin % BK == 0), "dua_pack_weight_f16f6: conv K must be 9*Cin, Cin %% 32 == 0");
-    int Npad = round_up(N, BN);
-    size_t plane = (size_t)Npad * K;
-    _Float16* hi = (_Float16*)packed;
-    hipLaunchKernelGGL(k_split_weight_f16f6, stream_grid((size_t)Npad * (K / 32), 64), 64, 0, as_stream(stream), w, hi,
-                       (unsigned char*)(hi + plane), N, K, Npad, conv_cin);
-    return dua_check_launch("dua_pack_weight_f16f6");
 }
 
 // ---- f16x3 weight format (fp32-equivalent split): plane 0 = fp16(w * 2^s) [Npad128][K], plane 1 = fp16(w * 2^s - plane 0), then
@@ -1794,14 +1340,14 @@ extern "C" int dua_conv3x3_f16x3_presplit(const void* xplanes, const void* packe
     return conv3x3_presplit_impl(xplanes, packed, bias, residual, y, N, H, W, Cin, Cout, nchw_out, colsum, 3, stream, act_scale);
 }
 
-// C[M][N] = A * W^T (+ bias) (+ residual) with A given as split planes (written by dua_groupnorm_apply_split / _f16f8) and W
-// packed by dua_pack_weight_bf16x3 / _f16f8: the LDS-DMA kernel with a single tap.
+// C[M][N] = A * W^T (+ bias) (+ residual) with A given as split planes (written by dua_groupnorm_apply_split / _split_f16x3) and W
+// packed by dua_pack_weight_bf16x3 / _f16x3: the LDS-DMA kernel with a single tap (f16x3: k_hgemm of gemm_f16x3.hip by default).
 static int gemm_presplit_impl(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
                               void* Csplit, int M, int N, int K, int act_out, float* colsum, int fmt, void* stream, float act_scale = 1.0f,
                               float split_scale = 1.0f) {
     DUA_REQUIRE(aplanes && planes && (C || Csplit) && M > 0 && N > 0 && K >= BK && K % BK == 0, "dua_gemm presplit: K must be a multiple of 32 (got %d)", K);
     DUA_REQUIRE(N % 4 == 0, "dua_gemm presplit: N must be a multiple of 4");
-    DUA_REQUIRE(!Csplit || fmt == 0 || N % 32 == 0, "dua_gemm_f16f8_presplit: a split output needs N %% 32 == 0");
+    DUA_REQUIRE(!Csplit || fmt == 0 || N % 32 == 0, "dua_gemm presplit: a split output needs N %% 32 == 0");
     size_t plane = dua_bf16x3_plane_elems(N, K);
     DUA_REQUIRE(4 * plane < 0x7FFFFFF0ull && (size_t)260 * K * 2 < 0x7FFFFFF0ull, "dua_gemm presplit: operand too large");
     if (fmt == 3 && dua_hgemm_enabled() && (!Csplit || N % 32 == 0) && (size_t)M * K * 2 < 0xFFFFFFF0ull) {
@@ -1819,7 +1365,6 @@ static int gemm_presplit_impl(const void* aplanes, const void* planes, const flo
     d.a_plane = (long)M * K; d.b_plane = (long)plane;
     d.M = M; d.N = N; d.K = K; d.H = 1; d.W = 1; d.Cin = K; d.nchw_out = 0; d.colsum = colsum; d.ntaps = 1;
     d.act_out = act_out; d.Csplit = (__bf16*)Csplit;
-    d.Bscale = (const signed char*)((const __bf16*)planes + 2 * plane);
     d.Cscale = (const float*)((const __bf16*)planes + 2 * plane);
     d.out_scale = 1.0f / act_scale;
     d.split_scale = split_scale;
@@ -1828,10 +1373,6 @@ static int gemm_presplit_impl(const void* aplanes, const void* planes, const flo
 extern "C" int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const float* bias, const float* residual, float* C,
                                         void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
     return gemm_presplit_impl(aplanes, planes, bias, residual, C, Csplit, M, N, K, act_out, colsum, 0, stream);
-}
-extern "C" int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
-                                       void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream) {
-    return gemm_presplit_impl(aplanes, packed, bias, residual, C, Csplit, M, N, K, act_out, colsum, 1, stream);
 }
 
 extern "C" int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,

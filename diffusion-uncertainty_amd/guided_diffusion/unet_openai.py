@@ -187,13 +187,12 @@ class AttentionBlock(nn.Module):
         qkv = ctx.qkv(xn if isinstance(xn, ops.SplitPlanes) else xn.view(N * T, C), self)
         a = ops.qkv_attention(qkv, N, T, self.num_heads, C // self.num_heads,
                               precision="f16x3" if ctx.model.precision == "f16x3" else ("bf16x3" if ctx.split_mode else "fp32"),
-                              planes_out=(ctx.gemm_split in ("f16f8", "f16x3")))
+                              planes_out=(ctx.gemm_split == "f16x3"))
         if isinstance(a, ops.SplitPlanes):        # attention output already in the operand format: proj_out on the LDS-DMA kernel
-            key = (id(self.proj_out), "w1f" if a.fmt == "f16f8" else "w1hp")
+            key = (id(self.proj_out), "w1hp")
             if key not in ctx.model._packed:
                 w = self.proj_out.weight.detach()
-                pack = ops.pack_weight_f16f8 if a.fmt == "f16f8" else ops.pack_weight_f16x3
-                ctx.model._packed[key] = pack(w.reshape(w.shape[0], w.shape[1]).contiguous())
+                ctx.model._packed[key] = ops.pack_weight_f16x3(w.reshape(w.shape[0], w.shape[1]).contiguous())
             out2d = ops.gemm_bf16x3_presplit(a, ctx.model._packed[key], C, bias=self.proj_out.bias, residual=x.view(N * T, C),
                                              colsum=ctx.model.fuse_gn_stats)
         else:
@@ -213,14 +212,14 @@ class _Ctx:
         self.emb = None
         self.film_all = None
         # split modes: GroupNorm+SiLU writes the conv input directly in the operand format of the conv kernel
-        # (False | True = bf16x3 planes | "f16f8" planes | "f16f6" planes: 3x3 convs whose width divides 256 only)
+        # (False | True = bf16x3 planes | "f16x3" planes)
         # "f16x3" (fp32-equivalent): 3x3 convs and qkv on fp16 hi / lo planes written by the GroupNorm kernels, 1x1 skip / proj_out
         # with the raw fp32 operand split on the fly (same 22-bit split), attention (head dims <= 256) on the split flash kernel in the same format
-        assert model.precision in ("fp32", "bf16x3", "f16f8", "f16f6", "f16x3"), model.precision
+        assert model.precision in ("fp32", "bf16x3", "f16x3"), model.precision
         self.split_mode = model.precision not in ("fp32", "f16x3")          # on-the-fly bf16 split of raw fp32 operands
         self.presplit = model.precision != "fp32"
-        self.split_acts = model.precision if model.precision in ("f16f8", "f16f6", "f16x3") else model.precision == "bf16x3"
-        self.gemm_split = "f16f8" if self.split_acts == "f16f6" else self.split_acts       # one-tap GEMMs (qkv, proj_out)
+        self.split_acts = model.precision if model.precision == "f16x3" else model.precision == "bf16x3"
+        self.gemm_split = self.split_acts                                                  # one-tap GEMMs (qkv, proj_out)
         # parity modes: whole ResBlocks / AttentionBlocks as single C-ABI calls (dua_adm_resblock_fwd / dua_adm_attnblock_fwd)
         self.block_abi = bool(getattr(model, "use_block_abi", True)) and model.precision in ("fp32", "f16x3") and not model.activation_noise
 
@@ -231,8 +230,6 @@ class _Ctx:
     def conv_split(self, width, conv_shape=None):
         """Operand format the GroupNorm in front of a 3x3 conv of this output width writes (conv_shape = (N, H, W, Cin, Cout) lets
         the f16x3 mode pick the Winograd operand where the kernel takes the shape)."""
-        if self.split_acts == "f16f6" and 256 % width != 0:
-            return "f16f8"
         if conv_shape is not None and self.wino_ok(*conv_shape):
             return "f16x3w" if self.model.precision == "f16x3" else "f32w"
         return self.split_acts
@@ -248,10 +245,6 @@ class _Ctx:
                 cache[key] = w.reshape(w.shape[0], w.shape[1]).contiguous()
             elif kind == "w3x":
                 cache[key] = ops.pack_weight_bf16x3(mod.weight.detach().contiguous())
-            elif kind == "w3f":
-                cache[key] = ops.pack_weight_f16f8(mod.weight.detach().contiguous())
-            elif kind == "w3s":
-                cache[key] = ops.pack_weight_f16f6(mod.weight.detach().contiguous())
             elif kind == "w3h":
                 cache[key] = ops.pack_weight_f16x3(mod.weight.detach().contiguous())
             elif kind == "w3w":
@@ -261,9 +254,6 @@ class _Ctx:
             elif kind == "qkvh":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16x3(wq), bq)
-            elif kind == "qkvf":
-                wq, bq = self.packed(mod, "qkv")
-                cache[key] = (ops.pack_weight_f16f8(wq), bq)
             elif kind == "w1h":
                 w = mod.weight.detach()
                 cache[key] = ops.pack_weight_f16x3(w.reshape(w.shape[0], w.shape[1]).contiguous())
@@ -311,7 +301,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16f8": "w3f", "f16f6": "w3s", "f16x3": "w3h", "f16x3w": "w3w", "f32w": "w3wf"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f32w": "w3wf"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -328,7 +318,7 @@ class _Ctx:
 
     def qkv(self, xn, blk):
         if isinstance(xn, ops.SplitPlanes):
-            planes, bq = self.packed(blk, {"f16f8": "qkvf", "f16x3": "qkvh"}.get(xn.fmt, "qkvx"))
+            planes, bq = self.packed(blk, "qkvh" if xn.fmt == "f16x3" else "qkvx")
             return ops.gemm_bf16x3_presplit(xn, planes, 3 * blk.channels, bias=bq)
         if self.split_mode and xn.shape[1] % 32 == 0:
             planes, bq = self.packed(blk, "qkvx")
@@ -396,10 +386,7 @@ class UNetModel(nn.Module):
         self._packed = {}
         # "fp32": exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x3": convs and weight GEMMs on the bf16 matrix cores
         # with split fp32 operands (csrc/mfma_bf16x3.hip); attention products, embeddings, norms stay fp32.
-        # "f16f8": as bf16x3, with the 3x3 convs and the qkv projections on the fp16 + block-scaled-fp8 form of the same
-        # kernel (2/3 of the matrix-core cycles; ~2.4x the bf16x3 error, still ~12x inside the 1e-3 bar).
-        # "f16f6": as f16f8, with the cross terms of the 3x3 convs in MXFP6 (e2m3 with an E8M0 exponent per 32 channels): half
-        # the matrix-core cycles of bf16x3.
+        # "f16x3": the fp32-equivalent split (fp16 hi + lo of the power-of-two-scaled operand, three fp16 MFMAs per product): the headline.
         # "f16w" (side mode, NOT a parity mode): the f16x3 engine with ONE fp16 product per tap in the Winograd-form 3x3 convs (fp16
         # operands, fp32 accumulation - the arithmetic of the reference's own GPU path under torch.autocast, script :83; GroupNorm,
         # softmax, the sampler and every GEMM outside those convs as in f16x3).  `precision` then reads "f16x3", `wino_single` True.

@@ -291,7 +291,7 @@ class SplitPlanes:
     """Activation tensor stored as two bf16 NHWC planes (hi | lo) - the operand format of the bf16x3 conv."""
 
     def __init__(self, buf, shape, fmt="bf16x3", scale=1.0):
-        # fmt "bf16x3": bf16 hi | bf16 lo;  "f16f8": fp16 hi | per 32-channel block [32 x e4m3(lo * 2^12) | 32 x e4m3(x)];
+        # fmt "bf16x3": bf16 hi | bf16 lo;
         # "f16x3": fp16 hi | fp16 lo of x * scale (the fp32-equivalent split; scale a power of two)
         self.buf, self.shape, self.device, self.fmt, self.scale = buf, tuple(shape), buf.device, fmt, float(scale)
 
@@ -310,7 +310,7 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
     C2 = 0 if x2 is None else x2.shape[3]
     Ho, Wo = (H // 2, W // 2) if resample < 0 else ((2 * H, 2 * W) if resample > 0 else (H, W))
     if split:
-        fmt = split if split in ("f16f8", "f16f6", "f16x3") else "bf16x3"
+        fmt = split if split == "f16x3" else "bf16x3"
         buf = torch.empty((2, N, Ho, Wo, C1 + C2), device=x1.device, dtype=torch.int16)
         for t, nm in ((gamma, "gamma"), (beta, "beta"), (stats, "stats")):
             _req(t, name=nm)
@@ -340,8 +340,7 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
                                                              _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
                                                              scale, _p(buf), _stream()), "dua_groupnorm_apply_split_f16x3")
             return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt, scale)
-        fn = {"f16f8": _lib.lib().dua_groupnorm_apply_split_f16f8, "f16f6": _lib.lib().dua_groupnorm_apply_split_f16f6}.get(
-            fmt, _lib.lib().dua_groupnorm_apply_split)
+        fn = _lib.lib().dua_groupnorm_apply_split
         check(fn(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film), _film_ld(film, N, C1 + C2),
                  int(act), int(resample), _p(dropmask), _p(buf), _stream()), "dua_groupnorm_apply_split")
         return SplitPlanes(buf, (N, Ho, Wo, C1 + C2), fmt)
@@ -549,22 +548,6 @@ def pack_weight_bf16x3(w):
     return planes
 
 
-def pack_weight_f16f8(w):
-    """fp32 [N][K] linear / 1x1 weight, or OIHW 3x3 conv weight -> the packed f16f8 weight (fp16 plane, fp8 cross plane, row
-    exponents) in one uint8 buffer."""
-    _req(w, name="w")
-    L = _lib.lib()
-    if w.ndim == 4 and w.shape[2] == 3:
-        N, cin = w.shape[0], w.shape[1]
-        K = 9 * cin
-    else:
-        N, cin = w.shape[0], 0
-        K = w.numel() // N
-    packed = torch.empty(L.dua_f16f8_weight_bytes(N, K), device=w.device, dtype=torch.uint8)
-    check(L.dua_pack_weight_f16f8(_p(w), _p(packed), N, K, cin, _stream()), "dua_pack_weight_f16f8")
-    return packed
-
-
 def pack_weight_f16x3(w):
     """fp32 [N][K] linear / 1x1 weight, or OIHW 3x3 conv weight -> the packed f16x3 weight (fp16 hi plane, fp16 lo plane of the
     row-scaled weight, per-row 2^-s floats) in one uint8 buffer."""
@@ -629,52 +612,6 @@ def conv3x3_wino_supported(N, H, W, cin, cout):
     return bool(_lib.lib().dua_conv3x3_f16x3_wino_supported(int(N), int(H), int(W), int(cin), int(cout)))
 
 
-def pack_weight_f16f6(w):
-    """As pack_weight_f16f8 with the cross plane in MXFP6 (e2m3 + E8M0 exponent per 32-k block); same buffer size."""
-    _req(w, name="w")
-    L = _lib.lib()
-    if w.ndim == 4 and w.shape[2] == 3:
-        N, cin = w.shape[0], w.shape[1]
-        K = 9 * cin
-    else:
-        N, cin = w.shape[0], 0
-        K = w.numel() // N
-    packed = torch.empty(L.dua_f16f8_weight_bytes(N, K), device=w.device, dtype=torch.uint8)
-    check(L.dua_pack_weight_f16f6(_p(w), _p(packed), N, K, cin, _stream()), "dua_pack_weight_f16f6")
-    return packed
-
-
-def planes_f16f6_reference(x):
-    """f16f6 activation planes of an NHWC fp32 tensor built with plain torch ops (tests / micro-benchmarks: the product writer is
-    dua_groupnorm_apply_split_f16f6).  Plane 0 fp16(x); plane 1 per 32-channel block [24 B e2m3(lo) | exp | 7 pad | 24 B e2m3(x) | exp | 7 pad]."""
-    N, H, W, C = x.shape
-    hi = x.to(torch.float16)
-    lo = x - hi.float()
-    blocks = []
-    for t in (lo, x):
-        tb = t.reshape(-1, C // 32, 32)
-        m = tb.abs().amax(-1, keepdim=True)
-        eb = (m.view(torch.int32) >> 23) & 0xff
-        sb = (eb - 2).clamp_min(0)
-        mul = ((254 - sb) << 23).view(torch.float32)
-        u = tb * mul
-        a = u.abs()
-        tt = torch.where(a < 1, a + 1, a)
-        b = tt.view(torch.int32)
-        rb = (b + 0x7FFFF + ((b >> 20) & 1)) >> 20
-        c = (rb - 1016 + torch.where(a < 1, 0, 8)).clamp(0, 31) | ((u.view(torch.int32) >> 31) & 1) << 5
-        c = c.to(torch.int64).reshape(-1, C // 32, 4, 8)
-        sh = torch.arange(8, device=x.device, dtype=torch.int64) * 6
-        w48 = (c << sh).sum(-1)                                                       # 8 codes = 48 bits
-        by = torch.stack([(w48 >> (8 * k)) & 0xff for k in range(6)], -1).reshape(-1, C // 32, 24).to(torch.uint8)
-        tail = torch.zeros(by.shape[0], C // 32, 8, dtype=torch.uint8, device=x.device)
-        tail[..., 0] = sb.squeeze(-1).to(torch.uint8)
-        blocks.append(torch.cat([by, tail], -1))
-    x6 = torch.cat(blocks, -1).reshape(-1)                                            # [rows][C/32][64] bytes
-    buf = torch.cat([hi.reshape(-1).view(torch.uint8), x6]).view(torch.int16).reshape(2, N, H, W, C)
-    return SplitPlanes(buf, (N, H, W, C), "f16f6")
-
-
 def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=False, res_resample=0):
     """Split-operand 3x3 convolution; a SplitPlanes input selects the kernel by its format (the weight must be packed to match).
     res_resample (Winograd formats only): +1 / -1 = `residual` is the half / double resolution map, added through nearest 2x upsampling /
@@ -710,8 +647,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
         check(_lib.lib().dua_conv3x3_f16x3_presplit(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out),
                                                     _p(ws), x.scale, _stream()), "dua_conv3x3_f16x3_presplit")
     elif pre:
-        fn = {"f16f8": _lib.lib().dua_conv3x3_f16f8_presplit, "f16f6": _lib.lib().dua_conv3x3_f16f6_presplit}.get(
-            x.fmt, _lib.lib().dua_conv3x3_bf16x3_presplit)
+        fn = _lib.lib().dua_conv3x3_bf16x3_presplit
         check(fn(_p(x.buf), _p(planes), _p(bias), _p(residual), _p(y), N, H, W, Cin, cout, int(nchw_out), _p(ws), _stream()),
               "dua_conv3x3 presplit")
     else:
@@ -770,19 +706,6 @@ def gemm_bf16x3_presplit(a, planes, n_out, bias=None, residual=None, act_out=0, 
             c._dua_colsums_rows = ws
         check(_lib.lib().dua_gemm_f16x3_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), M, n_out, K, int(act_out), _p(ws),
                                                  a.scale, _stream()), "dua_gemm_f16x3_presplit")
-        return c
-    if a.fmt == "f16f8":
-        if split_out:
-            buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
-            check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), None, _p(buf), M, n_out, K, int(act_out),
-                                                     None, _stream()), "dua_gemm_f16f8_presplit")
-            return SplitPlanes(buf, (M, n_out), "f16f8")
-        c = torch.empty((M, n_out), device=a.device, dtype=torch.float32)
-        ws = _colsum_ws(M, n_out, a.device, colsum)
-        if ws is not None:
-            c._dua_colsums_rows = ws
-        check(_lib.lib().dua_gemm_f16f8_presplit(_p(a.buf), _p(planes), _p(bias), _p(residual), _p(c), None, M, n_out, K, int(act_out),
-                                                 _p(ws), _stream()), "dua_gemm_f16f8_presplit")
         return c
     if split_out:
         buf = torch.empty((2, M, n_out), device=a.device, dtype=torch.int16)
@@ -1012,11 +935,6 @@ def qkv_attention(qkv, B, T, heads, ch, precision="fp32", planes_out=False):
             return out
         precision = "fp32"                       # heads wider than 256 / forced GEMM mode: the exact fp32 paths
     if precision == "bf16x3" and ch % 4 == 0 and 8 <= ch <= 128 and ATTENTION_MODE in ("auto", "fused_x"):
-        if planes_out and C % 32 == 0:       # result straight in the operand format of the presplit proj GEMM
-            buf = torch.empty((2, B * T, C), device=qkv.device, dtype=torch.int16)
-            check(_lib.lib().dua_attention_bf16x3_planes(_p(qkv), _p(buf), B, T, heads, ch, 1.0 / math.sqrt(ch), _stream()),
-                  "dua_attention_bf16x3_planes")
-            return SplitPlanes(buf, (B * T, C), "f16f8")
         return fused_attention_bf16x3(qkv, B, T, heads, ch)       # split-bf16 flash kernel: 2-3x the GEMM pair / the fp32 flash kernel
     fast = precision == "bf16x3" and ch % 32 == 0 and T % 32 == 0
     fusable = ch % 8 == 0 and ch <= 256
@@ -1061,11 +979,9 @@ def layernorm(x, gamma, beta, eps=1e-5, split=False):
               "dua_layernorm_split_f16x3")
         return SplitPlanes(buf, tuple(x.shape), "f16x3", F16X3_ACT_SCALE)
     if split:
-        fmt = "f16f8" if split == "f16f8" else "bf16x3"
         buf = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=torch.int16)
-        fn = _lib.lib().dua_layernorm_split_f16f8 if fmt == "f16f8" else _lib.lib().dua_layernorm_split
-        check(fn(_p(x), _p(gamma), _p(beta), _p(buf), x.numel() // D, D, float(eps), _stream()), "dua_layernorm_split")
-        return SplitPlanes(buf, tuple(x.shape), fmt)
+        check(_lib.lib().dua_layernorm_split(_p(x), _p(gamma), _p(beta), _p(buf), x.numel() // D, D, float(eps), _stream()), "dua_layernorm_split")
+        return SplitPlanes(buf, tuple(x.shape), "bf16x3")
     y = torch.empty_like(x)
     check(_lib.lib().dua_layernorm(_p(x), _p(gamma), _p(beta), _p(y), x.numel() // D, D, float(eps), _stream()), "dua_layernorm")
     return y

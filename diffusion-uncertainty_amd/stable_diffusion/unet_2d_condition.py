@@ -108,7 +108,7 @@ class BasicTransformerBlock(nn.Module):
         heads = self.attn1.heads
         n1 = ctx.norm_rows(h, self.norm1)
         qkv = ctx.gemm(n1, ctx.cat_weight(self.attn1, ("to_q", "to_k", "to_v")), None)
-        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision, planes_out=(ctx.split_acts in ("f16f8", "f16x3")))
+        a = ops.qkv_attention(qkv, B, T, heads, C // heads, precision=ctx.attn_precision, planes_out=(ctx.split_acts == "f16x3"))
         h = h1 = ctx.gemm(a, self.attn1.to_out[0].weight, self.attn1.to_out[0].bias, residual=h)
         n2 = ctx.norm_rows(h, self.norm2)
         q = ctx.gemm(n2, self.attn2.to_q.weight, None)
@@ -218,10 +218,10 @@ class TimestepEmbedding(nn.Module):
 class _Ctx:
     def __init__(self, model):
         self.model = model
-        assert model.precision in ("fp32", "bf16x3", "f16f8", "f16x3"), model.precision
+        assert model.precision in ("fp32", "bf16x3", "f16x3"), model.precision
         self.f16x3 = model.precision == "f16x3"                      # fp32-equivalent fp16 hi + lo split (22 operand bits)
-        self.split_mode = model.precision in ("bf16x3", "f16f8")     # on-the-fly bf16 split of raw fp32 operands
-        self.split_acts = model.precision if model.precision in ("f16f8", "f16x3") else model.precision == "bf16x3"
+        self.split_mode = model.precision == "bf16x3"                # on-the-fly bf16 split of raw fp32 operands
+        self.split_acts = model.precision if model.precision == "f16x3" else model.precision == "bf16x3"
         self.attn_precision = {"fp32": "fp32", "f16x3": "f16x3"}.get(model.precision, "bf16x3")
         self.emb = None
         self.temb_all = None
@@ -237,8 +237,6 @@ class _Ctx:
         if isinstance(h, ops.SplitPlanes):
             if h.fmt == "f16x3":
                 w = self.packed((id(conv), "w3h"), lambda: ops.pack_weight_f16x3(conv.weight.detach().contiguous()))
-            elif h.fmt == "f16f8":
-                w = self.packed((id(conv), "w3f"), lambda: ops.pack_weight_f16f8(conv.weight.detach().contiguous()))
             else:
                 w = self.packed((id(conv), "w3x"), lambda: ops.pack_weight_bf16x3(conv.weight.detach().contiguous()))
             return ops.conv3x3_bf16x3(h, w, conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
@@ -252,7 +250,7 @@ class _Ctx:
         """rows x weight^T in the model's precision (fp32 MFMA, or the split-bf16 tile engine with the operand split on the fly)."""
         if isinstance(a, ops.SplitPlanes):           # operand already split (norm / attention output): LDS-DMA GEMM
             n_out = weight.shape[0]
-            kind, pack = ("w1hp", ops.pack_weight_f16x3) if a.fmt == "f16x3" else ("w1f", ops.pack_weight_f16f8)
+            kind, pack = ("w1hp", ops.pack_weight_f16x3) if a.fmt == "f16x3" else ("w1xp", ops.pack_weight_bf16x3)
             packed = self.packed((id(weight), kind), lambda: pack(weight.detach().reshape(n_out, -1).contiguous()))
             return ops.gemm_bf16x3_presplit(a, packed, n_out, bias=bias, residual=residual, colsum=colsum)
         n_out, K = weight.shape[0], a.shape[1] + (0 if a2 is None else a2.shape[1])
@@ -406,7 +404,7 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(G, boc[0])
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
         self._packed = {}
-        self.precision = "fp32"          # "fp32" | "f16x3" | "bf16x3" | "f16f8" (see guided_diffusion/unet_openai.py)
+        self.precision = "fp32"          # "fp32" | "f16x3" | "bf16x3" (see guided_diffusion/unet_openai.py)
         # hipGraph replay of the forward (enable_hip_graph): at the CFG batch of 2 one forward is ~1000 launches of a few
         # microseconds each and the host cannot issue them fast enough; a captured graph removes the launch path.
         self._graphs = None

@@ -82,14 +82,14 @@ class Block(nn.Module):
                 x = ops.gemm_f16x3_presplit2(pl(xp), pl(sp), cache[key], D, bias=self.skip_linear.bias)
             else:
                 x = lin(x, self.skip_linear, a2=skip)                                              # :116-117
-        # split modes: LayerNorm / GELU outputs go out in the operand format of the LDS-DMA GEMMs (bf16 planes or f16f8 planes)
+        # split modes: LayerNorm / GELU outputs go out in the operand format of the LDS-DMA GEMMs (bf16 planes)
         # ("f16x3": the fp32-equivalent split, fp16 hi / lo planes)
-        fast = (precision if precision in ("f16f8", "f16x3") else precision == "bf16x3") if D % 32 == 0 else False
+        fast = (precision if precision == "f16x3" else precision == "bf16x3") if D % 32 == 0 else False
         h = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, split=fast)
         qkv = lin(h, self.attn.qkv)
         a = ops.qkv_attention(qkv, B, L, self.attn.num_heads, D // self.attn.num_heads,
                               precision=precision if precision in ("fp32", "f16x3") else "bf16x3",
-                              planes_out=(fast in ("f16f8", "f16x3")))                                               # :69-73
+                              planes_out=(fast == "f16x3"))                                               # :69-73
         x = lin(a, self.attn.proj, residual=x)                                                     # :118
         h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, split=fast)
         h = lin(h, self.mlp.fc1, act_out=2, split_out=bool(fast))                                  # fc1 + GELU
@@ -142,7 +142,7 @@ class UViT(nn.Module):
         self.apply(self._init_weights)
         self.img_size = img_size
         self.patch_size = patch_size
-        self.precision = "fp32"          # or "f16x3" (fp32-equivalent) / "bf16x3" / "f16f8" (see guided_diffusion/unet_openai.py)
+        self.precision = "fp32"          # or "f16x3" (fp32-equivalent) / "bf16x3" (see guided_diffusion/unet_openai.py)
         self.use_block_abi = True        # fp32 / f16x3: every Block runs as ONE C-ABI call (bit-identical to the composition)
         # f16x3: register the split-K workspace for the forward (ops.set_split_k): GEMM launches whose last round of tiles would be
         # mostly idle (N = 1152 projections at batch 64: 585 tiles on 256 CUs) run their tail rows split along K.  Opt-in: results
@@ -163,7 +163,7 @@ class UViT(nn.Module):
         if isinstance(a, ops.SplitPlanes):                # operand already in a split format: LDS-DMA GEMM
             key = (id(mod), a.fmt)
             if key not in self._planes:
-                pack = {"f16f8": ops.pack_weight_f16f8, "f16x3": ops.pack_weight_f16x3}.get(a.fmt, ops.pack_weight_bf16x3)
+                pack = ops.pack_weight_f16x3 if a.fmt == "f16x3" else ops.pack_weight_bf16x3
                 self._planes[key] = pack(mod.weight.detach().contiguous())
             return ops.gemm_bf16x3_presplit(a, self._planes[key], mod.weight.shape[0], bias=mod.bias, residual=residual,
                                             act_out=act_out, split_out=split_out)

@@ -208,9 +208,6 @@ int dua_attention(const float* qkv, float* out, int B, int T, int heads, int ch,
 /* Same contract on the bf16 matrix cores with split operands (hi*hi + hi*lo + lo*hi, ~2^-17 per product, both q.k^T and P.v):
  * the attention of the split precision modes.  ch a multiple of 4, <= 128 (the queries live in registers). */
 int dua_attention_bf16x3(const float* qkv, float* out, int B, int T, int heads, int ch, float scale, void* stream);
-/* Same, writing the result as f16f8 planes [B*T][heads*ch] (heads*ch % 32 == 0) for the presplit proj GEMM that follows
- * (unet_openai.py:295 proj_out, uvit/uvit.py:76 proj). */
-int dua_attention_bf16x3_planes(const float* qkv, void* out_planes, int B, int T, int heads, int ch, float scale, void* stream);
 
 /* LayerNorm over the last axis (U-ViT, uvit/uvit.py:108-110,225): y = (x-mean)*rstd*gamma+beta, eps 1e-5. */
 int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps,
@@ -249,36 +246,8 @@ int dua_gemm_bf16x3_presplit(const void* aplanes, const void* planes, const floa
 /* LayerNorm writing split bf16 planes ([rows][D] hi | lo): operand of the presplit GEMM (uvit/uvit.py:108-110). */
 int dua_layernorm_split(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
                         void* stream);
-/* ---- "f16f8" operand format: fp16 hi plane + one fp8 plane carrying both cross-term operands -----------------------
- * Same role, bytes and call shapes as the bf16x3 entry points above (conv / 1x1 / linear products of
- * guided_diffusion/unet_openai.py:186,212,223,287,483,616 evaluated to ~2^-15 per product), 2/3 of their matrix-core
- * cycles: product = fp16(a)*fp16(w) on v_mfma_f32_32x32x16_f16 + [a_lo*w + a*w_lo] on ONE block-scaled
- * v_mfma_scale_f32_32x32x64_f8f6f4 per 32-deep K block (csrc/mfma_bf16x3.hip, FMT 1).
- * Activation planes ([rows][C] each 2 bytes per element): plane 0 fp16(x); plane 1 per 32-channel block
- * [32 x e4m3((x - fp16 x) * 2^12) | 32 x e4m3(x)].  Packed weights (dua_f16f8_weight_bytes): plane 0 fp16(w) [Npad128][K];
- * plane 1 per (row, 32-k block) [32 x e4m3(w * 2^s) | 32 x e4m3((w - fp16 w) * 2^(s+12))]; then Npad row exponents s. */
-size_t dua_f16f8_weight_bytes(int N, int K);
-int dua_pack_weight_f16f8(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
-int dua_groupnorm_apply_split_f16f8(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                                    int resample, const float* dropmask, void* yplanes, void* stream);
-int dua_conv3x3_f16f8_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
-                               int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
-/* "f16f6": the f16f8 scheme with the two cross operands in MXFP6 (e2m3) and an E8M0 exponent per (row, 32-k block) - the
- * same scaled instruction at twice its fp8 rate (96 instead of 128 matrix-core cycles per 32x32x32 block), 3x3 convolutions
- * whose image width divides 256.  Plane 1 per 32-channel block (64 B): activations
- * [32 x e2m3(lo * 2^-El) (24 B) | 127 + El | 7 B pad | 32 x e2m3(x * 2^-Ex) (24 B) | 127 + Ex | 7 B pad], weights with the
- * full-value part first; packed weight size = dua_f16f8_weight_bytes. */
-int dua_groupnorm_apply_split_f16f6(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
-                                    int resample, const float* dropmask, void* yplanes, void* stream);
-int dua_pack_weight_f16f6(const float* w, void* packed, int N, int K, int conv_cin, void* stream);
-int dua_conv3x3_f16f6_presplit(const void* xplanes, const void* packed, const float* bias, const float* residual, float* y,
-                               int N, int H, int W, int Cin, int Cout, int nchw_out, float* colsum, void* stream);
-int dua_gemm_f16f8_presplit(const void* aplanes, const void* packed, const float* bias, const float* residual, float* C,
-                            void* Csplit, int M, int N, int K, int act_out, float* colsum, void* stream);
 /* ---- "f16x3" operand format: the fp32-EQUIVALENT split (22 significant operand bits) ---------------------------------
- * Same role and call shapes as the bf16x3 / f16f8 entry points (conv / 1x1 / linear products of
+ * Same role and call shapes as the bf16x3 entry points (conv / 1x1 / linear products of
  * guided_diffusion/unet_openai.py:186,212,287,483,616): every fp32 operand is scaled by a power of two into fp16's normal
  * range and split s = hi + lo with hi = fp16(s), lo = fp16(s - hi) (11 + 11 significant bits); the product is
  * hi*hi + hi*lo + lo*hi on three v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped lo*lo term is 2^-22 relative),
@@ -393,12 +362,8 @@ int dua_attention_f16x3(const float* qkv, float* out, void* out_planes, float pl
  * [B*Tq][ldq], k / v rows [B*Tk][ldkv], head h at column h*ch of each; Tk any (77 text tokens). */
 int dua_cross_attention_f16x3(const float* q, long ldq, const float* k, const float* v, long ldkv, float* out, void* out_planes,
                               float planes_scale, int B, int Tq, int Tk, int heads, int ch, float scale, void* stream);
-/* LayerNorm writing f16f8 planes (U-ViT: uvit/uvit.py:108-110 feeding the qkv / fc1 GEMMs); D % 32 == 0. */
-int dua_layernorm_split_f16f8(const float* x, const float* gamma, const float* beta, void* yplanes, long rows, int D, float eps,
-                              void* stream);
 /* A/B engine selector for the presplit conv / GEMM kernels (returns the previous mode, or DUA_EINVAL): 1 = LDS-DMA kernels,
- * 256x256 tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel (bf16x3); 6 = per-tap instead of
- * row-shift f16f8 loop / the 32x32x16 loop for every f16x3 tile; 7 = the 16x16x32 kernel (conv_f16x3.hip) for every f16x3 tile.  Process-global and unsynchronised: set it before queueing work.  The zero-record-descriptor modes
+ * 256x256 tile where it fits (default); 2 = LDS-DMA 256x128 only; 0 = register-staged kernel (bf16x3); 6 = the 32x32x16 loop for every f16x3 tile; 7 = the 16x16x32 kernel (conv_f16x3.hip) for every f16x3 tile.  Process-global and unsynchronised: set it before queueing work.  The zero-record-descriptor modes
  * 3 - 5 (timing-only, wrong results) exist only in the diagnostic library built with -DDUA_CONV_TIMING
  * (scripts/conv_tile_timing.py --build); the product library rejects them. */
 int dua_set_dma_conv(int mode);

@@ -16,7 +16,7 @@ for H, C in ((128, 256), (64, 256), (64, 512), (32, 512), (32, 1024), (16, 768),
     st = torch.tensor([0.1, 0.9], device=dev).repeat(N * 32, 1).contiguous()
     g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
     film = torch.randn(N, 2 * C, device=dev)
-    for split in ((sys.argv[1],) if len(sys.argv) > 1 else (False, True, "f16f8", "f16f6", "f16x3")):
+    for split in ((sys.argv[1],) if len(sys.argv) > 1 else (False, True, "f16x3", "f16x3w", "f16w")):
         for wide in (0, 1):
             L.dua_set_gn_apply_wide(wide)
             ops.groupnorm_apply(x, st, g, b, x2=x2, film=film, act=1, split=split)

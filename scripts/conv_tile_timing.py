@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--shape", default="128,256,256")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--res", action="store_true")
-    ap.add_argument("--fmt", default="bf16x3", choices=["bf16x3", "f16f8", "f16f6"])
+    ap.add_argument("--fmt", default="bf16x3", choices=["bf16x3", "f16x3"])
     a = ap.parse_args()
     if a.build:
         return build(a.flags.split(), a.lib)
@@ -61,13 +61,10 @@ def main():
         lo = (x - hi.float()).to(torch.bfloat16)
         xs = ops.SplitPlanes(torch.stack([hi, lo]).view(torch.int16), (N, H, H, Cin))
         planes = ops.pack_weight_bf16x3(w)
-    elif a.fmt == "f16f6":
-        xs = ops.planes_f16f6_reference(x)
-        planes = ops.pack_weight_f16f6(w)
     else:
         st = torch.tensor([0.0, 1.0], device=dev).repeat(N * 32, 1).contiguous()
-        xs = ops.groupnorm_apply(x, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16f8")
-        planes = ops.pack_weight_f16f8(w)
+        xs = ops.groupnorm_apply(x, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16x3")
+        planes = ops.pack_weight_f16x3(w)
     bias = torch.randn(Cout, device=dev)
     r = torch.randn(N, H, H, Cout, device=dev) if a.res else None
     for _ in range(3):

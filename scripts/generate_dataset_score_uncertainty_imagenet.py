@@ -75,7 +75,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         ae = load_autoencoder_uvit(device="cpu", load_checkpoint=ckpt)
         if not ckpt:
             randomize_parameters_(ae, seed=9)
-        uvit.precision = "f16f8" if args.precision == "f16f6" else args.precision            # f16f6 is a 3x3-conv format: ADM only
+        uvit.precision = "f16x3" if args.precision == "f16w" else args.precision             # f16w is a 3x3-conv mode: ADM only
         uvit.split_k = args.split_k != "off"                                                 # (tail split of under-filled GEMM rounds)
         ae.precision = args.precision if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch)
         model = UViTAE(uvit, ae).to(device)
@@ -157,9 +157,10 @@ def parse_args(argv=None):
     p.add_argument("--check-range", action="store_true", dest="check_range",
                    help="f16x3: count the operands that leave fp16's range after their static power-of-two scale (dua_range_check); "
                         "a non-zero saturation count means the run is not fp32-equivalent")
-    p.add_argument("--precision", choices=["f16x3", "fp32", "f16w", "f16f6", "f16f8", "bf16x3"], default="f16x3",
+    p.add_argument("--precision", choices=["f16x3", "fp32", "f16w", "bf16x3"], default="f16x3",
                    help="f16x3 (default): the fp32-equivalent split - trajectories match the reference CPU path like the exact fp32 mode's; "
-                        "fp32: exact fp32 MFMA; bf16x3 / f16f8 / f16f6: narrower throughput modes (16 / ~15 / ~14-15 operand bits)")
+                        "fp32: exact fp32 MFMA; bf16x3: split-bf16 (16 operand bits); f16w: one fp16 product per tap in the Winograd convs (the "
+                        "reference's fp16-autocast arithmetic class: NOT a parity mode)")
     p.add_argument("--noise", choices=["host", "device"], default="host", help="host: CPU-generator noise tape in the reference's draw order")
     p.add_argument("--synthetic", action="store_true", help="generate X_T / y like scripts/generate_diffusion_starting_data.py")
     p.add_argument("--random-weights", action="store_true", help="seeded random weights instead of checkpoints")

@@ -31,7 +31,7 @@ def main():
     p.add_argument("--lr", type=float, default=1.0, help="step of the gradient update (reference pipeline argument lr)")
     p.add_argument("-M", type=int, default=5)
     p.add_argument("--guidance-scale", type=float, default=7.5)
-    p.add_argument("--precision", choices=["f16x3", "f16f8", "bf16x3", "fp32"], default="f16x3")
+    p.add_argument("--precision", choices=["f16x3", "bf16x3", "fp32"], default="f16x3")
     p.add_argument("--backward-precision", choices=["fp32", "bf16x3"], default="fp32",
                    help="products of the input-gradient pass of the gradient update: exact fp32 MFMA, or split-bf16 convs / linears")
     p.add_argument("--unet-state-dict", type=str, default=None)

@@ -117,7 +117,7 @@ def test_cross_attention_bwd_q_vs_autograd():
 
 
 @pytest.mark.parametrize("cfg,hw,Tk", [(TINY, 16, 7), (MID, 32, 77)])
-@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16f8"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_sd_unet_input_vjp_vs_oracle(cfg, hw, Tk, precision):
     """d<g, unet(x)>/dx of the HIP UNet (taped forward in the model's precision, exact-fp32 backward) vs torch autograd
     through the CPU restatement."""

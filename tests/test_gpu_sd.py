@@ -39,7 +39,7 @@ def inputs(cfg, B, hw, Tk, seed):
 
 
 @pytest.mark.parametrize("cfg,hw,Tk", [(TINY, 16, 7), (MID, 32, 77)])
-@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3", "f16f8"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3"])
 def test_sd_unet_vs_oracle(cfg, hw, Tk, precision):
     from oracle import sd_unet
     m, sd = build(cfg, 11)
@@ -76,7 +76,7 @@ def test_sd15_full_size_vs_oracle():
     x, t, enc = inputs(cfg, 2, 64, 77, 5)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     ref = sd_unet.forward(sd, cfg, x, t, enc)
-    for precision in ("fp32", "f16x3", "f16f8"):
+    for precision in ("fp32", "f16x3"):
         m.precision = precision
         out = m(x.to(dev), t.to(dev), encoder_hidden_states=enc.to(dev), return_dict=False)[0]
         err = (out.cpu() - ref).abs().max().item()

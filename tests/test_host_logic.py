@@ -226,12 +226,12 @@ def test_oracle_sd_input_vjp_and_gradient_guidance_on_cpu():
 
 def test_precision_modes_pick_operand_formats():
     """Which operand format each GroupNorm in front of a matrix-core kernel writes, per precision mode (host logic only: no kernel
-    runs).  f16f6 planes go to the row-shift 3x3 convolutions only (image width divides 256); the one-tap GEMMs stay f16f8."""
+    runs)."""
     from diffusion_uncertainty_amd.guided_diffusion.unet_openai import UNetModel, _Ctx
     m = UNetModel(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1, attention_resolutions=(2,),
                   channel_mult=(1, 2), num_classes=10, num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)
     want = {"fp32": (False, False, False), "f16x3": ("f16x3", "f16x3", "f16x3"), "bf16x3": (True, True, True),
-            "f16f8": ("f16f8", "f16f8", "f16f8"), "f16f6": ("f16f6", "f16f8", "f16f8")}
+            "f16w": ("f16x3", "f16x3", "f16x3")}
     for mode, (w16, w24, gemm) in want.items():
         m.precision = mode
         ctx = _Ctx(m)
