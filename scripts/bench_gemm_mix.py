@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--splitk", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--skip-presplit", action="store_true",
+                    help="time the on-the-fly-split shapes ([s]) ALSO as presplit two-source GEMMs on planes, plus the pass that would write those planes")
     ap.add_argument("--hg", default="", help="dua_set_hgemm_mode: nt[,streamk]  (nt -1 = previous engine, 0 = auto, 2 / 3 / 4)")
     a = ap.parse_args()
     from diffusion_uncertainty_amd import _lib, ops
@@ -51,6 +53,7 @@ def main():
         ops.set_split_k(True, dev)
     shapes = {"uvit64": uvit_shapes(64), "uvit320": uvit_shapes(320), "adm": adm_shapes()}[a.set]
     tf, tt = 0.0, 0.0
+    tp = [0.0, 0.0, 0.0]
     for name, M, K1, K2, N, kind, cnt in shapes:
         if a.only and name not in a.only.split(","):
             continue
@@ -83,9 +86,40 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.reps
         fl = 2.0 * M * N * K
-        print(f"{name:8s} M={M:8d} K={K1}+{K2} N={N:5d} [{kind}] x{cnt:2d}: {ms:8.3f} ms  {fl / ms / 1e9:6.1f} TF", flush=True)
+        extra = ""
+        if kind == "s" and a.skip_presplit:
+            def planes(t):
+                v = t * ops.F16X3_RAW_SCALE
+                h = v.half()
+                return ops.SplitPlanes(torch.stack([h, (v - h.float()).half()]).contiguous().view(torch.int16), tuple(t.shape), "f16x3", ops.F16X3_RAW_SCALE)
+            p1, p2 = planes(a1), (planes(a2) if a2 is not None else None)
+            f2 = lambda: ops.gemm_f16x3_presplit2(p1, p2, pk, N, bias=b, colsum=(a.set == "adm"))  # noqa: E731
+            # the pass that writes the planes: an identity GroupNorm-apply at the raw scale (reads 4 B, writes 4 B per element) - an upper
+            # bound of what a second output of the in_layers writer (which reads the operand anyway) would cost: ~ its write half
+            cat = a1 if a2 is None else torch.cat([a1, a2], 1)
+            st = torch.tensor([0.0, 1.0], device=dev).repeat(32, 1).contiguous()
+            Cc = cat.shape[1]
+            f3 = lambda: ops.groupnorm_apply(cat.view(1, M, 1, Cc), st, torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev), act=0,  # noqa: E731
+                                             split="f16x3", split_scale=ops.F16X3_RAW_SCALE)
+            res2 = []
+            for f in (f2, f3):
+                f(); f()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.reps):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                res2.append(e0.elapsed_time(e1) / a.reps)
+            extra = f" | presplit2 {res2[0]:7.3f} ms {fl / res2[0] / 1e9:6.1f} TF, plane pass {res2[1]:7.3f} ms"
+            tp[0] += cnt * res2[0]
+            tp[1] += cnt * res2[1]
+            tp[2] += cnt * ms
+        print(f"{name:8s} M={M:8d} K={K1}+{K2} N={N:5d} [{kind}] x{cnt:2d}: {ms:8.3f} ms  {fl / ms / 1e9:6.1f} TF{extra}", flush=True)
         tf += cnt * fl
         tt += cnt * ms
+    if a.skip_presplit:
+        print(f"skip GEMMs per forward: on-the-fly split {tp[2]:.2f} ms | presplit two-source {tp[0]:.2f} ms + plane pass (upper bound) {tp[1]:.2f} ms")
     print(f"mix ({a.set}, engine {a.engine}, hgemm mode '{a.hg}'{', split-K' if a.splitk else ''}): {tt:.2f} ms per forward, {tf / tt / 1e9:.1f} TF algorithmic")
 
 
