@@ -257,8 +257,7 @@ int check_uvitblock(const dua_uvitblock_args* a) {
 }
 
 int check_resblock(const dua_resblock_args* a) {
-    DUA_REQUIRE(a && a->x1 && a->y && a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->conv1_packed && a->conv2_packed && a->film,
-                "dua_adm_resblock_fwd: null pointer");
+    DUA_REQUIRE(a && a->x1 && a->y && a->gn1_w && a->gn1_b && a->gn2_w && a->gn2_b && a->film, "dua_adm_resblock_fwd: null pointer");
     DUA_REQUIRE(a->precision == DUA_PREC_FP32 || a->precision == DUA_PREC_F16X3 || a->precision == DUA_PREC_F16W,
                 "dua_adm_resblock_fwd: precision must be DUA_PREC_FP32, DUA_PREC_F16X3 or DUA_PREC_F16W");
     DUA_REQUIRE(a->N > 0 && a->H > 0 && a->W > 0 && a->C1 > 0 && a->C2 >= 0 && a->Cout > 0 && (a->C1 + a->C2) % 32 == 0 && a->Cout % 32 == 0,
@@ -268,6 +267,13 @@ int check_resblock(const dua_resblock_args* a) {
                 "dua_adm_resblock_fwd: a resampling block takes one source, an identity skip and no dropout mask");
     DUA_REQUIRE(a->skip_packed || a->C1 + a->C2 == a->Cout, "dua_adm_resblock_fwd: a channel-changing block needs the 1x1 skip weights");
     DUA_REQUIRE(a->precision == DUA_PREC_FP32 || (a->act_scale > 0.f && a->raw_scale > 0.f && a->C1 % 32 == 0), "dua_adm_resblock_fwd: f16x3 needs positive scales and C1 %% 32 == 0");
+    {   // the direct-form weights of a conv may be NULL when its Winograd-form weights are given AND the kernel takes the shape
+        const int Ho = a->updown < 0 ? a->H / 2 : (a->updown > 0 ? 2 * a->H : a->H), Wo = a->updown < 0 ? a->W / 2 : (a->updown > 0 ? 2 * a->W : a->W);
+        const bool w1 = a->conv1_wino && a->C1 % 32 == 0 && dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->C1 + a->C2, a->Cout) != 0;
+        const bool w2 = a->conv2_wino && dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) != 0;
+        DUA_REQUIRE((a->conv1_packed || w1) && (a->conv2_packed || w2),
+                    "dua_adm_resblock_fwd: conv*_packed may only be NULL for a conv that runs in the Winograd form (conv*_wino given, shape supported)");
+    }
     return DUA_OK;
 }
 

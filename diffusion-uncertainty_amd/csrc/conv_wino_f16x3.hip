@@ -203,8 +203,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv(WConvP p) {
 
         // the first stages have landed; behind them in the (in-order) queue are only the previous epilogue's operations, of which the
         // last WCONV_EPILOGUE_STORES - output stores - may stay in flight
-        static_assert(WCONV_EPILOGUE_STORES == 16, "the immediate below");
-        if (after_epilogue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCONV_EPILOGUE_STORES) : "memory");      // (derived from the store loops: wconv.h)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -451,8 +450,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv1(WConvP p) {
             return *(const h16x8*)(ldsb + (sb == 2 ? aw2 : aw0) + ((sb == 2 ? 0 : sb * 2 * SB * 2) + 16 * jj * 64));
         };
 #define WSB() __builtin_amdgcn_sched_barrier(0)
-        static_assert(WCONV_EPILOGUE_STORES == 16, "the immediate below");
-        if (after_epilogue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCONV_EPILOGUE_STORES) : "memory");      // (derived from the store loops: wconv.h)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll

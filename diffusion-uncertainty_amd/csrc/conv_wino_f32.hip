@@ -164,8 +164,7 @@ __global__ __launch_bounds__(512, 2) void k_wconv32(WConvP p) {
 
         // the first stages have landed; behind them in the (in-order) queue are only the previous epilogue's operations, of which the
         // last WCONV_EPILOGUE_STORES - output stores - may stay in flight
-        static_assert(WCONV_EPILOGUE_STORES == 16, "the immediate below");
-        if (after_epilogue) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WCONV_EPILOGUE_STORES) : "memory");      // (derived from the store loops: wconv.h)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll

@@ -6,7 +6,13 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define WCONV_EPILOGUE_STORES 16     // output stores wconv_epilogue always issues (2 channel-block pairs x 4 position blocks x 2 half blocks)
+// The store loops of wconv_epilogue and the tile-start wait of the kernels share these bounds: the wait leaves exactly the epilogue's
+// always-issued output stores in flight (vmcnt retires in order), so the count is DERIVED from the loops, not a second literal.
+constexpr int WCONV_ST_PAIRS = 2;    // channel-block pairs (32 channels each) of a wave
+constexpr int WCONV_ST_BLOCKS = 4;   // 16-position blocks
+constexpr int WCONV_ST_HALVES = 2;   // 8-row halves of a block (one 128-byte row store instruction each)
+constexpr int WCONV_EPILOGUE_STORES = WCONV_ST_PAIRS * WCONV_ST_BLOCKS * WCONV_ST_HALVES;
+static_assert(WCONV_EPILOGUE_STORES <= 63, "vmcnt is a 6-bit counter");
 
 struct WConvP {
     const void* V;           // [4 f][ntm tiles of 128 positions][Cin / 32] stage blocks of 16 KB: [hi | lo][128][32] halves or [128][32] floats
@@ -116,7 +122,7 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
 #pragma unroll
     for (int i = 0; i < 4; ++i) res_ld(1, i, rn_[1][i]);
 #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
+    for (int jp = 0; jp < WCONV_ST_PAIRS; ++jp) {
         const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
         const bool cok = c < p.N;
         float4 sq = sq_[jp];
@@ -124,12 +130,12 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
         const float4 bq = bq_[jp];
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WCONV_ST_BLOCKS; ++i) {
             const float4 (&rq)[2] = rn_[jp][i];
             *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = acc0[2 * jp][i];
             *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = acc0[2 * jp + 1][i];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < WCONV_ST_HALVES; ++h) {
                 const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
                 const long row = opix(i, h);
                 float4 v;

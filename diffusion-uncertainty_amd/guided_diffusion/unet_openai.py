@@ -102,8 +102,9 @@ class ResBlock(TimestepBlock):
                 kw = "w3w" if ctx.model.precision == "f16x3" else "w3wf"
                 w1 = ctx.packed(conv1, kw) if ctx.wino_ok(N, Hb, Wb, cin, self.out_channels) else None
                 w2 = ctx.packed(conv2, kw) if ctx.wino_ok(N, Hb, Wb, self.out_channels, self.out_channels) else None
-                return ops.adm_resblock(x, skip, (gn1.weight, gn1.bias), ctx.packed(conv1, kind3), conv1.bias, ctx.film(self),
-                                        (gn2.weight, gn2.bias), ctx.packed(conv2, kind3), conv2.bias,
+                # (the direct-form weights are packed only for a conv that does not run in the Winograd form: ~2 GB less for ADM-128)
+                return ops.adm_resblock(x, skip, (gn1.weight, gn1.bias), ctx.packed(conv1, kind3) if w1 is None else None, conv1.bias, ctx.film(self),
+                                        (gn2.weight, gn2.bias), ctx.packed(conv2, kind3) if w2 is None else None, conv2.bias,
                                         None if ident else ctx.packed(self.skip_connection, kind1),
                                         None if ident else self.skip_connection.bias, self.out_channels, updown=self.resample,
                                         dropmask=mask, precision=("f16w" if ctx.model.wino_single else ctx.model.precision),

@@ -1046,9 +1046,9 @@ def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, c
     y = torch.empty((N, Ho, Wo, cout), device=x.device, dtype=torch.float32)
     ws_y = _colsum_ws(N * Ho * Wo, cout, x.device, want_colsum and not (conv2_wino is not None and (Ho * Wo) % 128))
     a = ResBlockArgs(x1=x.data_ptr(), C1=C1, x2=(skip.data_ptr() if skip is not None else None), C2=C2, N=N, H=H, W=W, Cout=cout,
-                     gn1_w=gn1[0].data_ptr(), gn1_b=gn1[1].data_ptr(), conv1_packed=conv1_packed.data_ptr(), conv1_b=conv1_b.data_ptr(),
+                     gn1_w=gn1[0].data_ptr(), gn1_b=gn1[1].data_ptr(), conv1_packed=(conv1_packed.data_ptr() if conv1_packed is not None else None), conv1_b=conv1_b.data_ptr(),
                      film=film.data_ptr(), film_ld=_film_ld(film, N, cout), gn2_w=gn2[0].data_ptr(), gn2_b=gn2[1].data_ptr(),
-                     conv2_packed=conv2_packed.data_ptr(), conv2_b=conv2_b.data_ptr(),
+                     conv2_packed=(conv2_packed.data_ptr() if conv2_packed is not None else None), conv2_b=conv2_b.data_ptr(),
                      skip_packed=(skip_packed.data_ptr() if skip_packed is not None else None),
                      skip_b=(skip_b.data_ptr() if skip_b is not None else None),
                      x1_colsums=(_cs(x).data_ptr() if _cs(x) is not None else None),

@@ -285,7 +285,8 @@ int dua_gemm_f16x3_presplit(const void* aplanes, const void* packed, const float
  * dua_conv3x3_f16x3_wino: y[N][H][W][Cout] = conv3x3(x) + bias (+ residual) from those two operands; colsum as dua_conv3x3 except
  *   that a 64-pixel slot holds the sums of every other row of a 128-pixel block (the per-image totals, which is what
  *   dua_groupnorm_stats_from_colsums folds, are exact).  Shapes: dua_conv3x3_f16x3_wino_supported returns 1 for H even, W a power
- *   of two <= 128, Cin % 32 == 0, Cout % 4 == 0, H*W % 128 == 0, and 2 for the same with a smaller map (colsum must then be NULL);
+ *   of two <= 128, Cin % 32 == 0, Cout % 4 == 0, H*W % 128 == 0, and 2 for the same with a smaller map whose H*W is still a multiple
+ *   of 32 (the 8 x 8 level of ADM-64 / 128: a wave's 64 positions then span several images, so colsum must be NULL);
  *   0 = not taken, the conv goes through dua_conv3x3_f16x3_presplit.  res_resample: 0 = residual is [N][H][W][Cout]; +1 = residual is
  *   [N][H/2][W/2][Cout] and is added through nearest-neighbour 2x upsampling, -1 = residual is [N][2H][2W][Cout] and is added through
  *   2x2 average pooling - the resampled identity skip of an ADM up / down block (unet_openai.py:238-243) read in place, bit-identical
@@ -421,8 +422,8 @@ typedef struct {
     float* y; float* y_colsums;          /* [N][Ho][Wo][Cout] */
     const void *conv1_wino, *conv2_wino; /* optional: the 3x3 weights also packed by dua_pack_weight_f16x3_wino (DUA_PREC_F16X3) /
                                             dua_pack_weight_f32_wino (DUA_PREC_FP32); a conv whose shape dua_conv3x3_f16x3_wino_supported
-                                            accepts then runs in the Winograd form (conv*_packed stays required: it serves every other
-                                            shape) */
+                                            accepts then runs in the Winograd form, and its conv*_packed may be NULL (the direct-form
+                                            weights serve every other shape and need not be packed for this one) */
 } dua_resblock_args;
 /* ResBlock.forward, guided_diffusion/unet_openai.py:237-257 (use_scale_shift_norm, resblock_updown). */
 size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* args_host);
