@@ -287,7 +287,9 @@ def other_config_uvit(dev, a):
     from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
     uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
     ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
-    uvit.skip_planes = os.environ.get("DUA_UVIT_SKIP_PLANES", "1") != "0"        # (A/B switch for scripts/diag/uvit_job.py)
+    uvit.skip_planes = os.environ.get("DUA_UVIT_SKIP_PLANES", "1") != "0"        # (A/B switches for scripts/diag/uvit_job.py)
+    uvit.stream_split = int(os.environ.get("DUA_UVIT_STREAMS", "2"))
+    uvit.stream_split_max_batch = int(os.environ.get("DUA_UVIT_STREAMS_MAXB", str(1 << 30)))
     uvit.split_k = bool(getattr(a, "uvit_split_k", True))     # tail rows of under-filled GEMM rounds split along K (deterministic)
     uvit.precision, ae.precision = "f16x3", "f16x3"           # the fp32-equivalent split for the U-ViT and the VAE decode (once per batch)
     model = UViTAE(uvit, ae).to(dev)
@@ -493,6 +495,7 @@ def main(argv=None):
 
     model, base, sd = build_model(dev)
     model.winograd = a.winograd == "on"
+    model.stream_split = int(os.environ.get("DUA_ADM_STREAMS", "1"))           # (A/B switch: the batch in chunks on HIP streams of their own)
     # synthetic inputs exactly as scripts/generate_diffusion_starting_data.py:27-49, sharded by rank like the script (:51)
     g = torch.Generator().manual_seed(49394 + 1)         # dataset index k = 1 (imagenet128), SURVEY 8(d)
     X_all = torch.randn(a.batch * world, 3, 128, 128, generator=g)
@@ -503,15 +506,26 @@ def main(argv=None):
     ranks_seen = [world]
 
     class PlainDDIM:
-        """The scheduler's plain DDIM steps behind an object that is NOT a SchedulerUncertaintyMixin: what the reference times as
-        `time_normal` (measure_times_imagenet.py:109-118 builds a diffusers DDIMScheduler from the same config; the driver then collects
-        no uncertainty maps).  The wrapped scheduler's window is empty, so every step() is the plain update (k_ddim_step)."""
+        """The scheduler's plain DDIM steps behind an object that is NOT a SchedulerUncertaintyMixin (a runtime-checkable Protocol: the
+        two window attributes must be absent): what the reference times as `time_normal` (measure_times_imagenet.py:109-118 builds a
+        diffusers DDIMScheduler from the same config; the driver then collects no uncertainty maps).  The wrapped scheduler's window
+        is empty, so every step() is the plain update (k_ddim_step)."""
 
         def __init__(self, inner):
             self._inner = inner
+            self.config, self.timesteps = inner.config, inner.timesteps
 
-        def __getattr__(self, name):
-            return getattr(self._inner, name)
+        prompt_embeds = property(lambda self: self._inner.prompt_embeds, lambda self, v: setattr(self._inner, "prompt_embeds", v))
+
+        def set_timesteps(self, *a_, **k_):
+            self._inner.set_timesteps(*a_, **k_)
+            self.timesteps = self._inner.timesteps
+
+        def scale_model_input(self, x, t):
+            return self._inner.scale_model_input(x, t)
+
+        def step(self, *a_, **k_):
+            return self._inner.step(*a_, **k_)
 
     def job(n_steps, start, num, seed, M=None, faithful=None, plain=False):
         s = make_scheduler(model, base, a.M if M is None else M, start, num, a.num_zigzag, seed,

@@ -481,6 +481,9 @@ class UNetModel(nn.Module):
                 self._graphs = {}
             self._packed_gen = gen
         graphs = getattr(self, "_graphs", None)
+        n = int(getattr(self, "stream_split", 1))
+        if n > 1 and graphs is None and not self.training and not self.activation_noise and x.shape[0] >= 2 * n:
+            return self._forward_streams(x, timesteps, y, out_channels_keep, n)
         if graphs is None or self.training or self.activation_noise:
             return self._forward_impl(x, timesteps, y, out_channels_keep)
         x = x.float().contiguous()
@@ -503,6 +506,28 @@ class UNetModel(nn.Module):
             sy.copy_(yy)
         graph.replay()
         return so.clone()
+
+    def _forward_streams(self, x, timesteps, y, out_channels_keep, n):
+        """The batch in n chunks, each chunk's whole forward on a HIP stream of its own (results identical per image: every kernel is
+        batch-invariant; split-K stays off: its workspace is process-global).  See uvit/uvit.py::_forward_streams."""
+        cur = torch.cuda.current_stream(x.device)
+        if len(getattr(self, "_streams", [])) < n:
+            self._streams = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+        xs, ts = torch.chunk(x, n), torch.chunk(timesteps, n)
+        ys = torch.chunk(y, n) if y is not None else [None] * len(xs)
+        outs = []
+        for i, (xc, tc, yc) in enumerate(zip(xs, ts, ys)):
+            st = self._streams[i]
+            st.wait_stream(cur)
+            n_packed = len(self._packed)
+            with torch.cuda.stream(st):
+                outs.append(self._forward_body(xc.contiguous(), tc.contiguous(), yc.contiguous() if yc is not None else None, out_channels_keep))
+            if len(self._packed) != n_packed:
+                st.synchronize()         # this chunk packed weights on ITS stream: the other chunks read them from the shared cache
+        for o, st in zip(outs, self._streams):
+            cur.wait_stream(st)
+            o.record_stream(cur)
+        return torch.cat(outs)
 
     def _forward_impl(self, x, timesteps, y=None, out_channels_keep=None):
         if not (self.split_k and self.precision == "f16x3"):

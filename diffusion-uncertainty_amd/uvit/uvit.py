@@ -148,6 +148,9 @@ class UViT(nn.Module):
         # mostly idle (N = 1152 projections at batch 64: 585 tiles on 256 CUs) run their tail rows split along K.  Opt-in: results
         # then depend on the batch size at fp32-rounding level
         self.split_k = False
+        self.stream_split = 1            # > 1: the batch in that many chunks on HIP streams of their own (see _forward_streams)
+        self.stream_split_max_batch = 1 << 30
+        self._streams = []
         self.skip_planes = True          # f16x3: block outputs that feed a skip_linear also leave the fc2 epilogue as f16x3 planes (A/B switch)
         self._planes = {}
 
@@ -192,6 +195,9 @@ class UViT(nn.Module):
     def forward(self, x, timesteps, y=None):
         if not x.is_cuda:
             raise RuntimeError("UViT.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        n = int(self.stream_split)
+        if n > 1 and 2 * n <= x.shape[0] <= self.stream_split_max_batch:
+            return self._forward_streams(x, timesteps, y, n)
         if not (self.split_k and self.precision == "f16x3"):
             return self._forward_body(x, timesteps, y)
         prev = ops.set_split_k(True, x.device)
@@ -199,6 +205,31 @@ class UViT(nn.Module):
             return self._forward_body(x, timesteps, y)
         finally:
             ops.set_split_k(prev, x.device)
+
+    def _forward_streams(self, x, timesteps, y, n):
+        """The batch in n chunks, each chunk's whole forward on a HIP stream of its own (results identical per image: every kernel is
+        batch-invariant).  At batch 64 a linear of U-ViT-H/2 is 390 - 1170 tiles for 256 persistent workgroups - 1.5 to 4.6 rounds, the
+        last one partly empty - and the HBM-bound kernels between the GEMMs leave the matrix cores idle; with two half batches in flight
+        the workgroups of one chunk's kernel start on the CUs the other chunk's kernel has left.  Stream-K / split-K use ONE
+        process-global workspace, so they stay off on this path."""
+        cur = torch.cuda.current_stream(x.device)
+        if len(self._streams) < n:
+            self._streams = [torch.cuda.Stream(device=x.device) for _ in range(n)]
+        xs, ts = torch.chunk(x, n), torch.chunk(timesteps, n)
+        ys = torch.chunk(y, n) if y is not None else [None] * len(xs)
+        outs = []
+        for i, (xc, tc, yc) in enumerate(zip(xs, ts, ys)):
+            st = self._streams[i]
+            st.wait_stream(cur)
+            n_packed = len(self._planes)
+            with torch.cuda.stream(st):
+                outs.append(self._forward_body(xc.contiguous(), tc.contiguous(), yc.contiguous() if yc is not None else None))
+            if len(self._planes) != n_packed:
+                st.synchronize()         # this chunk packed weights on ITS stream: the other chunks read them from the shared cache
+        for o, st in zip(outs, self._streams):
+            cur.wait_stream(st)
+            o.record_stream(cur)
+        return torch.cat(outs)
 
     def _forward_body(self, x, timesteps, y=None):
         B, C, H, W = x.shape
