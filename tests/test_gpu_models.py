@@ -1059,6 +1059,36 @@ def test_uvit_block_abi_bit_identical(precision):
     assert float(a.abs().max()) > 0
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_stream_split_bit_identical(precision):
+    """UViT.stream_split / UNetModel.stream_split: the batch in chunks on HIP streams of their own equals the single-stream forward bit
+    for bit - also on the very first call, when the chunks fill the shared packed-weight cache (the first chunk's stream is synchronised
+    before the next chunk reads it) - and for ragged chunk sizes."""
+    from diffusion_uncertainty_amd.uvit.uvit import UViT
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    x = torch.randn(5, 4, 8, 8, generator=torch.Generator().manual_seed(4)).to(dev)
+    t, y = torch.tensor([999, 3, 500, 40, 7]).to(dev), torch.tensor([10, 0, 5, 2, 9]).to(dev)
+    outs = []
+    for n in (2, 1, 2, 3):
+        m = UViT(**TINY_UVIT)
+        m.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 6))
+        m.eval().to(dev)
+        m.precision, m.stream_split = precision, n
+        outs.append(m(x, t, y))                        # (fresh model: the split run packs the weights itself)
+        outs.append(m(x, t, y))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    a, _ = build_adm(TINY_ADM, 5)
+    a.precision = precision
+    xa = torch.randn(5, 3, 16, 16, generator=torch.Generator().manual_seed(1)).to(dev)
+    ya = torch.tensor([0, 1, 2, 3, 4]).to(dev)
+    a.stream_split = 2
+    first = a(xa, t, y=ya, out_channels_keep=3)        # packs on the chunk streams
+    a.stream_split = 1
+    assert torch.equal(a(xa, t, y=ya, out_channels_keep=3), first)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16w"])
 def test_adm_hip_graph_replay_bit_identical(precision):
     """UNetModel.enable_hip_graph(): the eval forward captured into a HIP graph and replayed equals the eager forward bit for
