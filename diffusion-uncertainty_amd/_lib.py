@@ -124,6 +124,12 @@ SIGNATURES = {
     "dua_conv3x3_f16x3_wino": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P]),
     "dua_groupnorm_apply_wino_f16w": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _F, _P, _P]),
     "dua_conv3x3_f16w_wino": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P]),
+    "dua_f16x3_wino4_act_bytes": (_Z, [_I, _I, _I, _I]),
+    "dua_f16x3_wino4_weight_bytes": (_Z, [_I, _I]),
+    "dua_pack_weight_f16x3_wino4": (_I, [_P, _P, _I, _I, _P]),
+    "dua_groupnorm_apply_wino4_f16x3": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _F, _P, _P]),
+    "dua_conv3x3_f16x3_wino4_supported": (_I, [_I, _I, _I, _I, _I]),
+    "dua_conv3x3_f16x3_wino4": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P]),
     "dua_f32_wino_weight_bytes": (_Z, [_I, _I]),
     "dua_pack_weight_f32_wino": (_I, [_P, _P, _I, _I, _P]),
     "dua_groupnorm_apply_wino_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),

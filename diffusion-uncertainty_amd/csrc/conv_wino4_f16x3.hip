@@ -1,0 +1,773 @@
+// f16x3 3x3 convolution with a Winograd F(4,3) transform ALONG Y (gfx950): four output rows cost six 1x3 row convolutions instead of
+// twelve, i.e. 4.5 instead of 9 matrix-core taps per output pixel (x 3 fp16 products each; the F(2,3) form of conv_wino_f16x3.hip
+// spends 6), and the transformed input is 1.5 x the input instead of 2 x.  Operand precision is unchanged (22 significant bits per
+// operand, fp32 accumulation); the transform's constants (points 0, +-1, +-2, inf) amplify rounding by ~2.5 x against the direct fp32
+// convolution (scripts/diag/wino43_precision.py: rms 5.1e-7 vs 2.3e-7 of the output scale on a 256-channel layer).
+//
+//   d0..d5 = input rows 4j-1 .. 4j+4 (zero outside the image)                 g0..g2 = kernel rows (dy = -1, 0, +1)
+//   V0 = 4 d0 - 5 d2 + d4            V1 = (d3 + d4) - 4 (d1 + d2)             U0 = g0 / 4        U1 = -(g0 + g1 + g2) / 6
+//   V2 = (d4 - d3) + 4 (d1 - d2)     V3 = (d4 - d2) + 2 (d3 - d1)             U2 = -(g0 - g1 + g2) / 6
+//   V4 = (d4 - d2) - 2 (d3 - d1)     V5 = 4 d1 - 5 d3 + d5                    U3 = g0 / 24 + g1 / 12 + g2 / 6   U4 = g0 / 24 - g1 / 12 + g2 / 6   U5 = g2
+//   M_f = conv1x3_x(V_f, U_f)  (zero padding in x)
+//   out row 4j = M0 + M1 + M2 + M3 + M4          4j+1 = (M1 - M2) + 2 (M3 - M4)
+//   out row 4j+2 = (M1 + M2) + 4 (M3 + M4)       4j+3 = (M1 - M2) + 8 (M3 - M4) + M5
+//
+// Pieces (the layouts are those of conv_wino_f16x3.hip with six frequencies and a 128-row weight stage):
+//   k_gn_apply_wino4     GroupNorm * gamma + beta (+FiLM, SiLU, dropout mask, 2x resampling, virtual concat) -> the six V_f images as
+//                        f16x3 images [f][tile of 128 positions][C/32][hi | lo][128][32]; a position = (image, row group j, column x)
+//   k_pack_wino4         OIHW fp32 weights -> U_f, per-output-row power-of-two scale, fp16 hi | lo images, one contiguous 16 KB block
+//                        [hi | lo][128 channels][32] per (column tile, K step = (channel block, f, dx))
+//   k_wconv4             LDS-DMA implicit GEMM on v_mfma_f32_16x16x32_f16: a workgroup tile = 128 positions x 128 output channels x
+//                        6 frequencies = 98 304 accumulators on FOUR waves (one per SIMD, 512 registers each: 384 accumulators): wave =
+//                        64 positions x 64 channels x all six frequencies, so the inverse transform is wave-local (no partner
+//                        exchange, no barrier in the epilogue).  K steps (channel block, f, dx): one 128-row activation stage per
+//                        (channel block, f) serves the three dx taps through row-shifted fragment addresses, one 128-row weight stage
+//                        per step.  Per wave and step the DMA pieces, fragment reads and MFMAs are those of k_wconv.
+#include "common.h"
+#include "wconv.h"
+#include <type_traits>
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef WCONV4_DIAG
+#define WCONV4_DIAG 0             // timing-only diagnostic builds (WRONG results): bit 0 no in-loop barrier, bit 1 no epilogue
+#endif
+
+constexpr int W4_STORES = 4 * 2 * 4 * 2;          // output rows x channel-block pairs x position blocks x halves: always-issued stores of a wave
+static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
+
+// One matrix-core product into an accumulator that LIVES in the accumulation registers (AG: frequencies 0-3, 256 AGPRs) or in the
+// architectural registers (frequencies 4, 5: 128 VGPRs).  The compiler picks one form of MFMA per function (with more than 256
+// accumulators: the AGPR form, parking a third of them in VGPRs through ~340 v_accvgpr moves and 58 scratch accesses per channel block);
+// the explicit operand classes give the mixed form.  Every accumulator is next touched 16 MFMAs later (no back-to-back dependence); the
+// first non-MFMA read of an accumulator comes after the s_nop block that follows the K loop.
+template <int N, class F>
+__device__ __forceinline__ void w4_static_for(F&& f) {
+    if constexpr (N > 0) {
+        w4_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <bool AG>
+__device__ __forceinline__ void w4_mma(f32x4& c, const h16x8& a, const h16x8& b) {
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// The compiler does not know that w4_mma is a matrix-core instruction, so it would not keep the wait states between one and a copy /
+// arithmetic instruction that touches the same accumulator.  w4_fence ties all 16 quads of a frequency to a block of wait states: any
+// compiler-generated instruction that reads or writes them is ordered behind (zero initialisation: in front of) the block.
+template <bool AG>
+__device__ __forceinline__ void w4_fence(f32x4 (&A)[4][4]) {
+    if constexpr (AG)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+a"(A[0][0]), "+a"(A[0][1]), "+a"(A[0][2]), "+a"(A[0][3]), "+a"(A[1][0]), "+a"(A[1][1]), "+a"(A[1][2]), "+a"(A[1][3]),
+                                            "+a"(A[2][0]), "+a"(A[2][1]), "+a"(A[2][2]), "+a"(A[2][3]), "+a"(A[3][0]), "+a"(A[3][1]), "+a"(A[3][2]), "+a"(A[3][3]));
+    else
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[0][2]), "+v"(A[0][3]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[1][2]), "+v"(A[1][3]),
+                                            "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[2][2]), "+v"(A[2][3]), "+v"(A[3][0]), "+v"(A[3][1]), "+v"(A[3][2]), "+v"(A[3][3]));
+}
+
+__global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int RA = 2, RB = 3;
+    constexpr int SP = 128 * 32;                           // halves per plane of a stage (8 KB)
+    constexpr int STG = 2 * SP;                            // halves per stage: [hi | lo][128][32]
+    constexpr int BOFF = 0, AOFF = RB * STG;               // weight ring first: a shifted row -1 of activation stage 0 stays inside LDS
+    constexpr int EOFF = (RA + RB) * STG;                  // epilogue patches: 4 waves x 2 x (16 rows x 144 bytes)
+    constexpr int PATCH = 16 * 144;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(RA + RB) * STG + 4 * 2 * PATCH / 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;               // position half, channel half
+    const int ntiles = p.ntm * p.ntn;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk0 = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq, chunk_n = cq + (xcd < cr ? 1 : 0);
+
+    constexpr int OOBL = 0x40000;                          // LDS byte address beyond the allocation: DS reads there return zeros
+    static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU");
+    const int lr = lane & 15, lc = lane >> 4;
+
+    // ---- DMA state: one per-lane byte offset (this lane's 16 bytes of a 16-row piece; the chunk swizzle of k_wconv applied to the
+    // source), everything else - piece row group, channel block, K step, hi / lo image - is wave-uniform and travels as the scalar offset
+    const unsigned lanebase = (unsigned)((lane >> 2) * 64 + 16 * ((lane & 3) ^ (2 * ((lane >> 4) & 1))));
+    const int wrow0 = (16 * (2 * wave)) * 64, wrow1 = (16 * (2 * wave + 1)) * 64;      // bytes: this wave's two 16-row pieces of a 128-row image
+    const int ncb = p.Cin / 32;
+    const long fstride = (long)p.ntm * ncb * 16384;        // bytes between the images of consecutive frequencies
+    const char* vtile = (const char*)p.V;
+    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, 0, 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
+    constexpr int b_lo = SP * 2, a_lo = SP * 2;            // byte distance hi -> lo image inside a stage
+    int toffA = 0, sboff = 0;                              // scalar: channel block of the activation group being requested; weight stage of the next request
+    bool prefetched = false;
+
+    auto tile_geom = [&](int m0_, int tn_) {
+        sboff = tn_ * (p.K / 32) * 16384;                                  // stage 0 of the column tile
+        vtile = (const char*)p.V + (long)(m0_ >> 7) * ncb * 16384;       // the tile's stage blocks of frequency 0
+        toffA = 0;
+    };
+    // the activation stage of (channel block at toffA, frequency f): descriptor over the tile's ncb stage blocks of that frequency
+    auto a_setup = [&](int f) { ra = __builtin_amdgcn_make_buffer_rsrc((void*)(vtile + f * fstride), 0, ncb * 16384, 0x00020000); };
+    auto dma_a = [&](int sa, int i) {
+        _Float16* st = lds + AOFF + sa * STG;
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * 32, 16, lanebase, toffA + wrow0, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * 32 + SP, 16, lanebase, toffA + wrow0 + a_lo, 0, 0);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * 32, 16, lanebase, toffA + wrow1, 0, 0);
+        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * 32 + SP, 16, lanebase, toffA + wrow1 + a_lo, 0, 0);
+    };
+    auto dma_b = [&](int sb, int i) {
+        _Float16* st = lds + BOFF + sb * STG;
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + (16 * (2 * wave)) * 32, 16, lanebase, sboff + wrow0, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + (16 * (2 * wave)) * 32 + SP, 16, lanebase, sboff + wrow0 + b_lo, 0, 0);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + (16 * (2 * wave + 1)) * 32, 16, lanebase, sboff + wrow1, 0, 0);
+        if (i == 3) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, st + (16 * (2 * wave + 1)) * 32 + SP, 16, lanebase, sboff + wrow1 + b_lo, 0, 0);
+            sboff += 16384;                                // the next K step's stage
+        }
+    };
+    auto issue_prologue = [&]() {          // A(channel block 0, f = 0) B(0) B(1)
+        a_setup(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(0, i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b(0, i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_b(1, i);
+    };
+
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const int off_l = lr * 64 + 16 * (lc ^ (2 * ((lr >> 2) & 1)));
+    const int a_row0 = AOFF * 2 + wm * 64 * 64, b_row0 = BOFF * 2 + wn * 64 * 64;       // bytes, wave-uniform
+    auto x_off = [&](int dx) -> int {
+        const int r_ = lr + dx;                                           // -1 .. 16
+        return r_ * 64 + 16 * (lc ^ (2 * (((r_ + 64) >> 2) & 1)));
+    };
+#if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
+    constexpr bool ZSEL = true;
+#else
+    constexpr bool ZSEL = false;
+#endif
+    const int zero_addr = OOBL + (lane & 1) * 16;
+    const int ax0 = a_row0 + x_off(0);
+    int axm[4], axp[4];
+    unsigned xedge = 0;                                    // bit i: position block i at x == 0; bit 4 + i: at x == W - 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x_ = (wm * 64 + 16 * i + lr) & (p.W - 1);
+        xedge |= (x_ == 0 ? 1u : 0u) << i | (x_ == p.W - 1 ? 1u : 0u) << (4 + i);
+        axm[i] = (!ZSEL && x_ == 0) ? zero_addr : a_row0 + x_off(-1);
+        axp[i] = (!ZSEL && x_ == p.W - 1) ? zero_addr : a_row0 + x_off(1);
+    }
+    const int aw0 = b_row0 + off_l;
+
+    for (int ti = slot; ti < chunk_n; ti += nslot) {
+        const int lid = chunk0 + ti;
+        const int tn = lid % p.ntn, tm = lid / p.ntn;
+        const int m0 = tm * 128, n0 = tn * 128;
+        if (!prefetched) {
+            tile_geom(m0, tn);
+            issue_prologue();
+        }
+        const bool after_epilogue = prefetched;       // this tile's first stages were requested before the previous tile's epilogue
+        prefetched = false;
+
+        f32x4 acc[6][4][4];                           // [frequency][channel block][position block]
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[f][j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        w4_fence<true>(acc[0]); w4_fence<true>(acc[1]); w4_fence<true>(acc[2]); w4_fence<true>(acc[3]); w4_fence<false>(acc[4]); w4_fence<false>(acc[5]);
+
+        h16x8 xh[4], xl[4], wh[4], wl[4];
+        auto rd_x = [&](int sa, int pl, int i, int dx) -> h16x8 {
+            const int a = dx < 0 ? axm[i] : (dx > 0 ? axp[i] : ax0);
+            const h16x8 v = *(const h16x8*)(ldsb + a + (sa * STG * 2 + pl * SP * 2 + 16 * i * 64));
+            if (ZSEL && dx != 0) {
+                const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                return ((xedge >> (dx < 0 ? i : 4 + i)) & 1u) ? z : v;
+            }
+            return v;
+        };
+        auto rd_w = [&](int sb, int pl, int jj) -> h16x8 { return *(const h16x8*)(ldsb + aw0 + (sb * STG * 2 + pl * SP * 2 + 16 * jj * 64)); };
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+
+        // the first stages have landed; behind them in the (in-order) queue are only the previous epilogue's operations, of which the
+        // youngest 63 - output stores, W4_STORES of them always issue - may stay in flight
+        if (after_epilogue) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xl[i] = rd_x(0, 1, i, -1); xh[i] = rd_x(0, 0, i, -1); }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { wh[jj] = rd_w(0, 0, jj); wl[jj] = rd_w(0, 1, jj); }
+        WSB();
+
+        // One K step = (channel block, f, dx): 48 MFMAs into the accumulators of f.  Ring slots are static: the activation stage of
+        // (channel block, f) lives in slot f & 1, the weight stage of step dxi in slot dxi.  ONE copy of the 18 steps serves every channel
+        // block: in the tile's final group (last channel block, f = 5) the requests that would run past the tile are skipped by uniform
+        // branches around single instructions, so that no two regions of code hold the accumulators in different registers (the
+        // copies between them would sit next to matrix-core instructions the compiler cannot see).
+        auto step = [&](auto fi_c, auto dxi_c, const bool last_cb) __attribute__((always_inline)) {
+            constexpr int FI = decltype(fi_c)::value, DXI = decltype(dxi_c)::value;
+            constexpr bool AG = FI < 4;
+            const bool lastg = FI == 5 && last_cb;                              // (compile-time false for f < 5)
+            constexpr int FN = (FI + 1) % 6;
+            constexpr int sa_n = FN & 1, sb_n = (DXI + 2) % 3;
+            constexpr int sa_r = DXI == 2 ? (FN & 1) : (FI & 1), sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;   // the NEXT step's fragments
+            f32x4 (&A)[4][4] = acc[FI];
+            if (DXI == 0 && !lastg) {                                           // set up the next group's activation stage ...
+                if (FI == 5) toffA += 16384;                                    // (the next group opens the next channel block)
+                a_setup(FN);
+            }
+            auto early_piece = [&](int q) {
+                if (q < 4) { if (!lastg || DXI == 0) dma_b(sb_n, q); }          // the weight stage of step s + 2
+                else if (q < 6) { if (DXI < 2 && !lastg) dma_a(sa_n, q - 4 + 2 * DXI); }    // ... requested half in this group's first, half in its second step
+            };
+            WSB();
+            // P1: w_hi * x_lo | the DMA pieces of this step
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w4_mma<AG>(A[jj][i], wh[jj], xl[i]);
+                    WSB();
+                    const int m_ = jj * 4 + i;
+                    if ((m_ & 1) == 0) early_piece(m_ >> 1);
+                    WSB();
+                }
+            // every read of stage s was issued during the previous step: publish stage s + 1
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // in issue order: [B(s+1) x4, A x2] of the previous step, [B(s+2) x4, A x2] of this one.  B(s+1) must have landed; the group's
+            // last step also needs all four activation pieces.  In the final group nothing but B(s+2) of its first step is behind.
+            if (lastg) {
+                if (DXI == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (DXI == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (DXI == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            if (!(WCONV4_DIAG & 1)) __builtin_amdgcn_s_barrier();
+            WSB();
+            // P2: w_hi * x_hi | x_lo and w_hi of the next step (after the tile's last step: reads whose values nobody uses)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w4_mma<AG>(A[jj][i], wh[jj], xh[i]);
+                    WSB();
+                    if (jj == 0) { xl[i] = rd_x(sa_r, 1, i, dxn); WSB(); }
+                }
+                wh[jj] = rd_w(sb_r, 0, jj);
+                WSB();
+            }
+            // P3: w_lo * x_hi | w_lo and x_hi of the next step
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w4_mma<AG>(A[jj][i], wl[jj], xh[i]);
+                    WSB();
+                    if (jj == 3) { xh[i] = rd_x(sa_r, 0, i, dxn); WSB(); }
+                }
+                wl[jj] = rd_w(sb_r, 1, jj);
+                WSB();
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>;
+        using I5 = std::integral_constant<int, 5>;
+#define W4_GROUP(F) step(F{}, I0{}, last_cb); step(F{}, I1{}, last_cb); step(F{}, I2{}, last_cb);
+#pragma nounroll
+        for (int cbi = 0; cbi < ncb; ++cbi) {
+            int last_i = __builtin_amdgcn_readfirstlane(cbi == ncb - 1 ? 1 : 0);
+            asm volatile("" : "+s"(last_i));                                    // (opaque: the loop is neither peeled nor versioned on it)
+            const bool last_cb = last_i != 0;
+            W4_GROUP(I0) W4_GROUP(I1) W4_GROUP(I2) W4_GROUP(I3) W4_GROUP(I4) W4_GROUP(I5)
+        }
+#undef W4_GROUP
+        // the last barrier of the tile has retired every LDS read of the rings: request the first stages of the next tile now
+        if (ti + nslot < chunk_n) {
+            const int nl = chunk0 + ti + nslot;
+            tile_geom((nl / p.ntn) * 128, nl % p.ntn);
+            issue_prologue();
+            prefetched = true;
+        }
+#undef WSB
+        // the last MFMAs' results before any other instruction reads them
+        w4_fence<true>(acc[0]); w4_fence<true>(acc[1]); w4_fence<true>(acc[2]); w4_fence<true>(acc[3]); w4_fence<false>(acc[4]); w4_fence<false>(acc[5]);
+        if (WCONV4_DIAG & 2) {                       // (diagnostic: no epilogue - the accumulators are kept alive by a store that never happens)
+            float t_ = 0.f;
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t_ += acc[f][j][i][0] + acc[f][j][i][1] + acc[f][j][i][2] + acc[f][j][i][3];
+            if (t_ == 1.2345e-30f) p.C[0] = t_;
+            continue;
+        }
+
+        // ---- epilogue, per (channel-block pair jp, position block i): inverse transform of the pair's 2 x 6 accumulator quads in
+        // registers, then per output row r the store path of wconv_epilogue - the pair's 32 channels of 16 positions through a
+        // wave-private 16 x 144-byte patch, so that residual reads and output stores move whole 128-byte rows.  The residual rows of
+        // item q + 2 are requested before the stores of item q go out (ring of three).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int pr_e = lane_e >> 3, pc_e = lane_e & 7, lr_e = lane_e & 15, lc_e = lane_e >> 4;
+        const int pos0 = m0 + wm * 64;
+        auto opix = [&](int i, int h, int r) -> long {
+            const int pos = pos0 + 16 * i + 8 * h + pr_e;
+            return pos < p.Mv ? (long)pos + 3L * (pos & ~(p.W - 1)) + (long)r * p.W : -1L;
+        };
+        auto res_ld = [&](int q, float4 (&dst)[2]) {                       // q = (jp, i, r)
+            const int jp = q >> 4, i = (q >> 2) & 3, r = q & 3;
+            const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
+            const bool cok = c < p.N;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long row = opix(i, h, r);
+                dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(p.res && cok && row >= 0)) continue;
+                if (p.res_mode == 0) {
+                    dst[h] = *(const float4*)(p.res + row * p.N + c);
+                    continue;
+                }
+                const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
+                if (p.res_mode > 0) {
+                    const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
+                    dst[h] = *(const float4*)(p.res + src * p.N + c);
+                } else {                                                  // same order of additions as k_resample2x (denoiser.hip)
+                    const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
+                    const float4 a = *(const float4*)(p.res + src * p.N + c), b = *(const float4*)(p.res + (src + 1) * p.N + c);
+                    const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
+                    dst[h] = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
+                                         (a.w + b.w + d.w + e.w) * 0.25f);
+                }
+            }
+        };
+        const long cpix0 = 4L * m0;                                          // the tile's 128 positions are output pixels 4 m0 .. 4 m0 + 511
+        const long crem = (4L * p.Mv - cpix0) * p.N * 4;
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
+        char* pw0 = reinterpret_cast<char*>(lds) + EOFF * 2 + wave * 2 * PATCH;
+        float4 rn_[3][2];
+        res_ld(0, rn_[0]);
+        res_ld(1, rn_[1]);
+        w4_static_for<2>([&](auto jp_c) __attribute__((always_inline)) {
+            constexpr int jp = decltype(jp_c)::value;
+            const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
+            const bool cok = c < p.N;
+            float4 sq = *(const float4*)(p.Cscale + c);                      // (padded to the tile grid)
+            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && cok) bq = *(const float4*)(p.bias + c);
+            float4 cs[4], cq2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[r] = cq2[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            w4_static_for<4>([&](auto i_c) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_c)::value;
+                f32x4 R[4][2];                                               // [output row][channel block of the pair]
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = 2 * jp + u;
+                    const f32x4 s12 = acc[1][j][i] + acc[2][j][i], d12 = acc[1][j][i] - acc[2][j][i];
+                    const f32x4 s34 = acc[3][j][i] + acc[4][j][i], d34 = acc[3][j][i] - acc[4][j][i];
+                    R[0][u] = (acc[0][j][i] + s12) + s34;
+                    R[1][u] = d12 + 2.0f * d34;
+                    R[2][u] = s12 + 4.0f * s34;
+                    R[3][u] = (acc[5][j][i] + d12) + 8.0f * d34;
+                }
+                w4_static_for<4>([&](auto r_c) __attribute__((always_inline)) {
+                    constexpr int r = decltype(r_c)::value;
+                    constexpr int q = (jp * 4 + i) * 4 + r;
+                    if constexpr (q + 2 < 32) res_ld(q + 2, rn_[(q + 2) % 3]);
+                    const float4 (&rq)[2] = rn_[q % 3];
+                    char* pw = pw0 + (q & 1) * PATCH;
+                    *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = R[r][0];
+                    *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = R[r][1];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
+                        const long row = opix(i, h, r);
+                        float4 v;
+                        v.x = a[0] * sq.x + bq.x + rq[h].x;
+                        v.y = a[1] * sq.y + bq.y + rq[h].y;
+                        v.z = a[2] * sq.z + bq.z + rq[h].z;
+                        v.w = a[3] * sq.w + bq.w + rq[h].w;
+                        const bool ok = cok && row >= 0;
+                        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                        const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                        if (ok) {
+                            cs[r].x += v.x; cs[r].y += v.y; cs[r].z += v.z; cs[r].w += v.w;
+                            cq2[r].x += v.x * v.x; cq2[r].y += v.y * v.y; cq2[r].z += v.z * v.z; cq2[r].w += v.w * v.w;
+                        }
+                    }
+                });
+            });
+            if (p.colsum) {
+                // The wave's 64 positions x 4 output rows are 256 consecutive output pixels of ONE image (H*W % 256 == 0) = four 64-pixel
+                // slots of the column-sum array; output row r fills slot r of them.  The consumer (dua_groupnorm_stats_from_colsums)
+                // folds all slots of an image, so only the per-image totals matter.
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t[8] = {cs[r].x, cs[r].y, cs[r].z, cs[r].w, cq2[r].x, cq2[r].y, cq2[r].z, cq2[r].w};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        t[u] += __shfl_xor(t[u], 8);
+                        t[u] += __shfl_xor(t[u], 16);
+                        t[u] += __shfl_xor(t[u], 32);
+                    }
+                    if (pr_e == 0 && cok && pos0 < p.Mv) {
+                        float* o = p.colsum + ((long)(pos0 >> 4) + r) * 2 * p.N + c;
+                        *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
+                        *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
+                    }
+                }
+            }
+        });
+    }
+#endif
+}
+
+// =================================== weight packer ===========================================
+__device__ __forceinline__ double wino4_u(const float* __restrict__ w, int cout, int ci, int dx, int f, int Cin) {
+    const float* g = w + ((size_t)cout * Cin + ci) * 9 + dx;             // OIHW: [ky][kx], kx = dx
+    const double g0 = g[0], g1 = g[3], g2 = g[6];
+    switch (f) {
+        case 0: return g0 / 4.0;
+        case 1: return -(g0 + g1 + g2) / 6.0;
+        case 2: return -(g0 - g1 + g2) / 6.0;
+        case 3: return g0 / 24.0 + g1 / 12.0 + g2 / 6.0;
+        case 4: return g0 / 24.0 - g1 / 12.0 + g2 / 6.0;
+        default: return g2;
+    }
+}
+__global__ __launch_bounds__(256) void k_wino4_row_scale(const float* __restrict__ w, float* __restrict__ inv_scale, int Cout, int Cin) {
+    const int n = blockIdx.x;
+    float m = 0.f;
+    if (n < Cout)
+        for (int k = threadIdx.x; k < Cin * 3; k += blockDim.x) {
+            const int ci = k / 3, dx = k % 3;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) m = fmaxf(m, fabsf((float)wino4_u(w, n, ci, dx, f, Cin)));
+        }
+    __shared__ float red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        if (red[0] > 0.f) e = 14 - (int)((__float_as_uint(red[0]) >> 23) & 0xff) + 127;
+        e = max(-100, min(100, e));
+        inv_scale[n] = __uint_as_float((unsigned)(127 - e) << 23);
+    }
+}
+// Packed layout: [column tile][K step = (channel block, f, dx)][hi | lo][128 channels][32 input channels]: the 16 KB weight stage of a K
+// step is one contiguous block in the order of its LDS image.
+__global__ void k_pack_wino4(const float* __restrict__ w, _Float16* __restrict__ packed, const float* __restrict__ inv_scale, int Cout,
+                             int Cin, int ntn) {
+    const int nk = 18 * (Cin / 32);
+    const size_t total = (size_t)ntn * nk * 128 * 32;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 31), R = (int)((i >> 5) & 127);
+        const size_t st = i >> 12;                                       // (column tile, step)
+        const int tn = (int)(st / nk), s = (int)(st % nk);
+        const int cout = tn * 128 + R;
+        const int cb = s / 18, t = s % 18;
+        const int f = t / 3, dx = t % 3, ci = cb * 32 + c;
+        float v = 0.f;
+        if (cout < Cout) v = (float)(wino4_u(w, cout, ci, dx, f, Cin) * (double)(1.0f / inv_scale[cout]));
+        const _Float16 h = (_Float16)v;
+        _Float16* o = packed + st * (2 * 128 * 32) + R * 32 + c;
+        o[0] = h;
+        o[128 * 32] = (_Float16)(v - (float)h);
+    }
+}
+
+static inline int wino4_ntn(int Cout) { return (Cout + 127) / 128; }
+extern "C" size_t dua_f16x3_wino4_weight_bytes(int Cout, int Cin) {
+    return 4 * (size_t)wino4_ntn(Cout) * 128 * 18 * Cin + 4 * (size_t)((Cout + 255) / 256 * 256);
+}
+extern "C" int dua_pack_weight_f16x3_wino4(const float* w, void* packed, int Cout, int Cin, void* stream) {
+    DUA_REQUIRE(w && packed && Cout > 0 && Cin >= 32 && Cin % 32 == 0, "dua_pack_weight_f16x3_wino4: Cin must be a positive multiple of 32 (got %d)", Cin);
+    const int ntn = wino4_ntn(Cout), Nsc = (Cout + 255) / 256 * 256;
+    const size_t plane = (size_t)ntn * 128 * 18 * Cin;
+    _Float16* hi = (_Float16*)packed;
+    float* inv_scale = (float*)(hi + 2 * plane);
+    hipLaunchKernelGGL(k_wino4_row_scale, dim3(Nsc), 256, 0, as_stream(stream), w, inv_scale, Cout, Cin);
+    hipLaunchKernelGGL(k_pack_wino4, stream_grid(plane, 256), 256, 0, as_stream(stream), w, hi, inv_scale, Cout, Cin, ntn);
+    return dua_check_launch("dua_pack_weight_f16x3_wino4");
+}
+
+// 0 = not supported, 1 = supported, 2 = supported without the column-sum output (maps smaller than 256 pixels: a wave's 64 positions
+// then span several images)
+extern "C" int dua_conv3x3_f16x3_wino4_supported(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cin % 32 || Cout <= 0 || Cout % 4) return 0;
+    if (H % 4 || W < 2 || W > 128 || (W & (W - 1))) return 0;
+    const long Mv = (long)N * (H / 4) * W;
+    if (Mv >= (1L << 29) || ((long)H * W) % 64) return 0;                           // (16-position groups of the writer stay inside one image)
+    if ((size_t)wino4_ntn(Cout) * 128 * 18 * Cin * 4 >= 0x7FFFFFF0ull) return 0;
+    return ((long)H * W) % 256 == 0 ? 1 : 2;
+}
+
+extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                                       int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
+    DUA_REQUIRE(vplanes && packed && y, "dua_conv3x3_f16x3_wino4: null pointer");
+    DUA_REQUIRE(res_resample >= -1 && res_resample <= 1 && (res_resample <= 0 || W >= 2), "dua_conv3x3_f16x3_wino4: res_resample must be -1, 0 or +1");
+    DUA_REQUIRE(v_scale > 0.f, "dua_conv3x3_f16x3_wino4: v_scale must be positive");
+    const int sup = dua_conv3x3_f16x3_wino4_supported(N, H, W, Cin, Cout);
+    DUA_REQUIRE(sup, "dua_conv3x3_f16x3_wino4: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (H %% 4 == 0, W a power of two <= 128, "
+                "Cin %% 32 == 0, Cout %% 4 == 0)", N, H, W, Cin, Cout);
+    DUA_REQUIRE(!colsum || sup == 1, "dua_conv3x3_f16x3_wino4: the column-sum output needs H*W %% 256 == 0 (got %d x %d)", H, W);
+    WConvP p{};
+    p.V = vplanes; p.B = packed; p.bias = bias; p.res = residual; p.res_mode = residual ? res_resample : 0; p.C = y; p.colsum = colsum;
+    p.Mv = N * (H / 4) * W; p.N = Cout; p.Cin = Cin; p.K = 18 * Cin; p.H = H; p.W = W;
+    p.ntm = (p.Mv + 127) / 128; p.ntn = wino4_ntn(Cout);
+    p.b_plane = (long)p.ntn * 128 * p.K;
+    p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
+    p.out_scale = 1.0f / v_scale;
+    const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(k_wconv4, dim3(grid), 256, 0, as_stream(stream), p);
+    return dua_check_launch("dua_conv3x3_f16x3_wino4");
+}
+
+// =================================== GroupNorm apply -> V planes ===========================================
+struct GnWino4P {
+    const float *x1, *x2, *stats, *gamma, *beta, *film, *drop;
+    _Float16* v;
+    int C1, C2, N, H, W, G, act, resample;
+    int ntm;                 // position tiles of 128 per frequency image
+    long film_ld;
+    float oscale;
+    int JC;                  // row groups per chunk
+};
+
+// One wave = 16 consecutive positions of a row group x one 32-channel block: lane -> (position lane >> 2, channels 8 (lane & 3) ..+7),
+// so a wave reads 16 whole 128-byte lines per row and writes, per frequency, the 1-KB piece [16 positions][32 channels] of the hi image
+// and of the lo image of the conv's stage block (tile, channel block).  Maps narrower than 16 put 16 / W consecutive row groups in a wave.
+// STREAM (maps at least 16 wide, no pooling, no dropout mask): the four new rows of the NEXT row group are requested before this group's
+// twelve stores go out.  The sliding window over y keeps every input element read once (plus two halo rows per chunk).
+template <bool STREAM>
+__global__ __launch_bounds__(256) void k_gn_apply_wino4(GnWino4P p) {
+    const int C = p.C1 + p.C2, ncb = C / 32, cpg = C / p.G;
+    const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
+    const int P = Ho / 4;
+    const int JS = Wo >= 16 ? 1 : 16 / Wo;                 // row groups covered by one 16-position group
+    const int npg = Wo >= 16 ? Wo / 16 : 1;                // position groups per row-group row
+    const int nitems = npg * ncb, nxb = (nitems + 3) / 4;
+    const int n = blockIdx.y, jc = blockIdx.x / nxb, item = (blockIdx.x % nxb) * 4 + (threadIdx.x >> 6);
+    if (item >= nitems) return;
+    const int lane = threadIdx.x & 63, p16 = lane >> 2;
+    const int cbk = item % ncb, pg = item / ncb;
+    const int c = cbk * 32 + 8 * (lane & 3);
+    const int xo = Wo >= 16 ? pg * 16 + p16 : p16 % Wo, jo = Wo >= 16 ? 0 : p16 / Wo;
+    const bool second = c >= p.C1;
+    const float* src = second ? p.x2 : p.x1;
+    const int cs = second ? p.C2 : p.C1, cq = second ? c - p.C1 : c;
+    float ca[8], cb[8];
+    {
+        const float4 g0 = *(const float4*)(p.gamma + c), g1 = *(const float4*)(p.gamma + c + 4);
+        const float4 b0 = *(const float4*)(p.beta + c), b1 = *(const float4*)(p.beta + c + 4);
+        float2 st[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st[j] = *(const float2*)(p.stats + 2 * ((size_t)n * p.G + (c + j) / cpg));
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, h0 = s0, h1 = s0;
+        if (p.film) {
+            const float* fr = p.film + (size_t)n * p.film_ld + c;
+            s0 = *(const float4*)fr; s1 = *(const float4*)(fr + 4);
+            h0 = *(const float4*)(fr + C); h1 = *(const float4*)(fr + C + 4);
+        }
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float fs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, fh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = st[j].y * g[j];
+            float b = bt[j] - st[j].x * a;
+            if (p.film) {
+                const float sc = 1.0f + fs[j];
+                a *= sc;
+                b = b * sc + fh[j];
+            }
+            ca[j] = a;
+            cb[j] = b;
+        }
+    }
+    const size_t img_in = (size_t)n * p.H * p.W;
+    auto xf = [&](size_t pix, float (&r)[8]) {
+        const float4 v0 = *(const float4*)(src + pix * cs + cq), v1 = *(const float4*)(src + pix * cs + cq + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            r[j] = v[j] * ca[j] + cb[j];
+            if (p.act == 1) r[j] = silu_f(r[j]);
+        }
+        if (p.drop) {
+            const float4 d0 = *(const float4*)(p.drop + pix * C + c), d1 = *(const float4*)(p.drop + pix * C + c + 4);
+            r[0] *= d0.x; r[1] *= d0.y; r[2] *= d0.z; r[3] *= d0.w; r[4] *= d1.x; r[5] *= d1.y; r[6] *= d1.z; r[7] *= d1.w;
+        }
+    };
+    // value of the conv's input image (after the optional 2x resampling) at row yo of this thread's column, zero outside
+    auto val = [&](int yo, float (&r)[8]) {
+        if (yo < 0 || yo >= Ho) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = 0.f;
+            return;
+        }
+        if (p.resample == 0) {
+            xf(img_in + (size_t)yo * p.W + xo, r);
+        } else if (p.resample > 0) {
+            xf(img_in + (size_t)(yo >> 1) * p.W + (xo >> 1), r);
+        } else {
+            const size_t pix = img_in + (size_t)(2 * yo) * p.W + 2 * xo;
+            float a[8], b[8], d[8], e[8];
+            xf(pix, a); xf(pix + 1, b); xf(pix + p.W, d); xf(pix + p.W + 1, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (a[j] + b[j] + d[j] + e[j]) * 0.25f;
+        }
+    };
+    unsigned long long* const rctr = dua_range_ctr();          // f16x3 range check (debug facility; nullptr when off)
+    auto put = [&](int f, size_t m, const float (&v)[8]) {
+        h16x8 h, l;
+        if (rctr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dua_range_note(rctr, v[j] * p.oscale);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sv = fminf(fmaxf(v[j] * p.oscale, -65504.f), 65504.f);
+            const _Float16 t = (_Float16)sv;
+            h[j] = t;
+            l[j] = (_Float16)(sv - (float)t);
+        }
+        // stage block (f, tile m / 128, channel block): [hi | lo][128 positions][32 channels]
+        _Float16* o = p.v + ((((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 2) * 4096 + (m & 127) * 32 + (c & 31);
+        __builtin_nontemporal_store(h, (h16x8*)o);
+        __builtin_nontemporal_store(l, (h16x8*)(o + 4096));
+    };
+    // the six transformed rows of one row group from its six input rows
+    auto emit = [&](size_t m, const float (&d0)[8], const float (&d1)[8], const float (&d2)[8], const float (&d3)[8], const float (&d4)[8], const float (&d5)[8]) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (4.0f * d0[q] - 5.0f * d2[q]) + d4[q];
+        put(0, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (d3[q] + d4[q]) - 4.0f * (d1[q] + d2[q]);
+        put(1, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (d4[q] - d3[q]) + 4.0f * (d1[q] - d2[q]);
+        put(2, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (d4[q] - d2[q]) + 2.0f * (d3[q] - d1[q]);
+        put(3, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (d4[q] - d2[q]) - 2.0f * (d3[q] - d1[q]);
+        put(4, m, v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (4.0f * d1[q] - 5.0f * d3[q]) + d5[q];
+        put(5, m, v);
+    };
+    const int j0 = jc * p.JC + jo, j1 = min(P, (jc + 1) * p.JC);
+    float dA[8], dB[8], dC[8], dD[8], dE[8], dF[8];
+    if constexpr (STREAM) {
+        if (j0 >= j1) return;
+        struct Raw { float4 a, b; };
+        auto ld = [&](int yo) -> Raw {                                   // (rows outside the image: any valid address, zeroed in `fin`)
+            const int yc = min(max(yo, 0), Ho - 1);
+            const size_t pix = img_in + (p.resample > 0 ? (size_t)(yc >> 1) * p.W + (xo >> 1) : (size_t)yc * p.W + xo);
+            return Raw{*(const float4*)(src + pix * cs + cq), *(const float4*)(src + pix * cs + cq + 4)};
+        };
+        auto fin = [&](const Raw& w, int yo, float (&r)[8]) {
+            const float v[8] = {w.a.x, w.a.y, w.a.z, w.a.w, w.b.x, w.b.y, w.b.z, w.b.w};
+            const bool in = yo >= 0 && yo < Ho;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float t = v[q] * ca[q] + cb[q];
+                if (p.act == 1) t = silu_f(t);
+                r[q] = in ? t : 0.f;
+            }
+        };
+        Raw rA = ld(4 * j0 - 1), rB = ld(4 * j0), rC = ld(4 * j0 + 1), rD = ld(4 * j0 + 2), rE = ld(4 * j0 + 3), rF = ld(4 * j0 + 4);
+        fin(rA, 4 * j0 - 1, dA);
+        fin(rB, 4 * j0, dB);
+        auto group = [&](int j) {
+            fin(rC, 4 * j + 1, dC);
+            fin(rD, 4 * j + 2, dD);
+            fin(rE, 4 * j + 3, dE);
+            fin(rF, 4 * j + 4, dF);
+            if (j + 1 < j1) { rC = ld(4 * j + 5); rD = ld(4 * j + 6); rE = ld(4 * j + 7); rF = ld(4 * j + 8); }
+            emit(((size_t)n * P + j) * Wo + xo, dA, dB, dC, dD, dE, dF);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dA[q] = dE[q]; dB[q] = dF[q]; }
+        };
+        group(j0);
+        for (int j = j0 + 1; j < j1; ++j) group(j);
+        return;
+    }
+    if (j0 < j1) { val(4 * j0 - 1, dA); val(4 * j0, dB); }
+    for (int j = j0; j < j1; j += JS) {
+        val(4 * j + 1, dC);
+        val(4 * j + 2, dD);
+        val(4 * j + 3, dE);
+        val(4 * j + 4, dF);
+        emit(((size_t)n * P + j) * Wo + xo, dA, dB, dC, dD, dE, dF);
+        if (JS == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dA[q] = dE[q]; dB[q] = dF[q]; }
+        } else if (j + JS < j1) {
+            val(4 * (j + JS) - 1, dA);
+            val(4 * (j + JS), dB);
+        }
+    }
+}
+
+// bytes of the V planes of a conv input [N][Ho][Wo][C] (Ho, Wo after the resampling): 6 frequencies x 2 planes x N*(Ho/4)*Wo*C halves
+extern "C" size_t dua_f16x3_wino4_act_bytes(int N, int Ho, int Wo, int C) {
+    const size_t Mv = (size_t)N * (Ho / 4) * Wo;
+    return (size_t)24 * ((Mv + 127) / 128 * 128) * C;                 // whole tiles of 128 positions
+}
+
+extern "C" int dua_groupnorm_apply_wino4_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                               int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+    const int C = C1 + C2;
+    DUA_REQUIRE(x1 && stats && gamma && beta && vplanes, "dua_groupnorm_apply_wino4_f16x3: null pointer");
+    DUA_REQUIRE(C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % 32 == 0, "dua_groupnorm_apply_wino4_f16x3: channel counts must be multiples of 8 (sum of 32)");
+    DUA_REQUIRE((C2 == 0) == (x2 == nullptr), "dua_groupnorm_apply_wino4_f16x3: x2/C2 mismatch");
+    DUA_REQUIRE(resample >= -1 && resample <= 1 && (resample >= 0 || (H % 2 == 0 && W % 2 == 0)), "dua_groupnorm_apply_wino4_f16x3: pooling needs even H, W");
+    DUA_REQUIRE(!(dropmask && resample != 0), "dua_groupnorm_apply_wino4_f16x3: dropout mask with resampling unsupported");
+    DUA_REQUIRE(v_scale > 0.f && (__builtin_bit_cast(unsigned, v_scale) & 0x7FFFFFu) == 0, "dua_groupnorm_apply_wino4_f16x3: v_scale must be a power of two");
+    const int Ho = resample < 0 ? H / 2 : (resample > 0 ? 2 * H : H), Wo = resample < 0 ? W / 2 : (resample > 0 ? 2 * W : W);
+    DUA_REQUIRE(Ho >= 4 && Ho % 4 == 0, "dua_groupnorm_apply_wino4_f16x3: the conv input needs a multiple of four rows (got %d)", Ho);
+    if ((size_t)N * Ho * Wo == 0) return DUA_OK;
+    DUA_REQUIRE(C1 % 32 == 0 && Wo >= 2 && Wo <= 128 && (Wo & (Wo - 1)) == 0 && ((long)Ho * Wo) % 64 == 0,
+                "dua_groupnorm_apply_wino4_f16x3: C1 %% 32 == 0, the conv input width a power of two <= 128 and H*W %% 64 == 0 are required");
+    GnWino4P p{x1, x2, stats, gamma, beta, film, dropmask, (_Float16*)vplanes, C1, C2, N, H, W, G, act, resample, 0, film_ld ? film_ld : 2L * C, v_scale, 0};
+    DUA_REQUIRE(p.film_ld >= 2L * C, "dua_groupnorm_apply_wino4_f16x3: film_ld too small");
+    DUA_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)film) & 15) == 0 && (!film || p.film_ld % 4 == 0),
+                "dua_groupnorm_apply_wino4_f16x3: gamma, beta and the FiLM rows must be 16-byte aligned");
+    const int P = Ho / 4;
+    p.ntm = (int)(((long)N * P * Wo + 127) / 128);
+    const int nxb = ((Wo >= 16 ? Wo / 16 : 1) * (C / 32) + 3) / 4;
+    // Row groups per workgroup chunk: 4 (two halo rows re-read per 16 = +12 % reads), fewer while the grid would be small
+    int JC = P < 4 ? P : 4;
+    while ((long)N * nxb * ((P + JC - 1) / JC) < 1024 && JC > 2) JC = (JC + 1) / 2;
+    if (Wo < 16 && JC % (16 / Wo)) JC = (JC / (16 / Wo) + 1) * (16 / Wo);       // chunks hold whole 16-position groups
+    p.JC = JC;
+    const dim3 grid(nxb * ((P + JC - 1) / JC), N);
+    const bool strm = resample >= 0 && !dropmask && Wo >= 16;
+    if (strm) hipLaunchKernelGGL((k_gn_apply_wino4<true>), grid, 256, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_gn_apply_wino4<false>), grid, 256, 0, as_stream(stream), p);
+    return dua_check_launch("dua_groupnorm_apply_wino4_f16x3");
+}
+
+DUA_RANGE_TU(conv_wino4)

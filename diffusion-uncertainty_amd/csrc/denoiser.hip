@@ -1002,13 +1002,14 @@ DUA_RANGE_TU(denoiser)
 
 // ---- f16x3 range check: host side (see common.h).  Process-global debug facility; dua_range_check_read synchronises the device.
 void dua_range_set_conv_wino(unsigned long long*);
+void dua_range_set_conv_wino4(unsigned long long*);
 void dua_range_set_xtile(unsigned long long*);
 void dua_range_set_hgemm(unsigned long long*);
 void dua_range_set_attention(unsigned long long*);
 static unsigned long long* g_range_buf = nullptr;
 static int g_range_on = 0;
 static void range_set_all(unsigned long long* p) {
-    dua_range_set_denoiser(p); dua_range_set_conv_wino(p); dua_range_set_xtile(p); dua_range_set_hgemm(p); dua_range_set_attention(p);
+    dua_range_set_denoiser(p); dua_range_set_conv_wino(p); dua_range_set_conv_wino4(p); dua_range_set_xtile(p); dua_range_set_hgemm(p); dua_range_set_attention(p);
 }
 extern "C" int dua_range_check(int on) {
     const int was = g_range_on;

@@ -313,6 +313,22 @@ int dua_groupnorm_apply_wino_f16w(const float* x1, int C1, const float* x2, int 
                                   int resample, const float* dropmask, float v_scale, void* vplanes, void* stream);
 int dua_conv3x3_f16w_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                           int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
+/* Winograd F(4,3) along y for the f16x3 3x3 convolutions (csrc/conv_wino4_f16x3.hip): four output rows from six transformed rows -
+ * 4.5 instead of 6 matrix-core taps per output pixel and 1.5 x instead of 2 x the input as transformed images, at the same 22-bit
+ * operands (the transform's constants amplify rounding ~2.5 x against the direct fp32 convolution; replaces `self.conv2 = conv_nd(...)`
+ * style 3x3 convolutions of unet_openai.py:183-187,207-214 exactly like dua_conv3x3_f16x3_wino).  Same operand layouts with six
+ * frequency images of N*(Ho/4)*Wo positions and 16 KB weight stages; v_scale = the plane scale of the V images (a power of two; V reaches
+ * 10 x the input).  dua_conv3x3_f16x3_wino4_supported: 1 for H %% 4 == 0, W a power of two <= 128, Cin %% 32 == 0, Cout %% 4 == 0,
+ * H*W %% 64 == 0; 2 = without the column-sum output (H*W %% 256 != 0). */
+size_t dua_f16x3_wino4_act_bytes(int N, int Ho, int Wo, int C);
+size_t dua_f16x3_wino4_weight_bytes(int Cout, int Cin);
+int dua_pack_weight_f16x3_wino4(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
+int dua_groupnorm_apply_wino4_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                    const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                    int resample, const float* dropmask, float v_scale, void* vplanes, void* stream);
+int dua_conv3x3_f16x3_wino4_supported(int N, int H, int W, int Cin, int Cout);
+int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                            int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
 /* The same form in EXACT fp32 (csrc/conv_wino_f32.hip, v_mfma_f32_16x16x4_f32: products and sums in fp32 - the Winograd form of
  * dua_conv3x3): the transformed images and the packed weights hold floats in the same stage-block layout (same byte counts:
  * dua_f16x3_wino_act_bytes / dua_f32_wino_weight_bytes), shapes as dua_conv3x3_f16x3_wino_supported. */

@@ -1,0 +1,183 @@
+"""Winograd F(4,3)-along-y form of the f16x3 3x3 convolution (csrc/conv_wino4_f16x3.hip) through the C ABI: the six-image V writer
+against a torch restatement of GroupNorm-apply + transform, the packed weights against G g over the kernel rows, and the convolution
+against fp64 torch next to the F(2,3) form, the direct f16x3 kernel and the exact fp32 MFMA engine on the same problem.  The F(4,3)
+constants amplify rounding: the bar is 4x the exact-fp32 engine's error (F(2,3) and the direct kernel are held to 2x)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+dev = "cuda"
+
+BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+                  dtype=torch.float64)
+G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from diffusion_uncertainty_amd import ops as o
+    return o
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def v_reference(a):
+    """a: the conv's input image [N][H][W][C] (fp64) -> the six F(4,3) input transforms over row groups, [6][N][H/4][W][C]."""
+    N, H, W, C = a.shape
+    ap = F.pad(a, (0, 0, 0, 0, 1, 4))                         # rows 4j - 1 .. 4j + 4
+    d = torch.stack([ap[:, k:k + H:4] for k in range(6)])     # [6][N][H/4][W][C]
+    return torch.einsum("fk,knjwc->fnjwc", BT, d)
+
+
+def decode_v(pl):
+    buf = pl.buf.cpu()                                       # [f][tile][C/32][hi | lo][128 positions][32 channels]
+    N, H, W, C = pl.shape
+    h = buf.view(torch.float16).double()
+    v = (h[:, :, :, 0] + h[:, :, :, 1]) / pl.scale          # [f][tile][cb][128][32]
+    v = v.permute(0, 1, 3, 2, 4).reshape(6, -1, C)[:, :N * (H // 4) * W]
+    return v.reshape(6, N, H // 4, W, C)
+
+
+def identity_stats(N, groups=32):
+    return torch.tensor([0.0, 1.0], device=dev).repeat(N * groups, 1).contiguous()
+
+
+@pytest.mark.parametrize("N,H,W,C1,C2,resample,film,drop", [
+    (2, 16, 16, 64, 0, 0, False, False), (1, 32, 32, 32, 32, 0, True, False), (3, 8, 16, 96, 0, 0, True, True), (5, 8, 8, 64, 32, 0, True, False),
+    (2, 16, 4, 32, 0, 0, False, False), (2, 16, 16, 64, 0, 1, False, False), (2, 32, 32, 64, 0, -1, False, False), (1, 64, 64, 256, 0, 0, True, False),
+    (2, 16, 16, 768, 512, 0, False, False), (1, 128, 128, 32, 0, 0, True, False)])
+def test_wino4_writer_vs_torch(ops, N, H, W, C1, C2, resample, film, drop):
+    C = C1 + C2
+    x1 = rnd(1, N, H, W, C1) * 2
+    x2 = rnd(2, N, H, W, C2) if C2 else None
+    gamma, beta = 1 + 0.3 * rnd(3, C), 0.2 * rnd(4, C)
+    fl = 0.2 * rnd(5, N, 2 * C) if film else None
+    dm = (torch.rand(N, H, W, C, generator=torch.Generator().manual_seed(6)) > 0.1).float() / 0.9 if drop else None
+    dv = lambda t: None if t is None else t.to(dev)
+    stats = ops.groupnorm_stats(dv(x1), dv(x2))
+    pl = ops.groupnorm_apply(dv(x1), stats, dv(gamma), dv(beta), x2=dv(x2), film=dv(fl), act=1, resample=resample, dropmask=dv(dm),
+                             split="f16x3w4")
+    assert pl.fmt == "f16x3w4" and pl.scale == 0.125 * ops.F16X3_ACT_SCALE
+    st = stats.cpu().double().reshape(N, 32, 2)
+    x = (x1 if x2 is None else torch.cat([x1, x2], -1)).double()
+    cpg = C // 32
+    mean, rstd = st[:, :, 0].repeat_interleave(cpg, 1)[:, None, None, :], st[:, :, 1].repeat_interleave(cpg, 1)[:, None, None, :]
+    y = (x - mean) * rstd * gamma.double() + beta.double()
+    if film:
+        y = y * (1 + fl[:, None, None, :C].double()) + fl[:, None, None, C:].double()
+    y = F.silu(y)
+    if drop:
+        y = y * dm.double()
+    if resample > 0:
+        y = y.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    elif resample < 0:
+        y = nhwc(F.avg_pool2d(nchw(y), 2))
+    assert pl.shape == tuple(y.shape)
+    ref = v_reference(y)
+    got = decode_v(pl)
+    err = (got - ref).abs().max().item()
+    print(f"V planes max abs err {err:.2e} (|V| max {ref.abs().max().item():.1f})")
+    assert err < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_wino4_weight_pack(ops):
+    """The packed weights decode to U_f = G g over the kernel rows, in the stage order [column tile][channel block][f][dx] x
+    [hi | lo][128 channels][32 channels], scaled per output channel by a power of two."""
+    Cout, Cin = 160, 64
+    w = rnd(7, Cout, Cin, 3, 3) * torch.logspace(-2, 1, Cout).reshape(-1, 1, 1, 1)
+    packed = ops.pack_weight_f16x3_wino4(w.to(dev)).cpu()
+    ntn, K = 2, 18 * Cin
+    plane = ntn * 128 * K
+    h = packed[:4 * plane].view(torch.float16).double().reshape(ntn, Cin // 32, 6, 3, 2, 128, 32)      # [tn][cb][f][dx][hi|lo][col][c]
+    inv = packed[4 * plane:].view(torch.float32).double()
+    assert inv.numel() == 256
+    val = (h[:, :, :, :, 0] + h[:, :, :, :, 1]).permute(0, 4, 1, 5, 2, 3).reshape(ntn * 128, Cin, 6, 3)  # [cout][ci][f][dx]
+    U = torch.einsum("fk,ockx->ocfx", G, w.double())                                                  # [Cout][Cin][f][dx]
+    got = val[:Cout] * inv[:Cout, None, None, None]
+    err = ((got - U).abs() / U.abs().amax(dim=(1, 2, 3), keepdim=True)).max().item()
+    assert err < 2.0 ** -20, err
+    assert (val[Cout:] == 0).all()
+    e = torch.log2(inv[:Cout])
+    assert (e == e.round()).all()
+    assert (val[:Cout].abs().amax(dim=(1, 2, 3)) < 32768).all() and (val[:Cout].abs().amax(dim=(1, 2, 3)) >= 16384 * (1 - 2 ** -10)).all()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (2, 8, 16, 96, 64), (1, 32, 32, 256, 256),
+                                             (5, 16, 16, 128, 512), (3, 64, 64, 64, 256), (2, 128, 128, 32, 128), (4, 16, 8, 64, 36),
+                                             (130, 16, 16, 64, 64), (6, 8, 8, 96, 160), (3, 16, 4, 64, 64), (128, 8, 8, 128, 128),
+                                             # > 256 tiles with a ragged last row tile and a half-empty column tile: every workgroup runs the
+                                             # tile-after-epilogue path (counted wait, always-issued stores) with masked lanes
+                                             (1030, 16, 8, 32, 192), (2, 64, 64, 1024, 128)])
+def test_conv3x3_wino4_vs_fp64(ops, N, H, W, Cin, Cout):
+    assert ops.conv3x3_wino4_supported(N, H, W, Cin, Cout)
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    w = w * torch.logspace(-3, 1, Cout).reshape(-1, 1, 1, 1)
+    x = x * torch.logspace(-4, 1.5, Cin).reshape(1, -1, 1, 1)
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    scale_out = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+    st = identity_stats(N)
+    one, zero = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    xd = nhwc(x).to(dev)
+    xv4 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3w4")
+    wp4 = ops.pack_weight_f16x3_wino4(w.to(dev))
+    y = ops.conv3x3_bf16x3(xv4, wp4, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    assert (getattr(y, "_dua_colsums", None) is not None) == ((H * W) % 256 == 0)
+    xv2 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f16x3w")
+    y2 = ops.conv3x3_bf16x3(xv2, ops.pack_weight_f16x3_wino(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    y32 = ops.conv3x3(xd, ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err = ((nchw(y.cpu()).double() - ref).abs() / scale_out).max().item()
+    err2 = ((nchw(y2.cpu()).double() - ref).abs() / scale_out).max().item()
+    err32 = ((nchw(y32.cpu()).double() - ref).abs() / scale_out).max().item()
+    rms = lambda t: ((nchw(t.cpu()).double() - ref) / scale_out).pow(2).mean().sqrt().item()
+    print(f"F(4,3) f16x3 rel err {err:.2e} (rms {rms(y):.2e})  F(2,3) {err2:.2e} (rms {rms(y2):.2e})  fp32-MFMA {err32:.2e} (rms {rms(y32):.2e})")
+    assert err < max(4 * err32, 4e-6), (err, err2, err32)
+    if (H * W) % 256 == 0 and Cout % 32 == 0:
+        s1 = ops.groupnorm_stats(y)
+        s2 = ops.groupnorm_stats(y.clone())
+        np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    y0 = ops.conv3x3_bf16x3(xv4, wp4, None, Cout)
+    ref0 = F.conv2d(x.double(), w.double(), padding=1)
+    assert ((nchw(y0.cpu()).double() - ref0).abs() / scale_out).max().item() < max(4 * err32, 4e-6)
+    y1 = ops.conv3x3_bf16x3(xv4, wp4, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    assert torch.equal(y, y1)
+
+
+def test_wino4_resampled_residual_in_epilogue(ops):
+    """The identity skip of an ADM up / down block read through the resampling in the conv's epilogue (unet_openai.py:238-243)."""
+    N, H, W, C = 3, 16, 16, 64
+    x, w = rnd(40, N, C, H, W), rnd(41, C, C, 3, 3) / math.sqrt(9 * C)
+    st = identity_stats(N)
+    one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    xv = ops.groupnorm_apply(nhwc(x).to(dev), st, one, zero, act=0, split="f16x3w4")
+    wp = ops.pack_weight_f16x3_wino4(w.to(dev))
+    for mode, rshape in ((1, (N, C, H // 2, W // 2)), (-1, (N, C, 2 * H, 2 * W))):
+        r = rnd(42 + mode, *rshape)
+        full = F.interpolate(r, scale_factor=2, mode="nearest") if mode > 0 else F.avg_pool2d(r, 2)
+        y = ops.conv3x3_bf16x3(xv, wp, None, C, residual=nhwc(r).to(dev), res_resample=mode)
+        y_ref = ops.conv3x3_bf16x3(xv, wp, None, C, residual=nhwc(full).to(dev))
+        assert torch.equal(y, y_ref), mode
+
+
+def test_conv3x3_wino4_unsupported_shapes(ops):
+    assert ops.conv3x3_wino4_supported(2, 8, 8, 64, 64)              # small map: taken, without the column-sum output
+    assert not ops.conv3x3_wino4_supported(2, 6, 16, 64, 64)         # H % 4
+    assert not ops.conv3x3_wino4_supported(2, 4, 8, 64, 64)          # H*W % 64
+    assert not ops.conv3x3_wino4_supported(2, 16, 24, 64, 64)        # W not a power of two
+    assert not ops.conv3x3_wino4_supported(2, 16, 256, 64, 64)       # W > 128
+    assert not ops.conv3x3_wino4_supported(2, 16, 16, 48, 64)        # Cin % 32
