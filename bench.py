@@ -397,7 +397,7 @@ def parse_args(argv=None):
     ap.add_argument("--mc-group", type=int, default=1, help="Monte-Carlo chains of a UC step per denoiser call (stacked batch)")
     ap.add_argument("--precision", choices=PRECISIONS, default="f16x3")
     ap.add_argument("--secondary", default="fp32,f16w", help="comma list of precision modes run for ONE job each after the headline (N=1 only)")
-    ap.add_argument("--winograd", default="on", choices=["on", "off"],
+    ap.add_argument("--winograd", default="on", choices=["on", "off", "2", "4"],
                     help="off: every 3x3 conv on the direct kernels (k_tile<MODE_CONV> in fp32, k_xconv_dma / k_hconv in f16x3) - the round-2 baselines")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,7 +494,7 @@ def main(argv=None):
     from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
 
     model, base, sd = build_model(dev)
-    model.winograd = a.winograd == "on"
+    model.winograd = {"on": True, "off": False, "2": 2, "4": 4}[a.winograd]       # on = the library picks F(2,3) / F(4,3) per shape
     model.stream_split = int(os.environ.get("DUA_ADM_STREAMS", "1"))           # (A/B switch: the batch in chunks on HIP streams of their own)
     # synthetic inputs exactly as scripts/generate_diffusion_starting_data.py:27-49, sharded by rank like the script (:51)
     g = torch.Generator().manual_seed(49394 + 1)         # dataset index k = 1 (imagenet128), SURVEY 8(d)

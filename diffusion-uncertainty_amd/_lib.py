@@ -29,7 +29,7 @@ class ResBlockArgs(_c.Structure):
                 ("gn2_w", _P), ("gn2_b", _P), ("conv2_packed", _P), ("conv2_b", _P), ("skip_packed", _P), ("skip_b", _P),
                 ("x1_colsums", _P), ("x2_colsums", _P), ("updown", _I), ("dropmask", _P),
                 ("precision", _I), ("act_scale", _F), ("raw_scale", _F), ("workspace", _P), ("workspace_bytes", _Z),
-                ("y", _P), ("y_colsums", _P), ("conv1_wino", _P), ("conv2_wino", _P)]
+                ("y", _P), ("y_colsums", _P), ("conv1_wino", _P), ("conv2_wino", _P), ("conv1_wino_m", _I), ("conv2_wino_m", _I)]
 
 
 class AttnBlockArgs(_c.Structure):
@@ -129,6 +129,7 @@ SIGNATURES = {
     "dua_pack_weight_f16x3_wino4": (_I, [_P, _P, _I, _I, _P]),
     "dua_groupnorm_apply_wino4_f16x3": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _F, _P, _P]),
     "dua_conv3x3_f16x3_wino4_supported": (_I, [_I, _I, _I, _I, _I]),
+    "dua_conv3x3_f16x3_wino_pick": (_I, [_I, _I, _I, _I, _I]),
     "dua_conv3x3_f16x3_wino4": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P]),
     "dua_f32_wino_weight_bytes": (_Z, [_I, _I]),
     "dua_pack_weight_f32_wino": (_I, [_P, _P, _I, _I, _P]),

@@ -65,11 +65,12 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     // convolution's output (conv1's output is dead once the second GroupNorm has consumed it)
     // Winograd form of a 3x3 conv (csrc/conv_wino_f16x3.hip) where its packed weights are given and the shape allows: the GroupNorm
     // in front writes the four transformed images (8 bytes per element instead of 4)
-    const int wsup1 = (a->conv1_wino && a->C1 % 32 == 0) ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, C, a->Cout) : 0;
-    const int wsup2 = a->conv2_wino ? dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
+    const bool four1 = a->conv1_wino_m == 4, four2 = a->conv2_wino_m == 4;          // F(4,3) packing (csrc/conv_wino4_f16x3.hip), f16x3 three-product mode only
+    const int wsup1 = (a->conv1_wino && a->C1 % 32 == 0) ? (four1 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, C, a->Cout) : 0;
+    const int wsup2 = a->conv2_wino ? (four2 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
     const bool wino1 = wsup1 != 0, wino2 = wsup2 != 0;          // (== 2: no column sums from that conv; the statistics kernel runs instead)
-    const size_t szA1 = wino1 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, C) : (size_t)M * C * 4;             // (whole tiles of 128 positions)
-    const size_t szA2 = wino2 ? dua_f16x3_wino_act_bytes(a->N, Ho, Wo, a->Cout) : (size_t)M * a->Cout * 4;
+    const size_t szA1 = wino1 ? (four1 ? dua_f16x3_wino4_act_bytes : dua_f16x3_wino_act_bytes)(a->N, Ho, Wo, C) : (size_t)M * C * 4;             // (whole tiles of 128 positions)
+    const size_t szA2 = wino2 ? (four2 ? dua_f16x3_wino4_act_bytes : dua_f16x3_wino_act_bytes)(a->N, Ho, Wo, a->Cout) : (size_t)M * a->Cout * 4;
     void* regA = w.take(szA1 > szA2 ? szA1 : szA2);
     // the resampled identity skip x_upd (:243): the Winograd conv2 reads x through the resampling in its epilogue; the other forms take a copy
     const bool fuse_xr = a->updown && wino2;
@@ -88,6 +89,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     if ((rc = gn_stats(a->x1, a->C1, a->x1_colsums, a->x2, a->C2, a->x2_colsums, a->N, a->H * a->W, G, gnws, stats1, stream))) return rc;
     if (wino1 && !f16) rc = dua_groupnorm_apply_wino_f32(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1,
                                                           a->updown, nullptr, h1, stream);
+    else if (wino1 && four1) rc = dua_groupnorm_apply_wino4_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
+                                                                  nullptr, 0.125f * a->act_scale, h1, stream);
     else if (wino1) rc = (single ? dua_groupnorm_apply_wino_f16w : dua_groupnorm_apply_wino_f16x3)(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w,
                                                    a->gn1_b, nullptr, 0, 1, a->updown, nullptr, 0.5f * a->act_scale, h1, stream);
     else if (f16) rc = dua_groupnorm_apply_split_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
@@ -99,17 +102,20 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     {
         ConvTimer tm(stream);
         if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
+        else if (wino1 && four1) rc = dua_conv3x3_f16x3_wino4(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.125f * a->act_scale, stream);
         else if (wino1) rc = (single ? dua_conv3x3_f16w_wino : dua_conv3x3_f16x3_wino)(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2,
                                                                                        0.5f * a->act_scale, stream);
         else if (f16) rc = dua_conv3x3_f16x3_presplit(h1, a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, a->act_scale, stream);
         else rc = dua_conv3x3((const float*)h1, (const float*)a->conv1_packed, a->conv1_b, nullptr, h2, a->N, Ho, Wo, C, a->Cout, 0, cs2, stream);
-        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, (f16 ? ((single && wino1) ? 1.0 : 3.0) : 1.0) * (wino1 ? 2.0 / 3.0 : 1.0));
+        tm.done(2.0 * (double)M * 9.0 * C * a->Cout, (f16 ? ((single && wino1) ? 1.0 : 3.0) : 1.0) * (wino1 ? (four1 ? 0.5 : 2.0 / 3.0) : 1.0));
     }
     if (rc) return rc;
     // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
     if ((rc = gn_stats(h2, a->Cout, cs2, nullptr, 0, nullptr, a->N, Ho * Wo, G, gnws, stats2, stream))) return rc;
     if (wino2 && !f16) rc = dua_groupnorm_apply_wino_f32(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
                                                           a->dropmask, h3, stream);
+    else if (wino2 && four2) rc = dua_groupnorm_apply_wino4_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0, a->dropmask,
+                                                                  0.125f * a->act_scale, h3, stream);
     else if (wino2) rc = (single ? dua_groupnorm_apply_wino_f16w : dua_groupnorm_apply_wino_f16x3)(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b,
                                                    a->film, a->film_ld, 1, 0, a->dropmask, 0.5f * a->act_scale, h3, stream);
     else if (f16) rc = dua_groupnorm_apply_split_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
@@ -136,14 +142,15 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
         resid = res;
     }
     float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
-    DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0");
+    DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0 (F(4,3): %% 256)");
     ConvTimer tm(stream);
     if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
+    else if (wino2 && four2) rc = dua_conv3x3_f16x3_wino4(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.125f * a->act_scale, stream);
     else if (wino2) rc = (single ? dua_conv3x3_f16w_wino : dua_conv3x3_f16x3_wino)(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs,
                                                                                    0.5f * a->act_scale, stream);
     else if (f16) rc = dua_conv3x3_f16x3_presplit(h3, a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, a->act_scale, stream);
     else rc = dua_conv3x3((const float*)h3, (const float*)a->conv2_packed, a->conv2_b, resid, a->y, a->N, Ho, Wo, a->Cout, a->Cout, 0, ycs, stream);
-    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, (f16 ? ((single && wino2) ? 1.0 : 3.0) : 1.0) * (wino2 ? 2.0 / 3.0 : 1.0));
+    tm.done(2.0 * (double)M * 9.0 * a->Cout * a->Cout, (f16 ? ((single && wino2) ? 1.0 : 3.0) : 1.0) * (wino2 ? (four2 ? 0.5 : 2.0 / 3.0) : 1.0));
     return rc;
 }
 
@@ -269,8 +276,11 @@ int check_resblock(const dua_resblock_args* a) {
     DUA_REQUIRE(a->precision == DUA_PREC_FP32 || (a->act_scale > 0.f && a->raw_scale > 0.f && a->C1 % 32 == 0), "dua_adm_resblock_fwd: f16x3 needs positive scales and C1 %% 32 == 0");
     {   // the direct-form weights of a conv may be NULL when its Winograd-form weights are given AND the kernel takes the shape
         const int Ho = a->updown < 0 ? a->H / 2 : (a->updown > 0 ? 2 * a->H : a->H), Wo = a->updown < 0 ? a->W / 2 : (a->updown > 0 ? 2 * a->W : a->W);
-        const bool w1 = a->conv1_wino && a->C1 % 32 == 0 && dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->C1 + a->C2, a->Cout) != 0;
-        const bool w2 = a->conv2_wino && dua_conv3x3_f16x3_wino_supported(a->N, Ho, Wo, a->Cout, a->Cout) != 0;
+        DUA_REQUIRE((a->conv1_wino_m == 0 || a->conv1_wino_m == 2 || a->conv1_wino_m == 4) && (a->conv2_wino_m == 0 || a->conv2_wino_m == 2 || a->conv2_wino_m == 4),
+                    "dua_adm_resblock_fwd: conv*_wino_m must be 0, 2 or 4");
+        DUA_REQUIRE((a->conv1_wino_m != 4 && a->conv2_wino_m != 4) || a->precision == DUA_PREC_F16X3, "dua_adm_resblock_fwd: the F(4,3) packing is a DUA_PREC_F16X3 option");
+        const bool w1 = a->conv1_wino && a->C1 % 32 == 0 && (a->conv1_wino_m == 4 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, a->C1 + a->C2, a->Cout) != 0;
+        const bool w2 = a->conv2_wino && (a->conv2_wino_m == 4 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, a->Cout, a->Cout) != 0;
         DUA_REQUIRE((a->conv1_packed || w1) && (a->conv2_packed || w2),
                     "dua_adm_resblock_fwd: conv*_packed may only be NULL for a conv that runs in the Winograd form (conv*_wino given, shape supported)");
     }

@@ -26,14 +26,17 @@
 #include "common.h"
 #include "wconv.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef WCONV4_DIAG
-#define WCONV4_DIAG 0             // timing-only diagnostic builds (WRONG results): bit 0 no in-loop barrier, bit 1 no epilogue
+#define WCONV4_DIAG 0             // timing-only diagnostic builds (scripts/wconv_diag.py --kernel w4; WRONG results): bit 0 no in-loop barrier,
+                                  // bit 1 no epilogue, bit 2 no in-loop DMA, bit 3 no in-loop fragment reads, bit 4 output stores dropped by the buffer unit,
+                                  // bit 5 no residual loads
 #endif
 
-constexpr int W4_STORES = 4 * 2 * 4 * 2;          // output rows x channel-block pairs x position blocks x halves: always-issued stores of a wave
+constexpr int W4_STORES = 4 * 4 * 4;              // channel blocks x position blocks x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
 // One matrix-core product into an accumulator that LIVES in the accumulation registers (AG: frequencies 0-3, 256 AGPRs) or in the
@@ -74,9 +77,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
     constexpr int SP = 128 * 32;                           // halves per plane of a stage (8 KB)
     constexpr int STG = 2 * SP;                            // halves per stage: [hi | lo][128][32]
     constexpr int BOFF = 0, AOFF = RB * STG;               // weight ring first: a shifted row -1 of activation stage 0 stays inside LDS
-    constexpr int EOFF = (RA + RB) * STG;                  // epilogue patches: 4 waves x 2 x (16 rows x 144 bytes)
-    constexpr int PATCH = 16 * 144;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[(RA + RB) * STG + 4 * 2 * PATCH / 2];
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(RA + RB) * STG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;               // position half, channel half
@@ -88,6 +89,10 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
     constexpr int OOBL = 0x40000;                          // LDS byte address beyond the allocation: DS reads there return zeros
     static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU");
     const int lr = lane & 15, lc = lane >> 4;
+    if (p.stagger_phases > 1) {                            // (experiment: spread the epilogues' memory bursts over the tile time)
+        const int ph = slot % p.stagger_phases;
+        for (int i = 0; i < ph * p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- DMA state: one per-lane byte offset (this lane's 16 bytes of a 16-row piece; the chunk swizzle of k_wconv applied to the
     // source), everything else - piece row group, channel block, K step, hi / lo image - is wave-uniform and travels as the scalar offset
@@ -173,12 +178,18 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         prefetched = false;
 
         f32x4 acc[6][4][4];                           // [frequency][channel block][position block]
+        {
+            // (an opaque zero: a literal would be hoisted out of the tile loop as 96 live zero quads, spilled, and reloaded from scratch
+            // memory at every tile start behind a full drain of the vector-memory queue)
+            float z = 0.f;
+            asm volatile("" : "+v"(z));
 #pragma unroll
-        for (int f = 0; f < 6; ++f)
+            for (int f = 0; f < 6; ++f)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[f][j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < 4; ++i) acc[f][j][i] = (f32x4){z, z, z, z};
+        }
         w4_fence<true>(acc[0]); w4_fence<true>(acc[1]); w4_fence<true>(acc[2]); w4_fence<true>(acc[3]); w4_fence<false>(acc[4]); w4_fence<false>(acc[5]);
 
         h16x8 xh[4], xl[4], wh[4], wl[4];
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 a_setup(FN);
             }
             auto early_piece = [&](int q) {
+                if (WCONV4_DIAG & 4) return;
                 if (q < 4) { if (!lastg || DXI == 0) dma_b(sb_n, q); }          // the weight stage of step s + 2
                 else if (q < 6) { if (DXI < 2 && !lastg) dma_a(sa_n, q - 4 + 2 * DXI); }    // ... requested half in this group's first, half in its second step
             };
@@ -259,9 +271,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 for (int i = 0; i < 4; ++i) {
                     w4_mma<AG>(A[jj][i], wh[jj], xh[i]);
                     WSB();
-                    if (jj == 0) { xl[i] = rd_x(sa_r, 1, i, dxn); WSB(); }
+                    if (jj == 0 && !(WCONV4_DIAG & 8)) { xl[i] = rd_x(sa_r, 1, i, dxn); WSB(); }
                 }
-                wh[jj] = rd_w(sb_r, 0, jj);
+                if (!(WCONV4_DIAG & 8)) wh[jj] = rd_w(sb_r, 0, jj);
                 WSB();
             }
             // P3: w_lo * x_hi | w_lo and x_hi of the next step
@@ -271,9 +283,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 for (int i = 0; i < 4; ++i) {
                     w4_mma<AG>(A[jj][i], wl[jj], xh[i]);
                     WSB();
-                    if (jj == 3) { xh[i] = rd_x(sa_r, 0, i, dxn); WSB(); }
+                    if (jj == 3 && !(WCONV4_DIAG & 8)) { xh[i] = rd_x(sa_r, 0, i, dxn); WSB(); }
                 }
-                wl[jj] = rd_w(sb_r, 1, jj);
+                if (!(WCONV4_DIAG & 8)) wl[jj] = rd_w(sb_r, 1, jj);
                 WSB();
             }
         };
@@ -314,121 +326,126 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             continue;
         }
 
-        // ---- epilogue, per (channel-block pair jp, position block i): inverse transform of the pair's 2 x 6 accumulator quads in
-        // registers, then per output row r the store path of wconv_epilogue - the pair's 32 channels of 16 positions through a
-        // wave-private 16 x 144-byte patch, so that residual reads and output stores move whole 128-byte rows.  The residual rows of
-        // item q + 2 are requested before the stores of item q go out (ring of three).
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const int pr_e = lane_e >> 3, pc_e = lane_e & 7, lr_e = lane_e & 15, lc_e = lane_e >> 4;
-        const int pos0 = m0 + wm * 64;
-        auto opix = [&](int i, int h, int r) -> long {
-            const int pos = pos0 + 16 * i + 8 * h + pr_e;
-            return pos < p.Mv ? (long)pos + 3L * (pos & ~(p.W - 1)) + (long)r * p.W : -1L;
+        // ---- epilogue, straight from the accumulator layout (lane = position lane & 15, channels 4 (lane >> 4) .. + 3 of a 16-channel
+        // block): per (channel block jj, position block i) the inverse transform of its six quads in registers, then per output row
+        // one 16-byte store per lane - 64 contiguous bytes per pixel row and instruction, the write granularity of the L2 - with the
+        // residual read the same way.  No LDS round trip (one wave per SIMD has nobody to hide it behind).  vmcnt retires in order, so a
+        // wait for residual rows is also a wait for every OLDER output store: the rows of block b + 2 are requested before the stores
+        // of block b go out, which leaves three blocks of stores between a residual request and the wait that needs it.
+        // (lane-derived values are recomputed per block from a fresh lane id instead of living in registers across the K loop: the
+        // register file is full there, and a reload from scratch memory is a vector-memory wait that drains every store in flight)
+        auto lane_now = [&]() -> int {
+            int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(l));
+            return l;
         };
-        auto res_ld = [&](int q, float4 (&dst)[2]) {                       // q = (jp, i, r)
-            const int jp = q >> 4, i = (q >> 2) & 3, r = q & 3;
-            const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
-            const bool cok = c < p.N;
+        const int pos0 = m0 + wm * 64;
+        const long cpix0 = 4L * m0;                                          // the tile's 128 positions are output pixels 4 m0 .. 4 m0 + 511
+        const long crem = (4L * p.Mv - cpix0) * p.N * 4;
+        const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
+        // output pixel (row of C) of a lane's position in block i, output row 0; -1 beyond the tensor
+        auto opix = [&](int i, int lr_e) -> long {
+            const int pos = pos0 + 16 * i + lr_e;
+            return pos < p.Mv ? (long)pos + 3L * (pos & ~(p.W - 1)) : -1L;
+        };
+        auto res_ld = [&](int b, float4 (&dst)[4]) {                       // block b = (jj, i): the four output rows of this lane's pixel column
+            const int jj = b >> 2, i = b & 3;
+            const int le = lane_now();
+            const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4);
+            const long row0 = opix(i, le & 15);
+            const bool okl = p.res && c < p.N && row0 >= 0 && !(WCONV4_DIAG & 32);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long row = opix(i, h, r);
-                dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!(p.res && cok && row >= 0)) continue;
+            for (int r = 0; r < 4; ++r) {
+                dst[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!okl) continue;
+                const long row = row0 + (long)r * p.W;
                 if (p.res_mode == 0) {
-                    dst[h] = *(const float4*)(p.res + row * p.N + c);
+                    dst[r] = *(const float4*)(p.res + row * p.N + c);
                     continue;
                 }
                 const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
                 if (p.res_mode > 0) {
                     const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
-                    dst[h] = *(const float4*)(p.res + src * p.N + c);
+                    dst[r] = *(const float4*)(p.res + src * p.N + c);
                 } else {                                                  // same order of additions as k_resample2x (denoiser.hip)
                     const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
-                    const float4 a = *(const float4*)(p.res + src * p.N + c), b = *(const float4*)(p.res + (src + 1) * p.N + c);
+                    const float4 a = *(const float4*)(p.res + src * p.N + c), b2 = *(const float4*)(p.res + (src + 1) * p.N + c);
                     const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
-                    dst[h] = make_float4((a.x + b.x + d.x + e.x) * 0.25f, (a.y + b.y + d.y + e.y) * 0.25f, (a.z + b.z + d.z + e.z) * 0.25f,
-                                         (a.w + b.w + d.w + e.w) * 0.25f);
+                    dst[r] = make_float4((a.x + b2.x + d.x + e.x) * 0.25f, (a.y + b2.y + d.y + e.y) * 0.25f, (a.z + b2.z + d.z + e.z) * 0.25f,
+                                         (a.w + b2.w + d.w + e.w) * 0.25f);
                 }
             }
         };
-        const long cpix0 = 4L * m0;                                          // the tile's 128 positions are output pixels 4 m0 .. 4 m0 + 511
-        const long crem = (4L * p.Mv - cpix0) * p.N * 4;
-        const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
-        char* pw0 = reinterpret_cast<char*>(lds) + EOFF * 2 + wave * 2 * PATCH;
-        float4 rn_[3][2];
+        // column scale * 1 / v_scale and bias of a channel block: requested one block ahead, like the residual rows
+        auto sb_ld = [&](int jj, float4& sq, float4& bq) {
+            const int c = n0 + wn * 64 + 16 * jj + 4 * (lane_now() >> 4);
+            sq = *(const float4*)(p.Cscale + c);                             // (padded to the tile grid)
+            bq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && c < p.N) bq = *(const float4*)(p.bias + c);
+        };
+        float4 sqn, bqn;
+        sb_ld(0, sqn, bqn);
+        float4 rn_[3][4];
         res_ld(0, rn_[0]);
         res_ld(1, rn_[1]);
-        w4_static_for<2>([&](auto jp_c) __attribute__((always_inline)) {
-            constexpr int jp = decltype(jp_c)::value;
-            const int c = n0 + wn * 64 + 32 * jp + 4 * pc_e;
-            const bool cok = c < p.N;
-            float4 sq = *(const float4*)(p.Cscale + c);                      // (padded to the tile grid)
+        w4_static_for<4>([&](auto jj_c) __attribute__((always_inline)) {
+            constexpr int jj = decltype(jj_c)::value;
+            float4 sq = sqn;
+            const float4 bq = bqn;
             sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && cok) bq = *(const float4*)(p.bias + c);
-            float4 cs[4], cq2[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[r] = cq2[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (jj + 1 < 4) sb_ld(jj + 1, sqn, bqn);
+            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
             w4_static_for<4>([&](auto i_c) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_c)::value;
-                f32x4 R[4][2];                                               // [output row][channel block of the pair]
+                constexpr int b = jj * 4 + i;
+                if constexpr (b + 2 < 16) res_ld(b + 2, rn_[(b + 2) % 3]);
+                const f32x4 s12 = acc[1][jj][i] + acc[2][jj][i], d12 = acc[1][jj][i] - acc[2][jj][i];
+                const f32x4 s34 = acc[3][jj][i] + acc[4][jj][i], d34 = acc[3][jj][i] - acc[4][jj][i];
+                f32x4 R[4];
+                R[0] = (acc[0][jj][i] + s12) + s34;
+                R[1] = d12 + 2.0f * d34;
+                R[2] = s12 + 4.0f * s34;
+                R[3] = (acc[5][jj][i] + d12) + 8.0f * d34;
+                const int le = lane_now();
+                const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4);
+                const long row0 = opix(i, le & 15);
+                const bool ok = c < p.N && row0 >= 0 && !(WCONV4_DIAG & 16);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int j = 2 * jp + u;
-                    const f32x4 s12 = acc[1][j][i] + acc[2][j][i], d12 = acc[1][j][i] - acc[2][j][i];
-                    const f32x4 s34 = acc[3][j][i] + acc[4][j][i], d34 = acc[3][j][i] - acc[4][j][i];
-                    R[0][u] = (acc[0][j][i] + s12) + s34;
-                    R[1][u] = d12 + 2.0f * d34;
-                    R[2][u] = s12 + 4.0f * s34;
-                    R[3][u] = (acc[5][j][i] + d12) + 8.0f * d34;
-                }
-                w4_static_for<4>([&](auto r_c) __attribute__((always_inline)) {
-                    constexpr int r = decltype(r_c)::value;
-                    constexpr int q = (jp * 4 + i) * 4 + r;
-                    if constexpr (q + 2 < 32) res_ld(q + 2, rn_[(q + 2) % 3]);
-                    const float4 (&rq)[2] = rn_[q % 3];
-                    char* pw = pw0 + (q & 1) * PATCH;
-                    *(f32x4*)(pw + lr_e * 144 + 16 * lc_e) = R[r][0];
-                    *(f32x4*)(pw + lr_e * 144 + 64 + 16 * lc_e) = R[r][1];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x4 a = *(const f32x4*)(pw + (8 * h + pr_e) * 144 + 16 * pc_e);
-                        const long row = opix(i, h, r);
-                        float4 v;
-                        v.x = a[0] * sq.x + bq.x + rq[h].x;
-                        v.y = a[1] * sq.y + bq.y + rq[h].y;
-                        v.z = a[2] * sq.z + bq.z + rq[h].z;
-                        v.w = a[3] * sq.w + bq.w + rq[h].w;
-                        const bool ok = cok && row >= 0;
-                        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                        const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
-                        if (ok) {
-                            cs[r].x += v.x; cs[r].y += v.y; cs[r].z += v.z; cs[r].w += v.w;
-                            cq2[r].x += v.x * v.x; cq2[r].y += v.y * v.y; cq2[r].z += v.z * v.z; cq2[r].w += v.w * v.w;
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    const float4 rq = rn_[b % 3][r];
+                    float4 v;
+                    v.x = R[r][0] * sq.x + bq.x + rq.x;
+                    v.y = R[r][1] * sq.y + bq.y + rq.y;
+                    v.z = R[r][2] * sq.z + bq.z + rq.z;
+                    v.w = R[r][3] * sq.w + bq.w + rq.w;
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                    if (ok) {
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
                     }
-                });
+                }
             });
             if (p.colsum) {
                 // The wave's 64 positions x 4 output rows are 256 consecutive output pixels of ONE image (H*W % 256 == 0) = four 64-pixel
-                // slots of the column-sum array; output row r fills slot r of them.  The consumer (dua_groupnorm_stats_from_colsums)
-                // folds all slots of an image, so only the per-image totals matter.
+                // slots of the column-sum array: their sums go to the first, zeros to the other three.  The consumer
+                // (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
+                float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t[8] = {cs[r].x, cs[r].y, cs[r].z, cs[r].w, cq2[r].x, cq2[r].y, cq2[r].z, cq2[r].w};
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        t[u] += __shfl_xor(t[u], 8);
-                        t[u] += __shfl_xor(t[u], 16);
-                        t[u] += __shfl_xor(t[u], 32);
-                    }
-                    if (pr_e == 0 && cok && pos0 < p.Mv) {
-                        float* o = p.colsum + ((long)(pos0 >> 4) + r) * 2 * p.N + c;
-                        *(float4*)o = make_float4(t[0], t[1], t[2], t[3]);
-                        *(float4*)(o + p.N) = make_float4(t[4], t[5], t[6], t[7]);
-                    }
+                for (int u = 0; u < 8; ++u) {
+                    t[u] += __shfl_xor(t[u], 1);
+                    t[u] += __shfl_xor(t[u], 2);
+                    t[u] += __shfl_xor(t[u], 4);
+                    t[u] += __shfl_xor(t[u], 8);
+                }
+                const int le = lane_now();
+                const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4), lr_e = le & 15;
+                if (lr_e < 4 && c < p.N && pos0 < p.Mv) {
+                    const float z = lr_e == 0 ? 1.0f : 0.0f;
+                    float* o = p.colsum + ((long)(pos0 >> 4) + lr_e) * 2 * p.N + c;
+                    *(float4*)o = make_float4(t[0] * z, t[1] * z, t[2] * z, t[3] * z);
+                    *(float4*)(o + p.N) = make_float4(t[4] * z, t[5] * z, t[6] * z, t[7] * z);
                 }
             }
         });
@@ -520,6 +537,21 @@ extern "C" int dua_conv3x3_f16x3_wino4_supported(int N, int H, int W, int Cin, i
     return ((long)H * W) % 256 == 0 ? 1 : 2;
 }
 
+// Which Winograd form a 3x3 conv of this shape should run in: 0 none, 2 = F(2,3) (dua_conv3x3_f16x3_wino), 4 = F(4,3).  Both kernels are
+// persistent over 256 workgroups, so a launch costs whole rounds of tiles; F(4,3) has half as many (each with 1.5 x the products of an
+// F(2,3) tile) and runs ~0.82 of F(2,3)'s time per output at equal occupancy (profiles/r04s_convmix_*.txt): it is taken where that
+// still wins after the rounding to whole rounds (not the 8^2 level and some 16^2 layers of ADM-128 at batch 128).
+extern "C" int dua_conv3x3_f16x3_wino_pick(int N, int H, int W, int Cin, int Cout) {
+    const int s2 = dua_conv3x3_f16x3_wino_supported(N, H, W, Cin, Cout), s4 = dua_conv3x3_f16x3_wino4_supported(N, H, W, Cin, Cout);
+    if (!s4) return s2 ? 2 : 0;
+    if (!s2) return 4;
+    if ((s2 == 1) != (s4 == 1)) return 2;                                 // (keep the column-sum output where only F(2,3) has it)
+    const long ntn = (Cout + 127) / 128;
+    const long t2 = (((long)N * (H / 2) * W + 127) / 128) * ntn, t4 = (((long)N * (H / 4) * W + 127) / 128) * ntn;
+    const double c2 = (double)((t2 + 255) / 256) * 1.0, c4 = (double)((t4 + 255) / 256) * 2.0 * 0.82;      // rounds x time per tile
+    return c4 < c2 ? 4 : 2;
+}
+
 extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                                        int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream) {
     DUA_REQUIRE(vplanes && packed && y, "dua_conv3x3_f16x3_wino4: null pointer");
@@ -537,6 +569,14 @@ extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, 
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
     p.out_scale = 1.0f / v_scale;
     const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    if (const char* e = getenv("DUA_W4_STAGGER")) {        // "phases,percent": experiment switch (percent of one tile time spread over the phases)
+        int ph = 0, pct = 100;
+        if (sscanf(e, "%d,%d", &ph, &pct) >= 1 && ph > 1 && ntiles >= 6 * grid) {
+            const double tile_us = 18.0 * (Cin / 32) * 0.8;               // ~0.8 us per K step
+            p.stagger_phases = ph;
+            p.stagger_sleeps = (int)(tile_us * pct / 100.0 / ph / 4.0 + 0.5);   // s_sleep(127) ~ 4 us
+        }
+    }
     hipLaunchKernelGGL(k_wconv4, dim3(grid), 256, 0, as_stream(stream), p);
     return dua_check_launch("dua_conv3x3_f16x3_wino4");
 }

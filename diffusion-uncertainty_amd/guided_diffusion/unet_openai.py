@@ -99,16 +99,17 @@ class ResBlock(TimestepBlock):
             if not (drop.training and drop.p > 0 and self.updown):          # (a dropout mask on a resampling block: composed path)
                 Hb, Wb = (2 * H, 2 * W) if self.resample > 0 else ((H // 2, W // 2) if self.resample < 0 else (H, W))
                 cin = x.shape[3] + (0 if skip is None else skip.shape[3])
-                kw = "w3w" if ctx.model.precision == "f16x3" else "w3wf"
-                w1 = ctx.packed(conv1, kw) if ctx.wino_ok(N, Hb, Wb, cin, self.out_channels) else None
-                w2 = ctx.packed(conv2, kw) if ctx.wino_ok(N, Hb, Wb, self.out_channels, self.out_channels) else None
+                kw = {0: None, 2: "w3w" if ctx.model.precision == "f16x3" else "w3wf", 4: "w3w4"}
+                m1, m2 = ctx.wino_form(N, Hb, Wb, cin, self.out_channels), ctx.wino_form(N, Hb, Wb, self.out_channels, self.out_channels)
+                w1 = ctx.packed(conv1, kw[m1]) if m1 else None
+                w2 = ctx.packed(conv2, kw[m2]) if m2 else None
                 # (the direct-form weights are packed only for a conv that does not run in the Winograd form: ~2 GB less for ADM-128)
                 return ops.adm_resblock(x, skip, (gn1.weight, gn1.bias), ctx.packed(conv1, kind3) if w1 is None else None, conv1.bias, ctx.film(self),
                                         (gn2.weight, gn2.bias), ctx.packed(conv2, kind3) if w2 is None else None, conv2.bias,
                                         None if ident else ctx.packed(self.skip_connection, kind1),
                                         None if ident else self.skip_connection.bias, self.out_channels, updown=self.resample,
                                         dropmask=mask, precision=("f16w" if ctx.model.wino_single else ctx.model.precision),
-                                        want_colsum=ctx.model.fuse_gn_stats, conv1_wino=w1, conv2_wino=w2)
+                                        want_colsum=ctx.model.fuse_gn_stats, conv1_wino=w1, conv2_wino=w2, conv1_wino_m=m1, conv2_wino_m=m2)
         st = ops.groupnorm_stats(x, skip)
         Hc = H * 2 if self.resample > 0 else (H // 2 if self.resample < 0 else H)
         Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
@@ -224,15 +225,29 @@ class _Ctx:
         # parity modes: whole ResBlocks / AttentionBlocks as single C-ABI calls (dua_adm_resblock_fwd / dua_adm_attnblock_fwd)
         self.block_abi = bool(getattr(model, "use_block_abi", True)) and model.precision in ("fp32", "f16x3") and not model.activation_noise
 
+    def wino_form(self, N, H, W, cin, cout):
+        """0 / 2 / 4: this 3x3 conv (input / output size H x W) runs in the direct form / the Winograd F(2,3) / F(4,3)-along-y form.
+        model.winograd: True = the kernel library's choice per shape (f16x3: F(4,3) where whole rounds of tiles favour it), 2 / 4 = that
+        form wherever its kernel takes the shape, False = direct everywhere.  fp32 and f16w have the F(2,3) form only."""
+        w = getattr(self.model, "winograd", True)
+        if self.model.precision not in ("f16x3", "fp32") or not w:
+            return 0
+        if self.model.precision == "f16x3" and not self.model.wino_single:
+            if w is True:
+                return ops.conv3x3_wino_pick(N, H, W, cin, cout)
+            if w == 4 and ops.conv3x3_wino4_supported(N, H, W, cin, cout):
+                return 4
+        return 2 if ops.conv3x3_wino_supported(N, H, W, cin, cout) else 0
+
     def wino_ok(self, N, H, W, cin, cout):
-        """This 3x3 conv (input / output size H x W) runs in the Winograd F(2,3)-along-y form of the f16x3 kernel."""
-        return self.model.precision in ("f16x3", "fp32") and bool(getattr(self.model, "winograd", True)) and ops.conv3x3_wino_supported(N, H, W, cin, cout)
+        return self.wino_form(N, H, W, cin, cout) != 0
 
     def conv_split(self, width, conv_shape=None):
         """Operand format the GroupNorm in front of a 3x3 conv of this output width writes (conv_shape = (N, H, W, Cin, Cout) lets
         the f16x3 mode pick the Winograd operand where the kernel takes the shape)."""
-        if conv_shape is not None and self.wino_ok(*conv_shape):
-            return "f16x3w" if self.model.precision == "f16x3" else "f32w"
+        m = self.wino_form(*conv_shape) if conv_shape is not None else 0
+        if m:
+            return ("f16x3w4" if m == 4 else "f16x3w") if self.model.precision == "f16x3" else "f32w"
         return self.split_acts
 
     def packed(self, mod, kind):
@@ -250,6 +265,8 @@ class _Ctx:
                 cache[key] = ops.pack_weight_f16x3(mod.weight.detach().contiguous())
             elif kind == "w3w":
                 cache[key] = ops.pack_weight_f16x3_wino(mod.weight.detach().contiguous())
+            elif kind == "w3w4":
+                cache[key] = ops.pack_weight_f16x3_wino4(mod.weight.detach().contiguous())
             elif kind == "w3wf":
                 cache[key] = ops.pack_weight_f32_wino(mod.weight.detach().contiguous())
             elif kind == "qkvh":
@@ -302,7 +319,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f32w": "w3wf"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f16x3w4": "w3w4", "f32w": "w3wf"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -402,9 +419,10 @@ class UNetModel(nn.Module):
         # but the result then depends on the batch size at fp32-rounding level, so it is opt-in here: the Monte-Carlo chains of a
         # UC step stay bit-identical whether they run one by one or stacked)
         self.split_k = False
-        # f16x3 / fp32: 3x3 convs in the Winograd F(2,3)-along-y form where the kernel takes the shape (csrc/conv_wino_f16x3.hip,
-        # conv_wino_f32.hip: 6 instead of 9 matrix-core taps per pixel at the same operand precision; results differ from the direct
-        # form at fp32-rounding level)
+        # f16x3 / fp32: 3x3 convs in a Winograd-along-y form where a kernel takes the shape (csrc/conv_wino_f16x3.hip, conv_wino_f32.hip:
+        # F(2,3), 6 instead of 9 matrix-core taps per pixel; csrc/conv_wino4_f16x3.hip: F(4,3), 4.5 taps, f16x3 only) at the same operand
+        # precision; results differ from the direct form at fp32-rounding level.  True = the library picks the form per shape
+        # (dua_conv3x3_f16x3_wino_pick); 2 / 4 = that form wherever it applies; False = the direct kernels.
         self.winograd = True
         # fp32 / f16x3: the few-channel `out` conv as one-tap GEMM + tap gather (see _forward_body)
         self.out_conv_taps = True
@@ -490,7 +508,7 @@ class UNetModel(nn.Module):
         t = timesteps.to(torch.int64).contiguous()
         yy = y.to(torch.int64).contiguous() if y is not None else None
         key = (tuple(x.shape), self.precision_mode, out_channels_keep, self.use_block_abi, self.fuse_gn_stats, ops.ATTENTION_MODE, y is not None,
-               bool(self.split_k), bool(getattr(self, "winograd", True)), bool(getattr(self, "out_conv_taps", True)))
+               bool(self.split_k), getattr(self, "winograd", True), bool(getattr(self, "out_conv_taps", True)))
         entry = graphs.get(key)
         if entry is None:
             self._forward_impl(x, t, yy, out_channels_keep)            # eager once: packs the weights, warms the allocator

@@ -632,6 +632,11 @@ def conv3x3_wino_supported(N, H, W, cin, cout):
     return bool(_lib.lib().dua_conv3x3_f16x3_wino_supported(int(N), int(H), int(W), int(cin), int(cout)))
 
 
+def conv3x3_wino_pick(N, H, W, cin, cout):
+    """0 / 2 / 4: the Winograd form (none, F(2,3), F(4,3)) dua_conv3x3_f16x3_wino_pick chooses for this shape."""
+    return int(_lib.lib().dua_conv3x3_f16x3_wino_pick(int(N), int(H), int(W), int(cin), int(cout)))
+
+
 def conv3x3_wino4_supported(N, H, W, cin, cout):
     """Shapes dua_conv3x3_f16x3_wino4 (F(4,3) along y) takes."""
     return bool(_lib.lib().dua_conv3x3_f16x3_wino4_supported(int(N), int(H), int(W), int(cin), int(cout)))
@@ -1067,7 +1072,7 @@ def _cs(t):
 
 
 def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, conv2_b, skip_packed, skip_b, cout, updown=0,
-                 dropmask=None, precision="fp32", want_colsum=True, conv1_wino=None, conv2_wino=None):
+                 dropmask=None, precision="fp32", want_colsum=True, conv1_wino=None, conv2_wino=None, conv1_wino_m=2, conv2_wino_m=2):
     """One ADM ResBlock forward through dua_adm_resblock_fwd (guided_diffusion/unet_openai.py:237-257).  x / skip NHWC fp32,
     gn1 / gn2 = (weight, bias) pairs, weights packed for `precision`; returns y NHWC with its column sums attached."""
     _req(x, name="x")
@@ -1075,7 +1080,7 @@ def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, c
     C2 = 0 if skip is None else skip.shape[3]
     Ho, Wo = (H // 2, W // 2) if updown < 0 else ((2 * H, 2 * W) if updown > 0 else (H, W))
     y = torch.empty((N, Ho, Wo, cout), device=x.device, dtype=torch.float32)
-    ws_y = _colsum_ws(N * Ho * Wo, cout, x.device, want_colsum and not (conv2_wino is not None and (Ho * Wo) % 128))
+    ws_y = _colsum_ws(N * Ho * Wo, cout, x.device, want_colsum and not (conv2_wino is not None and (Ho * Wo) % (256 if conv2_wino_m == 4 else 128)))
     a = ResBlockArgs(x1=x.data_ptr(), C1=C1, x2=(skip.data_ptr() if skip is not None else None), C2=C2, N=N, H=H, W=W, Cout=cout,
                      gn1_w=gn1[0].data_ptr(), gn1_b=gn1[1].data_ptr(), conv1_packed=(conv1_packed.data_ptr() if conv1_packed is not None else None), conv1_b=conv1_b.data_ptr(),
                      film=film.data_ptr(), film_ld=_film_ld(film, N, cout), gn2_w=gn2[0].data_ptr(), gn2_b=gn2[1].data_ptr(),
@@ -1088,7 +1093,8 @@ def adm_resblock(x, skip, gn1, conv1_packed, conv1_b, film, gn2, conv2_packed, c
                      act_scale=F16X3_ACT_SCALE, raw_scale=F16X3_RAW_SCALE, workspace=None, workspace_bytes=0, y=y.data_ptr(),
                      y_colsums=(ws_y.data_ptr() if ws_y is not None else None),
                      conv1_wino=(conv1_wino.data_ptr() if conv1_wino is not None else None),
-                     conv2_wino=(conv2_wino.data_ptr() if conv2_wino is not None else None))
+                     conv2_wino=(conv2_wino.data_ptr() if conv2_wino is not None else None),
+                     conv1_wino_m=int(conv1_wino_m), conv2_wino_m=int(conv2_wino_m))
     L = _lib.lib()
     nbytes = L.dua_adm_resblock_workspace_bytes(ctypes.byref(a))
     if nbytes == 0:

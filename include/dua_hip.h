@@ -327,6 +327,9 @@ int dua_groupnorm_apply_wino4_f16x3(const float* x1, int C1, const float* x2, in
                                     const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
                                     int resample, const float* dropmask, float v_scale, void* vplanes, void* stream);
 int dua_conv3x3_f16x3_wino4_supported(int N, int H, int W, int Cin, int Cout);
+/* 0 / 2 / 4: the Winograd form (none, F(2,3), F(4,3)) this shape should run in - whole rounds of tiles on 256 persistent workgroups
+ * decide (F(4,3) has half as many, each 1.5 x as long). */
+int dua_conv3x3_f16x3_wino_pick(int N, int H, int W, int Cin, int Cout);
 int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                             int N, int H, int W, int Cin, int Cout, float* colsum, float v_scale, void* stream);
 /* The same form in EXACT fp32 (csrc/conv_wino_f32.hip, v_mfma_f32_16x16x4_f32: products and sums in fp32 - the Winograd form of
@@ -440,6 +443,8 @@ typedef struct {
                                             dua_pack_weight_f32_wino (DUA_PREC_FP32); a conv whose shape dua_conv3x3_f16x3_wino_supported
                                             accepts then runs in the Winograd form, and its conv*_packed may be NULL (the direct-form
                                             weights serve every other shape and need not be packed for this one) */
+    int conv1_wino_m, conv2_wino_m;      /* 0 / 2: conv*_wino is the F(2,3) packing; 4 (DUA_PREC_F16X3 only): the F(4,3) packing of
+                                            dua_pack_weight_f16x3_wino4, for a shape dua_conv3x3_f16x3_wino4_supported accepts */
 } dua_resblock_args;
 /* ResBlock.forward, guided_diffusion/unet_openai.py:237-257 (use_scale_shift_norm, resblock_updown). */
 size_t dua_adm_resblock_workspace_bytes(const dua_resblock_args* args_host);

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--engine", type=int, default=1)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--fmt", default="bf16x3", choices=["bf16x3", "f16x3", "f16x3w", "f16w", "f32w", "fp32"])
+    ap.add_argument("--fmt", default="bf16x3", choices=["bf16x3", "f16x3", "f16x3w", "f16x3w4", "f16w", "f32w", "fp32"])
     ap.add_argument("--check", action="store_true", help="compare with an fp64 torch convolution (small shapes only)")
     ap.add_argument("--lib", default="", help="alternative libdua_hip build to load")
     ap.add_argument("--stagger", type=str, default="", help="phases,percent,min_tiles")
@@ -72,6 +72,15 @@ def main():
                 else:
                     xs = x.clone()
                     planes = ops.pack_conv3x3_weight(w)
+                hi = lo = buf = None
+            elif a.fmt == "f16x3w4":                    # Winograd F(4,3) along y (k_wconv4)
+                st = torch.tensor([0.0, 1.0], device=dev).repeat(N * 32, 1).contiguous()
+                if ops.conv3x3_wino4_supported(N, H, H, Cin, Cout):
+                    xs = ops.groupnorm_apply(x, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16x3w4")
+                    planes = ops.pack_weight_f16x3_wino4(w)
+                else:
+                    xs = ops.groupnorm_apply(x, st, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16x3")
+                    planes = ops.pack_weight_f16x3(w)
                 hi = lo = buf = None
             elif a.fmt in ("f16x3w", "f16w"):           # Winograd form: three fp16 products per tap / one (mode "f16w")
                 st = torch.tensor([0.0, 1.0], device=dev).repeat(N * 32, 1).contiguous()

@@ -181,3 +181,49 @@ def test_conv3x3_wino4_unsupported_shapes(ops):
     assert not ops.conv3x3_wino4_supported(2, 16, 24, 64, 64)        # W not a power of two
     assert not ops.conv3x3_wino4_supported(2, 16, 256, 64, 64)       # W > 128
     assert not ops.conv3x3_wino4_supported(2, 16, 16, 48, 64)        # Cin % 32
+
+
+def test_wino4_pick_rule(ops):
+    """dua_conv3x3_f16x3_wino_pick: F(4,3) where whole rounds of tiles on 256 workgroups favour it (the 128^2 .. 32^2 levels of ADM-128 at
+    batch 128), F(2,3) where its twice-as-many tiles fill the chip better (the 8^2 level), nothing where neither kernel takes the shape."""
+    assert ops.conv3x3_wino_pick(128, 128, 128, 256, 256) == 4
+    assert ops.conv3x3_wino_pick(128, 64, 64, 512, 512) == 4
+    assert ops.conv3x3_wino_pick(128, 32, 32, 768, 512) == 4
+    assert ops.conv3x3_wino_pick(128, 8, 8, 1024, 1024) == 2
+    assert ops.conv3x3_wino_pick(128, 16, 16, 768, 768) == 2         # 384 F(4,3) tiles = 2 rounds at 75 %
+    assert ops.conv3x3_wino_pick(128, 16, 16, 1024, 1024) == 4
+    assert ops.conv3x3_wino_pick(2, 128, 128, 256, 256) == 2          # small batch: 128 F(4,3) tiles would leave half the chip idle
+    assert ops.conv3x3_wino_pick(2, 6, 16, 64, 64) == 2 and ops.conv3x3_wino_pick(2, 16, 256, 64, 64) == 0
+
+
+def test_winograd43_unet_vs_reference_and_direct(golden):
+    """Full-size ADM-64 / ADM-128 in f16x3 with EVERY 3x3 conv the F(4,3) kernel takes in that form (model.winograd = 4): inside the 1e-3
+    bar against the reference's own output (G5) at the distance of the direct form, within 5e-5 of the direct form, deterministic, and
+    the block-level C-ABI path bit-identical to the per-op composition with the same operands."""
+    from conftest import T
+    from oracle import adm
+    from test_gpu_models import build_adm
+    for name, cfg in (("adm64", adm.ADM64), ("adm128", adm.ADM128)):
+        g = golden(f"g5_{name}_full")
+        m, _ = build_adm(dict(cfg), int(g["seed"]))
+        m.precision = "f16x3"
+        x, t, y = T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev)
+        m.winograd = 4
+        w = m(x, t, y=y)
+        w2 = m(x, t, y=y)
+        m.use_block_abi = False
+        wop = m(x, t, y=y)
+        m.use_block_abi = True
+        m.winograd = 2
+        v = m(x, t, y=y)
+        m.winograd = False
+        d = m(x, t, y=y)
+        m.precision = "fp32"
+        e32 = np.abs(m(x, t, y=y).cpu().numpy() - g["out"]).max()
+        ew, ev, ed = (np.abs(a.cpu().numpy() - g["out"]).max() for a in (w, v, d))
+        print(f"{name} f16x3: F(4,3) err {ew:.3e}, F(2,3) err {ev:.3e}, direct err {ed:.3e}, exact-fp32 engine err {e32:.3e}, |F(4,3) - direct| {(w - d).abs().max().item():.3e}")
+        assert ew < 1e-3 and ew < 2 * max(ed, e32) + 2e-6
+        assert (w - d).abs().max().item() < 5e-5 and not torch.equal(w, v)
+        assert torch.equal(w, w2) and torch.equal(w, wop)
+        del m
+        torch.cuda.empty_cache()
