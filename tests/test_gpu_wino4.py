@@ -227,3 +227,71 @@ def test_winograd43_unet_vs_reference_and_direct(golden):
         assert torch.equal(w, w2) and torch.equal(w, wop)
         del m
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout", [(128, 128, 256, 256), (128, 64, 512, 512)])
+def test_headline_geometry_writer_wconv4(ops, N, H, Cin, Cout):
+    """The geometry of the headline job itself in the F(4,3) form (BASELINE configs[1]: batch 128 at 128^2 x 256 channels = 2^19 positions
+    x 6 frequencies, 6.4 GB of V planes, 8 192 tiles on 256 persistent workgroups; and 64^2 x 512): GroupNorm + FiLM + SiLU writer ->
+    k_wconv4 with a residual and the column sums, against the direct f16x3 kernel on planes written from the same input (every tile index,
+    descriptor rebase and persistent-loop path of the full-size launch), and against fp64 on sampled images.  Shapes of init_model.py:21 at
+    --batch-size 128 (readme.md:116)."""
+    torch.cuda.empty_cache()
+    W = H
+    assert ops.conv3x3_wino_pick(N, H, W, Cin, Cout) == 4
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(N, H, W, Cin, device=dev, generator=g)
+    x += 0.5 * torch.randn(N, 1, 1, Cin, device=dev, generator=g)                   # per-image channel offsets: statistics that differ per image
+    gamma, beta = torch.randn(Cin, device=dev, generator=g), 0.3 * torch.randn(Cin, device=dev, generator=g)
+    film = 0.5 * torch.randn(N, 2 * Cin, device=dev, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) / math.sqrt(9 * Cin)
+    b = 0.1 * torch.randn(Cout, device=dev, generator=g)
+    res = torch.randn(N, H, W, Cout, device=dev, generator=g)
+    st = ops.groupnorm_stats(x)
+    xv = ops.groupnorm_apply(x, st, gamma, beta, film=film, act=1, split="f16x3w4")
+    yw = ops.conv3x3_bf16x3(xv, ops.pack_weight_f16x3_wino4(w), b, Cout, residual=res, colsum=True)
+    del xv
+    xs = ops.groupnorm_apply(x, st, gamma, beta, film=film, act=1, split="f16x3")
+    yd = ops.conv3x3_bf16x3(xs, ops.pack_weight_f16x3(w), b, Cout, residual=res, colsum=True)
+    del xs
+    scale = yd.abs().max().item()
+    dmax = 0.0
+    for i in range(0, N, 16):                                                        # chunked: keeps the temporaries small
+        dmax = max(dmax, (yw[i:i + 16] - yd[i:i + 16]).abs().max().item())
+    print(f"N={N} {H}^2 {Cin}->{Cout}: max |F(4,3) - direct| = {dmax:.3e} (output scale {scale:.2f})")
+    assert dmax < 5e-5 * max(1.0, scale)
+    s_w, s_ref = ops.groupnorm_stats(yw), ops.groupnorm_stats(yd.clone())            # (a clone carries no column sums: the statistics kernel)
+    np.testing.assert_allclose(s_w.cpu().numpy(), s_ref.cpu().numpy(), rtol=3e-4, atol=3e-5)
+    stc = st.cpu().double().reshape(N, 32, 2)
+    for i in (0, 41, 86, N - 1):
+        xi = x[i].cpu().double().permute(2, 0, 1)[None]                               # [1, C, H, W]
+        mean, rstd = stc[i, :, 0].repeat_interleave(Cin // 32), stc[i, :, 1].repeat_interleave(Cin // 32)
+        a = (xi - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1) * gamma.cpu().double().view(1, -1, 1, 1) + beta.cpu().double().view(1, -1, 1, 1)
+        fi = film[i].cpu().double()
+        a = F.silu(a * (1 + fi[:Cin]).view(1, -1, 1, 1) + fi[Cin:].view(1, -1, 1, 1))
+        ref = F.conv2d(a, w.cpu().double(), b.cpu().double(), padding=1) + res[i].cpu().double().permute(2, 0, 1)[None]
+        e = (yw[i].cpu().double().permute(2, 0, 1)[None] - ref).abs().max().item()
+        print(f"  image {i}: max |F(4,3) - fp64| = {e:.3e}")
+        assert e < 3e-5 * max(1.0, ref.abs().max().item()), (i, e)
+    del x, yw, yd, res
+    torch.cuda.empty_cache()
+
+
+def test_wino4_range_counters(ops):
+    """The F(4,3) V writer counts the transformed operands whose scaled magnitude (scale 8) leaves fp16's range, as the other f16x3
+    writers do (dua_range_check, tests/test_gpu_range.py)."""
+    N, H, W, C = 2, 16, 16, 64
+    st = identity_stats(N)
+    one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    x = rnd(1, N, H, W, C).clamp(-8, 8)
+    x[x.abs() < 1e-2] = 0.5
+    x[0, 3, 4, 5] = 9000.0                                         # V = 4 d .. : |V| * 8 far beyond 65504
+    prev = ops.range_check(True)
+    try:
+        ops.groupnorm_apply(x.to(dev), st, one, zero, act=0, split="f16x3w4")
+        sat, sub = ops.range_check_read()
+    finally:
+        ops.range_check(prev)
+    v = v_reference(x.double()).float() * 8.0
+    assert sat == int((v.abs() > 65504).sum()) and sat > 0
+    assert sub == int(((v.abs() > 0) & (v.abs() < 2.0 ** -14)).sum())
