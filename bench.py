@@ -49,11 +49,12 @@ PRECISIONS = ["f16x3", "fp32", "f16w", "bf16x3"]
 
 # per precision mode: (kernel description, MFMA products executed per algorithmic product at the bf16 rate, dtype string)
 MODES = {
-    "f16x3": ("k_wconv (csrc/conv_wino_f16x3.hip): LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
-              "v_mfma_f32_16x16x32_f16 - four 1x3 row convolutions per two output rows (6 instead of 9 taps per pixel) on fp16 hi / lo "
-              "planes of the transformed, scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs per product, fp32 accumulate; every "
-              "ResBlock conv of the forward (70 of 72 conv3x3, the 8x8 level included); the input conv runs on the fp32 MFMA kernel and the "
-              "3-of-6-channel output conv as a one-tap GEMM + tap gather", 3.0,
+    "f16x3": ("k_wconv4 / k_wconv (csrc/conv_wino4_f16x3.hip, conv_wino_f16x3.hip): LDS-DMA implicit-GEMM conv3x3 in a Winograd-along-y form on "
+              "v_mfma_f32_16x16x32_f16 - F(4,3): six 1x3 row convolutions per four output rows (4.5 of 9 taps per pixel; four waves x 512 "
+              "registers per workgroup) where whole rounds of tiles favour it (the 128^2 .. 32^2 levels and part of 16^2 at batch 128), F(2,3) "
+              "(6 of 9 taps) elsewhere - on fp16 hi / lo planes of the transformed, scaled fp32 operands, lo*hi + hi*lo + hi*hi = 3 fp16 MFMAs "
+              "per product, fp32 accumulate; every ResBlock conv of the forward (70 of 72 conv3x3); the input conv runs on the fp32 MFMA kernel "
+              "and the 3-of-6-channel output conv as a one-tap GEMM + tap gather", 3.0,
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
               "(head dims <= 256) in this format, embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
@@ -68,10 +69,10 @@ MODES = {
                "bf16x3 (fp32 operands split into 2 bf16 terms = 16 significant bits, 3 bf16 MFMA products, fp32 accumulate)"),
 }
 PARITY_NOTE = ("full-size ADM-128 forward vs the reference CPU output (tests/test_gpu_models.py, tests/test_gpu_wino.py, tolerance 1e-3): max abs "
-               "err f16x3 5.2e-6 (3x3 convs in the Winograd form, the default; direct form 6.1e-6), fp32 6.8e-6 (Winograd form; direct 9.1e-6), "
+               "err f16x3 6.0e-6 with every eligible conv in the F(4,3) form (F(2,3) 4.9e-6, direct 5.6e-6), fp32 6.8e-6 (Winograd form; direct 9.1e-6), "
                "bf16x3 3.1e-5; free-running full-size 10-step guided chain (G13): score err f16x3 2.0e-4, fp32 2.4e-4, bf16x3 8.4e-4; "
-               "percentile-0.9 mask agreement >= 99.99 %; batch 128 x 128^2 geometry asserted (test_headline_geometry_writer_wconv: 1.3e-5 "
-               "from the direct kernel, 4e-6 from fp64), batch 9 == batch 1 bit for bit.  Side mode f16w (NOT parity): G13 per-call 6.0e-3, "
+               "percentile-0.9 mask agreement >= 99.99 %; batch 128 x 128^2 geometry asserted (test_headline_geometry_writer_wconv4 / _wconv: 2e-5 / 1.3e-5 "
+               "from the direct kernel, 1.2e-5 / 4e-6 from fp64 at output scale 7.7), batch 9 == batch 1 bit for bit.  Side mode f16w (NOT parity): G13 per-call 6.0e-3, "
                "end-to-end score 6.1e-2, mask agreement 99.75 %; G19 uncertainty 2.5e-2 relative")
 
 

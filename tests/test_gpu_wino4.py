@@ -295,3 +295,35 @@ def test_wino4_range_counters(ops):
     v = v_reference(x.double()).float() * 8.0
     assert sat == int((v.abs() > 65504).sum()) and sat > 0
     assert sub == int(((v.abs() > 0) & (v.abs() < 2.0 ** -14)).sum())
+
+
+def test_wino4_zero_padding_forms_agree(ops):
+    """k_wconv4 takes the dx = -1 / +1 fragments of its image-edge lanes from an LDS address beyond the allocation (zeros), like k_wconv.  The
+    same kernel built with -DDUA_RS_ZERO_SELECT=1 (scripts/diag/build/libdua_hip_select.so, made by __graft_entry__.build()) reads the
+    in-range fragment and zeroes it in registers; both must agree bit for bit."""
+    import ctypes
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "scripts", "diag", "build", "libdua_hip_select.so")
+    if not os.path.exists(alt):
+        import __graft_entry__
+        __graft_entry__.build()
+    A = ctypes.CDLL(alt)
+    from diffusion_uncertainty_amd import _lib
+    fn = A.dua_conv3x3_f16x3_wino4
+    fn.restype, fn.argtypes = _lib.SIGNATURES["dua_conv3x3_f16x3_wino4"]
+    for (N, H, W, Cin, Cout) in [(8, 32, 32, 64, 256), (2, 128, 128, 32, 128), (16, 16, 16, 96, 256), (130, 8, 8, 64, 128), (9, 64, 64, 128, 64)]:
+        x, w, b = rnd(50, N, Cin, H, W), rnd(51, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(52, Cout) * 0.1
+        xd = nhwc(x).to(dev)
+        xv = ops.groupnorm_apply(xd, identity_stats(N), torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev), act=0, split="f16x3w4")
+        packed = ops.pack_weight_f16x3_wino4(w.to(dev))
+        bd = b.to(dev)
+        y0 = ops.conv3x3_bf16x3(xv, packed, bd, Cout)
+        y1 = torch.empty_like(y0)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = fn(ctypes.c_void_p(xv.buf.data_ptr()), ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(bd.data_ptr()), None, 0,
+                ctypes.c_void_p(y1.data_ptr()), N, H, W, Cin, Cout, None, xv.scale, st)
+        assert rc == 0
+        assert torch.equal(y0, y1), (N, H, W, Cin, Cout)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        assert (nchw(y0.cpu()).double() - ref).abs().max().item() < 3e-5
