@@ -33,10 +33,10 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #ifndef WCONV4_DIAG
 #define WCONV4_DIAG 0             // timing-only diagnostic builds (scripts/wconv_diag.py --kernel w4; WRONG results): bit 0 no in-loop barrier,
                                   // bit 1 no epilogue, bit 2 no in-loop DMA, bit 3 no in-loop fragment reads, bit 4 output stores dropped by the buffer unit,
-                                  // bit 5 no residual loads
+                                  // bit 5 no residual loads, bit 6 wave 0 writes s_memrealtime at the start and end of every epilogue into the colsum buffer
 #endif
 
-constexpr int W4_STORES = 4 * 4 * 4;              // channel blocks x position blocks x output rows: always-issued stores of a wave
+constexpr int W4_STORES = 2 * 4 * 2 * 4;          // channel-block pairs x position blocks x halves x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
 // One matrix-core product into an accumulator that LIVES in the accumulation registers (AG: frequencies 0-3, 256 AGPRs) or in the
@@ -52,10 +52,17 @@ __device__ __forceinline__ void w4_static_for(F&& f) {
     }
 }
 
+// (the -DDUA_RS_ZERO_SELECT=1 test build zeroes edge fragments with VALU selects right in front of the products: it pays the wait states
+// between a VALU write and a matrix-core read that the compiler would have inserted for an instruction it knows)
+#if defined(DUA_RS_ZERO_SELECT) && DUA_RS_ZERO_SELECT
+#define W4_MMA_PRE "s_nop 3\n\t"
+#else
+#define W4_MMA_PRE
+#endif
 template <bool AG>
 __device__ __forceinline__ void w4_mma(f32x4& c, const h16x8& a, const h16x8& b) {
-    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    if constexpr (AG) asm volatile(W4_MMA_PRE "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile(W4_MMA_PRE "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
 // The compiler does not know that w4_mma is a matrix-core instruction, so it would not keep the wait states between one and a copy /
@@ -312,6 +319,8 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             prefetched = true;
         }
 #undef WSB
+        unsigned long long t_epi0 = 0;
+        if (WCONV4_DIAG & 64) t_epi0 = __builtin_amdgcn_s_memrealtime();
         // the last MFMAs' results before any other instruction reads them
         w4_fence<true>(acc[0]); w4_fence<true>(acc[1]); w4_fence<true>(acc[2]); w4_fence<true>(acc[3]); w4_fence<false>(acc[4]); w4_fence<false>(acc[5]);
         if (WCONV4_DIAG & 2) {                       // (diagnostic: no epilogue - the accumulators are kept alive by a store that never happens)
@@ -326,12 +335,15 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             continue;
         }
 
-        // ---- epilogue, straight from the accumulator layout (lane = position lane & 15, channels 4 (lane >> 4) .. + 3 of a 16-channel
-        // block): per (channel block jj, position block i) the inverse transform of its six quads in registers, then per output row
-        // one 16-byte store per lane - 64 contiguous bytes per pixel row and instruction, the write granularity of the L2 - with the
-        // residual read the same way.  No LDS round trip (one wave per SIMD has nobody to hide it behind).  vmcnt retires in order, so a
-        // wait for residual rows is also a wait for every OLDER output store: the rows of block b + 2 are requested before the stores
-        // of block b go out, which leaves three blocks of stores between a residual request and the wait that needs it.
+        // ---- epilogue.  The accumulator layout (lane = position lane & 15, channels 4 (lane >> 4) .. + 3 of a 16-channel block) puts the
+        // 16 bytes of ADJACENT lanes 1 KB apart (one pixel row each).  Stored as is - or as 64-byte pieces - the output costs the
+        // memory side a fill per partial 128-byte line: 3.4 TB/s against 5.4 TB/s for whole lines with all CUs writing
+        // (scripts/diag/store_pattern_bench.hip, profiles/r04y_store_pattern.txt).  So per (channel-block pair jp, position block i):
+        // inverse transform of the 2 x 6 quads in registers, then a lane transpose through ds_bpermute (the LDS crossbar: no LDS
+        // memory, no barrier) into the row layout - lane l' = position (l' >> 3) + 8 h, channels 4 (l' & 7) .. + 3 of the pair's 32:
+        // eight adjacent lanes hold one whole 128-byte line of a pixel row, and an instruction writes eight of them.  The residual is
+        // read in that layout too.  vmcnt retires in order, so a wait for residual rows is also a wait for every OLDER output store:
+        // the rows of the next half block are requested before the stores of this one go out.
         // (lane-derived values are recomputed per block from a fresh lane id instead of living in registers across the K loop: the
         // register file is full there, and a reload from scratch memory is a vector-memory wait that drains every store in flight)
         auto lane_now = [&]() -> int {
@@ -343,16 +355,17 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         const long cpix0 = 4L * m0;                                          // the tile's 128 positions are output pixels 4 m0 .. 4 m0 + 511
         const long crem = (4L * p.Mv - cpix0) * p.N * 4;
         const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
-        // output pixel (row of C) of a lane's position in block i, output row 0; -1 beyond the tensor
-        auto opix = [&](int i, int lr_e) -> long {
-            const int pos = pos0 + 16 * i + lr_e;
+        // output pixel (row of C) of position pl of block i, output row 0; -1 beyond the tensor
+        auto opix = [&](int i, int pl) -> long {
+            const int pos = pos0 + 16 * i + pl;
             return pos < p.Mv ? (long)pos + 3L * (pos & ~(p.W - 1)) : -1L;
         };
-        auto res_ld = [&](int b, float4 (&dst)[4]) {                       // block b = (jj, i): the four output rows of this lane's pixel column
-            const int jj = b >> 2, i = b & 3;
+        // sub-block sb = (jp, i, h): dst[r] = the lane's 16 bytes of output row r (position half h of block i, channel-block pair jp)
+        auto res_ld = [&](int sb, float4 (&dst)[4]) {
+            const int jp = sb >> 3, i = (sb >> 1) & 3, h = sb & 1;
             const int le = lane_now();
-            const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4);
-            const long row0 = opix(i, le & 15);
+            const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7);
+            const long row0 = opix(i, (le >> 3) + 8 * h);
             const bool okl = p.res && c < p.N && row0 >= 0 && !(WCONV4_DIAG & 32);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -376,79 +389,107 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             }
         };
-        // column scale * 1 / v_scale and bias of a channel block: requested one block ahead, like the residual rows
-        auto sb_ld = [&](int jj, float4& sq, float4& bq) {
-            const int c = n0 + wn * 64 + 16 * jj + 4 * (lane_now() >> 4);
+        // column scale * 1 / v_scale and bias of a channel-block pair (this lane's four channels of it)
+        auto sb_ld = [&](int jp, float4& sq, float4& bq) {
+            const int c = n0 + wn * 64 + 32 * jp + 4 * (lane_now() & 7);
             sq = *(const float4*)(p.Cscale + c);                             // (padded to the tile grid)
             bq = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias && c < p.N) bq = *(const float4*)(p.bias + c);
         };
         float4 sqn, bqn;
         sb_ld(0, sqn, bqn);
-        float4 rn_[3][4];
+        float4 rn_[2][4];
         res_ld(0, rn_[0]);
-        res_ld(1, rn_[1]);
-        w4_static_for<4>([&](auto jj_c) __attribute__((always_inline)) {
-            constexpr int jj = decltype(jj_c)::value;
+        w4_static_for<2>([&](auto jp_c) __attribute__((always_inline)) {
+            constexpr int jp = decltype(jp_c)::value;
             float4 sq = sqn;
             const float4 bq = bqn;
             sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-            if constexpr (jj + 1 < 4) sb_ld(jj + 1, sqn, bqn);
+            if constexpr (jp + 1 < 2) sb_ld(jp + 1, sqn, bqn);
             float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
             w4_static_for<4>([&](auto i_c) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_c)::value;
-                constexpr int b = jj * 4 + i;
-                if constexpr (b + 2 < 16) res_ld(b + 2, rn_[(b + 2) % 3]);
-                const f32x4 s12 = acc[1][jj][i] + acc[2][jj][i], d12 = acc[1][jj][i] - acc[2][jj][i];
-                const f32x4 s34 = acc[3][jj][i] + acc[4][jj][i], d34 = acc[3][jj][i] - acc[4][jj][i];
-                f32x4 R[4];
-                R[0] = (acc[0][jj][i] + s12) + s34;
-                R[1] = d12 + 2.0f * d34;
-                R[2] = s12 + 4.0f * s34;
-                R[3] = (acc[5][jj][i] + d12) + 8.0f * d34;
-                const int le = lane_now();
-                const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4);
-                const long row0 = opix(i, le & 15);
-                const bool ok = c < p.N && row0 >= 0 && !(WCONV4_DIAG & 16);
+                f32x4 R[2][4];                                               // [channel block of the pair][output row]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 rq = rn_[b % 3][r];
-                    float4 v;
-                    v.x = R[r][0] * sq.x + bq.x + rq.x;
-                    v.y = R[r][1] * sq.y + bq.y + rq.y;
-                    v.z = R[r][2] * sq.z + bq.z + rq.z;
-                    v.w = R[r][3] * sq.w + bq.w + rq.w;
-                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                    const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
-                    if (ok) {
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
-                    }
+                for (int u = 0; u < 2; ++u) {
+                    const int jj = 2 * jp + u;
+                    const f32x4 s12 = acc[1][jj][i] + acc[2][jj][i], d12 = acc[1][jj][i] - acc[2][jj][i];
+                    const f32x4 s34 = acc[3][jj][i] + acc[4][jj][i], d34 = acc[3][jj][i] - acc[4][jj][i];
+                    R[u][0] = (acc[0][jj][i] + s12) + s34;
+                    R[u][1] = d12 + 2.0f * d34;
+                    R[u][2] = s12 + 4.0f * s34;
+                    R[u][3] = (acc[5][jj][i] + d12) + 8.0f * d34;
                 }
+                w4_static_for<2>([&](auto h_c) __attribute__((always_inline)) {
+                    constexpr int h = decltype(h_c)::value;
+                    constexpr int sb = (jp * 4 + i) * 2 + h;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (sb + 1 < 16) res_ld(sb + 1, rn_[(sb + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int le = lane_now();
+                    const int q = le & 7, c = n0 + wn * 64 + 32 * jp + 4 * q, pl = (le >> 3) + 8 * h;
+                    const long row0 = opix(i, pl);
+                    const bool ok = c < p.N && row0 >= 0 && !(WCONV4_DIAG & 16);
+                    // The 32 lanes whose accumulator-layout position (lane & 15) lies in half h hold the first block's quads of the 8 rows
+                    // this instruction writes; the other 32 lanes are free to carry the second block's (a rotation by 8 inside the 16-lane
+                    // row, one DPP move): then ONE ds_bpermute per register gathers a row's eight 16-byte pieces into adjacent lanes.
+                    const bool mine = (((le & 15) >> 3) == h);
+                    const int src4 = 4 * ((q < 4 ? pl : (pl ^ 8)) + 16 * (q & 3));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(R[1][r][e]), 0x128, 0xf, 0xf, false);      // row_ror:8
+                            const int y = mine ? __float_as_int(R[0][r][e]) : other;
+                            t[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, y));
+                        }
+                        const float4 rq = rn_[sb & 1][r];
+                        float4 v;
+                        v.x = t[0] * sq.x + bq.x + rq.x;
+                        v.y = t[1] * sq.y + bq.y + rq.y;
+                        v.z = t[2] * sq.z + bq.z + rq.z;
+                        v.w = t[3] * sq.w + bq.w + rq.w;
+                        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                        const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                        if (ok) {
+                            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                            cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+                        }
+                    }
+                });
             });
-            if (p.colsum) {
+            if (p.colsum && !(WCONV4_DIAG & 64)) {
                 // The wave's 64 positions x 4 output rows are 256 consecutive output pixels of ONE image (H*W % 256 == 0) = four 64-pixel
                 // slots of the column-sum array: their sums go to the first, zeros to the other three.  The consumer
                 // (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
                 float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    t[u] += __shfl_xor(t[u], 1);
-                    t[u] += __shfl_xor(t[u], 2);
-                    t[u] += __shfl_xor(t[u], 4);
                     t[u] += __shfl_xor(t[u], 8);
+                    t[u] += __shfl_xor(t[u], 16);
+                    t[u] += __shfl_xor(t[u], 32);
                 }
                 const int le = lane_now();
-                const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4), lr_e = le & 15;
-                if (lr_e < 4 && c < p.N && pos0 < p.Mv) {
-                    const float z = lr_e == 0 ? 1.0f : 0.0f;
-                    float* o = p.colsum + ((long)(pos0 >> 4) + lr_e) * 2 * p.N + c;
+                const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7), lp_e = le >> 3;
+                if (lp_e < 4 && c < p.N && pos0 < p.Mv) {
+                    const float z = lp_e == 0 ? 1.0f : 0.0f;
+                    float* o = p.colsum + ((long)(pos0 >> 4) + lp_e) * 2 * p.N + c;
                     *(float4*)o = make_float4(t[0] * z, t[1] * z, t[2] * z, t[3] * z);
                     *(float4*)(o + p.N) = make_float4(t[4] * z, t[5] * z, t[6] * z, t[7] * z);
                 }
             }
         });
+        if (WCONV4_DIAG & 64) {                      // (diagnostic: [workgroup][tile of the workgroup][start, all issued, drained] in s_memrealtime ticks of 10 ns)
+            const unsigned long long tm_ = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0 && p.colsum) {
+                unsigned long long* o = (unsigned long long*)p.colsum + ((size_t)blockIdx.x * 64 + (size_t)(ti / nslot)) * 4;
+                if (ti / nslot < 64) { o[0] = t_epi0; o[1] = t1; o[2] = tm_; }
+            }
+        }
     }
 #endif
 }
