@@ -78,6 +78,9 @@ __device__ __forceinline__ void w4_fence(f32x4 (&A)[4][4]) {
                                             "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[2][2]), "+v"(A[2][3]), "+v"(A[3][0]), "+v"(A[3][1]), "+v"(A[3][2]), "+v"(A[3][3]));
 }
 
+// RMODE: 0 no residual, 1 residual [N][H][W][Cout], 2 residual read through 2x resampling (p.res_mode = +-1) - three kernels, so that each
+// holds only its own epilogue (the variants' different register needs would otherwise spill accumulators around the dispatch)
+template <int RMODE>
 __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int RA = 2, RB = 3;
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         // the rows of the next half block are requested before the stores of this one go out.
         // (lane-derived values are recomputed per block from a fresh lane id instead of living in registers across the K loop: the
         // register file is full there, and a reload from scratch memory is a vector-memory wait that drains every store in flight)
-        auto lane_now = [&]() -> int {
-            int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(l));
+        auto lane_now = [&]() -> int {                                      // (volatile: neither hoisted out of the tile loop nor shared between uses)
+            int l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
             return l;
         };
         const int pos0 = m0 + wm * 64;
@@ -356,26 +359,47 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         const long crem = (4L * p.Mv - cpix0) * p.N * 4;
         const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
         // output pixel (row of C) of position pl of block i, output row 0; -1 beyond the tensor
+        const bool tile_full = n0 + 128 <= p.N && m0 + 128 <= p.Mv;
         auto opix = [&](int i, int pl) -> long {
             const int pos = pos0 + 16 * i + pl;
-            return pos < p.Mv ? (long)pos + 3L * (pos & ~(p.W - 1)) : -1L;
+            return (tile_full || pos < p.Mv) ? (long)pos + 3L * (pos & ~(p.W - 1)) : -1L;
         };
+        // the residual descriptor mirrors the output's (same offsets); three variants of the epilogue: no residual, plain, resampled
+        const auto rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res + cpix0 * p.N : p.C), 0,
+                                                            p.res && p.res_mode == 0 ? (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L) : 0, 0x00020000);
+        // FULL: the tile lies inside the tensor (all 128 positions, all 128 channels): no lane is masked, so the stores, the residual loads and
+        // the column sums are straight-line code without selects - which is what lets the compiler count the vector-memory queue exactly.
+        auto epilogue = [&](auto mode_c, auto full_c) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
         // sub-block sb = (jp, i, h): dst[r] = the lane's 16 bytes of output row r (position half h of block i, channel-block pair jp)
         auto res_ld = [&](int sb, float4 (&dst)[4]) {
             const int jp = sb >> 3, i = (sb >> 1) & 3, h = sb & 1;
+            if constexpr (MODE == 0) {                                     // no residual: nothing to request, nothing to wait for
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                return;
+            }
             const int le = lane_now();
             const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7);
             const long row0 = opix(i, (le >> 3) + 8 * h);
-            const bool okl = p.res && c < p.N && row0 >= 0 && !(WCONV4_DIAG & 32);
+            const bool okl = FULL ? !(WCONV4_DIAG & 32) : (c < p.N && row0 >= 0 && !(WCONV4_DIAG & 32));
+            if constexpr (MODE == 1) {
+                // plain residual: buffer loads that ALWAYS issue (masked lanes read beyond the descriptor: zeros), so the code is straight
+                // and the compiler's vector-memory waits count the instructions exactly instead of assuming the worst at every join
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; ++r) {
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ q4 = __builtin_amdgcn_raw_buffer_load_b128(rres, okl ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                    dst[r] = make_float4(__uint_as_float(q4[0]), __uint_as_float(q4[1]), __uint_as_float(q4[2]), __uint_as_float(q4[3]));
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                  // resampled identity skip of an up / down block
                 dst[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!okl) continue;
                 const long row = row0 + (long)r * p.W;
-                if (p.res_mode == 0) {
-                    dst[r] = *(const float4*)(p.res + row * p.N + c);
-                    continue;
-                }
                 const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
                 if (p.res_mode > 0) {
                     const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
@@ -389,23 +413,22 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             }
         };
-        // column scale * 1 / v_scale and bias of a channel-block pair (this lane's four channels of it)
-        auto sb_ld = [&](int jp, float4& sq, float4& bq) {
+        // column scale * 1 / v_scale and bias of both channel-block pairs (this lane's four channels of each), before any store goes out
+        float4 sq_[2], bq_[2];
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
             const int c = n0 + wn * 64 + 32 * jp + 4 * (lane_now() & 7);
-            sq = *(const float4*)(p.Cscale + c);                             // (padded to the tile grid)
-            bq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && c < p.N) bq = *(const float4*)(p.bias + c);
-        };
-        float4 sqn, bqn;
-        sb_ld(0, sqn, bqn);
+            sq_[jp] = *(const float4*)(p.Cscale + c);                        // (padded to the tile grid)
+            bq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && c < p.N) bq_[jp] = *(const float4*)(p.bias + c);
+        }
         float4 rn_[2][4];
         res_ld(0, rn_[0]);
         w4_static_for<2>([&](auto jp_c) __attribute__((always_inline)) {
             constexpr int jp = decltype(jp_c)::value;
-            float4 sq = sqn;
-            const float4 bq = bqn;
+            float4 sq = sq_[jp];
+            const float4 bq = bq_[jp];
             sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-            if constexpr (jp + 1 < 2) sb_ld(jp + 1, sqn, bqn);
             float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
             w4_static_for<4>([&](auto i_c) __attribute__((always_inline)) {
                 constexpr int i = decltype(i_c)::value;
@@ -429,33 +452,39 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     const int le = lane_now();
                     const int q = le & 7, c = n0 + wn * 64 + 32 * jp + 4 * q, pl = (le >> 3) + 8 * h;
                     const long row0 = opix(i, pl);
-                    const bool ok = c < p.N && row0 >= 0 && !(WCONV4_DIAG & 16);
+                    const bool ok = FULL ? !(WCONV4_DIAG & 16) : (c < p.N && row0 >= 0 && !(WCONV4_DIAG & 16));
                     // The 32 lanes whose accumulator-layout position (lane & 15) lies in half h hold the first block's quads of the 8 rows
                     // this instruction writes; the other 32 lanes are free to carry the second block's (a rotation by 8 inside the 16-lane
                     // row, one DPP move): then ONE ds_bpermute per register gathers a row's eight 16-byte pieces into adjacent lanes.
                     const bool mine = (((le & 15) >> 3) == h);
                     const int src4 = 4 * ((q < 4 ? pl : (pl ^ 8)) + 16 * (q & 3));
+                    // all sixteen transposes of the half block are requested before the first is used (one crossbar latency, not four)
+                    float t4[4][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float t[4];
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(R[1][r][e]), 0x128, 0xf, 0xf, false);      // row_ror:8
                             const int y = mine ? __float_as_int(R[0][r][e]) : other;
-                            t[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, y));
+                            t4[r][e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, y));
                         }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float (&t)[4] = t4[r];
                         const float4 rq = rn_[sb & 1][r];
                         float4 v;
-                        v.x = t[0] * sq.x + bq.x + rq.x;
-                        v.y = t[1] * sq.y + bq.y + rq.y;
-                        v.z = t[2] * sq.z + bq.z + rq.z;
-                        v.w = t[3] * sq.w + bq.w + rq.w;
+                        v.x = __builtin_fmaf(t[0], sq.x, bq.x) + rq.x;            // (one fixed rounding order in every variant of the epilogue)
+                        v.y = __builtin_fmaf(t[1], sq.y, bq.y) + rq.y;
+                        v.z = __builtin_fmaf(t[2], sq.z, bq.z) + rq.z;
+                        v.w = __builtin_fmaf(t[3], sq.w, bq.w) + rq.w;
                         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
                         const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
-                        if (ok) {
+                        if (FULL || ok) {                                       // (explicit fma: the same rounding in every variant)
                             cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                            cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
+                            cq2.x = __builtin_fmaf(v.x, v.x, cq2.x); cq2.y = __builtin_fmaf(v.y, v.y, cq2.y);
+                            cq2.z = __builtin_fmaf(v.z, v.z, cq2.z); cq2.w = __builtin_fmaf(v.w, v.w, cq2.w);
                         }
                     }
                 });
@@ -481,6 +510,11 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             }
         });
+        };
+        using EF = std::integral_constant<bool, false>;
+        using ET = std::integral_constant<bool, true>;
+        if (RMODE == 2 || !tile_full) epilogue(std::integral_constant<int, RMODE>{}, EF{});
+        else epilogue(std::integral_constant<int, RMODE>{}, ET{});
         if (WCONV4_DIAG & 64) {                      // (diagnostic: [workgroup][tile of the workgroup][start, all issued, drained] in s_memrealtime ticks of 10 ns)
             const unsigned long long tm_ = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -609,7 +643,8 @@ extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, 
     p.b_plane = (long)p.ntn * 128 * p.K;
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
     p.out_scale = 1.0f / v_scale;
-    const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    if (const char* e = getenv("DUA_W4_GRID")) { const int g = atoi(e); if (g > 0 && g < grid) grid = g; }        // (experiment: fewer workgroups)
     if (const char* e = getenv("DUA_W4_STAGGER")) {        // "phases,percent": experiment switch (percent of one tile time spread over the phases)
         int ph = 0, pct = 100;
         if (sscanf(e, "%d,%d", &ph, &pct) >= 1 && ph > 1 && ntiles >= 6 * grid) {
@@ -618,7 +653,9 @@ extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, 
             p.stagger_sleeps = (int)(tile_us * pct / 100.0 / ph / 4.0 + 0.5);   // s_sleep(127) ~ 4 us
         }
     }
-    hipLaunchKernelGGL(k_wconv4, dim3(grid), 256, 0, as_stream(stream), p);
+    if (!residual) hipLaunchKernelGGL(k_wconv4<0>, dim3(grid), 256, 0, as_stream(stream), p);
+    else if (p.res_mode == 0) hipLaunchKernelGGL(k_wconv4<1>, dim3(grid), 256, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(k_wconv4<2>, dim3(grid), 256, 0, as_stream(stream), p);
     return dua_check_launch("dua_conv3x3_f16x3_wino4");
 }
 
