@@ -39,10 +39,14 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--splitk", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--lib", default="", help="alternative libdua_hip build to load")
     ap.add_argument("--skip-presplit", action="store_true",
                     help="time the on-the-fly-split shapes ([s]) ALSO as presplit two-source GEMMs on planes, plus the pass that would write those planes")
     ap.add_argument("--hg", default="", help="dua_set_hgemm_mode: nt[,streamk]  (nt -1 = previous engine, 0 = auto, 2 / 3 / 4)")
     a = ap.parse_args()
+    if a.lib:
+        from diffusion_uncertainty_amd import _lib as _l
+        _l.LIB_PATH = a.lib
     from diffusion_uncertainty_amd import _lib, ops
     _lib.lib().dua_set_dma_conv(a.engine)
     if a.hg:
