@@ -456,7 +456,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     // The 32 lanes whose accumulator-layout position (lane & 15) lies in half h hold the first block's quads of the 8 rows
                     // this instruction writes; the other 32 lanes are free to carry the second block's (a rotation by 8 inside the 16-lane
                     // row, one DPP move): then ONE ds_bpermute per register gathers a row's eight 16-byte pieces into adjacent lanes.
-                    const bool mine = (((le & 15) >> 3) == h);
                     const int src4 = 4 * ((q < 4 ? pl : (pl ^ 8)) + 16 * (q & 3));
                     // all sixteen transposes of the half block are requested before the first is used (one crossbar latency, not four)
                     float t4[4][4];
@@ -464,8 +463,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(R[1][r][e]), 0x128, 0xf, 0xf, false);      // row_ror:8
-                            const int y = mine ? __float_as_int(R[0][r][e]) : other;
+                            // row_ror:8 with a bank mask: the two banks (8 lanes of every 16) outside half h take the second block's value
+                            // from 8 lanes away, the others keep the first block's - one instruction, no select
+                            const int y = __builtin_amdgcn_update_dpp(__float_as_int(R[0][r][e]), __float_as_int(R[1][r][e]), 0x128, 0xf, h == 0 ? 0xc : 0x3, false);
                             t4[r][e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, y));
                         }
                     __builtin_amdgcn_sched_barrier(0);
