@@ -78,7 +78,7 @@ __device__ __forceinline__ void w4_fence(f32x4 (&A)[4][4]) {
                                             "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[2][2]), "+v"(A[2][3]), "+v"(A[3][0]), "+v"(A[3][1]), "+v"(A[3][2]), "+v"(A[3][3]));
 }
 
-// RMODE: 0 no residual, 1 residual [N][H][W][Cout], 2 residual read through 2x resampling (p.res_mode = +-1) - three kernels, so that each
+// RMODE: 0 no residual, 1 residual [N][H][W][Cout], 2 / 3 residual read through nearest 2x upsampling / 2x2 average pooling - four kernels, so that each
 // holds only its own epilogue (the variants' different register needs would otherwise spill accumulators around the dispatch)
 template <int RMODE>
 __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
@@ -364,9 +364,14 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             const int pos = pos0 + 16 * i + pl;
             return (tile_full || pos < p.Mv) ? (long)pos + 3L * (pos & ~(p.W - 1)) : -1L;
         };
-        // the residual descriptor mirrors the output's (same offsets); three variants of the epilogue: no residual, plain, resampled
-        const auto rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res + cpix0 * p.N : p.C), 0,
-                                                            p.res && p.res_mode == 0 ? (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L) : 0, 0x00020000);
+        // the residual descriptor: RMODE 1 mirrors the output's (same offsets); RMODE 2 / 3 start at the first image the tile touches in the
+        // half / double resolution tensor (offsets stay far below 2^32)
+        const unsigned res_n0 = RMODE >= 2 ? (unsigned)(cpix0 / ((long)p.H * p.W)) : 0u;
+        const long res_img = RMODE == 2 ? (long)(p.H >> 1) * (p.W >> 1) : (RMODE == 3 ? 4L * p.H * p.W : 0L);       // source pixels per image
+        const long res_tot = RMODE >= 2 ? (long)(4L * p.Mv / ((long)p.H * p.W)) * res_img : 0L;                      // ... in the whole tensor
+        const long rrem = RMODE >= 2 ? (res_tot - (long)res_n0 * res_img) * p.N * 4 : crem;
+        const auto rres = __builtin_amdgcn_make_buffer_rsrc((void*)(RMODE == 0 ? (const float*)p.C : (RMODE == 1 ? p.res + cpix0 * p.N : p.res + (long)res_n0 * res_img * p.N)), 0,
+                                                            RMODE == 0 ? 0 : (int)(rrem < 0x7FFFFFF0L ? rrem : 0x7FFFFFF0L), 0x00020000);
         // FULL: the tile lies inside the tensor (all 128 positions, all 128 channels): no lane is masked, so the stores, the residual loads and
         // the column sums are straight-line code without selects - which is what lets the compiler count the vector-memory queue exactly.
         auto epilogue = [&](auto mode_c, auto full_c) __attribute__((always_inline)) {
@@ -395,21 +400,30 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
                 return;
             }
+            // resampled identity skip of an up (MODE 2: nearest 2x upsampling of the half-resolution x) / down (MODE 3: 2x2 average of the
+            // double-resolution x) block: the same always-issued buffer loads, relative to the first image the tile touches
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                                  // resampled identity skip of an up / down block
-                dst[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!okl) continue;
+            for (int r = 0; r < 4; ++r) {
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
                 const long row = row0 + (long)r * p.W;
                 const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
-                if (p.res_mode > 0) {
-                    const long src = ((long)n * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
-                    dst[r] = *(const float4*)(p.res + src * p.N + c);
-                } else {                                                  // same order of additions as k_resample2x (denoiser.hip)
-                    const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
-                    const float4 a = *(const float4*)(p.res + src * p.N + c), b2 = *(const float4*)(p.res + (src + 1) * p.N + c);
-                    const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
-                    dst[r] = make_float4((a.x + b2.x + d.x + e.x) * 0.25f, (a.y + b2.y + d.y + e.y) * 0.25f, (a.z + b2.z + d.z + e.z) * 0.25f,
-                                         (a.w + b2.w + d.w + e.w) * 0.25f);
+                auto ld = [&](long src) -> float4 {
+                    const u32x4_ q4 = __builtin_amdgcn_raw_buffer_load_b128(rres, okl ? (unsigned)((src * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                    return make_float4(__uint_as_float(q4[0]), __uint_as_float(q4[1]), __uint_as_float(q4[2]), __uint_as_float(q4[3]));
+                };
+                if constexpr (MODE == 2) {
+                    dst[r] = ld(((long)(n - res_n0) * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1));
+                } else {
+                    // MODE 3: four loads per row would need a 128-register ring to be requested ahead: they stay conditional global loads
+                    // (conservative waits), in the order of additions of k_resample2x (denoiser.hip)
+                    dst[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (okl) {
+                        const long W2 = 2 * p.W, src = ((long)n * 2 * p.H + 2 * yo) * W2 + 2 * xo;
+                        const float4 a = *(const float4*)(p.res + src * p.N + c), b2 = *(const float4*)(p.res + (src + 1) * p.N + c);
+                        const float4 d = *(const float4*)(p.res + (src + W2) * p.N + c), e = *(const float4*)(p.res + (src + W2 + 1) * p.N + c);
+                        dst[r] = make_float4((a.x + b2.x + d.x + e.x) * 0.25f, (a.y + b2.y + d.y + e.y) * 0.25f, (a.z + b2.z + d.z + e.z) * 0.25f,
+                                             (a.w + b2.w + d.w + e.w) * 0.25f);
+                    }
                 }
             }
         };
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         };
         using EF = std::integral_constant<bool, false>;
         using ET = std::integral_constant<bool, true>;
-        if (RMODE == 2 || !tile_full) epilogue(std::integral_constant<int, RMODE>{}, EF{});
+        if (RMODE == 3 || !tile_full) epilogue(std::integral_constant<int, RMODE>{}, EF{});
         else epilogue(std::integral_constant<int, RMODE>{}, ET{});
         if (WCONV4_DIAG & 64) {                      // (diagnostic: [workgroup][tile of the workgroup][start, all issued, drained] in s_memrealtime ticks of 10 ns)
             const unsigned long long tm_ = __builtin_amdgcn_s_memrealtime();
@@ -655,7 +669,8 @@ extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, 
     }
     if (!residual) hipLaunchKernelGGL(k_wconv4<0>, dim3(grid), 256, 0, as_stream(stream), p);
     else if (p.res_mode == 0) hipLaunchKernelGGL(k_wconv4<1>, dim3(grid), 256, 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(k_wconv4<2>, dim3(grid), 256, 0, as_stream(stream), p);
+    else if (p.res_mode > 0) hipLaunchKernelGGL(k_wconv4<2>, dim3(grid), 256, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(k_wconv4<3>, dim3(grid), 256, 0, as_stream(stream), p);
     return dua_check_launch("dua_conv3x3_f16x3_wino4");
 }
 
