@@ -422,7 +422,9 @@ class UNetModel(nn.Module):
         # f16x3 / fp32: 3x3 convs in a Winograd-along-y form where a kernel takes the shape (csrc/conv_wino_f16x3.hip, conv_wino_f32.hip:
         # F(2,3), 6 instead of 9 matrix-core taps per pixel; csrc/conv_wino4_f16x3.hip: F(4,3), 4.5 taps, f16x3 only) at the same operand
         # precision; results differ from the direct form at fp32-rounding level.  True = the library picks the form per shape
-        # (dua_conv3x3_f16x3_wino_pick); 2 / 4 = that form wherever it applies; False = the direct kernels.
+        # (dua_conv3x3_f16x3_wino_pick); 2 / 4 = that form wherever it applies; False = the direct kernels.  The pick depends on the batch
+        # size (whole rounds of tiles), so with True a batch of 640 and five batches of 128 may run some layers in different forms and then
+        # agree to fp32-rounding level only; 2 or 4 keeps every batch size on the same arithmetic (bit-identical per image).
         self.winograd = True
         # fp32 / f16x3: the few-channel `out` conv as one-tap GEMM + tap gather (see _forward_body)
         self.out_conv_taps = True
