@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_wino4(GnWino4P p) {
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            r[j] = v[j] * ca[j] + cb[j];
+            r[j] = __builtin_fmaf(v[j], ca[j], cb[j]);
             if (p.act == 1) r[j] = silu_f(r[j]);
         }
         if (p.drop) {
@@ -789,24 +789,26 @@ __global__ __launch_bounds__(256) void k_gn_apply_wino4(GnWino4P p) {
     };
     // the six transformed rows of one row group from its six input rows
     auto emit = [&](size_t m, const float (&d0)[8], const float (&d1)[8], const float (&d2)[8], const float (&d3)[8], const float (&d4)[8], const float (&d5)[8]) {
+        // (explicit fma: the row groups of a chunk are emitted by two inlined copies of this code - the first group and the loop body - and
+        // a sample's result must not depend on which copy, i.e. on the chunking, i.e. on the batch size)
         float v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (4.0f * d0[q] - 5.0f * d2[q]) + d4[q];
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(4.0f, d0[q], __builtin_fmaf(-5.0f, d2[q], d4[q]));
         put(0, m, v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (d3[q] + d4[q]) - 4.0f * (d1[q] + d2[q]);
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(-4.0f, d1[q] + d2[q], d3[q] + d4[q]);
         put(1, m, v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (d4[q] - d3[q]) + 4.0f * (d1[q] - d2[q]);
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(4.0f, d1[q] - d2[q], d4[q] - d3[q]);
         put(2, m, v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (d4[q] - d2[q]) + 2.0f * (d3[q] - d1[q]);
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(2.0f, d3[q] - d1[q], d4[q] - d2[q]);
         put(3, m, v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (d4[q] - d2[q]) - 2.0f * (d3[q] - d1[q]);
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(-2.0f, d3[q] - d1[q], d4[q] - d2[q]);
         put(4, m, v);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (4.0f * d1[q] - 5.0f * d3[q]) + d5[q];
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(4.0f, d1[q], __builtin_fmaf(-5.0f, d3[q], d5[q]));
         put(5, m, v);
     };
     const int j0 = jc * p.JC + jo, j1 = min(P, (jc + 1) * p.JC);
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_wino4(GnWino4P p) {
             const bool in = yo >= 0 && yo < Ho;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float t = v[q] * ca[q] + cb[q];
+                float t = __builtin_fmaf(v[q], ca[q], cb[q]);
                 if (p.act == 1) t = silu_f(t);
                 r[q] = in ? t : 0.f;
             }

@@ -119,6 +119,13 @@ def test_full_size_adm128_batch_consistency():
         same += int(torch.equal(one, full[i:i + 1]))
     print(f"ADM-128 f16x3 batch 9 vs batch 1: max abs difference {worst:.3e} ({same} of 4 samples bit-identical); output scale {full.abs().max().item():.3f}")
     assert worst < 2e-5
+    # the default picks the Winograd form per shape AND batch size; with one form everywhere (winograd = 4: F(4,3) where its kernel takes
+    # the shape) a sample's result does not depend on the batch it runs in
+    m.winograd = 4
+    full4 = m(x, t, y=y)
+    for i in (0, 4, 8):
+        assert torch.equal(m(x[i:i + 1].contiguous(), t[i:i + 1], y=y[i:i + 1]), full4[i:i + 1]), i
+    assert (full4 - full).abs().max().item() < 2e-5
     del m
     torch.cuda.empty_cache()
 
