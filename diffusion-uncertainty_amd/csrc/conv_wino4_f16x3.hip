@@ -26,7 +26,6 @@
 #include "common.h"
 #include "wconv.h"
 #include <type_traits>
-#include <stdlib.h>
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
@@ -99,10 +98,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
     constexpr int OOBL = 0x40000;                          // LDS byte address beyond the allocation: DS reads there return zeros
     static_assert(OOBL >= 160 * 1024 + 64 * 64 + 64, "the out-of-range LDS address must lie beyond the 160 KB of a gfx950 CU");
     const int lr = lane & 15, lc = lane >> 4;
-    if (p.stagger_phases > 1) {                            // (experiment: spread the epilogues' memory bursts over the tile time)
-        const int ph = slot % p.stagger_phases;
-        for (int i = 0; i < ph * p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     // ---- DMA state: one per-lane byte offset (this lane's 16 bytes of a 16-row piece; the chunk swizzle of k_wconv applied to the
     // source), everything else - piece row group, channel block, K step, hi / lo image - is wave-uniform and travels as the scalar offset
@@ -657,16 +652,7 @@ extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, 
     p.b_plane = (long)p.ntn * 128 * p.K;
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
     p.out_scale = 1.0f / v_scale;
-    int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
-    if (const char* e = getenv("DUA_W4_GRID")) { const int g = atoi(e); if (g > 0 && g < grid) grid = g; }        // (experiment: fewer workgroups)
-    if (const char* e = getenv("DUA_W4_STAGGER")) {        // "phases,percent": experiment switch (percent of one tile time spread over the phases)
-        int ph = 0, pct = 100;
-        if (sscanf(e, "%d,%d", &ph, &pct) >= 1 && ph > 1 && ntiles >= 6 * grid) {
-            const double tile_us = 18.0 * (Cin / 32) * 0.8;               // ~0.8 us per K step
-            p.stagger_phases = ph;
-            p.stagger_sleeps = (int)(tile_us * pct / 100.0 / ph / 4.0 + 0.5);   // s_sleep(127) ~ 4 us
-        }
-    }
+    const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
     if (!residual) hipLaunchKernelGGL(k_wconv4<0>, dim3(grid), 256, 0, as_stream(stream), p);
     else if (p.res_mode == 0) hipLaunchKernelGGL(k_wconv4<1>, dim3(grid), 256, 0, as_stream(stream), p);
     else if (p.res_mode > 0) hipLaunchKernelGGL(k_wconv4<2>, dim3(grid), 256, 0, as_stream(stream), p);

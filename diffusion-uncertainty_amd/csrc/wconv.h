@@ -23,7 +23,6 @@ struct WConvP {
     long b_plane;            // ntn * 256 * K
     int Mv, N, Cin, K, H, W, ntm, ntn;
     float out_scale;
-    int stagger_phases, stagger_sleeps;      // k_wconv4 experiment: start-up stagger of the persistent workgroups (0 = off)
     int res_mode;            // 0: res is [N][H][W][Cout]; +1: res is [N][H/2][W/2][Cout], read through nearest-neighbour 2x upsampling;
                              // -1: res is [N][2H][2W][Cout], read through 2x2 average pooling (the resampled identity skip of an ADM
                              // up / down block, unet_openai.py:238-243, without materialising it)
