@@ -92,7 +92,7 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         const int pr_e = lane_e >> 3, pc_e = lane_e & 7;         // row-major side: row of the half block, 16-B chunk of the 128-B row
         // every global operand of the epilogue is requested up front (column scales, bias, the first residual rows): one exposed
         // latency instead of two per pair; the residual rows of slot t + 2 are requested while slot t is stored
-        float4 sq_[NT], bq_[NT], rres[3][2];
+        float4 rres[3][2];
         auto res_ld = [&](int t, float4 (&dst)[2]) {
             const int c = n0 + wn * 32 * NT + 32 * (t >> 2) + 4 * pc_e;
 #pragma unroll
@@ -102,16 +102,19 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
                 if (p.res && c < p.N && row < p.M) dst[h] = *(const float4*)(p.res + (long)row * p.N + c);
             }
         };
-#pragma unroll
-        for (int jp = 0; jp < NT; ++jp) {
+        // (column scale and bias of a pair are requested one pair ahead: all NT pairs up front cost 32 registers at NT = 4)
+        float4 sqn, bqn;
+        auto sb_ld = [&](int jp) {
             const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
-            sq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
-            bq_[jp] = sq_[jp];
+            sqn = make_float4(0.f, 0.f, 0.f, 0.f);
+            bqn = sqn;
             if (c < p.N) {
-                sq_[jp] = *(const float4*)(p.Cscale + c);
-                if (p.bias) bq_[jp] = *(const float4*)(p.bias + c);
+                sqn = *(const float4*)(p.Cscale + c);
+                if (p.bias) bqn = *(const float4*)(p.bias + c);
             }
-        }
+        };
+        sb_ld(0);
+        float4 sq_cur = sqn, bq_cur = bqn;
         res_ld(0, rres[0]);
         res_ld(1, rres[1]);
         patch_put(0);
@@ -133,9 +136,13 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
             const bool cok = c < p.N;
             if (t + 1 < T) patch_get(t + 1, pa[(t + 1) & 1]);
             if (t + 2 < T) res_ld(t + 2, rres[(t + 2) % 3]);
-            float4 sq = sq_[jp];
+            if (i == 0) {
+                sq_cur = sqn; bq_cur = bqn;
+                if (jp + 1 < NT) sb_ld(jp + 1);
+            }
+            float4 sq = sq_cur;
             sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-            const float4 bq = bq_[jp];
+            const float4 bq = bq_cur;
             const float4 (&rq)[2] = rres[t % 3];
             if (i == 0) { cs = make_float4(0.f, 0.f, 0.f, 0.f); cq2 = cs; }
 #pragma unroll
@@ -248,81 +255,6 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
     }
 }
 
-// Direct form (fp32 output, no planes beside it): straight from the accumulators, no LDS.  A store instruction then covers 16 rows x 64 B
-// (the four lanes that share a row hold 4 x 16 B of consecutive channels; the other half of each 128-byte line follows in the next
-// instruction).  Fewer bytes per request than the patch form's whole lines, but no transposition and no dependent LDS round trip per
-// slot: the better trade for the short K loops of one-tap GEMMs (measured: scripts/hgemm_diag.py).
-template <int NT>
-__device__ __forceinline__ void hgemm_epilogue_direct(const HGemmP& p, f32x4 (&acc)[2 * NT][4], int wave, int lane, int m0, int n0) {
-    constexpr int NB = 2 * NT;
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
-    const int row0 = m0 + wm * 64, c0 = n0 + wn * 32 * NT + 4 * lc_e;
-    const unsigned OOB = 0xFFFFFFF0u;
-    const long crem = ((long)p.M - m0) * p.N * 4;
-    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long)m0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
-    // channel block j: its column scales / bias and the residual of its four row blocks are requested while block j - 1 is stored
-    float4 sb[2][2], rres[2][4];
-    auto blk_ld = [&](int j, float4 (&sbd)[2], float4 (&dst)[4]) {
-        const int c = c0 + 16 * j;
-        sbd[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sbd[1] = sbd[0];
-        if (c < p.N) {
-            sbd[0] = *(const float4*)(p.Cscale + c);
-            if (p.bias) sbd[1] = *(const float4*)(p.bias + c);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + 16 * i + lr_e;
-            dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.res && c < p.N && row < p.M) dst[i] = *(const float4*)(p.res + (long)row * p.N + c);
-        }
-    };
-    blk_ld(0, sb[0], rres[0]);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j + 1 < NB) blk_ld(j + 1, sb[(j + 1) & 1], rres[(j + 1) & 1]);
-        const int c = c0 + 16 * j;
-        float4 sq = sb[j & 1][0];
-        sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-        const float4 bq = sb[j & 1][1];
-        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + 16 * i + lr_e;
-            const bool ok = c < p.N && row < p.M;
-            const f32x4 a = acc[j][i];
-            const float4 rq = rres[j & 1][i];
-            float4 v;
-            v.x = a[0] * sq.x + bq.x; v.y = a[1] * sq.y + bq.y; v.z = a[2] * sq.z + bq.z; v.w = a[3] * sq.w + bq.w;
-            if (p.act_out == 2) { v.x = hg_gelu(v.x); v.y = hg_gelu(v.y); v.z = hg_gelu(v.z); v.w = hg_gelu(v.w); }
-            v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w;
-            const u32x4 vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (ok && !(HG_DIAG & 2)) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
-            if (ok) {
-                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                cq2.x += v.x * v.x; cq2.y += v.y * v.y; cq2.z += v.z * v.z; cq2.w += v.w * v.w;
-            }
-        }
-        if (p.colsum) {          // fold the 16 row lanes that share these channels
-            float u_[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                u_[u] += __shfl_xor(u_[u], 1);
-                u_[u] += __shfl_xor(u_[u], 2);
-                u_[u] += __shfl_xor(u_[u], 4);
-                u_[u] += __shfl_xor(u_[u], 8);
-            }
-            if (lr_e == 0 && c < p.N && row0 < p.M) {
-                float* o = p.colsum + (long)(row0 >> 6) * 2 * p.N + c;
-                *(float4*)o = make_float4(u_[0], u_[1], u_[2], u_[3]);
-                *(float4*)(o + p.N) = make_float4(u_[4], u_[5], u_[6], u_[7]);
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int NT, int EPI>
@@ -608,8 +540,6 @@ __global__ __launch_bounds__(512, 2) void k_hgemm(HGemmP p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) t_ += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
             if (t_ == 1.2345e-30f) p.C[0] = t_;
-        } else if (EPI == 0 && p.direct_epi) {
-            hgemm_epilogue_direct<NT>(p, acc, wave, lane, m0, n0);
         } else {
             hgemm_epilogue<NT, EPI>(p, acc, lds + 2 * ABY + wave * 4096, wave, lane, m0, n0);
         }
@@ -648,8 +578,7 @@ __global__ __launch_bounds__(512) void k_hgemm_reduce(HGemmP p) {
     }
     const int tile = p.n_full + t;
     const int m0 = (tile / p.ntn) * HG_ROWS, n0 = (tile % p.ntn) * 64 * NT;
-    if (EPI == 0 && p.direct_epi) hgemm_epilogue_direct<NT>(p, acc, wave, lane, m0, n0);
-    else hgemm_epilogue<NT, EPI>(p, acc, patch + wave * 4096, wave, lane, m0, n0);
+    hgemm_epilogue<NT, EPI>(p, acc, patch + wave * 4096, wave, lane, m0, n0);
 #endif
 }
 
@@ -657,17 +586,16 @@ __global__ __launch_bounds__(512) void k_hgemm_reduce(HGemmP p) {
 static float* hg_ws = nullptr;
 static size_t hg_ws_bytes = 0;
 static int hg_sk_whole = -1;              // stream-K over the whole launch: -1 = per shape, 0 = tail only, 1 = always
-static int hg_force_nt = 0, hg_streamk = 1, hg_direct = -1;     // hg_direct: -1 = per shape, 0 = patch epilogue, 1 = direct epilogue
+static int hg_force_nt = 0, hg_streamk = 1;
 void dua_hgemm_set_workspace(void* ws, size_t bytes) { hg_ws = (float*)ws; hg_ws_bytes = bytes; }
 // A/B switches (process-global, correct kernels only): nt = 0 picks the tile width per shape, 2 / 3 / 4 forces 128 / 192 / 256 columns,
 // -1 sends the presplit GEMMs back to the previous engine (k_xconv_dma<NT, 3> / k_hconv<NT, false>); streamk bit 0 = 0 runs whole tiles
-// only, bits 1-2 pick the fp32 epilogue (0 per shape, 2 patch, 4 direct)
+// only (bits 1-2 are ignored: they selected the since-removed epilogue straight from the accumulators, measured no better)
 int dua_hgemm_enabled() { return hg_force_nt >= 0; }
 extern "C" int dua_set_hgemm_mode(int nt, int streamk) {
     DUA_REQUIRE(nt == -1 || nt == 0 || (nt >= 2 && nt <= 4), "dua_set_hgemm_mode: nt must be -1 (previous engine), 0, 2, 3 or 4");
     hg_force_nt = nt;
     hg_streamk = (streamk & 1) != 0;
-    hg_direct = (streamk & 6) == 2 ? 0 : ((streamk & 6) == 4 ? 1 : -1);          // bits 1-2 of `streamk`: 2 = patch epilogue, 4 = direct epilogue
     hg_sk_whole = (streamk & 24) == 8 ? 0 : ((streamk & 24) == 16 ? 1 : -1);      // bits 3-4: 8 = stream-K on the tail round only, 16 = on the whole launch
     return DUA_OK;
 }
@@ -723,7 +651,6 @@ int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what) {
         }
     }
     const bool planes = p.Cplanes != nullptr;
-    p.direct_epi = (!planes && !p.Cextra && hg_direct == 1) ? 1 : 0;
     if (nt == 4) hg_launch<4>(p, grid, planes, st);
     else if (nt == 3) hg_launch<3>(p, grid, planes, st);
     else hg_launch<2>(p, grid, planes, st);

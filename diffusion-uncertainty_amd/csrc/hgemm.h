@@ -15,7 +15,6 @@ struct HGemmP {
     float* colsum;               // optional [ceil(M / 64)][2][N] column sums / sums of squares per 64-row block
     int M, N, K1, K2, ntm, ntn;
     int act_out;                 // 2 = GELU
-    int direct_epi;              // EPI 0: stores straight from the accumulator layout (no LDS transposition); set by dua_launch_hgemm
     float out_scale, split_scale;
     // Work list of the persistent grid: items [0, n_full) are whole tiles (tile id = tm * ntn + tn).  The K-step units of the remaining
     // tail_tiles tiles are cut into tail_p contiguous ranges (stream-K), range c = [c U / tail_p, (c + 1) U / tail_p) owned by workgroup c:

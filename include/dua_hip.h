@@ -354,8 +354,7 @@ int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void* a2planes,
 /* A/B switches of the one-tap f16x3 GEMM kernel behind the presplit entry points (csrc/gemm_f16x3.hip; correct kernels only, process-global):
  * nt = 0 picks the tile width per shape (default), 2 / 3 / 4 force 128 / 192 / 256 columns, -1 sends the calls to the previous engine
  * (k_xconv_dma<NT, 3> / k_hconv<NT, false>); bit 0 of streamk = 0 runs whole tiles only even when dua_set_splitk_workspace registered a
- * buffer; bits 1-2 of streamk select the fp32 epilogue: 0 / 2 = through the LDS patch (default), 4 = straight from the accumulators; bits 3-4 the
- * stream-K extent: 0 = per shape (default), 8 = the last partly filled round of tiles only, 16 = the whole launch (workgroups out of phase). */
+ * buffer; bits 1-2 are ignored; bits 3-4 the stream-K extent: 0 = per shape (default), 8 = the last partly filled round of tiles only, 16 = the whole launch (workgroups out of phase). */
 int dua_set_hgemm_mode(int nt, int streamk);
 /* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
  * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */
