@@ -92,7 +92,8 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         const int pr_e = lane_e >> 3, pc_e = lane_e & 7;         // row-major side: row of the half block, 16-B chunk of the 128-B row
         // every global operand of the epilogue is requested up front (column scales, bias, the first residual rows): one exposed
         // latency instead of two per pair; the residual rows of slot t + 2 are requested while slot t is stored
-        float4 rres[3][2];
+        constexpr int RR = NT == 4 ? 2 : 3;                      // residual ring: slots ahead + 1 (the 256-column kernel has no registers for three)
+        float4 rres[RR][2];
         auto res_ld = [&](int t, float4 (&dst)[2]) {
             const int c = n0 + wn * 32 * NT + 32 * (t >> 2) + 4 * pc_e;
 #pragma unroll
@@ -116,7 +117,7 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         sb_ld(0);
         float4 sq_cur = sqn, bq_cur = bqn;
         res_ld(0, rres[0]);
-        res_ld(1, rres[1]);
+        if (RR == 3) res_ld(1, rres[1]);
         patch_put(0);
         patch_put(1);
         f32x4 pa[2][2];
@@ -135,7 +136,7 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
             const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
             const bool cok = c < p.N;
             if (t + 1 < T) patch_get(t + 1, pa[(t + 1) & 1]);
-            if (t + 2 < T) res_ld(t + 2, rres[(t + 2) % 3]);
+            if (t + RR - 1 < T) res_ld(t + RR - 1, rres[(t + RR - 1) % RR]);
             if (i == 0) {
                 sq_cur = sqn; bq_cur = bqn;
                 if (jp + 1 < NT) sb_ld(jp + 1);
@@ -143,7 +144,7 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
             float4 sq = sq_cur;
             sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
             const float4 bq = bq_cur;
-            const float4 (&rq)[2] = rres[t % 3];
+            const float4 (&rq)[2] = rres[t % RR];
             if (i == 0) { cs = make_float4(0.f, 0.f, 0.f, 0.f); cq2 = cs; }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
