@@ -708,12 +708,14 @@ FULL_CHAIN_TOL = {"fp32": (1e-3, 1e-3, 2.5e-2, 1, 0.99), "f16x3": (1e-3, 1e-3, 2
                   "f16w": (1.5e-2, 0.15, 1.0, 16, 0.98)}      # observed 6.0e-3 / 6.1e-2 / 0.39 / 7 / 99.75 %
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3", "f16w"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16x3/F(4,3)", "bf16x3", "f16w"])
 def test_full_size_chain_vs_golden(golden, precision):
     """Full-size ADM-128 through the driver, 10 DDIM steps, M=2, num_zigzag=3, window (6, 3), against the reference driver's own
     run (G13): teacher-forced per step (the fixture's x_t in, eps compared; scheduler.step on the fixture's eps with the same
     noise tape), free-running end to end, and the agreement of the percentile-0.9 mask of the final uncertainty map
-    (uncertainty_guidance.py:112).  The fp32-equivalent modes (fp32, f16x3) are held to the north star's 1e-3 END TO END."""
+    (uncertainty_guidance.py:112).  The fp32-equivalent modes (fp32, f16x3) are held to the north star's 1e-3 END TO END.
+    "f16x3/F(4,3)": f16x3 with every 3x3 conv the F(4,3) kernel takes in that form (at this batch the default pick would choose F(2,3):
+    the headline job's batch 128 runs F(4,3) at the 128^2 .. 32^2 levels) - same bars as f16x3."""
     from oracle import adm
     from diffusion_uncertainty_amd import ops
     from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
@@ -721,6 +723,9 @@ def test_full_size_chain_vs_golden(golden, precision):
     from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
     g = golden("g13_adm128_chain")
     m, _ = build_adm(dict(adm.ADM128), int(g["seed"]))
+    if precision == "f16x3/F(4,3)":
+        precision = "f16x3"
+        m.winograd = 4
     m.precision = precision
     tol_tf, tol_s, tol_u, tol_lsb, tol_mask = FULL_CHAIN_TOL[precision]
     after, num = int(g["window"][0]), int(g["window"][1])
