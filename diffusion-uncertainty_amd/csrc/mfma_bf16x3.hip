@@ -71,11 +71,18 @@ __device__ __forceinline__ void split4(float4 v, bf16x4& hi, bf16x4& lo) {
 // f16x3 split of four values scaled by sc: hi = fp16(s), lo = fp16(s - hi).  hi saturates at +-65504 and lo then takes the
 // remainder (also saturating): out-of-range operands degrade gracefully instead of turning into inf.
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split4h(float4 v, float sc, h16x4& hi, h16x4& lo) {
+// The f16x3 range check counts in REGISTERS (n_sat / n_sub, reported once at the end of the kernel): an atomic inside the K loop - even
+// one that never executes - is a vector-memory operation behind a branch, and the compiler then waits for vmcnt(0) in front of every
+// staged operand, i.e. for the prefetch it has just issued.
+__device__ __forceinline__ void split4h(float4 v, float sc, h16x4& hi, h16x4& lo, bool rc_on, unsigned& n_sat, unsigned& n_sub) {
     float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-    if (unsigned long long* rc_ = dua_range_ctr()) {
+    if (rc_on) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dua_range_note(rc_, f[j]);
+        for (int j = 0; j < 4; ++j) {
+            const float af = fabsf(f[j]);
+            n_sat += af > 65504.f ? 1u : 0u;
+            n_sub += (af > 0.f && af < 6.103515625e-05f) ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -228,26 +235,36 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         uint4 bh0, bh1, bl0, bl1;        // pre-split weight chunks
         unsigned mask;                   // conv: in-image bits of the staged rows, captured at load time
     };
-    auto xload = [&](Stage& S, int kt) {
-        if (a_left == 0) setup_a(kt);
-        --a_left;
+    // `live` = false (past the last K step): the loads STILL issue - from the last valid tile - and nothing advances.  Unconditional
+    // loads keep the K loop straight-line for the compiler's s_waitcnt bookkeeping: behind `if (kt + 3 < nk)` it had to assume that the
+    // other stage's prefetch was not issued and waited for vmcnt(0) in front of every staged operand, i.e. for the loads requested
+    // one step - not two - earlier.
+    auto xload = [&](Stage& S, int kt, bool live) {
+        if (live) {
+            if (a_left == 0) setup_a(kt);
+            --a_left;
+        }
+        const int back = live ? 0 : -BK;                       // (elements; the pointers stand one tile past the last loaded one)
         S.mask = amask;
         if (PRESPLIT) {
-            S.a0 = *(const uint4*)qh[0]; S.a1 = *(const uint4*)qh[1]; S.a2 = *(const uint4*)ql[0]; S.a3 = *(const uint4*)ql[1];
-            qh[0] += BK; qh[1] += BK; ql[0] += BK; ql[1] += BK;
+            S.a0 = *(const uint4*)(qh[0] + back); S.a1 = *(const uint4*)(qh[1] + back); S.a2 = *(const uint4*)(ql[0] + back); S.a3 = *(const uint4*)(ql[1] + back);
+            if (live) { qh[0] += BK; qh[1] += BK; ql[0] += BK; ql[1] += BK; }
         } else {
-            S.a0 = *(const uint4*)pa[0]; S.a1 = *(const uint4*)pa[1]; S.a2 = *(const uint4*)pa[2]; S.a3 = *(const uint4*)pa[3];
-            pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK;
+            S.a0 = *(const uint4*)(pa[0] + back); S.a1 = *(const uint4*)(pa[1] + back); S.a2 = *(const uint4*)(pa[2] + back); S.a3 = *(const uint4*)(pa[3] + back);
+            if (live) { pa[0] += BK; pa[1] += BK; pa[2] += BK; pa[3] += BK; }
         }
         if (!BSPLIT) {
-            S.bh0 = *(const uint4*)pbh[0]; S.bh1 = *(const uint4*)pbh[1]; S.bl0 = *(const uint4*)pbl[0]; S.bl1 = *(const uint4*)pbl[1];
             constexpr int BSTEP = F16 ? 8192 : BK;                                // halves to the next K step
-            pbh[0] += BSTEP; pbh[1] += BSTEP; pbl[0] += BSTEP; pbl[1] += BSTEP;
+            const int bback = live ? 0 : -BSTEP;
+            S.bh0 = *(const uint4*)(pbh[0] + bback); S.bh1 = *(const uint4*)(pbh[1] + bback); S.bl0 = *(const uint4*)(pbl[0] + bback); S.bl1 = *(const uint4*)(pbl[1] + bback);
+            if (live) { pbh[0] += BSTEP; pbh[1] += BSTEP; pbl[0] += BSTEP; pbl[1] += BSTEP; }
         } else {
-            S.bh0 = *(const uint4*)pbf[0]; S.bh1 = *(const uint4*)pbf[1]; S.bl0 = *(const uint4*)pbf[2]; S.bl1 = *(const uint4*)pbf[3];
-            pbf[0] += BK; pbf[1] += BK; pbf[2] += BK; pbf[3] += BK;
+            S.bh0 = *(const uint4*)(pbf[0] + back); S.bh1 = *(const uint4*)(pbf[1] + back); S.bl0 = *(const uint4*)(pbf[2] + back); S.bl1 = *(const uint4*)(pbf[3] + back);
+            if (live) { pbf[0] += BK; pbf[1] += BK; pbf[2] += BK; pbf[3] += BK; }
         }
     };
+    unsigned n_sat = 0, n_sub = 0;                     // f16x3 range check (debug facility): per-thread counts, reported after the K loop
+    const bool rc_on = F16 && dua_range_ctr() != nullptr;
     auto store_a = [&](int buf, int i, uint4 u, unsigned mask) {
         float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         if (MODE == XMODE_CONV) {
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         __bf16* base = lds + buf * BUF + row * LDH + 8 * ((c4 >> 1) ^ ((row >> 2) & 3)) + 4 * (c4 & 1);
         if (F16) {
             h16x4 hi, lo;
-            split4h(v, p.a_scale, hi, lo);
+            split4h(v, p.a_scale, hi, lo, rc_on, n_sat, n_sub);
             *(h16x4*)base = hi;
             *(h16x4*)(base + PLANE) = lo;
         } else {
@@ -334,10 +351,10 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
     // pipeline per K step: [MFMA s0 | read s1] [write tile kt+1 from its stage] barrier
     //                      [MFMA s1 | read s0 of tile kt+1 | request tile kt+3 into the stage just written]
     Stage st0, st1;
-    xload(st0, 0);
+    xload(st0, 0, true);
     xstore(st0, 0);
-    if (nk > 1) xload(st1, 1);
-    if (nk > 2) xload(st0, 2);
+    xload(st1, 1, nk > 1);
+    xload(st0, 2, nk > 2);
     __syncthreads();
     XFrag f0 = read_frag(0, 0), f1;
 #define XSTEP(kt, S)                                                     \
@@ -348,12 +365,20 @@ __global__ __launch_bounds__(256, 2) void k_xtile(XTileP p) {
         if ((kt) + 1 < nk) xstore(S, buf ^ 1);                           \
         __syncthreads();                                                 \
         if ((kt) + 1 < nk) f0 = read_frag(buf ^ 1, 0);                   \
-        if ((kt) + 3 < nk) xload(S, (kt) + 3);                           \
+        xload(S, (kt) + 3, (kt) + 3 < nk);                               \
         XMFMA12(f1)                                                      \
     }
-    for (int kt = 0; kt < nk; kt += 2) {
-        XSTEP(kt, st1)                       // tile kt+1 lives in st1 (odd tiles), kt+2 in st0
-        if (kt + 1 < nk) XSTEP(kt + 1, st0)
+    int kt2 = 0;
+    for (; kt2 + 1 < nk; kt2 += 2) {         // whole pairs of steps, nothing conditional inside (see xload)
+        XSTEP(kt2, st1)                      // tile kt+1 lives in st1 (odd tiles), kt+2 in st0
+        XSTEP(kt2 + 1, st0)
+    }
+    if (kt2 < nk) XSTEP(kt2, st1)            // an odd number of K steps
+
+    if (rc_on && (n_sat | n_sub)) {
+        unsigned long long* rc_ = dua_range_ctr();
+        if (n_sat) atomicAdd(rc_, (unsigned long long)n_sat);
+        if (n_sub) atomicAdd(rc_ + 1, (unsigned long long)n_sub);
     }
 
     // ---- epilogue.  Fast path: each wave re-lays its 32 x 64 half tile as rows in a private LDS patch (the K loop's
