@@ -74,8 +74,11 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // The f16x3 range check counts in REGISTERS (n_sat / n_sub, reported once at the end of the kernel): an atomic inside the K loop - even
 // one that never executes - is a vector-memory operation behind a branch, and the compiler then waits for vmcnt(0) in front of every
 // staged operand, i.e. for the prefetch it has just issued.
+// Four operations per element (the K loop of the skip GEMMs is VALU-issue bound: the plain C form compiled to 7.5): clamp, packed RNE
+// conversion of two hi halves, clamp of the remainder's minuend, and ONE v_fma_mix that forms s - hi and rounds it to fp16 (s - hi is
+// exact in fp32, so the single rounding equals the two-step form bit for bit).
 __device__ __forceinline__ void split4h(float4 v, float sc, h16x4& hi, h16x4& lo, bool rc_on, unsigned& n_sat, unsigned& n_sub) {
-    float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    const float f[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
     if (rc_on) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -84,12 +87,23 @@ __device__ __forceinline__ void split4h(float4 v, float sc, h16x4& hi, h16x4& lo
             n_sub += (af > 0.f && af < 6.103515625e-05f) ? 1u : 0u;
         }
     }
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    unsigned hp[2], lp[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const _Float16 h = (_Float16)fminf(fmaxf(f[j], -65504.f), 65504.f);
-        hi[j] = h;
-        lo[j] = (_Float16)fminf(fmaxf(f[j] - (float)h, -65504.f), 65504.f);
+    for (int j = 0; j < 2; ++j) {
+        const float c0 = __builtin_amdgcn_fmed3f(f[2 * j], -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(f[2 * j + 1], -65504.f, 65504.f);
+        const h16x2 h2 = {(_Float16)c0, (_Float16)c1};                      // (one v_cvt_pk_f16_f32)
+        hp[j] = __builtin_bit_cast(unsigned, h2);
+        // the remainder stays finite up to twice the range (hi saturated, lo carries the rest), as before
+        const float g0 = __builtin_amdgcn_fmed3f(f[2 * j], -131008.f, 131008.f), g1 = __builtin_amdgcn_fmed3f(f[2 * j + 1], -131008.f, 131008.f);
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(g0), "v"(hp[j]));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(g1), "v"(hp[j]));
+        lp[j] = d;
     }
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(h16x4, (u32x2_){hp[0], hp[1]});
+    lo = __builtin_bit_cast(h16x4, (u32x2_){lp[0], lp[1]});
 }
 
 template <int MODE, bool SILU_IN, bool PRESPLIT, bool BSPLIT, bool F16 = false>
