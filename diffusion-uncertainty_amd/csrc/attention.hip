@@ -266,22 +266,39 @@ __global__ __launch_bounds__(64 * QW, CT16 > 8 ? 1 : 2) void k_flash_attn_x(Attn
     abf16x8 qh[CT16], ql[QL_LDS ? 1 : CT16];
     {
         const float* qrow = base + (long)min(q0 + wave * 32 + lr, T - 1) * ldq;
+        // The row is requested in groups of four 16-channel steps (eight float4 in flight) from addresses that are ALWAYS valid (a channel
+        // beyond the head is clamped and zeroed afterwards): behind `if (c0 + j < ch)` every load was followed by its own vmcnt(0), CT16
+        // memory latencies in a row at the start of a workgroup that lives for 9 key tiles at U-ViT's 258 tokens.
+        constexpr int QG = 4;
 #pragma unroll
-        for (int c = 0; c < CT16; ++c) {
-            const int c0 = 16 * c + 8 * kh;
-            float v[8];
+        for (int cg = 0; cg < CT16; cg += QG) {
+            float4 tq[QG][2];
 #pragma unroll
-            for (int j = 0; j < 8; j += 4) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + j < ch) t = *(const float4*)(qrow + c0 + j);       // ch % 4 == 0: a float4 is all in or all out
-                const float qs = F16 ? p.scale * DUA_AX_SQ : p.scale;
-                v[j] = t.x * qs; v[j + 1] = t.y * qs; v[j + 2] = t.z * qs; v[j + 3] = t.w * qs;
+            for (int u = 0; u < QG; ++u)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const int cc = 16 * (cg + u) + 8 * kh + 4 * jh;
+                    tq[u][jh] = (cg + u < CT16) ? *(const float4*)(qrow + min(cc, ch - 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int u = 0; u < QG; ++u) {
+                const int c = cg + u;
+                if (c >= CT16) continue;
+                const int c0 = 16 * c + 8 * kh;
+                float v[8];
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    const bool in = c0 + 4 * jh < ch;                        // ch % 4 == 0: a float4 is all in or all out
+                    const float4 t = tq[u][jh];
+                    const float qs = F16 ? p.scale * DUA_AX_SQ : p.scale;
+                    v[4 * jh] = in ? t.x * qs : 0.f; v[4 * jh + 1] = in ? t.y * qs : 0.f; v[4 * jh + 2] = in ? t.z * qs : 0.f; v[4 * jh + 3] = in ? t.w * qs : 0.f;
+                }
+                abf16x8 lo_;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { el a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; lo_[j] = b_; }
+                if (QL_LDS) *(abf16x8*)(qlds + ((wave * CT16 + c) * 64 + lane) * 8) = lo_;
+                else ql[QL_LDS ? 0 : c] = lo_;
             }
-            abf16x8 lo_;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { el a_, b_; asplit(v[j], a_, b_); qh[c][j] = a_; lo_[j] = b_; }
-            if (QL_LDS) *(abf16x8*)(qlds + ((wave * CT16 + c) * 64 + lane) * 8) = lo_;
-            else ql[QL_LDS ? 0 : c] = lo_;
         }
     }
     // ---- zero the padded channel columns of the K tile (they meet zero Q channels: must not be NaN patterns) and all of V^T
