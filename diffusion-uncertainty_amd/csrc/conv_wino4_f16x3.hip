@@ -1,4 +1,5 @@
-// f16x3 3x3 convolution with a Winograd F(4,3) transform ALONG Y (gfx950): four output rows cost six 1x3 row convolutions instead of
+// f16x3 3x3 convolution (ResBlock in_layers / out_layers convs, guided_diffusion/unet_openai.py:183-187,207-214 of the reference) with a
+// Winograd F(4,3) transform ALONG Y (gfx950): four output rows cost six 1x3 row convolutions instead of
 // twelve, i.e. 4.5 instead of 9 matrix-core taps per output pixel (x 3 fp16 products each; the F(2,3) form of conv_wino_f16x3.hip
 // spends 6), and the transformed input is 1.5 x the input instead of 2 x.  Operand precision is unchanged (22 significant bits per
 // operand, fp32 accumulation); the transform's constants (points 0, +-1, +-2, inf) amplify rounding by ~2.5 x against the direct fp32
