@@ -83,7 +83,7 @@ __device__ __forceinline__ void w4_fence(f32x4 (&A)[4][4]) {
 template <int RMODE>
 __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int RA = 2, RB = 3;
+    constexpr int RA = 3, RB = 3;                          // activation ring: the stage of group g + 2 is requested while group g runs
     constexpr int SP = 128 * 32;                           // halves per plane of a stage (8 KB)
     constexpr int STG = 2 * SP;                            // halves per stage: [hi | lo][128][32]
     constexpr int BOFF = 0, AOFF = RB * STG;               // weight ring first: a shifted row -1 of activation stage 0 stays inside LDS
@@ -110,22 +110,23 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
     auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, 0, 0x00020000);
     const auto rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(2 * p.b_plane * 2), 0x00020000);
     constexpr int b_lo = SP * 2, a_lo = SP * 2;            // byte distance hi -> lo image inside a stage
-    int toffA = 0, sboff = 0;                              // scalar: channel block of the activation group being requested; weight stage of the next request
+    int toffA = 0, toffReq = 0, sboff = 0;                 // scalar: channel block of the running group / of the activation group being requested; weight stage of the next request
     bool prefetched = false;
 
     auto tile_geom = [&](int m0_, int tn_) {
         sboff = tn_ * (p.K / 32) * 16384;                                  // stage 0 of the column tile
         vtile = (const char*)p.V + (long)(m0_ >> 7) * ncb * 16384;       // the tile's stage blocks of frequency 0
         toffA = 0;
+        toffReq = 0;
     };
     // the activation stage of (channel block at toffA, frequency f): descriptor over the tile's ncb stage blocks of that frequency
     auto a_setup = [&](int f) { ra = __builtin_amdgcn_make_buffer_rsrc((void*)(vtile + f * fstride), 0, ncb * 16384, 0x00020000); };
     auto dma_a = [&](int sa, int i) {
         _Float16* st = lds + AOFF + sa * STG;
-        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * 32, 16, lanebase, toffA + wrow0, 0, 0);
-        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * 32 + SP, 16, lanebase, toffA + wrow0 + a_lo, 0, 0);
-        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * 32, 16, lanebase, toffA + wrow1, 0, 0);
-        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * 32 + SP, 16, lanebase, toffA + wrow1 + a_lo, 0, 0);
+        if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * 32, 16, lanebase, toffReq + wrow0, 0, 0);
+        if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave)) * 32 + SP, 16, lanebase, toffReq + wrow0 + a_lo, 0, 0);
+        if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * 32, 16, lanebase, toffReq + wrow1, 0, 0);
+        if (i == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, st + (16 * (2 * wave + 1)) * 32 + SP, 16, lanebase, toffReq + wrow1 + a_lo, 0, 0);
     };
     auto dma_b = [&](int sb, int i) {
         _Float16* st = lds + BOFF + sb * STG;
@@ -137,10 +138,14 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             sboff += 16384;                                // the next K step's stage
         }
     };
-    auto issue_prologue = [&]() {          // A(channel block 0, f = 0) B(0) B(1)
+    auto issue_prologue = [&]() {          // A(channel block 0, f = 0) A(channel block 0, f = 1) B(0) B(1)
+        toffReq = 0;
         a_setup(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_a(0, i);
+        a_setup(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma_a(1, i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_b(0, i);
 #pragma unroll
@@ -223,26 +228,27 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         WSB();
 
         // One K step = (channel block, f, dx): 48 MFMAs into the accumulators of f.  Ring slots are static: the activation stage of
-        // (channel block, f) lives in slot f & 1, the weight stage of step dxi in slot dxi.  ONE copy of the 18 steps serves every channel
+        // (channel block, f) lives in slot f % 3, the weight stage of step dxi in slot dxi.  ONE copy of the 18 steps serves every channel
         // block: in the tile's final group (last channel block, f = 5) the requests that would run past the tile are skipped by uniform
         // branches around single instructions, so that no two regions of code hold the accumulators in different registers (the
         // copies between them would sit next to matrix-core instructions the compiler cannot see).
         auto step = [&](auto fi_c, auto dxi_c, const bool last_cb) __attribute__((always_inline)) {
             constexpr int FI = decltype(fi_c)::value, DXI = decltype(dxi_c)::value;
             constexpr bool AG = FI < 4;
-            const bool lastg = FI == 5 && last_cb;                              // (compile-time false for f < 5)
-            constexpr int FN = (FI + 1) % 6;
-            constexpr int sa_n = FN & 1, sb_n = (DXI + 2) % 3;
-            constexpr int sa_r = DXI == 2 ? (FN & 1) : (FI & 1), sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;   // the NEXT step's fragments
+            const bool lastg = FI == 5 && last_cb;                              // (compile-time false for f < 5): no weight stage beyond the tile
+            const bool lastA = FI >= 4 && last_cb;                              // group g + 2 lies beyond the tile: no activation request
+            constexpr int FN = (FI + 1) % 6, F2 = (FI + 2) % 6;
+            constexpr int sa_n = F2 % 3, sb_n = (DXI + 2) % 3;
+            constexpr int sa_r = DXI == 2 ? (FN % 3) : (FI % 3), sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;   // the NEXT step's fragments
             f32x4 (&A)[4][4] = acc[FI];
-            if (DXI == 0 && !lastg) {                                           // set up the next group's activation stage ...
-                if (FI == 5) toffA += 16384;                                    // (the next group opens the next channel block)
-                a_setup(FN);
+            if (DXI == 0 && !lastA) {                                           // set up the activation stage of group g + 2 ...
+                toffReq = toffA + (FI >= 4 ? 16384 : 0);                        // (f = 4, 5: it opens the next channel block)
+                a_setup(F2);
             }
             auto early_piece = [&](int q) {
                 if (WCONV4_DIAG & 4) return;
                 if (q < 4) { if (!lastg || DXI == 0) dma_b(sb_n, q); }          // the weight stage of step s + 2
-                else if (q < 6) { if (DXI < 2 && !lastg) dma_a(sa_n, q - 4 + 2 * DXI); }    // ... requested half in this group's first, half in its second step
+                else if (q < 6) { if (DXI < 2 && !lastA) dma_a(sa_n, q - 4 + 2 * DXI); }    // ... requested half in this group's first, half in its second step
             };
             WSB();
             // P1: w_hi * x_lo | the DMA pieces of this step
@@ -258,15 +264,15 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             // every read of stage s was issued during the previous step: publish stage s + 1
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // in issue order: [B(s+1) x4, A x2] of the previous step, [B(s+2) x4, A x2] of this one.  B(s+1) must have landed; the group's
-            // last step also needs all four activation pieces.  In the final group nothing but B(s+2) of its first step is behind.
-            if (lastg) {
-                if (DXI == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (DXI == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (DXI == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // in issue order: [B(s+1) x4, A x2] of the previous step, [B(s+2) x4, A x2] of this one (A pieces in a group's first two steps
+            // only).  B(s+1) must have landed; the activation stage the next group reads was requested a whole group earlier.  In the
+            // last two groups of the tile no activation pieces are requested, in the final one no weight stage beyond its last step.
+            if (lastA) {
+                if (FI == 5 && DXI > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                if (DXI == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             }
             if (!(WCONV4_DIAG & 1)) __builtin_amdgcn_s_barrier();
             WSB();
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
 #define W4_GROUP(F) step(F{}, I0{}, last_cb); step(F{}, I1{}, last_cb); step(F{}, I2{}, last_cb);
 #pragma nounroll
         for (int cbi = 0; cbi < ncb; ++cbi) {
+            toffA = cbi * 16384;
             int last_i = __builtin_amdgcn_readfirstlane(cbi == ncb - 1 ? 1 : 0);
             asm volatile("" : "+s"(last_i));                                    // (opaque: the loop is neither peeled nor versioned on it)
             const bool last_cb = last_i != 0;
