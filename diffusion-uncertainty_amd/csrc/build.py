@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libdua_hip.so")
-SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []), ("mfma_bf16x3.hip", []), ("conv_f16x3.hip", []), ("gemm_f16x3.hip", []), ("conv_wino_f16x3.hip", []), ("conv_wino4_f16x3.hip", []), ("conv_wino_f32.hip", []), ("attention.hip", []), ("blocks.hip", []), ("backward.hip", [])]
+SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []), ("mfma_bf16x3.hip", []), ("conv_f16x3.hip", []), ("gemm_f16x3.hip", []), ("gemm_skip_f16x3.hip", []), ("conv_wino_f16x3.hip", []), ("conv_wino4_f16x3.hip", []), ("conv_wino_f32.hip", []), ("attention.hip", []), ("blocks.hip", []), ("backward.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 

@@ -1005,19 +1005,20 @@ void dua_range_set_conv_wino(unsigned long long*);
 void dua_range_set_conv_wino4(unsigned long long*);
 void dua_range_set_xtile(unsigned long long*);
 void dua_range_set_hgemm(unsigned long long*);
+void dua_range_set_sgemm(unsigned long long*);
 void dua_range_set_attention(unsigned long long*);
 static unsigned long long* g_range_buf = nullptr;
 static int g_range_on = 0;
 static void range_set_all(unsigned long long* p) {
-    dua_range_set_denoiser(p); dua_range_set_conv_wino(p); dua_range_set_conv_wino4(p); dua_range_set_xtile(p); dua_range_set_hgemm(p); dua_range_set_attention(p);
+    dua_range_set_denoiser(p); dua_range_set_conv_wino(p); dua_range_set_conv_wino4(p); dua_range_set_xtile(p); dua_range_set_hgemm(p); dua_range_set_sgemm(p); dua_range_set_attention(p);
 }
 extern "C" int dua_range_check(int on) {
     const int was = g_range_on;
     if (on && !g_range_buf) {
         if (hipMalloc((void**)&g_range_buf, 2 * sizeof(unsigned long long)) != hipSuccess) { dua_set_error("dua_range_check: hipMalloc failed"); return DUA_EHIP; }
     }
-    if (on) (void)hipMemset(g_range_buf, 0, 2 * sizeof(unsigned long long));
-    (void)hipDeviceSynchronize();
+    if (on && hipMemset(g_range_buf, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { dua_set_error("dua_range_check: hipMemset failed"); return DUA_EHIP; }
+    if (hipDeviceSynchronize() != hipSuccess) { dua_set_error("dua_range_check: device error"); return DUA_EHIP; }
     range_set_all(on ? g_range_buf : nullptr);
     g_range_on = on != 0;
     return was;

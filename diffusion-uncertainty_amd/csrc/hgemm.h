@@ -27,3 +27,18 @@ struct HGemmP {
 int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what);
 void dua_hgemm_set_workspace(void* ws, size_t bytes);
 int dua_hgemm_enabled();
+
+// Parameter block of the raw-operand f16x3 GEMM kernel (gemm_skip_f16x3.hip: k_sgemm): fp32 A (two sources concatenated along K), split on the fly.
+struct SGemmP {
+    const float *A1, *A2;        // [M][lda1] / [M][lda2] fp32; A2 optional
+    long lda1, lda2;             // floats, multiples of 4
+    const _Float16* B;           // dua_pack_weight_f16x3
+    long b_bytes;
+    const float *Cscale, *bias;
+    float* C;                    // fp32 [M][N] = acc * Cscale * out_scale + bias
+    int M, N, K1, K2, ntm, ntn;
+    float a_scale, out_scale;    // power of two applied to A before the split; alpha / a_scale
+    unsigned long long* range_ctr;   // f16x3 range check counters (NULL: off)
+};
+int dua_launch_sgemm(SGemmP& p, hipStream_t st, const char* what);
+int dua_sgemm_enabled();

@@ -1475,6 +1475,17 @@ extern "C" int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A
     DUA_REQUIRE(lda1 % 4 == 0 && (K2 == 0 || lda2 % 4 == 0) && (K2 == 0) == (A2 == nullptr), "dua_gemm_f16x3: bad A operands");
     DUA_REQUIRE(act_in == 0 || act_in == 1, "dua_gemm_f16x3: act_in must be 0 or 1");
     DUA_REQUIRE(act_scale > 0.f, "dua_gemm_f16x3: act_scale must be positive");
+    const size_t wplane = dua_bf16x3_plane_elems(N, K1 + K2);
+    // The plain form (bias only: the ADM 1x1 skip convolutions) runs on the persistent raw-operand kernel of gemm_skip_f16x3.hip.  The
+    // choice depends on the operation's FORM only, never on M: a row's result does not depend on the batch it runs in.
+    if (dua_sgemm_enabled() && !act_in && !act_out && !residual && !colsum && ldc == N && N % 4 == 0 && K1 + K2 >= 2 * BK && lda1 < (1L << 20) &&
+        lda2 < (1L << 20) && 4 * wplane < 0x7FFFFFF0ull && ((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)C) & 15) == 0)) {
+        SGemmP g{};
+        g.A1 = A1; g.A2 = A2; g.lda1 = lda1; g.lda2 = K2 ? lda2 : 0; g.B = (const _Float16*)packed; g.b_bytes = (long)(4 * wplane);
+        g.Cscale = (const float*)((const __bf16*)packed + 2 * wplane); g.bias = bias; g.C = C; g.M = M; g.N = N; g.K1 = K1; g.K2 = K2;
+        g.a_scale = act_scale; g.out_scale = alpha / act_scale;
+        return dua_launch_sgemm(g, as_stream(stream), "dua_gemm_f16x3 (sgemm)");
+    }
     XTileP p{};
     size_t plane = dua_bf16x3_plane_elems(N, K1 + K2);
     p.A1 = A1; p.A2 = A2; p.Bhi = (const __bf16*)packed; p.Blo = p.Bhi + plane; p.bias = bias; p.res = residual; p.C = C;

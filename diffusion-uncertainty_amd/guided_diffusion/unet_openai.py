@@ -110,6 +110,12 @@ class ResBlock(TimestepBlock):
                                         None if ident else self.skip_connection.bias, self.out_channels, updown=self.resample,
                                         dropmask=mask, precision=("f16w" if ctx.model.wino_single else ctx.model.precision),
                                         want_colsum=ctx.model.fuse_gn_stats, conv1_wino=w1, conv2_wino=w2, conv1_wino_m=m1, conv2_wino_m=m2)
+        if ctx.model.wino_single and not getattr(ctx.model, "_warned_f16w_composed", False):
+            # "f16w" (one fp16 product per tap) exists on the block-level C ABI only: this composed per-op path runs the THREE-product convs
+            ctx.model._warned_f16w_composed = True
+            import warnings
+            warnings.warn("precision 'f16w': a ResBlock runs on the composed per-op path (use_block_abi off, activation noise, or dropout on a "
+                          "resampling block) and uses the three-product f16x3 convolutions there", RuntimeWarning, stacklevel=2)
         st = ops.groupnorm_stats(x, skip)
         Hc = H * 2 if self.resample > 0 else (H // 2 if self.resample < 0 else H)
         Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
@@ -233,9 +239,17 @@ class _Ctx:
         if self.model.precision not in ("f16x3", "fp32") or not w:
             return 0
         if self.model.precision == "f16x3" and not self.model.wino_single:
+            s4 = ops.conv3x3_wino4_supported(N, H, W, cin, cout)
             if w is True:
-                return ops.conv3x3_wino_pick(N, H, W, cin, cout)
-            if w == 4 and ops.conv3x3_wino4_supported(N, H, W, cin, cout):
+                # The library's rule counts whole rounds of tiles, i.e. it depends on the batch.  It is evaluated at the model's PLANNING
+                # batch (wino_plan_batch, default 128 = BASELINE configs[1] per GPU), never at the batch of the call: the form of a layer
+                # - and with it every image's arithmetic - is then the same whatever batch the image runs in.
+                s2 = ops.conv3x3_wino_supported(N, H, W, cin, cout)
+                form = ops.conv3x3_wino_pick(int(getattr(self.model, "wino_plan_batch", 128)), H, W, cin, cout)
+                if form == 4 and s4:
+                    return 4
+                return 2 if s2 else (4 if s4 else 0)
+            if w == 4 and s4:
                 return 4
         return 2 if ops.conv3x3_wino_supported(N, H, W, cin, cout) else 0
 
@@ -422,9 +436,10 @@ class UNetModel(nn.Module):
         # f16x3 / fp32: 3x3 convs in a Winograd-along-y form where a kernel takes the shape (csrc/conv_wino_f16x3.hip, conv_wino_f32.hip:
         # F(2,3), 6 instead of 9 matrix-core taps per pixel; csrc/conv_wino4_f16x3.hip: F(4,3), 4.5 taps, f16x3 only) at the same operand
         # precision; results differ from the direct form at fp32-rounding level.  True = the library picks the form per shape
-        # (dua_conv3x3_f16x3_wino_pick); 2 / 4 = that form wherever it applies; False = the direct kernels.  The pick depends on the batch
-        # size (whole rounds of tiles), so with True a batch of 640 and five batches of 128 may run some layers in different forms and then
-        # agree to fp32-rounding level only; 2 or 4 keeps every batch size on the same arithmetic (bit-identical per image).
+        # (dua_conv3x3_f16x3_wino_pick, a rule over whole rounds of tiles) evaluated at `wino_plan_batch`, NOT at the batch of the call:
+        # a layer's form - and every image's arithmetic - does not depend on the batch the image runs in (bit-identical per image across
+        # batch sizes, stacked Monte-Carlo chains == one by one); 2 / 4 = that form wherever it applies; False = the direct kernels.
+        self.wino_plan_batch = 128
         self.winograd = True
         # fp32 / f16x3: the few-channel `out` conv as one-tap GEMM + tap gather (see _forward_body)
         self.out_conv_taps = True
@@ -536,6 +551,15 @@ class UNetModel(nn.Module):
         xs, ts = torch.chunk(x, n), torch.chunk(timesteps, n)
         ys = torch.chunk(y, n) if y is not None else [None] * len(xs)
         outs = []
+        # the split-K / stream-K workspace is ONE process-global buffer: concurrent chunks would fold each other's parts.  Force it off
+        # here - also when the CALLER had registered it (ops.set_split_k(True)) - and restore the caller's setting afterwards.
+        prev_splitk = ops.set_split_k(False, x.device)
+        try:
+            return self._forward_chunks(xs, ts, ys, cur, outs, out_channels_keep)
+        finally:
+            ops.set_split_k(prev_splitk, x.device)
+
+    def _forward_chunks(self, xs, ts, ys, cur, outs, out_channels_keep=None):
         for i, (xc, tc, yc) in enumerate(zip(xs, ts, ys)):
             st = self._streams[i]
             st.wait_stream(cur)

@@ -481,7 +481,10 @@ def set_split_k(on, device=None):
 
 def range_check(on):
     """Switch the f16x3 range counters on / off (dua_range_check); returns the previous setting."""
-    return bool(_lib.lib().dua_range_check(1 if on else 0))
+    was = _lib.lib().dua_range_check(1 if on else 0)
+    if was < 0:                       # DUA_EHIP: the counters could not be allocated / cleared - not "was on"
+        check(was, "dua_range_check")
+    return bool(was)
 
 
 def range_check_read(reset=True):

@@ -218,6 +218,15 @@ class UViT(nn.Module):
         xs, ts = torch.chunk(x, n), torch.chunk(timesteps, n)
         ys = torch.chunk(y, n) if y is not None else [None] * len(xs)
         outs = []
+        # the split-K / stream-K workspace is ONE process-global buffer: concurrent chunks would fold each other's parts.  Force it off
+        # here - also when the CALLER had registered it (ops.set_split_k(True)) - and restore the caller's setting afterwards.
+        prev_splitk = ops.set_split_k(False, x.device)
+        try:
+            return self._forward_chunks(xs, ts, ys, cur, outs)
+        finally:
+            ops.set_split_k(prev_splitk, x.device)
+
+    def _forward_chunks(self, xs, ts, ys, cur, outs):
         for i, (xc, tc, yc) in enumerate(zip(xs, ts, ys)):
             st = self._streams[i]
             st.wait_stream(cur)

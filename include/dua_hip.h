@@ -370,6 +370,12 @@ int dua_layernorm_split_f16x3(const float* x, const float* gamma, const float* b
 int dua_gemm_f16x3(const float* A1, int K1, long lda1, const float* A2, int K2, long lda2, const void* packed,
                    const float* bias, const float* residual, long ldr, float* C, long ldc, int M, int N, int act_in,
                    int act_out, float alpha, float* colsum, float act_scale, void* stream);
+/* The plain form of dua_gemm_f16x3 (bias only, no activation / residual / column sums, dense C: the ADM 1x1 skip convolutions over the
+ * virtual concat, unet_openai.py:219-223,257,662) runs on the persistent raw-operand kernel csrc/gemm_skip_f16x3.hip (k_sgemm: 256-row
+ * tiles, LDS-DMA of the raw fp32 rows, split in registers after the fragment read).  A/B switch, process-global, correct kernels only:
+ * nt = 0 picks the tile width per shape (default), 2 / 4 force 128 / 256 columns (same results bit for bit), -1 sends these calls back
+ * to the previous engine (k_xtile; different rounding order). */
+int dua_set_sgemm_mode(int nt);
 /* Fused attention (dua_attention) with both products on the f16x3 split: q, k, P and v scaled by powers of two and split
  * into fp16 hi + lo, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (2^-22 per product), softmax in fp32.  Head dims <= 256 (above 128: a
  * 512-register build of the same kernel, one workgroup of 128 queries per CU - ADM-128's 192- and 256-channel heads).
@@ -511,8 +517,8 @@ int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C
  * 0 < |x * plane scale| < 2^-14, hi is an fp16 subnormal - harmless (the pair stays exact to 2^-25 / scale absolutely), reported for
  * completeness.  The plane scales are static (64 for GroupNorm / SiLU / LayerNorm outputs: |x| <= 1023; 16 for raw-stream operands, GELU
  * and attention outputs: |x| <= 4094; 32 for the Winograd images): a non-zero saturation count on real checkpoints says the activations
- * exceed those bounds and the run should use precision "fp32" (INTEGRATION.md section 4).  dua_range_check returns the previous setting
- * and zeroes the counters when switched on; dua_range_check_read copies them out (reset != 0 zeroes them). */
+ * exceed those bounds and the run should use precision "fp32" (INTEGRATION.md section 4).  dua_range_check returns the previous setting (0 / 1;
+ * a negative DUA_E* code when the counters cannot be allocated or cleared) and zeroes the counters when switched on; dua_range_check_read copies them out (reset != 0 zeroes them). */
 int dua_range_check(int on);
 int dua_range_check_read(unsigned long long* saturated, unsigned long long* subnormal, int reset);
 

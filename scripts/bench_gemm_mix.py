@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--skip-presplit", action="store_true",
                     help="time the on-the-fly-split shapes ([s]) ALSO as presplit two-source GEMMs on planes, plus the pass that would write those planes")
     ap.add_argument("--hg", default="", help="dua_set_hgemm_mode: nt[,streamk]  (nt -1 = previous engine, 0 = auto, 2 / 3 / 4)")
+    ap.add_argument("--sg", type=int, default=0, help="dua_set_sgemm_mode for the on-the-fly-split shapes [s]: -1 = previous engine (k_xtile), 0 = auto, 2 / 4")
     a = ap.parse_args()
     if a.lib:
         from diffusion_uncertainty_amd import _lib as _l
@@ -52,6 +53,7 @@ def main():
     if a.hg:
         v = [int(t) for t in a.hg.split(",")]
         assert _lib.lib().dua_set_hgemm_mode(v[0], v[1] if len(v) > 1 else 1) == 0
+    assert _lib.lib().dua_set_sgemm_mode(a.sg) == 0
     dev = torch.device("cuda")
     if a.splitk:
         ops.set_split_k(True, dev)
@@ -69,7 +71,7 @@ def main():
         if kind == "s":
             a1 = torch.randn(M, K1, device=dev)
             a2 = torch.randn(M, K2, device=dev) if K2 else None
-            fn = lambda: ops.gemm_f16x3(a1, pk, N, bias=b, a2=a2, colsum=(a.set == "adm"))  # noqa: E731
+            fn = lambda: ops.gemm_f16x3(a1, pk, N, bias=b, a2=a2)  # noqa: E731   (the ResBlock's call: bias only, blocks.hip / unet_openai.py)
         else:
             x = torch.randn(M, K, device=dev) * ops.F16X3_ACT_SCALE
             hi = x.half()

@@ -119,8 +119,13 @@ def test_full_size_adm128_batch_consistency():
         same += int(torch.equal(one, full[i:i + 1]))
     print(f"ADM-128 f16x3 batch 9 vs batch 1: max abs difference {worst:.3e} ({same} of 4 samples bit-identical); output scale {full.abs().max().item():.3f}")
     assert worst < 2e-5
-    # the default picks the Winograd form per shape AND batch size; with one form everywhere (winograd = 4: F(4,3) where its kernel takes
-    # the shape) a sample's result does not depend on the batch it runs in
+    # the default evaluates the form rule at the model's planning batch, not at the batch of the call - every layer runs the
+    # same form at batch 9 and at batch 1, and (every kernel's accumulation order being per output row) the results are the same bits;
+    # a batch of 9 equals a batch of 5 followed by a batch of 4
+    assert same == 4, "default dispatch: a sample's result must not depend on the batch it runs in"
+    parts = torch.cat([m(x[:5].contiguous(), t[:5], y=y[:5]), m(x[5:].contiguous(), t[5:], y=y[5:])])
+    assert torch.equal(parts, full)
+    # ... and so does one form everywhere (winograd = 4: F(4,3) where its kernel takes the shape)
     m.winograd = 4
     full4 = m(x, t, y=y)
     for i in (0, 4, 8):

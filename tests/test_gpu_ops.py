@@ -578,6 +578,68 @@ def test_gemm_f16x3(ops, M, N, K1, K2):
     assert torch.isfinite(cb).all() and ((cb.cpu().double() - refb).abs() / refb.abs().amax(dim=0, keepdim=True)).max().item() < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [(4096, 256, 256, 256), (33000, 256, 512, 256), (700, 512, 768, 512), (300, 1024, 1024, 1024), (257, 768, 1280, 0),
+                                        (5, 2048, 256, 0), (1000, 72, 64, 0), (9000, 136, 96, 32), (64, 16, 1152, 0), (65536, 256, 32, 32)])
+def test_gemm_f16x3_skip_kernel(ops, M, N, K1, K2):
+    """The plain form of dua_gemm_f16x3 (bias only: the ADM 1x1 skip convolutions over the virtual concat, unet_openai.py:219-223,257,662)
+    on the persistent raw-operand kernel k_sgemm (csrc/gemm_skip_f16x3.hip): held to the exact fp32 engine's error against fp64, within
+    rounding of the previous engine (k_xtile), bit-identical between its two tile widths and for any subset of the rows (batch-invariant)."""
+    from diffusion_uncertainty_amd import _lib
+    L = _lib.lib()
+    a1 = rnd(50, M, K1) * torch.logspace(-3, 2, K1)             # residual-stream-like dynamic range
+    a2 = rnd(51, M, K2) * 3 if K2 else None
+    w, b = rnd(52, N, K1 + K2) / math.sqrt(K1 + K2) * torch.logspace(-2, 1, N).reshape(-1, 1), rnd(53, N) * 0.1
+    a = a1 if a2 is None else torch.cat([a1, a2], 1)
+    ref = a.double() @ w.double().t() + b.double()
+    sc = ref.abs().amax(dim=0, keepdim=True)
+    dv = lambda t: None if t is None else t.to(dev)
+    pk = ops.pack_weight_f16x3(w.to(dev))
+    try:
+        assert L.dua_set_sgemm_mode(0) == 0
+        c = ops.gemm_f16x3(dv(a1), pk, N, bias=dv(b), a2=dv(a2))
+        assert L.dua_set_sgemm_mode(2) == 0
+        c2 = ops.gemm_f16x3(dv(a1), pk, N, bias=dv(b), a2=dv(a2))
+        assert L.dua_set_sgemm_mode(4) == 0
+        c4 = ops.gemm_f16x3(dv(a1), pk, N, bias=dv(b), a2=dv(a2))
+        assert L.dua_set_sgemm_mode(-1) == 0
+        cx = ops.gemm_f16x3(dv(a1), pk, N, bias=dv(b), a2=dv(a2))              # previous engine (k_xtile)
+        assert L.dua_set_sgemm_mode(0) == 0
+        # a subset of the rows (another "batch"): same bits per row
+        lo, hi = M // 3, M // 3 + max(1, M // 2)
+        cs = ops.gemm_f16x3(dv(a1[lo:hi].contiguous()), pk, N, bias=dv(b), a2=dv(None if a2 is None else a2[lo:hi].contiguous()))
+        nb = ops.gemm_f16x3(dv(a1), pk, N, a2=dv(a2))                          # no bias
+    finally:
+        L.dua_set_sgemm_mode(0)
+    c32 = ops.gemm(dv(a1), w.to(dev), bias=dv(b), a2=dv(a2))
+    e, ex, e32 = [((t.cpu().double() - ref).abs() / sc).max().item() for t in (c, cx, c32)]
+    print(f"skip gemm rel err {e:.2e}  previous engine {ex:.2e}  fp32-MFMA {e32:.2e}")
+    assert e < max(2 * e32, 2e-6), (e, e32)
+    assert torch.equal(c, c2) and torch.equal(c, c4), "tile widths must agree bit for bit"
+    assert torch.equal(cs, c[lo:hi]), "a row's result must not depend on the rows around it"
+    assert ((nb.cpu().double() + b.double() - c.cpu().double()).abs() / sc).max().item() < 1e-6
+
+
+def test_gemm_f16x3_skip_kernel_saturation_and_range_check(ops):
+    """Out-of-range operands on the raw-operand kernel: hi saturates and lo carries the remainder (finite, close); the range check counts
+    each operand element once (two waves share a row block, several column tiles share a row tile)."""
+    M, K, N = 600, 128, 384
+    a = rnd(60, M, K)
+    a[3, 5] = 6000.0                                            # * 16 = 96000 > 65504
+    a[400, 77] = 1e-7                                           # * 16 < 2^-14: subnormal hi
+    w = rnd(61, N, K) / math.sqrt(K)
+    pk = ops.pack_weight_f16x3(w.to(dev))
+    c = ops.gemm_f16x3(a.to(dev), pk, N)
+    ref = a.double() @ w.double().t()
+    assert torch.isfinite(c).all() and ((c.cpu().double() - ref).abs() / ref.abs().amax(dim=0, keepdim=True)).max().item() < 1e-3
+    ops.range_check(True)
+    try:
+        ops.gemm_f16x3(a.to(dev), pk, N)
+        sat, sub = ops.range_check_read(reset=True)
+    finally:
+        ops.range_check(False)
+    assert (sat, sub) == (1, 1), (sat, sub)
+
+
 def test_row_shift_zero_padding_forms_agree(ops):
     """the row-shift conv gets its left / right zero padding from DS reads beyond the LDS allocation.  The same kernel
     built with -DDUA_RS_ZERO_SELECT=1 (scripts/diag/build/libdua_hip_select.so, made by __graft_entry__.build()) zeroes those

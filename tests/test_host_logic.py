@@ -241,6 +241,28 @@ def test_precision_modes_pick_operand_formats():
         _Ctx(m)
 
 
+def test_winograd_form_does_not_depend_on_the_batch():
+    """with the default `winograd = True` the F(2,3) / F(4,3) choice of a layer is the library's whole-rounds rule evaluated at
+    the model's planning batch (wino_plan_batch), so an image's arithmetic is the same whatever batch it runs in; the planning batch of
+    128 reproduces the headline's per-shape pick (host logic only: the pick and the support predicates are host functions of the library)."""
+    from diffusion_uncertainty_amd import ops
+    from diffusion_uncertainty_amd.guided_diffusion.unet_openai import UNetModel, _Ctx
+    m = UNetModel(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1, attention_resolutions=(2,),
+                  channel_mult=(1, 2), num_classes=10, num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)
+    m.precision = "f16x3"
+    ctx = _Ctx(m)
+    layers = [(128, 128, 256, 256), (128, 128, 512, 256), (64, 64, 256, 256), (32, 32, 512, 512), (16, 16, 768, 768), (16, 16, 1536, 768),
+              (8, 8, 1024, 1024), (8, 8, 2048, 1024)]
+    for H, W, cin, cout in layers:
+        forms = {ctx.wino_form(N, H, W, cin, cout) for N in (1, 2, 5, 9, 128, 256, 640)}
+        assert len(forms) == 1, (H, W, cin, cout, forms)
+        assert forms.pop() == ops.conv3x3_wino_pick(128, H, W, cin, cout)
+    # the rule itself does depend on the batch (that is why it is evaluated at a fixed one): 16^2 x 768 is F(2,3) at 128 images, F(4,3) at 640
+    assert ops.conv3x3_wino_pick(128, 16, 16, 768, 768) == 2 and ops.conv3x3_wino_pick(640, 16, 16, 768, 768) == 4
+    m.wino_plan_batch = 640
+    assert {_Ctx(m).wino_form(N, 16, 16, 768, 768) for N in (1, 128, 640)} == {4}
+
+
 def test_winograd_f23_along_y_identity():
     """The algebra csrc/conv_wino_f16x3.hip implements, restated in fp64 torch: with V = (d0-d2, d1+d2, d2-d1, d1-d3) over the input rows
     2j-1 .. 2j+2 (zero outside the image), U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) over the kernel rows and M_f = conv1x3(V_f, U_f) with
