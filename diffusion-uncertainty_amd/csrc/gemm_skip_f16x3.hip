@@ -11,8 +11,11 @@
 //     128-byte pieces - every piece reads eight whole 128-byte lines of A, once;
 //   * the split a * S = hi + lo (fp16 hi, fp16 remainder; S a power of two) happens in REGISTERS after the fragment read, four VALU
 //     operations per element between the MFMAs of the same step - no staging registers across the barrier, no ds_write, no second LDS
-//     image.  The two waves that share a row block (wn = 0, 1) both split it: with all N = 256 columns of the 128^2 / 64^2 levels in ONE
-//     tile an operand element is split twice per launch instead of 2 x ceil(N / 128) times;
+//     image.  The eight waves tile the 256 rows (wave w = rows 32 w .. + 31, ALL columns of the tile): every operand element is split by
+//     exactly one wave, once per column tile - with all N = 256 columns of the 128^2 / 64^2 levels in ONE tile, once per launch (the
+//     first version of this kernel used k_hgemm's 4 x 2 wave grid, where the two waves of a row block both split it: the split was 19 %
+//     of the launch time, profiles/r05b_sgemm_diag.txt).  The weight fragments stream through two register sets, one pair of channel
+//     blocks ahead of the MFMAs that use them;
 //   * 256 x 256 or 256 x 128 tiles chosen per shape by whole rounds on 256 CUs; both widths run the same per-element sequence of
 //     products, so the result does not depend on the width (or on M: per-image results are batch-invariant).
 // LDS image of an activation stage: row r = 128 bytes, 16-byte chunk c at chunk position c ^ g(r), g(r) = (((r & 15) >> 1) + 6) & 7.
@@ -36,57 +39,59 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SG_DIAG
 #define SG_DIAG 0
 #endif
+#ifndef SG_STORE_AUX                  // cache policy bits of the output stores (A/B builds: 2 = non-temporal)
+#define SG_STORE_AUX 0
+#endif
+#ifndef SG_SPLIT_SPREAD
+#define SG_SPLIT_SPREAD 0
+#endif
 #define SG_TAIL_WAIT 8               // vector-memory operations an epilogue ALWAYS issues after the next item's prologue DMA (stores)
 
-// hi = fp16(x S) (RNE, saturating), lo = fp16(x S - hi): the arithmetic of split4h (mfma_bf16x3.hip) on the eight floats of a fragment.
-__device__ __forceinline__ void sg_split8(const f32x4 r0, const f32x4 r1, float sc, h16x8& hi, h16x8& lo, bool rc_on, unsigned& n_sat, unsigned& n_sub) {
-    const float f[8] = {r0[0] * sc, r0[1] * sc, r0[2] * sc, r0[3] * sc, r1[0] * sc, r1[1] * sc, r1[2] * sc, r1[3] * sc};
+// hi = fp16(x S) (RNE, saturating), lo = fp16(x S - hi): the arithmetic of split4h (mfma_bf16x3.hip) on two neighbouring floats of a
+// fragment -> one packed register of hi halves, one of lo halves (nine VALU operations; a step's 16 floats per lane are eight such chunks,
+// placed one by one between the MFMAs of the step's last pairs).
+__device__ __forceinline__ void sg_split2(float a, float b, float sc, unsigned& hp, unsigned& lp, bool rc_on, unsigned& n_sat, unsigned& n_sub) {
+    const float f0 = a * sc, f1 = b * sc;
     if (rc_on) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float af = fabsf(f[j]);
-            n_sat += af > 65504.f ? 1u : 0u;
-            n_sub += (af > 0.f && af < 6.103515625e-05f) ? 1u : 0u;
-        }
+        const float a0 = fabsf(f0), a1 = fabsf(f1);
+        n_sat += (a0 > 65504.f ? 1u : 0u) + (a1 > 65504.f ? 1u : 0u);
+        n_sub += ((a0 > 0.f && a0 < 6.103515625e-05f) ? 1u : 0u) + ((a1 > 0.f && a1 < 6.103515625e-05f) ? 1u : 0u);
     }
-    unsigned hp[4], lp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float c0 = __builtin_amdgcn_fmed3f(f[2 * j], -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(f[2 * j + 1], -65504.f, 65504.f);
-        const h16x2 h2 = {(_Float16)c0, (_Float16)c1};
-        hp[j] = __builtin_bit_cast(unsigned, h2);
-        const float g0 = __builtin_amdgcn_fmed3f(f[2 * j], -131008.f, 131008.f), g1 = __builtin_amdgcn_fmed3f(f[2 * j + 1], -131008.f, 131008.f);
-        unsigned d;
-        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(g0), "v"(hp[j]));
-        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(g1), "v"(hp[j]));
-        lp[j] = d;
-    }
-    hi = __builtin_bit_cast(h16x8, (u32x4){hp[0], hp[1], hp[2], hp[3]});
-    lo = __builtin_bit_cast(h16x8, (u32x4){lp[0], lp[1], lp[2], lp[3]});
+    const float c0 = __builtin_amdgcn_fmed3f(f0, -65504.f, 65504.f), c1 = __builtin_amdgcn_fmed3f(f1, -65504.f, 65504.f);
+    const h16x2 h2 = {(_Float16)c0, (_Float16)c1};
+    hp = __builtin_bit_cast(unsigned, h2);
+    const float g0 = __builtin_amdgcn_fmed3f(f0, -131008.f, 131008.f), g1 = __builtin_amdgcn_fmed3f(f1, -131008.f, 131008.f);
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(g0), "v"(hp));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(d) : "v"(g1), "v"(hp));
+    lp = d;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Epilogue of one 256 x (64 NT) tile: k_hgemm's patch form (channel-block pairs of one 16-row block through a 16 x 128-byte LDS patch
-// of the wave, two patches alternating, whole 128-byte rows out) without residual / extra planes / column sums.  sq / bq: the column
-// scales and biases of the wave's NT pairs (channels 4 (lane & 7) .. + 3 of pair jp), loaded by the caller BEFORE the next item's
-// prologue DMA was issued, so that waiting for them does not wait for that DMA (vmcnt retires in order).  Every output store is a
-// buffer store that ALWAYS issues (lanes outside the tensor get an out-of-range offset, which the buffer unit drops).
+// of the wave, two patches alternating, whole 128-byte rows out) without residual / extra planes / column sums.  sqv / bqv: the column
+// scales (times out_scale) and biases of columns n0 + 4 lane .. + 3 - the tile's 64 NT columns spread over the wave, 8 registers - loaded
+// by the caller BEFORE the next item's prologue DMA was issued, so that waiting for them does not wait for that DMA (vmcnt retires in
+// order); the lane that stores columns 32 jp + 4 (lane & 7) .. + 3 fetches them from lane 8 jp + (lane & 7) by ds_bpermute, once per
+// pair.  Every output store is a buffer store that ALWAYS issues (lanes outside the tensor get an out-of-range offset: dropped).
 template <int NT>
-__device__ __forceinline__ void sgemm_epilogue(const SGemmP& p, f32x4 (&acc)[2 * NT][4], const float4 (&sq)[NT], const float4 (&bq)[NT], char* pw,
+__device__ __forceinline__ void sgemm_epilogue(const SGemmP& p, f32x4 (&acc)[4 * NT][2], const float4 sqv, const float4 bqv, char* pw,
                                                int wave, int lane, int m0, int n0) {
     static_assert(8 * NT >= SG_TAIL_WAIT, "the item-start wait counts on this many stores");
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));             // keep the epilogue's addresses out of the K loop's register budget
-    const int wm = wave >> 1, wn = wave & 1;
+    // the lane id is recomputed here (volatile: not shared with the K loop's copy, which would live - spilled - across the loop; its reload
+    // in front of the first patch write would be an s_waitcnt vmcnt(0), i.e. a wait for the prologue DMA just queued)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    (void)lane;
     const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
-    const int row0 = m0 + wm * 64;
+    const int row0 = m0 + wave * 32;
     const unsigned OOB = 0xFFFFFFF0u;
-    constexpr int T = 4 * NT;                                    // slots (pair jp = t >> 2, row block i = t & 3)
+    constexpr int T = 4 * NT;                                    // slots (pair jp = t >> 1, row block i = t & 1)
     const int wr_off = lr_e * 128, wr_sw = (lr_e >> 1) & 7;
     auto patch_put = [&](int t) {
         char* b = pw + (t & 1) * 2048 + wr_off;
-        *(f32x4*)(b + 16 * (lc_e ^ wr_sw)) = acc[2 * (t >> 2)][t & 3];
-        *(f32x4*)(b + 16 * ((4 + lc_e) ^ wr_sw)) = acc[2 * (t >> 2) + 1][t & 3];
+        *(f32x4*)(b + 16 * (lc_e ^ wr_sw)) = acc[2 * (t >> 1)][t & 1];
+        *(f32x4*)(b + 16 * ((4 + lc_e) ^ wr_sw)) = acc[2 * (t >> 1) + 1][t & 1];
     };
     const long crem = ((long)p.M - m0) * p.N * 4;
     const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (long)m0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
@@ -102,19 +107,30 @@ __device__ __forceinline__ void sgemm_epilogue(const SGemmP& p, f32x4 (&acc)[2 *
         }
     };
     patch_get(0, pa[0]);
+    float sq[4], bq[4];
+    auto gather = [&](int jp) {
+        const int src = 4 * (8 * jp + pc_e);
+        const float s_[4] = {sqv.x, sqv.y, sqv.z, sqv.w}, b_[4] = {bqv.x, bqv.y, bqv.z, bqv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sq[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s_[k])));
+            bq[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(b_[k])));
+        }
+    };
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const int jp = t >> 2, i = t & 3;
-        const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
+        const int jp = t >> 1, i = t & 1;
+        const int c = n0 + 32 * jp + 4 * pc_e;
         const bool cok = c < p.N;
+        if (i == 0) gather(jp);
         if (t + 1 < T) patch_get(t + 1, pa[(t + 1) & 1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x4 a = pa[t & 1][h];
             const int row = row0 + 16 * i + 8 * h + pr_e;
-            const u32x4 vb = {__float_as_uint(fmaf(a[0], sq[jp].x, bq[jp].x)), __float_as_uint(fmaf(a[1], sq[jp].y, bq[jp].y)),
-                              __float_as_uint(fmaf(a[2], sq[jp].z, bq[jp].z)), __float_as_uint(fmaf(a[3], sq[jp].w, bq[jp].w))};
-            __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (cok && row < p.M) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, 0);
+            const u32x4 vb = {__float_as_uint(fmaf(a[0], sq[0], bq[0])), __float_as_uint(fmaf(a[1], sq[1], bq[1])),
+                              __float_as_uint(fmaf(a[2], sq[2], bq[2])), __float_as_uint(fmaf(a[3], sq[3], bq[3]))};
+            __builtin_amdgcn_raw_buffer_store_b128(vb, rc, (cok && row < p.M) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB, 0, SG_STORE_AUX);
         }
         if (t + 2 < T) patch_put(t + 2);         // (its patch was read for slot t: the LDS queue is in order)
     }
@@ -124,8 +140,8 @@ __device__ __forceinline__ void sgemm_epilogue(const SGemmP& p, f32x4 (&acc)[2 *
 template <int NT, bool RC>
 __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NB = 2 * NT;                               // 16-channel blocks of a wave (wave tile = 64 rows x 32 NT channels)
-    constexpr int HB = 2, H2 = NB / HB;                      // the weight fragments are held two channel blocks at a time
+    constexpr int NB = 4 * NT;                               // 16-channel blocks of a wave (wave tile = 32 rows x 64 NT channels: all columns of the tile)
+    constexpr int G = NB / 2;                                // ... taken in pairs (even: pair g's weight fragments live in register set g & 1)
     constexpr int RA = 3, RB = NT == 2 ? 3 : 2;              // ring depths (stages)
     constexpr int ABY = SG_ROWS * 128;                       // bytes per activation stage (raw fp32 rows)
     constexpr int BPL = 64 * NT * 64, BBY = 2 * BPL;         // weight stage: hi | lo planes of 64 NT rows x 64 B
@@ -134,7 +150,6 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
     __shared__ __attribute__((aligned(16))) char lds[RA * ABY + RB * BBY];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
     const int nk = (p.K1 + p.K2) / 32, nk1 = p.K1 / 32;
     // persistent workgroups; whole tiles chunked per XCD (blockIdx % 8): neighbouring row tiles of the same operand panel share an L2
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = (gridDim.x + 7 - xcd) >> 3;
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
         const long rows = (long)p.M - m0_;
         const long rec1 = rows * p.lda1 * 4, rec2 = rows * p.lda2 * 4;
         ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A1 + (long)m0_ * p.lda1), 0, (int)(rec1 < 0x7FFFFFF0L ? rec1 : 0x7FFFFFF0L), 0x00020000);
-        if (p.K2) ra2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 + (long)m0_ * p.lda2), 0, (int)(rec2 < 0x7FFFFFF0L ? rec2 : 0x7FFFFFF0L), 0x00020000);
+        ra2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 + (long)m0_ * p.lda2), 0, (int)(rec2 < 0x7FFFFFF0L ? rec2 : 0x7FFFFFF0L), 0x00020000);
         lda4_1 = (unsigned)p.lda1 * 4u;
         lda4_2 = (unsigned)p.lda2 * 4u;
         ka = 0;
@@ -227,11 +242,8 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
     const int g_l = ((lr >> 1) + 6) & 7;
     const int offa_l = lr * 128 + 16 * ((2 * lc) ^ g_l);                   // first chunk of this lane's raw fragment (the second: ^ 16)
     const int offb_l = lr * 64 + 16 * (lc ^ (2 * ((lr >> 2) & 1)));        // this lane's weight fragment chunk inside a 16-row block
-    int axs[RA], bws[RB];
-#pragma unroll
-    for (int s_ = 0; s_ < RA; ++s_) axs[s_] = s_ * ABY + wm * 64 * 128 + offa_l;
-#pragma unroll
-    for (int s_ = 0; s_ < RB; ++s_) bws[s_] = BOFF + s_ * BBY + wn * 32 * NT * 64 + offb_l;
+    // (ring slots are run-time scalars: a fragment address is this per-lane base + slot * stage bytes, one v_add per base and step)
+    const int axb = wave * 32 * 128 + offa_l, bwb = BOFF + offb_l;
 
     unsigned n_sat = 0, n_sub = 0;                           // f16x3 range check (debug facility, its own instantiation): counted once per operand element
 
@@ -245,29 +257,41 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
         }
         const int m0 = (tile / p.ntn) * SG_ROWS, n0 = (tile % p.ntn) * 64 * NT;
         const bool after_epilogue = prefetched;
-        const bool rc_on = RC && wn == 0 && n0 == 0;
+        const bool rc_on = RC && n0 == 0;
         prefetched = false;
 
-        f32x4 acc[NB][4];
+        f32x4 acc[NB][2];
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        h16x8 xh[4], xl[4], wh[HB], wl[HB];
-        f32x4 raw[4][2];
-        auto rd_raw = [&](int sa, int i) {
-            raw[i][0] = *(const f32x4*)(ldsb + axs[sa] + i * 2048);
-            raw[i][1] = *(const f32x4*)(ldsb + (axs[sa] ^ 16) + i * 2048);
+            for (int i = 0; i < 2; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        h16x8 xh[2], xl[2];                                  // [row block]: this step's fragments
+        unsigned nhu[2][4], nlu[2][4];                       // the next step's, chunk by chunk (parked: xh / xl are in use until the step's last MFMAs)
+        h16x8 wh[2][2], wl[2][2];                            // [register set][block of the pair]
+        f32x4 raw[2];                                        // (one row block at a time)
+        int ax0 = 0, ax1 = 0, bw_cur = 0, bw_nxt = 0;       // fragment address registers of the step (set at its start)
+        auto rd_raw = [&](int i) {                           // row block i of the NEXT stage's raw rows (item start: of stage 0)
+            raw[0] = *(const f32x4*)(ldsb + ax0 + i * 2048);
+            raw[1] = *(const f32x4*)(ldsb + ax1 + i * 2048);
         };
-        auto split = [&](int i) {
-            if (SG_DIAG & 2) {
-                xh[i] = __builtin_bit_cast(h16x8, raw[i][0]);
-                xl[i] = __builtin_bit_cast(h16x8, raw[i][1]);
-            } else {
-                sg_split8(raw[i][0], raw[i][1], p.a_scale, xh[i], xl[i], rc_on, n_sat, n_sub);
+        auto chunk = [&](int c) {                            // chunk c & 3 of the raw fragment in registers -> packed hi / lo halves of row block c >> 2
+            const int i = c >> 2, j = c & 3;
+            const f32x4 r = raw[j >> 1];
+            if (SG_DIAG & 2) { nhu[i][j] = __float_as_uint(r[2 * (j & 1)]); nlu[i][j] = __float_as_uint(r[2 * (j & 1) + 1]); }
+            else sg_split2(r[2 * (j & 1)], r[2 * (j & 1) + 1], p.a_scale, nhu[i][j], nlu[i][j], rc_on, n_sat, n_sub);
+        };
+        auto adopt = [&]() {                                 // the parked fragments become the current ones
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xh[i] = __builtin_bit_cast(h16x8, (u32x4){nhu[i][0], nhu[i][1], nhu[i][2], nhu[i][3]});
+                xl[i] = __builtin_bit_cast(h16x8, (u32x4){nlu[i][0], nlu[i][1], nlu[i][2], nlu[i][3]});
             }
         };
-        auto rd_w = [&](int sb, int pl, int jj) -> h16x8 { return *(const h16x8*)(ldsb + bws[sb] + (pl * BPL + jj * 1024)); };
+        auto rd_wq = [&](int base, int g, int set, int q) {  // q-th of the four fragments of pair g: hi a, hi b, lo a, lo b
+            const h16x8 v = *(const h16x8*)(ldsb + base + ((q >> 1) * BPL + (2 * g + (q & 1)) * 1024));
+            if (q < 2) wh[set][q] = v;
+            else wl[set][q - 2] = v;
+        };
 #define GSB() __builtin_amdgcn_sched_barrier(0)
 
         // ---- item start: the first stages have landed; behind them in the (in-order) queue are only the previous epilogue's
@@ -275,23 +299,44 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
         if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_TAIL_WAIT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        ax0 = axb; ax1 = axb ^ 16; bw_cur = bwb;
+        rd_raw(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rd_raw(0, i);
+        for (int q = 0; q < 4; ++q) rd_wq(bw_cur, 0, 0, q);
 #pragma unroll
-        for (int jj = 0; jj < HB; ++jj) { wh[jj] = rd_w(0, 0, jj); wl[jj] = rd_w(0, 1, jj); }
+        for (int c = 0; c < 4; ++c) chunk(c);
+        rd_raw(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split(i);
+        for (int c = 4; c < 8; ++c) chunk(c);
+        adopt();
+        int sa = 0, sb = 0;                                  // ring slots of the current stage
         GSB();
 
-        // One K step: 12 NB MFMAs per wave.  Stage s lives in activation slot SA_ = s % 3 and weight slot SB_ = s % RB (compile-time: the
-        // loop body is six steps).  `more`: a stage s + 1 exists; `pre`: a stage s + 2 exists and is requested in this step.  The last
-        // half's third product runs row block by row block: once block i's hi fragment has had its last use, the raw fragment of the
-        // NEXT stage's block i (read one block earlier) is split into xh[i] / xl[i] - no second set of fragment registers.
-        auto step = [&](auto sa_c, auto sb_c, auto tail_c, bool more_rt, bool pre_rt) __attribute__((always_inline)) {
-            constexpr int SA_ = decltype(sa_c)::value, SB_ = decltype(sb_c)::value;
-            constexpr bool TAIL = decltype(tail_c)::value;
-            constexpr int sa_n = (SA_ + 2) % RA, sb_n = (SB_ + 2) % RB, sa_r = (SA_ + 1) % RA, sb_r = (SB_ + 1) % RB;
-            const bool more = TAIL ? more_rt : true, pre = TAIL ? pre_rt : true;
+        // One K step: 6 NB MFMAs per wave, pair by pair of channel blocks (a, b) x the two row blocks: w_hi x_lo | w_hi x_hi | w_lo x_hi,
+        // so an accumulator is touched every fourth MFMA.  Stage s lives in activation slot sa = s % 3 and weight slot sb = s % RB
+        // (run-time scalars), its fragments in xh / xl.  `more`: a stage s + 1 exists; `pre`: a stage s + 2 exists and is requested in
+        // this step - both compile-time: the item's last two steps are their own straight-line instances behind the loop, so no step
+        // carries a run-time condition.  While pair g runs, the weight fragments of pair g + 1 are read into the other register set and
+        // (first pair) the DMA pieces go out, one per MFMA pair.
+        // The operand split of stage s + 1 (eight nine-operation chunks per lane) runs under the last pair's MFMAs, behind the barrier.
+        // SG_SPLIT_SPREAD = 1 (A/B build) spreads it over the step's last three pairs instead, one chunk per three MFMAs - a wave's rows of a
+        // stage are written by its OWN DMA pieces, so it needs no barrier for them, only its own counted vmcnt (SPLIT_WAIT: everything
+        // queued behind those four pieces stays in flight).  Measured no better (mix 9.66 against 9.54 ms per forward, 128^2 1.97 against
+        // 1.92 ms: the earlier wait shortens the prefetch distance of the HBM-streamed operand; profiles/r05e_sgemm_diag.txt): the
+        // split's cost (13 % of the launch against a build without it) is not one of placement.
+        // Before the LAST pair every read of stage s's weights has been issued: lgkmcnt(0), the counted vmcnt, the barrier that publishes
+        // stage s + 1's weights; under the last pair's MFMAs the wave reads the first weight pair of stage s + 1 and (weight ring of two)
+        // requests the weight pieces of stage s + 2 into the slot this step has just finished reading.
+        auto step = [&](auto more_c, auto pre_c) __attribute__((always_inline)) {
+            constexpr bool more = decltype(more_c)::value, pre = decltype(pre_c)::value;
+            constexpr int GS = G - 3;                        // first pair of the split (>= 1: the early pieces all go out in pair 0)
+            static_assert(GS >= 1 && 4 + (RB == 3 ? NT : 0) <= 6, "schedule of a step");
+            constexpr int SPLIT_WAIT = pre ? 8 : NT;         // queue behind stage s + 1's activation pieces: its weight pieces (NT) [+ stage s + 2's pieces]
+            static_assert(!pre || NT + 4 + (RB == 3 ? NT : 0) == 8, "SPLIT_WAIT");
+            const int sa_r = sa + 1 == RA ? 0 : sa + 1, sa_n = sa_r + 1 == RA ? 0 : sa_r + 1;
+            const int sb_r = sb + 1 == RB ? 0 : sb + 1, sb_n = RB == 2 ? sb : (sb_r + 1 == RB ? 0 : sb_r + 1);
+            ax0 = axb + sa_r * ABY; ax1 = (axb ^ 16) + sa_r * ABY;
+            bw_cur = bwb + sb * BBY; bw_nxt = bwb + sb_r * BBY;
             if (pre) a_setup();
             auto early_piece = [&](int q) {
                 if (q < 4) { if (pre) dma_a(sa_n, q); }
@@ -299,118 +344,81 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
             };
             GSB();
 #pragma unroll
-            for (int h = 0; h < H2; ++h) {
-                const bool lasth = h == H2 - 1;
-                // P1: w_hi * x_lo | the early DMA pieces (before the step's barrier), one per MFMA pair
-#pragma unroll
-                for (int jj = 0; jj < HB; ++jj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[h * HB + jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xl[i], acc[h * HB + jj][i], 0, 0, 0);
-                        GSB();
-                        const int m_ = jj * 4 + i;
-                        if ((m_ & 1) == 0) { early_piece(h * 2 * HB + (m_ >> 1)); GSB(); }
-                    }
-                if (lasth) {
-                    // every read of stage s has been issued: publish stage s + 1
+            for (int g = 0; g < G; ++g) {
+                const int set = g & 1;
+                const bool last = g == G - 1;
+                const int r = g - GS;                        // pair of the split window (0, 1, 2 = last)
+                if (last) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (pre) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RB == 3 ? 4 + NT : 4) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     GSB();
                 }
-                // P2: w_hi * x_hi | the hi weight fragments of the next pair of channel blocks (same stage) or of the next stage
-#pragma unroll
-                for (int jj = 0; jj < HB; ++jj) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[h * HB + jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[jj], xh[i], acc[h * HB + jj][i], 0, 0, 0);
-                        GSB();
-                    }
-                    if (!lasth) wh[jj] = rd_w(SB_, 0, (h + 1) * HB + jj);
-                    else if (more) wh[jj] = rd_w(sb_r, 0, jj);
+                if (SG_SPLIT_SPREAD && more && r == 0) {     // this wave's rows of stage s + 1 have landed
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPLIT_WAIT) : "memory");
+                    rd_raw(0);
                     GSB();
-                    if (lasth && RB == 2 && pre) {           // (weight ring of two: the slot of stage s + 2 is the one this step has just finished reading)
-#pragma unroll
-                        for (int q = jj * NT / HB; q < (jj + 1) * NT / HB; ++q) { dma_b(sb_n, q); GSB(); }
-                    }
-                    if (lasth && jj == HB - 1 && more) { rd_raw(sa_r, 0); GSB(); }
                 }
-                // P3: w_lo * x_hi | the lo weight fragments likewise
-                if (!lasth) {
 #pragma unroll
-                    for (int jj = 0; jj < HB; ++jj) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            acc[h * HB + jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[jj], xh[i], acc[h * HB + jj][i], 0, 0, 0);
-                            GSB();
-                        }
-                        wl[jj] = rd_w(SB_, 1, (h + 1) * HB + jj);
-                        GSB();
+                for (int m = 0; m < 12; ++m) {
+                    const int ph = m >> 2, b_ = (m >> 1) & 1, i = m & 1, blk = 2 * g + b_;
+                    const h16x8 wv = ph < 2 ? wh[set][b_] : wl[set][b_];
+                    const h16x8 xv = ph == 0 ? xl[i] : xh[i];
+                    acc[blk][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[blk][i], 0, 0, 0);
+                    GSB();
+                    if (!last) {
+                        if ((m & 1) == 0) { early_piece(g * 6 + (m >> 1)); GSB(); }
+                        if ((m & 1) == 1 && m < 8) { rd_wq(bw_cur, g + 1, set ^ 1, m >> 1); GSB(); }
+                    } else {
+                        const int wq_ = (m >= 1 && m <= 3) ? m - 1 : (m == 6 ? 3 : -1);
+                        if (more && wq_ >= 0) { rd_wq(bw_nxt, 0, 0, wq_); GSB(); }
+                        const int bq_ = m == 2 ? 0 : (m == 7 ? 1 : (m == 8 ? 2 : (m == 10 ? 3 : -1)));
+                        if (RB == 2 && pre && bq_ >= 0 && bq_ < NT) { dma_b(sb_n, bq_); GSB(); }
                     }
-                } else {
+                    if (more && SG_SPLIT_SPREAD) {
+                        // chunks 0..3 = row block 0 (read at the window's start), 4..7 = row block 1 (read once chunk 3 has consumed the registers)
+                        const int c = r == 0 ? (m == 3 ? 0 : (m == 6 ? 1 : (m == 9 ? 2 : -1)))
+                                    : (r == 1 ? (m == 0 ? 3 : (m == 5 ? 4 : (m == 8 ? 5 : (m == 10 ? 6 : -1)))) : (r == 2 ? (m == 4 ? 7 : -1) : -1));
+                        if (c >= 0) { chunk(c); GSB(); }
+                        if (r == 1 && m == 2) { rd_raw(1); GSB(); }
+                    }
+                    if (more && !SG_SPLIT_SPREAD && last) {  // behind the barrier, in two bursts: row block 0 read at m = 0 and split at m = 4, row block 1 at m = 5 / 9
+                        if (m == 0 || m == 5) { rd_raw(m == 0 ? 0 : 1); GSB(); }
+                        if (m == 4 || m == 9) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                        for (int jj = 0; jj < HB; ++jj) {
-                            acc[h * HB + jj][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[jj], xh[i], acc[h * HB + jj][i], 0, 0, 0);
+                            for (int c = 0; c < 4; ++c) chunk((m == 4 ? 0 : 4) + c);
                             GSB();
-                            if (jj == 0 && i + 1 < 4 && more) { rd_raw(sa_r, i + 1); GSB(); }
-                            if (i == 3 && more) { wl[jj] = rd_w(sb_r, 1, jj); GSB(); }
                         }
-                        if (more) { split(i); GSB(); }
                     }
                 }
             }
+            if (more) adopt();
+            sa = sa_r;
+            sb = sb_r;
         };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
         using BF = std::integral_constant<bool, false>;
         using BT = std::integral_constant<bool, true>;
-        using B1 = std::integral_constant<int, 1 % RB>;
-        using B2 = std::integral_constant<int, 2 % RB>;
-        using B3 = std::integral_constant<int, 3 % RB>;
-        using B4 = std::integral_constant<int, 4 % RB>;
-        using B5 = std::integral_constant<int, 5 % RB>;
-        const int n = nk;
-        int s = 0;
+        // every step but the item's last two requests a stage two ahead; those two are straight-line instances of their own behind the loop
 #pragma nounroll
-        for (; s + 8 <= n; s += 6) {                         // steady state: every one of the six steps has a stage s + 2 to request
-            step(I0{}, I0{}, BF{}, true, true); step(I1{}, B1{}, BF{}, true, true); step(I2{}, B2{}, BF{}, true, true);
-            step(I0{}, B3{}, BF{}, true, true); step(I1{}, B4{}, BF{}, true, true); step(I2{}, B5{}, BF{}, true, true);
-        }
-        {
-            const int r = n - s;                              // 1 .. 7 steps left (slots continue from 0: s is a multiple of six)
-            if (r > 0) step(I0{}, I0{}, BT{}, 1 < r, 2 < r);
-            if (r > 1) step(I1{}, B1{}, BT{}, 2 < r, 3 < r);
-            if (r > 2) step(I2{}, B2{}, BT{}, 3 < r, 4 < r);
-            if (r > 3) step(I0{}, B3{}, BT{}, 4 < r, 5 < r);
-            if (r > 4) step(I1{}, B4{}, BT{}, 5 < r, 6 < r);
-            if (r > 5) step(I2{}, B5{}, BT{}, 6 < r, false);
-            if (r > 6) step(I0{}, I0{}, BT{}, false, false);
-        }
+        for (int s_ = 2; s_ < nk; ++s_) step(BT{}, BT{});
+        step(BT{}, BF{});
+        step(BF{}, BF{});
+        GSB();                                               // (nothing of the epilogue is hoisted into the last step: its registers are full)
 #undef GSB
         // Column scales and biases of this tile: loaded, waited for and scaled BEFORE the next item's first stages are requested (one L2-hit
         // latency per tile).  Behind the - conditional - prologue issue the compiler would wait vmcnt(0) at their first use, i.e. for the
         // DMA it has just queued (vmcnt retires in order); the empty asm pins the finished values in front of the issue.
-        float4 sq[NT], bq[NT];
+        float4 sqv, bqv;
         {
-            const int pc_e = lane & 7;
             // (buffer loads that always issue: columns >= N of the bias - or all of them when there is none - read zeros)
             const auto rbi = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
-#pragma unroll
-            for (int jp = 0; jp < NT; ++jp) {
-                const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
-                sq[jp] = *(const float4*)(p.Cscale + c);             // (padded to a multiple of 256 columns)
-                const u32x4 b_ = __builtin_amdgcn_raw_buffer_load_b128(rbi, (unsigned)c * 4u, 0, 0);
-                bq[jp] = make_float4(__uint_as_float(b_[0]), __uint_as_float(b_[1]), __uint_as_float(b_[2]), __uint_as_float(b_[3]));
-            }
-#pragma unroll
-            for (int jp = 0; jp < NT; ++jp) {
-                sq[jp].x *= p.out_scale; sq[jp].y *= p.out_scale; sq[jp].z *= p.out_scale; sq[jp].w *= p.out_scale;
-                asm volatile("" : "+v"(sq[jp].x), "+v"(sq[jp].y), "+v"(sq[jp].z), "+v"(sq[jp].w), "+v"(bq[jp].x), "+v"(bq[jp].y), "+v"(bq[jp].z), "+v"(bq[jp].w)::"memory");
-            }
+            const int c = n0 + 4 * lane;                             // (NT = 2: the upper half of the wave holds columns the tile does not have)
+            sqv = *(const float4*)(p.Cscale + (c & 255) + (n0 & ~255));      // (Cscale is padded to a multiple of 256 columns)
+            const u32x4 b_ = __builtin_amdgcn_raw_buffer_load_b128(rbi, (unsigned)c * 4u, 0, 0);
+            bqv = make_float4(__uint_as_float(b_[0]), __uint_as_float(b_[1]), __uint_as_float(b_[2]), __uint_as_float(b_[3]));
+            sqv.x *= p.out_scale; sqv.y *= p.out_scale; sqv.z *= p.out_scale; sqv.w *= p.out_scale;
+            asm volatile("" : "+v"(sqv.x), "+v"(sqv.y), "+v"(sqv.z), "+v"(sqv.w), "+v"(bqv.x), "+v"(bqv.y), "+v"(bqv.z), "+v"(bqv.w)::"memory");
         }
         // the last barrier of the item has retired every LDS read: request the first stages of the next item now (activation slots
         // 0, 1 and weight slots 0, 1); their latency runs under the epilogue, whose patches live in activation slot 2
@@ -421,14 +429,14 @@ __global__ __launch_bounds__(512, 2) void k_sgemm(SGemmP p) {
             prefetched = true;
         }
         if (SG_DIAG & 1) {                                   // (diagnostic: no epilogue - the accumulators are kept alive by a store that never happens)
-            float t_ = sq[0].x + bq[0].x;
+            float t_ = sqv.x + bqv.x;
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t_ += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+                for (int i = 0; i < 2; ++i) t_ += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
             if (t_ == 1.2345e-30f) p.C[0] = t_;
         } else {
-            sgemm_epilogue<NT>(p, acc, sq, bq, lds + 2 * ABY + wave * 4096, wave, lane, m0, n0);
+            sgemm_epilogue<NT>(p, acc, sqv, bqv, lds + 2 * ABY + wave * 4096, wave, lane, m0, n0);
         }
         // the patches must be done before another wave's DMA of the next item's third stage lands in activation slot 2: that piece is
         // requested after the next item's opening barrier
