@@ -135,6 +135,44 @@ def test_full_size_adm128_batch_consistency():
     torch.cuda.empty_cache()
 
 
+def test_headline_dispatch_batch128(golden):
+    """the dispatch the driver times, asserted as a whole.  Full-size ADM-128, f16x3, default form pick, block-level
+    C ABI at B = 128 (the headline's batch): (1) bench.py's own post-timing check - samples 0, 77, 127 of the batched forward are the bits of
+    their own batch-1 forwards; (2) G5's input (the reference's full-size ADM-128 case) in rows 0 and 127 of an otherwise random batch:
+    both rows against the REFERENCE's output (1e-3, north star) and against each other bit for bit; (3) the forms the levels run in at
+    this batch are the headline's (F(4,3) from 128^2 to 32^2, F(2,3) at 8^2)."""
+    import importlib.util
+    import os
+    from oracle import adm
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod_gpu", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = golden("g5_adm128_full")
+    m, _ = build_adm(dict(adm.ADM128), int(g["seed"]))
+    m.precision = "f16x3"
+    assert m.winograd is True and m.use_block_abi and m.wino_plan_batch == 128
+    B = 128
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 3, 128, 128, generator=gen)
+    y = torch.randint(0, 1000, (B,), generator=gen)
+    chk = bench.dispatch_check(m, x.to(dev), y.to(dev), torch.device(dev))
+    print("dispatch check:", {k: v for k, v in chk.items() if k != "what"})
+    assert chk["ok"] and chk["bit_identical"] == 3 and chk["max_abs_diff"] == 0.0
+    f = chk["conv3x3_forms"]
+    assert f["128^2:256->256"] == "F(4,3)" and f["64^2:256->256"] == "F(4,3)" and f["32^2:512->512"] == "F(4,3)" and f["8^2:1024->1024"] == "F(2,3)"
+    t = torch.linspace(999, 0, B).round().to(torch.int64)
+    for row in (0, 127):
+        x[row], t[row], y[row] = T(g["x"])[0], T(g["t"])[0], T(g["y"])[0]
+    with torch.no_grad():
+        o = m(x.to(dev), t.to(dev), y=y.to(dev))
+    err = max(np.abs(o[row:row + 1].cpu().numpy() - g["out"]).max() for row in (0, 127))
+    print(f"ADM-128 f16x3 at batch 128, rows 0 / 127 = G5's input: max|hip - reference| = {err:.3e}")
+    assert err < TOL and torch.equal(o[0], o[127])
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_uvit_vs_golden(golden):
     from diffusion_uncertainty_amd.uvit.uvit import UViT
     from diffusion_uncertainty_amd.utils import seeded_state_dict

@@ -1,0 +1,113 @@
+"""scripts/isa_lint.py on the CPU: the hand-scheduled gfx950 kernels of the built library satisfy their ISA-level rules, and the rules BITE
+(both round-4 miscompiles of k_wconv4 were found by wrong results on metered GPU time; a compiler bump can break any of
+these silently).  Doctored listings: a deleted wait-state fence, a uniform branch around epilogue stores and a spill inside the K loop
+are each reported."""
+import importlib.util
+import os
+import re
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lint():
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "scripts", "isa_lint.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    if not os.path.exists(os.path.join(m.CSRC, "conv_wino4_f16x3.o")):
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return m
+
+
+@pytest.fixture(scope="module")
+def wconv4_listing(lint):
+    with tempfile.TemporaryDirectory() as tmp:
+        dis, notes = lint.disassemble(os.path.join(lint.CSRC, "conv_wino4_f16x3.o"), tmp)
+    # one kernel only (the no-residual instantiation), as text lines
+    lines, keep = [], False
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
+        if m:
+            keep = m.group(1) == "_Z8k_wconv4ILi0EEv6WConvP"
+        if keep:
+            lines.append(ln)
+    return lines, notes
+
+
+def spec_of(lint, name):
+    return [s for s in lint.SPECS if s["name"] == name][0]
+
+
+def test_built_library_passes(lint):
+    assert lint.run() == []
+
+
+def test_clean_listing_passes(lint, wconv4_listing):
+    lines, notes = wconv4_listing
+    res = lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(lines), notes)
+    assert res == {"_Z8k_wconv4ILi0EEv6WConvP": []}
+
+
+def test_deleted_fence_is_caught(lint, wconv4_listing):
+    """w4_fence (s_nop 15 / s_nop 3 tied to the accumulators) deleted once: the fence count is off (and, where a compiler copy follows the
+    K loop's last MFMAs, the hazard rule fires too)."""
+    lines, notes = wconv4_listing
+    idx = [k for k in range(len(lines) - 1) if re.match(r"^\s+s_nop 15\b", lines[k]) and re.match(r"^\s+s_nop 3\b", lines[k + 1])]
+    assert len(idx) == spec_of(lint, "k_wconv4")["fences"]
+    doctored = lines[:idx[-1]] + lines[idx[-1] + 2:]
+    errs = lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(doctored), notes)["_Z8k_wconv4ILi0EEv6WConvP"]
+    assert any("fence" in e for e in errs), errs
+
+
+def test_branch_around_epilogue_stores_is_caught(lint, wconv4_listing):
+    """A uniform branch over four of the always-issued epilogue stores (the shortest DMA-to-wait path of the clean kernel holds 66: the 64
+    output stores plus the column sums): a path from the next tile's prefetch DMA to the tile-start wait then issues 62 stores, one fewer
+    than s_waitcnt vmcnt(63) leaves in flight."""
+    lines, notes = wconv4_listing
+    ins = lint.parse_disassembly("\n".join(lines))["_Z8k_wconv4ILi0EEv6WConvP"]
+    stores = [k for k, i in enumerate(ins) if i.op.startswith("buffer_store")]
+    # the kernel holds several epilogue variants (whole tiles / masked tiles): in EVERY scalar-branch-free run of at least eight stores,
+    # branch from the instruction in front of its third store to behind its sixth
+    scalar_br = [k for k, i in enumerate(ins) if i.target is not None and not i.op.startswith("s_cbranch_exec")]
+    groups = [[stores[0]]]
+    for k in stores[1:]:
+        if any(groups[-1][-1] < q < k for q in scalar_br):
+            groups.append([k])
+        else:
+            groups[-1].append(k)
+    doctored = list(lines)
+    n_doctored = 0
+    for g in groups:
+        if len(g) < 8:
+            continue
+        src, dst = ins[g[2] - 1], ins[g[5] + 1]
+        imm = (dst.addr - src.addr - 4) // 4
+        assert 0 < imm < 0x7fff and src.target is None
+        pat = re.compile(r"//\s*0*%X:" % src.addr, re.I)
+        doctored = [re.sub(r"^\s+\S.*?//", f"\ts_cbranch_scc1 {imm} //", ln) if pat.search(ln) else ln for ln in doctored]
+        n_doctored += 1
+    assert n_doctored >= 2 and doctored != lines
+    errs = lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(doctored), notes)["_Z8k_wconv4ILi0EEv6WConvP"]
+    assert any("tile-start wait" in e for e in errs), errs
+
+
+def test_spill_inside_k_loop_is_caught(lint, wconv4_listing):
+    lines, notes = wconv4_listing
+    ins = lint.parse_disassembly("\n".join(lines))["_Z8k_wconv4ILi0EEv6WConvP"]
+    lo, hi, n = lint.innermost_mfma_loop(ins, "v_mfma_f32_16x16x32_f16")
+    assert n == 864
+    victim = [i for i in ins[lo:hi] if i.op == "s_nop" or i.op.startswith("s_mov") or i.op.startswith("v_add")][0]
+    pat = re.compile(r"//\s*0*%X:" % victim.addr, re.I)
+    doctored = [re.sub(r"^\s+\S.*?//", "\tscratch_load_dword v1, off, off //", ln) if pat.search(ln) else ln for ln in lines]
+    errs = lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(doctored), notes)["_Z8k_wconv4ILi0EEv6WConvP"]
+    assert any("inside the K loop" in e for e in errs), errs
+    # ... and an accumulator move there likewise
+    doctored = [re.sub(r"^\s+\S.*?//", "\tv_accvgpr_read_b32 v1, a0 //", ln) if pat.search(ln) else ln for ln in lines]
+    errs = lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(doctored), notes)["_Z8k_wconv4ILi0EEv6WConvP"]
+    assert any("inside the K loop" in e for e in errs), errs
