@@ -204,17 +204,20 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         const auto rch = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cplanes + (long)m0 * p.N), 0, crec, 0x00020000);
         const auto rcl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Cplanes + (long)p.M * p.N + (long)m0 * p.N), 0, crec, 0x00020000);
         const int r16 = lane_e >> 2, ch8 = lane_e & 3;
-        float4 s0_[NT], s1_[NT], b0_[NT], b1_[NT];               // requested up front: one exposed latency for all pairs
-#pragma unroll
-        for (int jp = 0; jp < NT; ++jp) {
+        // column scales and biases of a pair (this lane's eight channels), requested ONE pair ahead (all NT pairs up front are 64 registers
+        // at NT = 4: the K loop of that instantiation then reloaded a spilled LDS address behind an s_waitcnt vmcnt(0) - scripts/isa_lint.py)
+        float4 s0n, s1n, b0n, b1n;
+        auto sb_ld8 = [&](int jp) {
             const int c = n0 + wn * 32 * NT + 32 * jp + 8 * ch8;
-            s0_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s1_[jp] = s0_[jp]; b0_[jp] = s0_[jp]; b1_[jp] = s0_[jp];
+            s0n = make_float4(0.f, 0.f, 0.f, 0.f);
+            s1n = s0n; b0n = s0n; b1n = s0n;
             if (c < p.N) {
-                s0_[jp] = *(const float4*)(p.Cscale + c); s1_[jp] = *(const float4*)(p.Cscale + c + 4);
-                if (p.bias) { b0_[jp] = *(const float4*)(p.bias + c); b1_[jp] = *(const float4*)(p.bias + c + 4); }
+                s0n = *(const float4*)(p.Cscale + c); s1n = *(const float4*)(p.Cscale + c + 4);
+                if (p.bias) { b0n = *(const float4*)(p.bias + c); b1n = *(const float4*)(p.bias + c + 4); }
             }
-        }
+        };
+        sb_ld8(0);
+        float4 s0c = s0n, s1c = s1n, b0c = b0n, b1c = b1n;
         patch_put(0);
         patch_put(1);
         f32x4 pa[2][2];
@@ -231,7 +234,11 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
             const int c = n0 + wn * 32 * NT + 32 * jp + 8 * ch8;
             const bool cok = c < p.N;
             if (t + 1 < T) patch_get(t + 1, pa[(t + 1) & 1]);
-            const float4 s0 = s0_[jp], s1 = s1_[jp], b0 = b0_[jp], b1 = b1_[jp];
+            if (i == 0) {
+                s0c = s0n; s1c = s1n; b0c = b0n; b1c = b1n;
+                if (jp + 1 < NT) sb_ld8(jp + 1);
+            }
+            const float4 s0 = s0c, s1 = s1c, b0 = b0c, b1 = b1c;
             const float sq[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
             const float bq[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             const f32x4 a0 = pa[t & 1][0], a1 = pa[t & 1][1];
