@@ -58,9 +58,10 @@ MODES = {
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
               "(head dims <= 256) in this format, embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
-    "fp32": ("k_wconv32 (csrc/conv_wino_f32.hip): exact-fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd F(2,3)-along-y form on "
-             "v_mfma_f32_16x16x4_f32 (6 instead of 9 taps per pixel, products and sums in fp32); in / out convs on the direct fp32 MFMA "
-             "kernel k_tile<MODE_CONV>", 1.0, "f32"),
+    "fp32": ("k_wconv432 / k_wconv32 (csrc/conv_wino4_f32.hip, conv_wino_f32.hip): exact-fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd "
+             "F(4,3)-along-y form on v_mfma_f32_16x16x4_f32 (4.5 instead of 9 taps per pixel, products and sums in fp32; tile 128 positions x 64 "
+             "channels x 6 frequencies on eight waves) wherever its kernel takes the shape, F(2,3) (6 taps) elsewhere; in / out convs on the "
+             "direct fp32 MFMA kernel k_tile<MODE_CONV>", 1.0, "f32"),
     "f16w": ("k_wconv1 (csrc/conv_wino_f16x3.hip): the Winograd F(2,3)-along-y LDS-DMA conv3x3 with ONE fp16 MFMA per tap on the hi images "
              "of the transformed operands (fp16 x fp16 products, fp32 accumulate; half the DMA pieces and a third of the MFMAs of k_wconv)", 1.0,
              "f16w (3x3 convs of the ResBlocks: fp16 operands, one product per tap, fp32 accumulation - the arithmetic class of the "

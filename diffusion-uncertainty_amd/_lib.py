@@ -136,6 +136,10 @@ SIGNATURES = {
     "dua_pack_weight_f32_wino": (_I, [_P, _P, _I, _I, _P]),
     "dua_groupnorm_apply_wino_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dua_conv3x3_f32_wino": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "dua_f32_wino4_weight_bytes": (_Z, [_I, _I]),
+    "dua_pack_weight_f32_wino4": (_I, [_P, _P, _I, _I, _P]),
+    "dua_groupnorm_apply_wino4_f32": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "dua_conv3x3_f32_wino4": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dua_gemm_f16x3": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _F, _P]),
     "dua_attention_f16x3": (_I, [_P, _P, _P, _F, _I, _I, _I, _I, _F, _P]),
     "dua_cross_attention_f16x3": (_I, [_P, _L, _P, _P, _L, _P, _P, _F, _I, _I, _I, _I, _I, _F, _P]),

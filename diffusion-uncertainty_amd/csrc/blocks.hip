@@ -65,7 +65,7 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     // convolution's output (conv1's output is dead once the second GroupNorm has consumed it)
     // Winograd form of a 3x3 conv (csrc/conv_wino_f16x3.hip) where its packed weights are given and the shape allows: the GroupNorm
     // in front writes the four transformed images (8 bytes per element instead of 4)
-    const bool four1 = a->conv1_wino_m == 4, four2 = a->conv2_wino_m == 4;          // F(4,3) packing (csrc/conv_wino4_f16x3.hip), f16x3 three-product mode only
+    const bool four1 = a->conv1_wino_m == 4, four2 = a->conv2_wino_m == 4;          // F(4,3) packing (csrc/conv_wino4_f16x3.hip / conv_wino4_f32.hip): the f16x3 three-product mode and fp32
     const int wsup1 = (a->conv1_wino && a->C1 % 32 == 0) ? (four1 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, C, a->Cout) : 0;
     const int wsup2 = a->conv2_wino ? (four2 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, a->Cout, a->Cout) : 0;
     const bool wino1 = wsup1 != 0, wino2 = wsup2 != 0;          // (== 2: no column sums from that conv; the statistics kernel runs instead)
@@ -87,7 +87,9 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     int rc;
     // in_layers: GroupNorm32 -> SiLU (-> 2x resampling of h, :238-243) -> conv3x3                       unet_openai.py:183-187
     if ((rc = gn_stats(a->x1, a->C1, a->x1_colsums, a->x2, a->C2, a->x2_colsums, a->N, a->H * a->W, G, gnws, stats1, stream))) return rc;
-    if (wino1 && !f16) rc = dua_groupnorm_apply_wino_f32(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1,
+    if (wino1 && !f16 && four1) rc = dua_groupnorm_apply_wino4_f32(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1,
+                                                                    a->updown, nullptr, h1, stream);
+    else if (wino1 && !f16) rc = dua_groupnorm_apply_wino_f32(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1,
                                                           a->updown, nullptr, h1, stream);
     else if (wino1 && four1) rc = dua_groupnorm_apply_wino4_f16x3(a->x1, a->C1, a->x2, a->C2, a->N, a->H, a->W, G, stats1, a->gn1_w, a->gn1_b, nullptr, 0, 1, a->updown,
                                                                   nullptr, 0.125f * a->act_scale, h1, stream);
@@ -101,7 +103,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     if (xr && (rc = dua_resample2x(a->x1, xr, a->N, a->H, a->W, a->C1, a->updown, stream))) return rc;          // x_upd :243
     {
         ConvTimer tm(stream);
-        if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
+        if (wino1 && !f16 && four1) rc = dua_conv3x3_f32_wino4(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
+        else if (wino1 && !f16) rc = dua_conv3x3_f32_wino(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, stream);
         else if (wino1 && four1) rc = dua_conv3x3_f16x3_wino4(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2, 0.125f * a->act_scale, stream);
         else if (wino1) rc = (single ? dua_conv3x3_f16w_wino : dua_conv3x3_f16x3_wino)(h1, a->conv1_wino, a->conv1_b, nullptr, 0, h2, a->N, Ho, Wo, C, a->Cout, cs2,
                                                                                        0.5f * a->act_scale, stream);
@@ -112,7 +115,9 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     if (rc) return rc;
     // out_layers: GroupNorm32 * (1 + scale) + shift -> SiLU -> dropout -> conv3x3 (+ skip)               :207-214,245-257
     if ((rc = gn_stats(h2, a->Cout, cs2, nullptr, 0, nullptr, a->N, Ho * Wo, G, gnws, stats2, stream))) return rc;
-    if (wino2 && !f16) rc = dua_groupnorm_apply_wino_f32(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
+    if (wino2 && !f16 && four2) rc = dua_groupnorm_apply_wino4_f32(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
+                                                                    a->dropmask, h3, stream);
+    else if (wino2 && !f16) rc = dua_groupnorm_apply_wino_f32(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0,
                                                           a->dropmask, h3, stream);
     else if (wino2 && four2) rc = dua_groupnorm_apply_wino4_f16x3(h2, a->Cout, nullptr, 0, a->N, Ho, Wo, G, stats2, a->gn2_w, a->gn2_b, a->film, a->film_ld, 1, 0, a->dropmask,
                                                                   0.125f * a->act_scale, h3, stream);
@@ -144,7 +149,8 @@ int resblock_run(const dua_resblock_args* a, Carver& w, void* stream) {
     float* ycs = (a->y_colsums && colsum2) ? a->y_colsums : nullptr;
     DUA_REQUIRE(!(ycs && wsup2 == 2), "dua_adm_resblock_fwd: y_colsums with the Winograd conv needs H*W %% 128 == 0 (F(4,3): %% 256)");
     ConvTimer tm(stream);
-    if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
+    if (wino2 && !f16 && four2) rc = dua_conv3x3_f32_wino4(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
+    else if (wino2 && !f16) rc = dua_conv3x3_f32_wino(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, stream);
     else if (wino2 && four2) rc = dua_conv3x3_f16x3_wino4(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs, 0.125f * a->act_scale, stream);
     else if (wino2) rc = (single ? dua_conv3x3_f16w_wino : dua_conv3x3_f16x3_wino)(h3, a->conv2_wino, a->conv2_b, resid, rmode, a->y, a->N, Ho, Wo, a->Cout, a->Cout, ycs,
                                                                                    0.5f * a->act_scale, stream);
@@ -278,7 +284,8 @@ int check_resblock(const dua_resblock_args* a) {
         const int Ho = a->updown < 0 ? a->H / 2 : (a->updown > 0 ? 2 * a->H : a->H), Wo = a->updown < 0 ? a->W / 2 : (a->updown > 0 ? 2 * a->W : a->W);
         DUA_REQUIRE((a->conv1_wino_m == 0 || a->conv1_wino_m == 2 || a->conv1_wino_m == 4) && (a->conv2_wino_m == 0 || a->conv2_wino_m == 2 || a->conv2_wino_m == 4),
                     "dua_adm_resblock_fwd: conv*_wino_m must be 0, 2 or 4");
-        DUA_REQUIRE((a->conv1_wino_m != 4 && a->conv2_wino_m != 4) || a->precision == DUA_PREC_F16X3, "dua_adm_resblock_fwd: the F(4,3) packing is a DUA_PREC_F16X3 option");
+        DUA_REQUIRE((a->conv1_wino_m != 4 && a->conv2_wino_m != 4) || a->precision == DUA_PREC_F16X3 || a->precision == DUA_PREC_FP32,
+                    "dua_adm_resblock_fwd: the F(4,3) packing is a DUA_PREC_F16X3 / DUA_PREC_FP32 option");
         const bool w1 = a->conv1_wino && a->C1 % 32 == 0 && (a->conv1_wino_m == 4 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, a->C1 + a->C2, a->Cout) != 0;
         const bool w2 = a->conv2_wino && (a->conv2_wino_m == 4 ? dua_conv3x3_f16x3_wino4_supported : dua_conv3x3_f16x3_wino_supported)(a->N, Ho, Wo, a->Cout, a->Cout) != 0;
         DUA_REQUIRE((a->conv1_packed || w1) && (a->conv2_packed || w2),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libdua_hip.so")
-SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []), ("mfma_bf16x3.hip", []), ("conv_f16x3.hip", []), ("gemm_f16x3.hip", []), ("gemm_skip_f16x3.hip", []), ("conv_wino_f16x3.hip", []), ("conv_wino4_f16x3.hip", []), ("conv_wino_f32.hip", []), ("attention.hip", []), ("blocks.hip", []), ("backward.hip", [])]
+SOURCES = [("sampler.hip", ["-ffp-contract=off"]), ("denoiser.hip", []), ("mfma_gemm.hip", []), ("mfma_bf16x3.hip", []), ("conv_f16x3.hip", []), ("gemm_f16x3.hip", []), ("gemm_skip_f16x3.hip", []), ("conv_wino_f16x3.hip", []), ("conv_wino4_f16x3.hip", []), ("conv_wino_f32.hip", []), ("conv_wino4_f32.hip", []), ("attention.hip", []), ("blocks.hip", []), ("backward.hip", [])]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
 
@@ -48,7 +48,7 @@ def build_select_variant(verbose=True):
     out = os.path.join(out_dir, "libdua_hip_select.so")
     hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "dconv.h"), os.path.join(HERE, "wconv.h"), os.path.join(HERE, "hgemm.h"), os.path.join(os.path.dirname(PKG), "include", "dua_hip.h")]
     alt = {}
-    for name in ("conv_f16x3.hip", "conv_wino_f16x3.hip", "conv_wino4_f16x3.hip", "conv_wino_f32.hip"):          # the kernels with row-shifted fragment reads
+    for name in ("conv_f16x3.hip", "conv_wino_f16x3.hip", "conv_wino4_f16x3.hip", "conv_wino_f32.hip"):   # (conv_wino4_f32.hip has the out-of-range form only)          # the kernels with row-shifted fragment reads
         src = os.path.join(HERE, name)
         obj = os.path.join(out_dir, name.replace(".hip", ".select.o"))
         if _stale(obj, [src] + hdrs):

@@ -684,7 +684,9 @@ struct GnWino4P {
 // and of the lo image of the conv's stage block (tile, channel block).  Maps narrower than 16 put 16 / W consecutive row groups in a wave.
 // STREAM (maps at least 16 wide, no pooling, no dropout mask): the four new rows of the NEXT row group are requested before this group's
 // twelve stores go out.  The sliding window over y keeps every input element read once (plus two halo rows per chunk).
-template <bool STREAM>
+// F32: the six images as fp32 stage blocks [128 positions][32 channels] floats (the operand of the exact-fp32 kernel, conv_wino4_f32.hip):
+// the same 16 KB per (frequency, tile, channel block) as the [hi | lo] fp16 pair, no scale.
+template <bool STREAM, bool F32 = false>
 __global__ __launch_bounds__(256) void k_gn_apply_wino4(GnWino4P p) {
     const int C = p.C1 + p.C2, ncb = C / 32, cpg = C / p.G;
     const int Ho = p.resample < 0 ? p.H / 2 : (p.resample > 0 ? 2 * p.H : p.H), Wo = p.resample < 0 ? p.W / 2 : (p.resample > 0 ? 2 * p.W : p.W);
@@ -764,6 +766,12 @@ __global__ __launch_bounds__(256) void k_gn_apply_wino4(GnWino4P p) {
     };
     unsigned long long* const rctr = dua_range_ctr();          // f16x3 range check (debug facility; nullptr when off)
     auto put = [&](int f, size_t m, const float (&v)[8]) {
+        if constexpr (F32) {
+            float* o = (float*)p.v + (((size_t)f * p.ntm + (m >> 7)) * ncb + cbk) * 4096 + (m & 127) * 32 + (c & 31);
+            __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, (f32x4*)o);
+            __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, (f32x4*)(o + 4));
+            return;
+        }
         h16x8 h, l;
         if (rctr) {
 #pragma unroll
@@ -865,9 +873,9 @@ extern "C" size_t dua_f16x3_wino4_act_bytes(int N, int Ho, int Wo, int C) {
     return (size_t)24 * ((Mv + 127) / 128 * 128) * C;                 // whole tiles of 128 positions
 }
 
-extern "C" int dua_groupnorm_apply_wino4_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
-                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
-                                               int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+static int gn_apply_wino4_impl(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                               int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream, bool f32_planes) {
     const int C = C1 + C2;
     DUA_REQUIRE(x1 && stats && gamma && beta && vplanes, "dua_groupnorm_apply_wino4_f16x3: null pointer");
     DUA_REQUIRE(C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % 32 == 0, "dua_groupnorm_apply_wino4_f16x3: channel counts must be multiples of 8 (sum of 32)");
@@ -894,9 +902,26 @@ extern "C" int dua_groupnorm_apply_wino4_f16x3(const float* x1, int C1, const fl
     p.JC = JC;
     const dim3 grid(nxb * ((P + JC - 1) / JC), N);
     const bool strm = resample >= 0 && !dropmask && Wo >= 16;
-    if (strm) hipLaunchKernelGGL((k_gn_apply_wino4<true>), grid, 256, 0, as_stream(stream), p);
-    else hipLaunchKernelGGL((k_gn_apply_wino4<false>), grid, 256, 0, as_stream(stream), p);
-    return dua_check_launch("dua_groupnorm_apply_wino4_f16x3");
+    if (f32_planes) {
+        if (strm) hipLaunchKernelGGL((k_gn_apply_wino4<true, true>), grid, 256, 0, as_stream(stream), p);
+        else hipLaunchKernelGGL((k_gn_apply_wino4<false, true>), grid, 256, 0, as_stream(stream), p);
+    } else {
+        if (strm) hipLaunchKernelGGL((k_gn_apply_wino4<true>), grid, 256, 0, as_stream(stream), p);
+        else hipLaunchKernelGGL((k_gn_apply_wino4<false>), grid, 256, 0, as_stream(stream), p);
+    }
+    return dua_check_launch(f32_planes ? "dua_groupnorm_apply_wino4_f32" : "dua_groupnorm_apply_wino4_f16x3");
+}
+
+extern "C" int dua_groupnorm_apply_wino4_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                               const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                               int act, int resample, const float* dropmask, float v_scale, void* vplanes, void* stream) {
+    return gn_apply_wino4_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, v_scale, vplanes, stream, false);
+}
+// ... with the six images as fp32 planes (same bytes: dua_f16x3_wino4_act_bytes): the operand of dua_conv3x3_f32_wino4
+extern "C" int dua_groupnorm_apply_wino4_f32(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                             const float* stats, const float* gamma, const float* beta, const float* film, long film_ld,
+                                             int act, int resample, const float* dropmask, void* vplanes, void* stream) {
+    return gn_apply_wino4_impl(x1, C1, x2, C2, N, H, W, G, stats, gamma, beta, film, film_ld, act, resample, dropmask, 1.0f, vplanes, stream, true);
 }
 
 DUA_RANGE_TU(conv_wino4)

@@ -99,7 +99,7 @@ class ResBlock(TimestepBlock):
             if not (drop.training and drop.p > 0 and self.updown):          # (a dropout mask on a resampling block: composed path)
                 Hb, Wb = (2 * H, 2 * W) if self.resample > 0 else ((H // 2, W // 2) if self.resample < 0 else (H, W))
                 cin = x.shape[3] + (0 if skip is None else skip.shape[3])
-                kw = {0: None, 2: "w3w" if ctx.model.precision == "f16x3" else "w3wf", 4: "w3w4"}
+                kw = {0: None, 2: "w3w" if ctx.model.precision == "f16x3" else "w3wf", 4: "w3w4" if ctx.model.precision == "f16x3" else "w3w4f"}
                 m1, m2 = ctx.wino_form(N, Hb, Wb, cin, self.out_channels), ctx.wino_form(N, Hb, Wb, self.out_channels, self.out_channels)
                 w1 = ctx.packed(conv1, kw[m1]) if m1 else None
                 w2 = ctx.packed(conv2, kw[m2]) if m2 else None
@@ -234,10 +234,13 @@ class _Ctx:
     def wino_form(self, N, H, W, cin, cout):
         """0 / 2 / 4: this 3x3 conv (input / output size H x W) runs in the direct form / the Winograd F(2,3) / F(4,3)-along-y form.
         model.winograd: True = the kernel library's choice per shape (f16x3: F(4,3) where whole rounds of tiles favour it), 2 / 4 = that
-        form wherever its kernel takes the shape, False = direct everywhere.  fp32 and f16w have the F(2,3) form only."""
+        form wherever its kernel takes the shape, False = direct everywhere.  fp32: F(4,3) wherever its kernel takes the shape (the fp32
+        matrix pipe is the only limit there: 4.5 against 6 taps, whatever the number of tiles), else F(2,3); f16w has the F(2,3) form only."""
         w = getattr(self.model, "winograd", True)
         if self.model.precision not in ("f16x3", "fp32") or not w:
             return 0
+        if self.model.precision == "fp32" and w != 2 and ops.conv3x3_wino4_supported(N, H, W, cin, cout):
+            return 4
         if self.model.precision == "f16x3" and not self.model.wino_single:
             s4 = ops.conv3x3_wino4_supported(N, H, W, cin, cout)
             if w is True:
@@ -261,7 +264,7 @@ class _Ctx:
         the f16x3 mode pick the Winograd operand where the kernel takes the shape)."""
         m = self.wino_form(*conv_shape) if conv_shape is not None else 0
         if m:
-            return ("f16x3w4" if m == 4 else "f16x3w") if self.model.precision == "f16x3" else "f32w"
+            return ("f16x3w4" if m == 4 else "f16x3w") if self.model.precision == "f16x3" else ("f32w4" if m == 4 else "f32w")
         return self.split_acts
 
     def packed(self, mod, kind):
@@ -283,6 +286,8 @@ class _Ctx:
                 cache[key] = ops.pack_weight_f16x3_wino4(mod.weight.detach().contiguous())
             elif kind == "w3wf":
                 cache[key] = ops.pack_weight_f32_wino(mod.weight.detach().contiguous())
+            elif kind == "w3w4f":
+                cache[key] = ops.pack_weight_f32_wino4(mod.weight.detach().contiguous())
             elif kind == "qkvh":
                 wq, bq = self.packed(mod, "qkv")
                 cache[key] = (ops.pack_weight_f16x3(wq), bq)
@@ -333,7 +338,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f16x3w4": "w3w4", "f32w": "w3wf"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f16x3w4": "w3w4", "f32w": "w3wf", "f32w4": "w3w4f"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 

@@ -322,6 +322,14 @@ def groupnorm_apply(x1, stats, gamma, beta, x2=None, film=None, act=1, resample=
                                                           _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
                                                           _p(vbuf), _stream()), "dua_groupnorm_apply_wino_f32")
             return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), "f32w", 1.0)
+        if split == "f32w4":
+            # exact-fp32 F(4,3) operand (csrc/conv_wino4_f32.hip): the six V_f images as floats, stage-block layout of the f16x3 form
+            ntm = (N * (Ho // 4) * Wo + 127) // 128
+            vbuf = torch.empty((6, ntm, (C1 + C2) // 32, 128, 32), device=x1.device, dtype=torch.float32)
+            check(_lib.lib().dua_groupnorm_apply_wino4_f32(_p(x1), C1, _p(x2), C2, N, H, W, groups, _p(stats), _p(gamma), _p(beta), _p(film),
+                                                           _film_ld(film, N, C1 + C2), int(act), int(resample), _p(dropmask),
+                                                           _p(vbuf), _stream()), "dua_groupnorm_apply_wino4_f32")
+            return SplitPlanes(vbuf, (N, Ho, Wo, C1 + C2), "f32w4", 1.0)
         if split in ("f16x3w", "f16w"):
             # Winograd F(2,3)-along-y operand of conv3x3 (csrc/conv_wino_f16x3.hip): the four V_f images as f16x3 planes of V * scale
             # ("f16w": only the hi images are written - the operand of the single-product conv, mode "f16w")
@@ -630,6 +638,17 @@ def pack_weight_f32_wino(w):
     return packed
 
 
+def pack_weight_f32_wino4(w):
+    """OIHW 3x3 conv weight -> the packed exact-fp32 F(4,3) weight of dua_conv3x3_f32_wino4."""
+    _req(w, name="w")
+    assert w.ndim == 4 and w.shape[2] == 3 and w.shape[3] == 3
+    L = _lib.lib()
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(L.dua_f32_wino4_weight_bytes(cout, cin), device=w.device, dtype=torch.uint8)
+    check(L.dua_pack_weight_f32_wino4(_p(w), _p(packed), cout, cin, _stream()), "dua_pack_weight_f32_wino4")
+    return packed
+
+
 def conv3x3_wino_supported(N, H, W, cin, cout):
     """Shapes dua_conv3x3_f16x3_wino takes (H, W = the conv's input / output size)."""
     return bool(_lib.lib().dua_conv3x3_f16x3_wino_supported(int(N), int(H), int(W), int(cin), int(cout)))
@@ -655,7 +674,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
     N, H, W, Cin = x.shape
     y = torch.empty((N, cout, H, W) if nchw_out else (N, H, W, cout), device=x.device, dtype=torch.float32)
     ws = _colsum_ws(N * H * W, cout, x.device, colsum and not nchw_out)
-    assert res_resample == 0 or (pre and x.fmt in ("f16x3w", "f16x3w4", "f16w", "f32w") and residual is not None), "res_resample is a Winograd-conv option"
+    assert res_resample == 0 or (pre and x.fmt in ("f16x3w", "f16x3w4", "f16w", "f32w", "f32w4") and residual is not None), "res_resample is a Winograd-conv option"
     if res_resample:
         rs = (N, H // 2, W // 2, cout) if res_resample > 0 else (N, 2 * H, 2 * W, cout)
         assert tuple(residual.shape) == rs and residual.is_contiguous() and residual.dtype == torch.float32, f"residual must be fp32 {rs}"
@@ -669,6 +688,12 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
             ws = None
         check(_lib.lib().dua_conv3x3_f32_wino(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws), _stream()),
               "dua_conv3x3_f32_wino")
+    elif pre and x.fmt == "f32w4":
+        assert not nchw_out, "the Winograd conv writes NHWC"
+        if (H * W) % 256:
+            ws = None
+        check(_lib.lib().dua_conv3x3_f32_wino4(_p(x.buf), _p(planes), _p(bias), _p(residual), int(res_resample), _p(y), N, H, W, Cin, cout, _p(ws), _stream()),
+              "dua_conv3x3_f32_wino4")
     elif pre and x.fmt == "f16x3w4":
         assert not nchw_out, "the Winograd conv writes NHWC"
         if (H * W) % 256:
@@ -694,7 +719,7 @@ def conv3x3_bf16x3(x, planes, bias, cout, residual=None, nchw_out=False, colsum=
                                             _p(ws), _stream()), "dua_conv3x3_bf16x3")
     if PROFILE is not None:
         e1.record()
-        PROFILE.record("conv3x3_wino" if (pre and x.fmt in ("f16x3w", "f16x3w4", "f16w", "f32w")) else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
+        PROFILE.record("conv3x3_wino" if (pre and x.fmt in ("f16x3w", "f16x3w4", "f16w", "f32w", "f32w4")) else "conv3x3_bf16x3", 2.0 * N * H * W * 9 * Cin * cout, e0, e1)
     return _attach_colsums(y, ws, H * W)
 
 

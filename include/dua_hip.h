@@ -342,6 +342,18 @@ int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float* x2, int C
                                  int resample, const float* dropmask, void* vplanes, void* stream);
 int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                          int N, int H, int W, int Cin, int Cout, float* colsum, void* stream);
+/* The F(4,3)-along-y form in EXACT fp32 (csrc/conv_wino4_f32.hip: k_wconv432 on v_mfma_f32_16x16x4_f32, 4.5 of 9 taps per pixel - the
+ * best form of `precision = "fp32"`, the one mode whose products are the reference's own arithmetic, unet_openai.py:186,212).  The six
+ * transformed images hold floats in the stage-block layout of dua_groupnorm_apply_wino4_f16x3 (same bytes: dua_f16x3_wino4_act_bytes),
+ * the packed weights [column tile of 64][K step = (channel block, fi, dx)][group * 64 + channel][32] floats; shapes as
+ * dua_conv3x3_f16x3_wino4_supported; colsum needs H * W % 256 == 0. */
+size_t dua_f32_wino4_weight_bytes(int Cout, int Cin);
+int dua_pack_weight_f32_wino4(const float* w_oihw, void* packed, int Cout, int Cin, void* stream);
+int dua_groupnorm_apply_wino4_f32(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,
+                                  const float* stats, const float* gamma, const float* beta, const float* film, long film_ld, int act,
+                                  int resample, const float* dropmask, void* vplanes, void* stream);
+int dua_conv3x3_f32_wino4(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
+                          int N, int H, int W, int Cin, int Cout, float* colsum, void* stream);
 /* dua_gemm_f16x3_presplit with the A operand concatenated along K from TWO plane sets (rows [M][K1] and [M][K2], each K % 32 == 0):
  * the 1x1 skip convolution of an ADM output block on torch.cat([h, hs.pop()]) (unet_openai.py:219-223,662) and U-ViT's
  * skip_linear(cat([x, skip])) (uvit/uvit.py:116-117) without materialising the concatenation.  a2planes may be NULL (K2 = 0).
@@ -448,7 +460,7 @@ typedef struct {
                                             dua_pack_weight_f32_wino (DUA_PREC_FP32); a conv whose shape dua_conv3x3_f16x3_wino_supported
                                             accepts then runs in the Winograd form, and its conv*_packed may be NULL (the direct-form
                                             weights serve every other shape and need not be packed for this one) */
-    int conv1_wino_m, conv2_wino_m;      /* 0 / 2: conv*_wino is the F(2,3) packing; 4 (DUA_PREC_F16X3 only): the F(4,3) packing of
+    int conv1_wino_m, conv2_wino_m;      /* 0 / 2: conv*_wino is the F(2,3) packing; 4 (DUA_PREC_F16X3: dua_pack_weight_f16x3_wino4; DUA_PREC_FP32: dua_pack_weight_f32_wino4): the F(4,3) packing of
                                             dua_pack_weight_f16x3_wino4, for a shape dua_conv3x3_f16x3_wino4_supported accepts */
 } dua_resblock_args;
 /* ResBlock.forward, guided_diffusion/unet_openai.py:237-257 (use_scale_shift_norm, resblock_updown). */

@@ -158,6 +158,94 @@ def test_conv3x3_wino4_vs_fp64(ops, N, H, W, Cin, Cout):
     assert torch.equal(y, y1)
 
 
+def decode_v32(pl):
+    buf = pl.buf.cpu().double()                              # [f][tile][C/32][128 positions][32 channels] floats
+    N, H, W, C = pl.shape
+    v = buf.permute(0, 1, 3, 2, 4).reshape(6, -1, C)[:, :N * (H // 4) * W]
+    return v.reshape(6, N, H // 4, W, C)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 32), (1, 16, 16, 64, 96), (2, 8, 16, 96, 64), (1, 32, 32, 256, 256), (5, 16, 16, 128, 160),
+                                             (3, 64, 64, 64, 128), (4, 16, 8, 64, 36), (130, 16, 16, 64, 64), (6, 8, 8, 96, 160), (3, 16, 4, 64, 64),
+                                             (1030, 16, 8, 32, 100), (2, 128, 128, 32, 64)])
+def test_conv3x3_f32_wino4_vs_fp64(ops, N, H, W, Cin, Cout):
+    """The F(4,3) form in EXACT fp32 (csrc/conv_wino4_f32.hip: k_wconv432, mode "fp32" of the UNet): the fp32 V writer
+    against the torch transform, the conv (bias, residual, column sums; ragged tiles) against fp64 next to the F(2,3) fp32 kernel and the
+    direct fp32 MFMA engine.  The F(4,3) constants amplify rounding: the bar is 4x the direct engine's error, as for the f16x3 form."""
+    assert ops.conv3x3_wino4_supported(N, H, W, Cin, Cout)
+    x, w, b = rnd(20, N, Cin, H, W), rnd(21, Cout, Cin, 3, 3) / math.sqrt(9 * Cin), rnd(22, Cout) * 0.1
+    w = w * torch.logspace(-3, 1, Cout).reshape(-1, 1, 1, 1)
+    x = x * torch.logspace(-4, 1.5, Cin).reshape(1, -1, 1, 1)
+    res = rnd(23, N, Cout, H, W)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    scale_out = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+    st = identity_stats(N)
+    one, zero = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    xd = nhwc(x).to(dev)
+    xv4 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f32w4")
+    assert xv4.fmt == "f32w4"
+    vref = v_reference(nhwc(x).double())
+    verr = ((decode_v32(xv4) - vref).abs().max() / vref.abs().max()).item()
+    assert verr < 1e-6, verr
+    wp4 = ops.pack_weight_f32_wino4(w.to(dev))
+    y = ops.conv3x3_bf16x3(xv4, wp4, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True)
+    assert (getattr(y, "_dua_colsums", None) is not None) == ((H * W) % 256 == 0)
+    xv2 = ops.groupnorm_apply(xd, st, one, zero, act=0, split="f32w")
+    y2 = ops.conv3x3_bf16x3(xv2, ops.pack_weight_f32_wino(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    y32 = ops.conv3x3(xd, ops.pack_conv3x3_weight(w.to(dev)), b.to(dev), Cout, residual=nhwc(res).to(dev))
+    err, err2, err32 = (((nchw(t.cpu()).double() - ref).abs() / scale_out).max().item() for t in (y, y2, y32))
+    print(f"F(4,3) fp32 rel err {err:.2e}  F(2,3) fp32 {err2:.2e}  direct fp32-MFMA {err32:.2e}")
+    assert err < max(4 * err32, 4e-6), (err, err2, err32)
+    if (H * W) % 256 == 0 and Cout % 32 == 0:
+        s1 = ops.groupnorm_stats(y)                          # from the conv's column sums
+        s2 = ops.groupnorm_stats(y.clone())                  # by the stand-alone kernel
+        np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    y0 = ops.conv3x3_bf16x3(xv4, wp4, None, Cout)
+    ref0 = F.conv2d(x.double(), w.double(), padding=1)
+    assert ((nchw(y0.cpu()).double() - ref0).abs() / scale_out).max().item() < max(4 * err32, 4e-6)
+    assert torch.equal(y, ops.conv3x3_bf16x3(xv4, wp4, b.to(dev), Cout, residual=nhwc(res).to(dev), colsum=True))
+    if N <= 6:                                               # the resampled identity skip read in the epilogue (unet_openai.py:238-243)
+        for mode, rshape in ((1, (N, Cout, H // 2, W // 2)), (-1, (N, Cout, 2 * H, 2 * W))):
+            r = rnd(42 + mode, *rshape)
+            full = F.interpolate(r, scale_factor=2, mode="nearest") if mode > 0 else F.avg_pool2d(r, 2)
+            ya = ops.conv3x3_bf16x3(xv4, wp4, None, Cout, residual=nhwc(r).to(dev), res_resample=mode)
+            yb = ops.conv3x3_bf16x3(xv4, wp4, None, Cout, residual=nhwc(full).to(dev))
+            assert torch.equal(ya, yb), mode
+
+
+def test_fp32_unet_runs_f43_and_matches_reference(golden):
+    """Mode "fp32" of the full-size ADM-64 / ADM-128 with the default form choice (F(4,3) wherever its kernel takes the shape): inside the
+    1e-3 bar against the reference's own output (G5) at the distance of the F(2,3) and direct forms; block-level C ABI == per-op
+    composition bit for bit; deterministic."""
+    from conftest import T
+    from oracle import adm
+    from test_gpu_models import build_adm
+    from diffusion_uncertainty_amd.guided_diffusion.unet_openai import _Ctx
+    for name, cfg in (("adm64", adm.ADM64), ("adm128", adm.ADM128)):
+        g = golden(f"g5_{name}_full")
+        m, _ = build_adm(dict(cfg), int(g["seed"]))
+        m.precision = "fp32"
+        x, t, y = T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev)
+        hw = int(g["x"].shape[-1])
+        assert _Ctx(m).wino_form(1, hw, hw, cfg["model_channels"], cfg["model_channels"]) == 4
+        w4 = m(x, t, y=y)
+        assert torch.equal(w4, m(x, t, y=y))
+        m.use_block_abi = False
+        wop = m(x, t, y=y)
+        m.use_block_abi = True
+        m.winograd = 2
+        w2 = m(x, t, y=y)
+        m.winograd = False
+        d = m(x, t, y=y)
+        e4, e2, ed = (np.abs(a.cpu().numpy() - g["out"]).max() for a in (w4, w2, d))
+        print(f"{name} fp32: F(4,3) err {e4:.3e}, F(2,3) err {e2:.3e}, direct err {ed:.3e}, |F(4,3) - direct| {(w4 - d).abs().max().item():.3e}")
+        assert e4 < 1e-3 and e4 < 2 * max(e2, ed) + 2e-6
+        assert (w4 - d).abs().max().item() < 5e-5 and not torch.equal(w4, w2)
+        assert torch.equal(w4, wop)
+        del m
+        torch.cuda.empty_cache()
+
+
 def test_wino4_resampled_residual_in_epilogue(ops):
     """The identity skip of an ADM up / down block read through the resampling in the conv's epilogue (unet_openai.py:238-243)."""
     N, H, W, C = 3, 16, 16, 64
