@@ -91,7 +91,9 @@ def pmc_traffic(precision):
             continue
         k = d.get("kernels", {}).get("k_wconv") or d.get("kernels", {}).get("k_xconv_dma") or d.get("kernels", {}).get("conv")
         if k and "hbm_side_bytes_per_launch" in k:
-            best = (float(k["hbm_side_bytes_per_launch"]), os.path.relpath(f, ROOT))
+            by_symbol = {n[len("symbol:"):]: {"hbm_side_bytes_per_launch": v.get("hbm_side_bytes_per_launch"), "launches": v.get("launches")}
+                         for n, v in d.get("kernels", {}).items() if n.startswith("symbol:")}
+            best = (float(k["hbm_side_bytes_per_launch"]), os.path.relpath(f, ROOT), by_symbol)
     return best
 
 
@@ -147,7 +149,8 @@ class ConvProfile:
         r = dict(bound="mfma", achieved=round(cs["tflops"], 2), peak=peak, unit="TFLOP/s", frac=round(frac, 4),
                  frac_basis=("algorithmic FLOPs / peak" if eff_ >= 1.0 else "executed matrix-core FLOPs / peak (fewer executed than algorithmic products)"),
                  algorithmic_over_peak=round(cs["tflops"] / peak, 4),
-                 traffic=(tr[0] if tr else None), traffic_source=(tr[1] if tr else None), kernel=kernel, launches=cs["launches"],
+                 traffic=(tr[0] if tr else None), traffic_source=(tr[1] if tr else None), traffic_by_kernel=((tr[2] or None) if tr else None),
+                 kernel=kernel, launches=cs["launches"],
                  flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
         if mult:
             eff = cs["mfma_tflops"] / cs["tflops"]                 # executed matrix-core products per algorithmic product (measured mix)

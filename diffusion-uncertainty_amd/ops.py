@@ -455,7 +455,9 @@ def pack_conv3x3_weight(w):
 
 
 # Power-of-two scale of the f16x3 activation planes (GroupNorm / SiLU outputs): |x| up to 1023 stays finite in fp16 and
-# every |x| >= 2^-9 keeps its 22 significant bits.
+# every |x| >= 2^-9 keeps its 22 significant bits.  The Winograd images derive their scales from it: F(2,3) 0.5 * 64 = 32 (|V| <= 2 |x|:
+# the same |x| <= 1023), F(4,3) 0.125 * 64 = 8 (|V| <= 10 |x|: the rows of B^T sum to 4 + 5 + 1 in absolute value, so the hi half
+# saturates for |x| > 818 - a fifth less headroom - and values below 2^-6 lose low bits); dua_range_check counts both ends.
 F16X3_ACT_SCALE = 64.0
 # ... of raw residual-stream operands split on the fly (1x1 skip convolutions, proj_out): |x| up to 4094 stays in fp16's range
 # (beyond it the lo half takes over at reduced precision), 22 significant bits down to 2^-7.

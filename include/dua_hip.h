@@ -528,7 +528,8 @@ int dua_unpatchify(const float* tok, float* img, int B, int L, int extras, int C
  * clamps and the hi + lo pair no longer carries 22 bits of x: the "fp32-equivalent" claim does not hold for that operand; (b) subnormal:
  * 0 < |x * plane scale| < 2^-14, hi is an fp16 subnormal - harmless (the pair stays exact to 2^-25 / scale absolutely), reported for
  * completeness.  The plane scales are static (64 for GroupNorm / SiLU / LayerNorm outputs: |x| <= 1023; 16 for raw-stream operands, GELU
- * and attention outputs: |x| <= 4094; 32 for the Winograd images): a non-zero saturation count on real checkpoints says the activations
+ * and attention outputs: |x| <= 4094; 32 for the Winograd F(2,3) images: |x| <= 1023; 8 for the F(4,3) images, whose transform rows sum to 10
+ * in absolute value: |x| <= 818): a non-zero saturation count on real checkpoints says the activations
  * exceed those bounds and the run should use precision "fp32" (INTEGRATION.md section 4).  dua_range_check returns the previous setting (0 / 1;
  * a negative DUA_E* code when the counters cannot be allocated or cleared) and zeroes the counters when switched on; dua_range_check_read copies them out (reset != 0 zeroes them). */
 int dua_range_check(int on);
