@@ -742,7 +742,7 @@ def short_line(line, legs_path):
         out["checked"] = {k: ch.get(k) for k in ("ok", "max_abs_diff", "bit_identical", "of", "error") if k in ch}
     for k, name in (("other_precision_modes", "precision"), ("other_configs", "config")):
         if line.get(k):
-            out[k + "_summary"] = {str(o.get(name, "?"))[:40]: o.get("value", o.get("error")) for o in line[k]}
+            out[k + "_summary"] = {str(o.get(name, "?"))[:28]: o.get("value", o.get("error")) for o in line[k]}
     out["full_record"] = legs_path and os.path.relpath(legs_path, ROOT)
     return out
 

@@ -48,6 +48,10 @@ SPECS = [
          mfma=("v_mfma_f32_16x16x32_f16", {6 * 48, 6 * 72, 6 * 96}), loop_vmcnt={4, 6, 7}, loop_vmcnt_need=set(), tail_wait=None),
     dict(name="k_sgemm", obj="gemm_skip_f16x3.o", sym=r"^_Z7k_sgemmILi[24]ELb0EEv6SGemmP$", regs=256, scratch=0,
          mfma=("v_mfma_f32_16x16x32_f16", {48, 96}), loop_vmcnt={4, 6}, loop_vmcnt_need=set(), tail_wait=8),
+    dict(name="k_wconv432", obj="conv_wino4_f32.o", sym=r"^_Z10k_wconv4326WConvP$", regs=256, scratch=128,
+         mfma=("v_mfma_f32_16x16x4_f32", {9 * 64}), loop_vmcnt={2, 4, 6}, loop_vmcnt_need={2, 4, 6}, tail_wait=16),
+    dict(name="k_wconv32", obj="conv_wino_f32.o", sym=r"^_Z9k_wconv326WConvP$", regs=256, scratch=192,
+         mfma=("v_mfma_f32_16x16x4_f32", {6 * 128}), loop_vmcnt={4, 6, 8}, loop_vmcnt_need=set(), tail_wait=16),
     dict(name="k_xtile<f16x3>", obj="mfma_bf16x3.o", sym=r"^_Z7k_xtileILi0ELb[01]ELb0ELb0ELb1EEv6XTileP$", regs=256, scratch=0,
          mfma=("v_mfma_f32_32x32x16_f16", {48}), loop_vmcnt=set(range(8, 16)), loop_vmcnt_need=set(), tail_wait=None),
 ]
@@ -313,6 +317,20 @@ def run(objdir=CSRC, verbose=False, json_path=None):
         for obj, (dis, notes) in cache.items():
             for sym, m in parse_metadata(notes).items():
                 table[sym] = {k: v for k, v in m.items() if k != "name"}
+        if json_path:                                    # the record covers EVERY translation unit, not only the linted ones
+            for f in sorted(os.listdir(objdir)):
+                obj = os.path.join(objdir, f)
+                if not f.endswith(".o") or obj in cache:
+                    continue
+                sub = os.path.join(tmp, f + ".d")
+                os.makedirs(sub)
+                try:
+                    co = extract_code_object(obj, sub)
+                    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+                except Exception as e:                   # (an object without device code)
+                    continue
+                for sym, m in parse_metadata(notes).items():
+                    table[sym] = {k: v for k, v in m.items() if k != "name"}
     if json_path:
         ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.strip().splitlines()
         with open(json_path, "w") as f:
