@@ -36,6 +36,12 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
                                   // bit 5 no residual loads, bit 6 wave 0 writes s_memrealtime at the start and end of every epilogue into the colsum buffer
 #endif
 
+// (A/B build -DW4_EPI_NOFENCE=1: the epilogue's sub-blocks without scheduling fences - the compiler may interleave their dependent chains)
+#if defined(W4_EPI_NOFENCE) && W4_EPI_NOFENCE
+#define W4_EPI_FENCE()
+#else
+#define W4_EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 constexpr int W4_STORES = 2 * 4 * 2 * 4;          // channel-block pairs x position blocks x halves x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
@@ -463,9 +469,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 w4_static_for<2>([&](auto h_c) __attribute__((always_inline)) {
                     constexpr int h = decltype(h_c)::value;
                     constexpr int sb = (jp * 4 + i) * 2 + h;
-                    __builtin_amdgcn_sched_barrier(0);
+                    W4_EPI_FENCE();
                     if constexpr (sb + 1 < 16) res_ld(sb + 1, rn_[(sb + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    W4_EPI_FENCE();
                     const int le = lane_now();
                     const int q = le & 7, c = n0 + wn * 64 + 32 * jp + 4 * q, pl = (le >> 3) + 8 * h;
                     const long row0 = opix(i, pl);
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                             const int y = __builtin_amdgcn_update_dpp(__float_as_int(R[0][r][e]), __float_as_int(R[1][r][e]), 0x128, 0xf, h == 0 ? 0xc : 0x3, false);
                             t4[r][e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, y));
                         }
-                    __builtin_amdgcn_sched_barrier(0);
+                    W4_EPI_FENCE();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float (&t)[4] = t4[r];
