@@ -579,7 +579,8 @@ def test_gemm_f16x3(ops, M, N, K1, K2):
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(4096, 256, 256, 256), (33000, 256, 512, 256), (700, 512, 768, 512), (300, 1024, 1024, 1024), (257, 768, 1280, 0),
-                                        (5, 2048, 256, 0), (1000, 72, 64, 0), (9000, 136, 96, 32), (64, 16, 1152, 0), (65536, 256, 32, 32)])
+                                        (5, 2048, 256, 0), (1000, 72, 64, 0), (9000, 136, 96, 32), (64, 16, 1152, 0), (65536, 256, 32, 32),
+                                        (500, 128, 96, 0), (700, 256, 96, 64), (2000, 320, 224, 0)])           # (odd numbers of 32-deep K steps: 3, 5, 7)
 def test_gemm_f16x3_skip_kernel(ops, M, N, K1, K2):
     """The plain form of dua_gemm_f16x3 (bias only: the ADM 1x1 skip convolutions over the virtual concat, unet_openai.py:219-223,257,662)
     on the persistent raw-operand kernel k_sgemm (csrc/gemm_skip_f16x3.hip): held to the exact fp32 engine's error against fp64, within
