@@ -369,10 +369,15 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         const auto rc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + cpix0 * p.N), 0, (int)(crem < 0x7FFFFFF0L ? crem : 0x7FFFFFF0L), 0x00020000);
         // output pixel (row of C) of position pl of block i, output row 0; -1 beyond the tensor
         const bool tile_full = n0 + 128 <= p.N && m0 + 128 <= p.Mv;
-        auto opix = [&](int i, int pl) -> long {
-            const int pos = pos0 + 16 * i + pl;
-            return (tile_full || pos < p.Mv) ? (long)pos + 3L * (pos & ~(p.W - 1)) : -1L;
+        // ... RELATIVE to the tile's first output pixel cpix0 = 4 m0 (m0 is a multiple of 128 >= W): d + 3 (d & ~(W - 1)) for the position d of
+        // the tile - small 32-bit numbers.  (As 64-bit pixel indices every sub-block paid a v_mad_u64_u32 and every store a v_mul_lo_u32 by N:
+        // quarter-rate instructions, ~1 300 of the epilogue's ~9 000 issue cycles per wave and tile.)
+        const int w_mask = ~(p.W - 1);
+        auto opix = [&](int i, int pl) -> int {
+            const int d = wm * 64 + 16 * i + pl;
+            return (tile_full || m0 + d < p.Mv) ? d + 3 * (d & w_mask) : -1;
         };
+        const unsigned row_bytes = (unsigned)p.W * (unsigned)p.N * 4u;         // one output row further (wave-uniform)
         // the residual descriptor: RMODE 1 mirrors the output's (same offsets); RMODE 2 / 3 start at the first image the tile touches in the
         // half / double resolution tensor (offsets stay far below 2^32)
         const unsigned res_n0 = RMODE >= 2 ? (unsigned)(cpix0 / ((long)p.H * p.W)) : 0u;
@@ -396,15 +401,17 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             }
             const int le = lane_now();
             const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7);
-            const long row0 = opix(i, (le >> 3) + 8 * h);
-            const bool okl = FULL ? !(WCONV4_DIAG & 32) : (c < p.N && row0 >= 0 && !(WCONV4_DIAG & 32));
+            const int rel0 = opix(i, (le >> 3) + 8 * h);
+            const long row0 = rel0 < 0 ? -1L : cpix0 + rel0;                 // (the absolute pixel: the resampled modes only)
+            const bool okl = FULL ? !(WCONV4_DIAG & 32) : (c < p.N && rel0 >= 0 && !(WCONV4_DIAG & 32));
             if constexpr (MODE == 1) {
                 // plain residual: buffer loads that ALWAYS issue (masked lanes read beyond the descriptor: zeros), so the code is straight
                 // and the compiler's vector-memory waits count the instructions exactly instead of assuming the worst at every join
+                const unsigned o0 = (__umul24((unsigned)rel0, (unsigned)p.N) + (unsigned)c) * 4u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                    const u32x4_ q4 = __builtin_amdgcn_raw_buffer_load_b128(rres, okl ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                    const u32x4_ q4 = __builtin_amdgcn_raw_buffer_load_b128(rres, okl ? o0 + (unsigned)r * row_bytes : 0xFFFFFFF0u, 0, 0);
                     dst[r] = make_float4(__uint_as_float(q4[0]), __uint_as_float(q4[1]), __uint_as_float(q4[2]), __uint_as_float(q4[3]));
                 }
                 return;
@@ -474,8 +481,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     W4_EPI_FENCE();
                     const int le = lane_now();
                     const int q = le & 7, c = n0 + wn * 64 + 32 * jp + 4 * q, pl = (le >> 3) + 8 * h;
-                    const long row0 = opix(i, pl);
-                    const bool ok = FULL ? !(WCONV4_DIAG & 16) : (c < p.N && row0 >= 0 && !(WCONV4_DIAG & 16));
+                    const int rel0 = opix(i, pl);
+                    const bool ok = FULL ? !(WCONV4_DIAG & 16) : (c < p.N && rel0 >= 0 && !(WCONV4_DIAG & 16));
+                    const unsigned o0 = (__umul24((unsigned)rel0, (unsigned)p.N) + (unsigned)c) * 4u;
                     // The 32 lanes whose accumulator-layout position (lane & 15) lies in half h hold the first block's quads of the 8 rows
                     // this instruction writes; the other 32 lanes are free to carry the second block's (a rotation by 8 inside the 16-lane
                     // row, one DPP move): then ONE ds_bpermute per register gathers a row's eight 16-byte pieces into adjacent lanes.
@@ -497,13 +505,16 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                         const float (&t)[4] = t4[r];
                         const float4 rq = rn_[sb & 1][r];
                         float4 v;
-                        v.x = __builtin_fmaf(t[0], sq.x, bq.x) + rq.x;            // (one fixed rounding order in every variant of the epilogue)
-                        v.y = __builtin_fmaf(t[1], sq.y, bq.y) + rq.y;
-                        v.z = __builtin_fmaf(t[2], sq.z, bq.z) + rq.z;
-                        v.w = __builtin_fmaf(t[3], sq.w, bq.w) + rq.w;
+                        v.x = __builtin_fmaf(t[0], sq.x, bq.x);                   // (one fixed rounding order in every variant of the epilogue)
+                        v.y = __builtin_fmaf(t[1], sq.y, bq.y);
+                        v.z = __builtin_fmaf(t[2], sq.z, bq.z);
+                        v.w = __builtin_fmaf(t[3], sq.w, bq.w);
+                        // (no residual: no `+ 0` either - IEEE keeps x + 0.0 as an instruction (it turns -0 into +0): two packed adds and two
+                        // wait states per row, 256 instructions per tile of the kernel that is 31 % of the headline job)
+                        if constexpr (MODE != 0) { v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w; }
                         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
                         const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? (unsigned)(((row0 + (long)r * p.W - cpix0) * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? o0 + (unsigned)r * row_bytes : 0xFFFFFFF0u, 0, 0);
                         if (FULL || ok) {                                       // (explicit fma: the same rounding in every variant)
                             cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
                             cq2.x = __builtin_fmaf(v.x, v.x, cq2.x); cq2.y = __builtin_fmaf(v.y, v.y, cq2.y);
