@@ -3,6 +3,9 @@
 // Built with -ffp-contract=off so the elementwise arithmetic rounds like the reference's separate ATen ops.
 #include "common.h"
 #include <stdarg.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 extern "C" void dua_set_error(const char* fmt, ...) {
@@ -468,8 +471,505 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
     }
 }
 
-static int quantile_force_stream = 0;      // A/B switch for tests: 1 = always the streaming (multi-pass) kernel
+// ---- several workgroups per sample (16384 < n <= 65536, 16-byte aligned rows: the [B,3,128,128] maps of the ADM path) --------
+// One workgroup per sample leaves half of the 256 CUs idle at B = 128 and each busy one pulls its 192 KB alone (~17 us, the
+// floor of the kernel above); a full LDS-atomic histogram level retires about one key per clock and CU (~15 us at any split).
+// Here G workgroups of 1024 threads share a sample (16-KB stripes interleaved), and no pass puts every key through an atomic:
+//   1. every workgroup loads its stripes into registers as keys, and - all G of them the same - 768 scattered float4 of the
+//      whole sample (3072 keys: 1/16 of the [3,128,128] map, columns rotating from row to row);
+//   2. 2048-bin histogram levels over the SAMPLE bracket the target: bin edges A <= B such that the sample's ranks
+//      r - delta .. r + delta (r = lo scaled to the sample, delta = 5.7 sigma of a rank under independent draws) lie inside;
+//      every workgroup computes the same A, B from the same keys - no exchange;
+//   3. one register pass counts the own keys below A and ballot-packs those in [A, B] (~6 - 10 % of them) into LDS; the counts
+//      and the packed keys go to the sample's slot of a global workspace (one reserving atomic per workgroup), then the G
+//      workgroups meet at an arrival counter (agent-scope release / acquire: the L2s of different XCDs are not coherent);
+//   4. each workgroup reads the totals and ALL candidates (<= 12 per thread) and - if lo and hi fall inside the bracket, which
+//      the exact counts decide - selects s[lo], s[lo+1] among them exactly as the kernel above does among all keys;
+//      otherwise (a bracket that missed: correlated or tied data) workgroup 0 of the sample runs the streaming select and
+//      writes the whole mask.  Exact either way; the result never depends on the sample.
+//   5. mask from the registers; the last workgroup to leave zeroes the sample's counters for the next launch.
+// Deadlock freedom: every workgroup reaches the arrival counter unconditionally, and the G workgroups of a sample have
+// consecutive block indices, so with in-order dispatch a waiting workgroup's partners are resident or next to be placed.
+#define QM_TH 1024
+#define QM_CAP 12288                         // candidate slots per sample (12 per thread in the final select)
+#define QM_S4 768                            // float4 of the common sample
+#define QM_CTR 16                            // counter words per sample: left, -, the 64-bit arrival word, pad
+#define QM_G 2                               // workgroups per sample (the packed arrival word of step 3 is laid out for two)
+
+// Wavefront reductions / scan on DPP row shifts and row broadcasts (six VALU operations; __shfl_* are ds_bpermute round trips
+// through the LDS pipe, ~0.3 us per six of them with sixteen wavefronts on the CU)
+template <class Op>
+__device__ __forceinline__ uint32_t qm_dpp_fold(uint32_t v, const uint32_t ident, Op op) {      // result in lane 63 of: op over lanes 0..l
+#define QM_DPP(ctrl, rmask) op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, ctrl, rmask, 0xf, false))
+    v = QM_DPP(0x111, 0xf);                                  // row_shr:1
+    v = QM_DPP(0x112, 0xf);                                  // row_shr:2
+    v = QM_DPP(0x114, 0xf);                                  // row_shr:4
+    v = QM_DPP(0x118, 0xf);                                  // row_shr:8
+    v = QM_DPP(0x142, 0xa);                                  // row_bcast:15 into rows 1, 3
+    v = QM_DPP(0x143, 0xc);                                  // row_bcast:31 into rows 2, 3
+#undef QM_DPP
+    return v;
+}
+__device__ __forceinline__ uint32_t qm_wave_min(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)qm_dpp_fold(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return min(a, b); }), 63);
+}
+__device__ __forceinline__ uint32_t qm_wave_max(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)qm_dpp_fold(v, 0u, [](uint32_t a, uint32_t b) { return max(a, b); }), 63);
+}
+__device__ __forceinline__ uint32_t qm_wave_scan_add(uint32_t v) {                                // inclusive prefix sum over the lanes
+    return qm_dpp_fold(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+}
+
+struct QmSel { uint32_t klo, next; bool need_next; };
+// -DQM_DIAG (scripts/diag/quantile_diag.py, never the product library): tid 0 of every workgroup stamps the phases with the
+// 100-MHz counter into the last 256 words of its sample's candidate area (which a bracket never fills): 32 slots per workgroup
+#ifdef QM_DIAG
+#define QM_STAMP_AT(p, i) do { if (threadIdx.x == 0) (p)[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QM_STAMP_AT(p, i) do { } while (0)
+#endif
+#define QM_STAMP(i) QM_STAMP_AT(stp, i)
+
+// Exact selection of rank `rank` among the NK keys per thread of one QM_TH-thread workgroup (NONE = absent): the histogram
+// levels, candidate ranking and successor scan of k_quantile_mask_reg.  All threads return the same values.
+template <int NK>
+__device__ __forceinline__ QmSel qm_select(const uint32_t (&key)[NK], uint32_t rank, bool two, uint32_t* hist, uint32_t* cand,
+                                           uint32_t (*part)[QM_TH / 64], uint32_t* sv, uint64_t* stp) {
+    (void)stp;
+    constexpr int NW = QM_TH / 64, BPT = QBINS / QM_TH;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QM_STAMP(16);
+    uint32_t kmin = NONE, kmax = 0;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        kmin = min(kmin, key[i]);
+        kmax = key[i] != NONE ? max(kmax, key[i]) : kmax;
+    }
+    kmin = qm_wave_min(kmin);
+    kmax = qm_wave_max(kmax);
+    __syncthreads();
+    if (lane == 0) { part[0][wave] = kmin; part[1][wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { kmin = min(kmin, part[0][i]); kmax = max(kmax, part[1][i]); }
+    uint32_t base = kmin, span = kmax - kmin, shift, bsel, csel;
+    QM_STAMP(17);
+    for (;;) {
+        shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const uint32_t d = key[i] - base;              // (d <= span is base <= key <= base + span; NONE never passes)
+            if (d <= span) atomicAdd(&hist[d >> shift], 1u);
+        }
+        __syncthreads();
+        QM_STAMP(18);
+        uint32_t cb[BPT], own = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) { cb[i] = hist[BPT * tid + i]; own += cb[i]; }
+        const uint32_t incl = qm_wave_scan_add(own);
+        if (lane == 63) part[0][wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) off += i < wave ? part[0][i] : 0u;
+        uint32_t excl = incl - own + off;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            if (rank >= excl && rank < excl + cb[i]) { sv[0] = BPT * tid + i; sv[1] = rank - excl; sv[2] = cb[i]; }
+            excl += cb[i];
+        }
+        __syncthreads();
+        bsel = sv[0];
+        rank = sv[1];
+        csel = sv[2];
+        QM_STAMP(19);
+        if (csel <= QCAP || shift == 0) break;
+        base += bsel << shift;
+        span = (1u << shift) - 1u;
+    }
+    __syncthreads();
+    if (shift == 0) {
+        if (tid == 0) { sv[3] = base + bsel; sv[4] = csel; sv[5] = rank; }
+    } else {
+        if (tid == 0) sv[6] = 0;
+        __syncthreads();
+        // the bin's keys -> cand[] in any order (they are ranked by counting): usually a handful, so one exec-masked LDS atomic
+        // per key position and no wavefront bookkeeping; positions without a member in the wavefront are skipped
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const uint32_t d = key[i] - base;
+            if (d <= span && (d >> shift) == bsel) cand[atomicAdd(&sv[6], 1u)] = key[i];
+        }
+        __syncthreads();
+        QM_STAMP(20);
+        for (uint32_t t = tid; t < csel; t += QM_TH) {
+            const uint32_t k = cand[t];
+            uint32_t less = 0, eq = 0;
+            for (uint32_t j2 = 0; j2 < csel; ++j2) {
+                const uint32_t kj = cand[j2];
+                less += kj < k ? 1u : 0u;
+                eq += kj == k ? 1u : 0u;
+            }
+            if (less <= rank && rank < less + eq) { sv[3] = k; sv[4] = eq; sv[5] = rank - less; }
+        }
+    }
+    if (tid == 0) sv[7] = NONE;
+    __syncthreads();
+    QM_STAMP(21);
+    QmSel r;
+    r.klo = sv[3];
+    r.need_next = two && sv[5] + 1 >= sv[4];
+    if (r.need_next) {
+        uint32_t best = NONE;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) best = key[i] > r.klo ? min(best, key[i]) : best;
+        best = qm_wave_min(best);
+        if (lane == 0) atomicMin(&sv[7], best);
+    }
+    __syncthreads();
+    r.next = sv[7];
+    return r;
+}
+
+__device__ __forceinline__ float qm_lerp(uint32_t klo, uint32_t knext, bool need_next, float w) {
+    const float a = key2f(klo);
+    const float b = need_next ? key2f(knext) : a;
+    const float d = __fsub_rn(b, a);
+    return (w < 0.5f) ? __fadd_rn(a, __fmul_rn(w, d)) : __fsub_rn(b, __fmul_rn(d, __fsub_rn(1.0f, w)));
+}
+
+template <int V4>
+__global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __restrict__ u, int n, int lo, int hi, float w,
+                                                               uint8_t* __restrict__ mask, float* __restrict__ q,
+                                                               uint32_t* ws, int delta, int force_miss) {
+    constexpr int NW = QM_TH / 64, BPT = QBINS / QM_TH, NKF = QM_CAP / QM_TH;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    __shared__ uint32_t hist[QBINS];
+    __shared__ uint32_t cand[QCAP];                          // the <= QCAP keys ranked by counting
+    __shared__ uint32_t part[2][NW];
+    __shared__ uint32_t sv[32];
+    __shared__ float s_q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = QM_G;
+    const int smp = blockIdx.x / G, g = blockIdx.x - smp * G;
+    const float* ub = u + (size_t)smp * n;
+    uint8_t* mb = mask + (size_t)smp * n;
+    uint32_t* ctr = ws + (size_t)smp * (QM_CTR + QM_CAP);
+    uint32_t* gcand = ctr + QM_CTR;
+    uint64_t* stp = (uint64_t*)(gcand + QM_CAP - 256) + g * 32;
+    (void)stp;
+    const int n4 = n >> 2;
+
+    // ---- 1. own stripes and the common sample -> keys
+    QM_STAMP(0);
+    // Every load in ONE asm statement together with its wait (V4 + 1 of 16 bytes in flight per lane): left to the compiler the
+    // loads are sunk to their conversions one by one, each behind its own vmcnt(0); with the wait inside the statement no
+    // compiler-placed copy can read a register before its data has arrived.  (Tried: the stripes by LDS-DMA, read back after
+    // step 2, with the sample requested first or in the middle - the same 18.7 us: the first data of a fresh workgroup takes
+    // ~3 us to arrive whatever is asked for, and the sample does not come sooner than the stripes.)
+    // Sample position: float4 i * st4 + (7 i mod 2^k), 2^k <= st4 = n4 / 768 (>= 5): the column rotates from one sampled row to the next
+    uint32_t key[4 * V4], sk[4];
+    {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const int st4 = n4 / QM_S4, si = min(tid, QM_S4 - 1);
+        const f4v* ad[V4 + 1];
+        f4v raw[V4 + 1];
+#pragma unroll
+        for (int j = 0; j < V4; ++j) ad[j] = (const f4v*)ub + min((j * G + g) * QM_TH + tid, n4 - 1);
+        ad[V4] = (const f4v*)ub + (si * st4 + ((si * 7) & ((1 << (31 - __clz(st4))) - 1)));
+#define QL(o, a) "global_load_dwordx4 %" #o ", %" #a ", off\n"
+        if constexpr (V4 == 3)
+            asm volatile(QL(0, 4) QL(1, 5) QL(2, 6) QL(3, 7) "s_waitcnt vmcnt(0)"
+                         : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3]) : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]) : "memory");
+        else if constexpr (V4 == 4)
+            asm volatile(QL(0, 5) QL(1, 6) QL(2, 7) QL(3, 8) QL(4, 9) "s_waitcnt vmcnt(0)"
+                         : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3]), "=&v"(raw[4])
+                         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]) : "memory");
+        else if constexpr (V4 == 6)
+            asm volatile(QL(0, 7) QL(1, 8) QL(2, 9) QL(3, 10) QL(4, 11) QL(5, 12) QL(6, 13) "s_waitcnt vmcnt(0)"
+                         : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3]), "=&v"(raw[4]), "=&v"(raw[5]), "=&v"(raw[6])
+                         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]) : "memory");
+        else {
+            static_assert(V4 == 8, "k_quantile_mask_multi: V4 in {3, 4, 6, 8}");
+            asm volatile(QL(0, 9) QL(1, 10) QL(2, 11) QL(3, 12) QL(4, 13) QL(5, 14) QL(6, 15) QL(7, 16) QL(8, 17) "s_waitcnt vmcnt(0)"
+                         : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3]), "=&v"(raw[4]), "=&v"(raw[5]), "=&v"(raw[6]), "=&v"(raw[7]), "=&v"(raw[8])
+                         : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "v"(ad[8]) : "memory");
+        }
+#undef QL
+#pragma unroll
+        for (int j = 0; j <= V4; ++j) {
+            const uint32_t none = (j < V4 ? (j * G + g) * QM_TH + tid < n4 : tid < QM_S4) ? 0u : NONE;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t k = f2key(raw[j][e]) | none;
+                asm("" : "+v"(k));                           // opaque: only the key lives on, not the float it came from
+                if (j < V4) key[4 * j + e] = k;
+                else sk[e] = k;
+            }
+        }
+    }
+    QM_STAMP(1);
+    // ---- 2. the bracket [A, B] from the sample (identical in every workgroup of the sample)
+    constexpr uint32_t S = 4 * QM_S4;
+    const uint32_t rs = (uint32_t)(((uint64_t)(uint32_t)lo * S) / (uint32_t)n);
+    const bool openA = rs < (uint32_t)delta, openB = rs + (uint32_t)delta + 1u >= S - 1u;
+    uint32_t ra = openA ? 0u : rs - (uint32_t)delta, rb = openB ? S - 1u : rs + (uint32_t)delta + 1u;
+    const uint32_t cap_s = (rb - ra + 1u) + 96u;
+    uint32_t smin = min(min(sk[0], sk[1]), min(sk[2], sk[3])), smax = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) smax = sk[e] != NONE ? max(smax, sk[e]) : smax;
+    smin = qm_wave_min(smin);
+    smax = qm_wave_max(smax);
+    if (lane == 0) { part[0][wave] = smin; part[1][wave] = smax; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { smin = min(smin, part[0][i]); smax = max(smax, part[1][i]); }
+    uint32_t base = smin, span = smax - smin;
+    QM_STAMP(9);
+    for (int level = 0; level < 4; ++level) {
+        const uint32_t shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t d = sk[e] - base;               // (d <= span is base <= key <= base + span; NONE never passes)
+            if (d <= span) atomicAdd(&hist[d >> shift], 1u);
+        }
+        __syncthreads();
+        if (level == 0) QM_STAMP(10);
+        uint32_t cb[BPT], own = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) { cb[i] = hist[BPT * tid + i]; own += cb[i]; }
+        const uint32_t incl = qm_wave_scan_add(own);
+        if (lane == 63) part[0][wave] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) off += i < wave ? part[0][i] : 0u;
+        uint32_t excl = incl - own + off;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            if (ra >= excl && ra < excl + cb[i]) { sv[0] = BPT * tid + i; sv[1] = excl; }
+            if (rb >= excl && rb < excl + cb[i]) { sv[2] = BPT * tid + i; sv[3] = excl + cb[i]; }
+            excl += cb[i];
+        }
+        __syncthreads();
+        if (level == 0) QM_STAMP(11);
+        const uint32_t binA = sv[0], exA = sv[1], binB = sv[2], inB = sv[3];
+        const uint64_t hi_edge = (((uint64_t)binB + 1u) << shift) - 1u;
+        const uint32_t lo_off = binA << shift, hi_off = (uint32_t)(hi_edge < (uint64_t)span ? hi_edge : (uint64_t)span);
+        const uint32_t nspan = hi_off - lo_off;
+        const bool stuck = nspan == span;
+        base += lo_off;
+        span = nspan;
+        ra -= exA;
+        rb -= exA;
+        if (inB - exA <= cap_s || shift == 0 || stuck) break;
+    }
+    const uint32_t A = openA ? 0u : base, Bk = openB ? 0xFFFFFFFEu : base + span;
+
+    QM_STAMP(2);
+    // ---- 3. own keys: count below A, pack [A, B] into the own region of the sample's candidate area, publish, meet.
+    // What the workgroups exchange goes through agent-scope atomic stores / loads (written through, read past the
+    // non-coherent levels), ordered by the barrier and ONE release / acquire pair per workgroup: a fence per wavefront writes
+    // back / invalidates the whole L2 sixteen times per workgroup (measured: 38 + 34 us of a 105-us kernel).
+    __syncthreads();
+    if (tid == 0) { sv[8] = 0; sv[9] = 0; }
+    __syncthreads();
+    constexpr uint32_t RC = (uint32_t)QM_CAP / (uint32_t)G;  // candidate slots per workgroup
+    {
+        // One unsigned compare per test, straight into an SGPR pair (key - A <= B - A is A <= key <= B: no wrap since B < 2^32 - 1;
+        // NONE never passes), counts by scalar popcount; the second pass repeats the compare (cheaper than parking 24 masks)
+        // and turns mask + running base into the slot with one v_mbcnt pair per key.
+        uint32_t* greg = gcand + (uint32_t)g * RC;
+        const uint32_t width = Bk - A;
+        uint32_t below = 0, wtot = 0;
+#pragma unroll
+        for (int i = 0; i < 4 * V4; ++i) {
+            below += (uint32_t)__popcll(__builtin_amdgcn_uicmp(key[i], A, 36));               // ICMP_ULT
+            wtot += (uint32_t)__popcll(__builtin_amdgcn_uicmp(key[i] - A, width, 37));        // ICMP_ULE
+        }
+        uint32_t run = 0;                                    // one LDS atomic per wavefront reserves its run of slots
+        if (lane == 0) { run = atomicAdd(&sv[8], wtot); atomicAdd(&sv[9], below); }
+        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+        const bool room = run + wtot <= RC;                  // (uniform) else the sample falls back: nothing needs storing
+        if (room) {
+#pragma unroll
+            for (int i = 0; i < 4 * V4; ++i) {
+                const uint64_t m = __builtin_amdgcn_uicmp(key[i] - A, width, 37);
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, run));
+                if (key[i] - A <= width) {
+#ifdef QM_PLAIN_STORE                                         // A/B (diag): write-back stores, flushed by the release below
+                    greg[at] = key[i];
+#else
+                    __hip_atomic_store(greg + at, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+                }
+                run += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    QM_STAMP(3);
+    QM_STAMP(4);
+    if (tid == 0) {
+        // ONE 64-bit word per sample carries everything the workgroups tell each other: candidates of workgroup 0 / 1 (14 bits
+        // each, saturated at RC + 1), keys below A (18 bits, summed), arrivals (bits 60..62).  The add that publishes the own
+        // counts is the arrival; the poll that sees both arrivals has the totals in hand: two memory round trips, not four.
+        uint64_t* word = (uint64_t*)(ctr + 2);
+        const uint64_t add = (1ull << 60) | ((uint64_t)sv[9] << 28) | ((uint64_t)min(sv[8], RC + 1u) << (14 * g));
+        __hip_atomic_fetch_add(word, add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t wv;
+        while (((wv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 60) < (uint64_t)QM_G) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t c0 = (uint32_t)wv & 0x3FFFu, c1 = (uint32_t)(wv >> 14) & 0x3FFFu;
+        sv[16] = c0;
+        sv[17] = c1;
+        sv[11] = (uint32_t)(wv >> 28) & 0x3FFFFu;
+        sv[12] = c0 + c1;
+        sv[13] = c0 <= RC && c1 <= RC ? 1u : 0u;
+    }
+    __syncthreads();
+    QM_STAMP(5);
+    const uint32_t tot_below = sv[11], tot_in = sv[12];
+    const bool inside = !force_miss && sv[13] && tot_below <= (uint32_t)lo && (uint32_t)hi < tot_below + tot_in;
+
+    // ---- 4. exact select among the candidates (or the streaming select of the whole sample by workgroup 0)
+    bool write_own = true;
+    if (inside) {
+        uint32_t ck[NKF];                                    // slot `at` of the candidate area: region at / RC, valid below that region's count
+#pragma unroll
+        for (int i = 0; i < NKF; ++i) {
+            const uint32_t at = (uint32_t)(i * QM_TH + tid), r = at >= RC ? 1u : 0u;
+            ck[i] = NONE;
+            if (at - r * RC < sv[16 + r]) ck[i] = __hip_atomic_load(gcand + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        QM_STAMP(15);
+        const QmSel r = qm_select<NKF>(ck, (uint32_t)lo - tot_below, hi != lo, hist, cand, part, sv, stp);
+        if (tid == 0) {
+            const float qv = qm_lerp(r.klo, r.next, r.need_next, w);
+            s_q = qv;
+            if (g == 0) q[smp] = qv;
+        }
+        __syncthreads();
+    } else {
+        write_own = false;
+        if (g == 0) {                                        // (uniform) four radix passes + successor pass + mask pass over global memory
+            uint32_t prefix = 0, rank = (uint32_t)lo, cnt_eq = 0;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                __syncthreads();
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                const uint32_t pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+                for (int i = tid; i < n; i += QM_TH) {
+                    const uint32_t k = f2key(ub[i]);
+                    if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t c = 0;
+                    int d = 0;
+                    for (; d < 256; ++d) {
+                        if (c + hist[d] > rank) break;
+                        c += hist[d];
+                    }
+                    sv[0] = prefix | ((uint32_t)d << shift);
+                    sv[1] = rank - c;
+                    sv[2] = hist[d];
+                }
+                __syncthreads();
+                prefix = sv[0];
+                rank = sv[1];
+                cnt_eq = sv[2];
+            }
+            const bool need_next = hi != lo && rank + 1 >= cnt_eq;
+            __syncthreads();
+            if (tid == 0) sv[7] = NONE;
+            __syncthreads();
+            if (need_next) {
+                uint32_t best = NONE;
+                for (int i = tid; i < n; i += QM_TH) {
+                    const uint32_t k = f2key(ub[i]);
+                    if (k > prefix && k < best) best = k;
+                }
+                best = qm_wave_min(best);
+                if (lane == 0) atomicMin(&sv[7], best);
+            }
+            __syncthreads();
+            const float thr = qm_lerp(prefix, sv[7], need_next, w);
+            if (tid == 0) q[smp] = thr;
+            for (int i = tid; i < n4; i += QM_TH) {
+                const float4 v = ((const float4*)ub)[i];
+                ((uint32_t*)mb)[i] = (v.x > thr ? 1u : 0u) | (v.y > thr ? 0x100u : 0u) | (v.z > thr ? 0x10000u : 0u) | (v.w > thr ? 0x1000000u : 0u);
+            }
+        }
+    }
+
+    QM_STAMP(6);
+#ifdef QM_DIAG
+    if (tid == 0) stp[8] = inside ? 1 : 0;
+#endif
+    // ---- 5. the own stripes of the mask; counters back to zero behind the last workgroup
+    if (write_own) {
+        const float thr = s_q;
+        const uint32_t tkey = f2key(thr == 0.0f ? 0.0f : thr);
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int f = (j * G + g) * QM_TH + tid;
+            uint32_t m4 = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m4 |= (key[4 * j + e] > tkey && key[4 * j + e] != NONE ? 1u : 0u) << (8 * e);
+            if (f < n4) ((uint32_t*)mb)[f] = m4;
+        }
+    }
+    QM_STAMP(7);
+    if (tid == 0) {
+        // (every workgroup has consumed the word it polled before it counts itself out; the last one zeroes both counters)
+        const uint32_t left = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == (uint32_t)QM_G - 1u) {
+            __hip_atomic_store((uint64_t*)(ctr + 2), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// A/B switch for tests: 0 = default dispatch, 1 = always the streaming (multi-pass) kernel, 2 = never the multi-workgroup
+// kernel, 3 = the multi-workgroup kernel with its bracket declared missed (the fallback inside it)
+static int quantile_force_stream = 0;
 extern "C" int dua_set_quantile_stream(int on) { int o = quantile_force_stream; quantile_force_stream = on; return o; }
+
+// Workspace of the multi-workgroup kernel: per (device, stream) so that launches on different streams never share counters;
+// zeroed once when allocated, left zeroed by every launch.
+static uint32_t* quantile_workspace(hipStream_t st, int B);
+#ifdef QM_DIAG
+extern "C" void* dua_quantile_diag_workspace(void* stream, int B) { return quantile_workspace(as_stream(stream), B); }
+#endif
+static uint32_t* quantile_workspace(hipStream_t st, int B) {
+    struct Buf { uint32_t* p; int cap; };
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[std::make_pair(dev, st)];
+    if (b.cap < B) {
+        if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        const size_t bytes = (size_t)B * (QM_CTR + QM_CAP) * sizeof(uint32_t);
+        if (hipMalloc((void**)&b.p, bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
+        if (hipMemset(b.p, 0, bytes) != hipSuccess) { (void)hipFree(b.p); b.p = nullptr; return nullptr; }
+        b.cap = B;
+    }
+    return b.p;
+}
 
 extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uint8_t* mask, float* q, void* stream) {
     DUA_REQUIRE(u && mask && q, "dua_quantile_mask: null pointer");
@@ -484,7 +984,24 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
         if (vec) hipLaunchKernelGGL((k_quantile_mask_reg<V, TH, true>), B, TH, 0, st, u, n, lo, hi, w, mask, q); \
         else hipLaunchKernelGGL((k_quantile_mask_reg<V, TH, false>), B, TH, 0, st, u, n, lo, hi, w, mask, q);   \
     }
-    if (quantile_force_stream || n > 65536 || n < 4) hipLaunchKernelGGL(k_quantile_mask, B, QT, 0, st, u, n, lo, hi, w, mask, q);
+    const int mode = quantile_force_stream;
+    if (vec && n > 16384 && n <= 65536 && (mode == 0 || mode == 3)) {
+        // two workgroups per sample; delta: 5.7 sigma of the sample rank of s[lo] under independent draws (+ 8)
+        constexpr int G = QM_G;
+        uint32_t* ws = quantile_workspace(st, B);
+        DUA_REQUIRE(ws, "dua_quantile_mask: no workspace (%d samples)", B);
+        const double pr = (double)lo / (double)n;
+        const int delta = (int)ceil(5.7 * sqrt(pr * (1.0 - pr) * 4.0 * QM_S4)) + 8;
+        const int n4 = n / 4, force_miss = mode == 3;
+#define QMULTI(V) hipLaunchKernelGGL((k_quantile_mask_multi<V>), B * G, QM_TH, 0, st, u, n, lo, hi, w, mask, q, ws, delta, force_miss)
+        if (n4 <= 3 * G * QM_TH) QMULTI(3);
+        else if (n4 <= 4 * G * QM_TH) QMULTI(4);
+        else if (n4 <= 6 * G * QM_TH) QMULTI(6);
+        else QMULTI(8);
+#undef QMULTI
+        return dua_check_launch("dua_quantile_mask");
+    }
+    if (mode == 1 || n > 65536 || n < 4) hipLaunchKernelGGL(k_quantile_mask, B, QT, 0, st, u, n, lo, hi, w, mask, q);
     else if (n <= 4096) QREG(1, 1024)
     else if (n <= 8192) QREG(2, 1024)
     else if (n <= 16384) QREG(4, 1024)

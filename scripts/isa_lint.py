@@ -52,6 +52,9 @@ SPECS = [
          mfma=("v_mfma_f32_16x16x4_f32", {9 * 64}), loop_vmcnt={2, 4, 6}, loop_vmcnt_need={2, 4, 6}, tail_wait=16),
     dict(name="k_wconv32", obj="conv_wino_f32.o", sym=r"^_Z9k_wconv326WConvP$", regs=256, scratch=192,
          mfma=("v_mfma_f32_16x16x4_f32", {6 * 128}), loop_vmcnt={4, 6, 8}, loop_vmcnt_need=set(), tail_wait=16),
+    # (no matrix cores: 1024 threads = 128 registers, no scratch, and the asm statement that holds its V4 + 1 loads AND their wait)
+    dict(name="k_quantile_mask_multi", obj="sampler.o", sym=r"^_Z21k_quantile_mask_multiILi[3468]EEv", regs=128, scratch=0, mfma=None,
+         load_block={4, 5, 7, 9}),
     dict(name="k_xtile<f16x3>", obj="mfma_bf16x3.o", sym=r"^_Z7k_xtileILi0ELb[01]ELb0ELb0ELb1EEv6XTileP$", regs=256, scratch=0,
          mfma=("v_mfma_f32_32x32x16_f16", {48}), loop_vmcnt=set(range(8, 16)), loop_vmcnt_need=set(), tail_wait=None),
 ]
@@ -206,14 +209,40 @@ def check_tail_wait(insns, w, N):
     return errs
 
 
+def check_load_block(insns, lengths):
+    """The inline-asm load block of a kernel without a K loop (k_quantile_mask_multi): its global_load_dwordx4 run - the first run of two
+    or more in the kernel - has one of the expected lengths and the very next instruction is the s_waitcnt vmcnt(0) of the same asm
+    statement: nothing the compiler placed can read a destination register before its data has arrived."""
+    k = 0
+    while k < len(insns):
+        if insns[k].op == "global_load_dwordx4":
+            e = k
+            while e + 1 < len(insns) and insns[e + 1].op == "global_load_dwordx4":
+                e += 1
+            if e > k:
+                n = e - k + 1
+                errs = [] if n in lengths else [f"load block of {n} global_load_dwordx4 at {insns[k].addr:#x}, expected one of {sorted(lengths)}"]
+                nxt = insns[e + 1] if e + 1 < len(insns) else None
+                if nxt is None or nxt.op != "s_waitcnt" or "vmcnt(0)" not in nxt.args:
+                    errs.append(f"the load block at {insns[k].addr:#x} is followed by {nxt.op if nxt else 'nothing'} instead of its s_waitcnt vmcnt(0)")
+                return errs
+            k = e
+        k += 1
+    return ["no block of consecutive global_load_dwordx4 found"]
+
+
 def lint_kernel(spec, sym, insns, meta):
     errs = []
-    mfma_op, counts = spec["mfma"]
     if meta:
         if meta.get("vgpr_count", 0) > spec["regs"]:
             errs.append(f"vgpr_count {meta.get('vgpr_count')} > {spec['regs']}")
         if meta.get("private_segment_fixed_size", 0) > spec["scratch"]:
             errs.append(f"scratch {meta.get('private_segment_fixed_size')} B per lane > {spec['scratch']} (new spills: check they are outside the K loop and raise the bound)")
+    if spec["mfma"] is None:                # no matrix-core loop: only the rules named in the spec
+        if spec.get("load_block"):
+            errs += check_load_block(insns, spec["load_block"])
+        return errs
+    mfma_op, counts = spec["mfma"]
     loop = innermost_mfma_loop(insns, mfma_op)
     if loop is None:
         return errs + [f"no K loop with {mfma_op} found"]

@@ -111,3 +111,30 @@ def test_spill_inside_k_loop_is_caught(lint, wconv4_listing):
     doctored = [re.sub(r"^\s+\S.*?//", "\tv_accvgpr_read_b32 v1, a0 //", ln) if pat.search(ln) else ln for ln in lines]
     errs = lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(doctored), notes)["_Z8k_wconv4ILi0EEv6WConvP"]
     assert any("inside the K loop" in e for e in errs), errs
+
+
+def test_quantile_load_block_without_its_wait_is_caught(lint):
+    """k_quantile_mask_multi issues its V4 + 1 loads AND their s_waitcnt vmcnt(0) in one asm statement; an instruction between the last
+    load and the wait (a compiler copy of a destination register would sit there) and a split block are each reported."""
+    with tempfile.TemporaryDirectory() as tmp:
+        dis, notes = lint.disassemble(os.path.join(lint.CSRC, "sampler.o"), tmp)
+    lines, keep = [], False
+    for ln in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
+        if m:
+            keep = m.group(1).startswith("_Z21k_quantile_mask_multiILi6E")
+        if keep:
+            lines.append(ln)
+    spec = spec_of(lint, "k_quantile_mask_multi")
+    res = lint.lint_listing(spec, "\n".join(lines), notes)
+    assert list(res.values()) == [[]]
+    loads = [k for k, ln in enumerate(lines) if "global_load_dwordx4" in ln]
+    last = [k for k in loads if k + 1 not in loads][0]                   # the last load of the first run
+    assert "s_waitcnt" in lines[last + 1] and "vmcnt(0)" in lines[last + 1]
+    addr = re.search(r"//\s*([0-9A-Fa-f]+):", lines[last]).group(1)
+    moved = lines[:last + 1] + [f"\tv_mov_b32_e32 v1, v2                                        // {addr}: 00000000"] + lines[last + 1:]
+    errs = list(lint.lint_listing(spec, "\n".join(moved), notes).values())[0]
+    assert any("instead of its s_waitcnt vmcnt(0)" in e for e in errs), errs
+    split = lines[:last] + [f"\tv_mov_b32_e32 v1, v2                                        // {addr}: 00000000"] + lines[last:]
+    errs = list(lint.lint_listing(spec, "\n".join(split), notes).values())[0]
+    assert any("load block of 6" in e for e in errs), errs
