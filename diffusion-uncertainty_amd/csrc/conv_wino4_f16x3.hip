@@ -42,9 +42,6 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #else
 #define W4_EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifndef W4_EPI_STRAIGHT
-#define W4_EPI_STRAIGHT 1                          // 0: the row-layout epilogue (lane transpose, whole 128-byte lines per instruction)
-#endif
 constexpr int W4_STORES = 2 * 4 * 2 * 4;          // channel-block pairs x position blocks x halves x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
@@ -389,11 +386,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         const long rrem = RMODE >= 2 ? (res_tot - (long)res_n0 * res_img) * p.N * 4 : crem;
         const auto rres = __builtin_amdgcn_make_buffer_rsrc((void*)(RMODE == 0 ? (const float*)p.C : (RMODE == 1 ? p.res + cpix0 * p.N : p.res + (long)res_n0 * res_img * p.N)), 0,
                                                             RMODE == 0 ? 0 : (int)(rrem < 0x7FFFFFF0L ? rrem : 0x7FFFFFF0L), 0x00020000);
-#if W4_EPI_STRAIGHT
-        // the column-sum array [4 Mv / 64 slots][sum | sum of squares][N] (none: an empty descriptor drops the stores)
-        const long csb = ((long)(p.Mv >> 4) + 4) * 2 * p.N * 4;
-        const auto rcs = __builtin_amdgcn_make_buffer_rsrc((void*)p.colsum, 0, p.colsum ? (int)(csb < 0x7FFFFFF0L ? csb : 0x7FFFFFF0L) : 0, 0x00020000);
-#endif
         // FULL: the tile lies inside the tensor (all 128 positions, all 128 channels): no lane is masked, so the stores, the residual loads and
         // the column sums are straight-line code without selects - which is what lets the compiler count the vector-memory queue exactly.
         auto epilogue = [&](auto mode_c, auto full_c) __attribute__((always_inline)) {
@@ -401,21 +393,15 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         constexpr bool FULL = decltype(full_c)::value;
         // sub-block sb = (jp, i, h): dst[r] = the lane's 16 bytes of output row r (position half h of block i, channel-block pair jp)
         auto res_ld = [&](int sb, float4 (&dst)[4]) {
+            const int jp = sb >> 3, i = (sb >> 1) & 3, h = sb & 1;
             if constexpr (MODE == 0) {                                     // no residual: nothing to request, nothing to wait for
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[r] = make_float4(0.f, 0.f, 0.f, 0.f);
                 return;
             }
             const int le = lane_now();
-#if W4_EPI_STRAIGHT
-            // sub-block sb = (jj, i): the lane's 16 bytes of output row r in the ACCUMULATOR layout (position le & 15 of block i, channels 4 (le >> 4) .. + 3 of block jj)
-            const int c = n0 + wn * 64 + 16 * (sb >> 2) + 4 * (le >> 4);
-            const int rel0 = opix(sb & 3, le & 15);
-#else
-            const int jp = sb >> 3, i = (sb >> 1) & 3, h = sb & 1;
             const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7);
             const int rel0 = opix(i, (le >> 3) + 8 * h);
-#endif
             const long row0 = rel0 < 0 ? -1L : cpix0 + rel0;                 // (the absolute pixel: the resampled modes only)
             const bool okl = FULL ? !(WCONV4_DIAG & 32) : (c < p.N && rel0 >= 0 && !(WCONV4_DIAG & 32));
             if constexpr (MODE == 1) {
@@ -457,93 +443,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             }
         };
-#if W4_EPI_STRAIGHT
-        // Straight from the accumulator layout: per (channel block jj, position block i) the inverse transform in registers and four
-        // stores of 16 positions x 64 bytes - no lane transpose (the row layout cost a DPP move + a ds_bpermute per register: 512 of the
-        // ~3 400 instructions of the epilogue, and one LDS-crossbar latency per sub-block on the only wavefront of the SIMD).  The two
-        // 64-byte halves of a 128-byte line leave in different instructions; the L2 merges them before they reach HBM.
-        float4 sq_[4], bq_[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int c = n0 + wn * 64 + 16 * jj + 4 * (lane_now() >> 4);
-            sq_[jj] = *(const float4*)(p.Cscale + c);                        // (padded to the tile grid)
-            bq_[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && c < p.N) bq_[jj] = *(const float4*)(p.bias + c);
-        }
-        float4 rn_[2][4];
-        res_ld(0, rn_[0]);
-        w4_static_for<4>([&](auto jj_c) __attribute__((always_inline)) {
-            constexpr int jj = decltype(jj_c)::value;
-            float4 sq = sq_[jj];
-            const float4 bq = bq_[jj];
-            sq.x *= p.out_scale; sq.y *= p.out_scale; sq.z *= p.out_scale; sq.w *= p.out_scale;
-            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq2 = cs;
-            w4_static_for<4>([&](auto i_c) __attribute__((always_inline)) {
-                constexpr int i = decltype(i_c)::value;
-                constexpr int sb = jj * 4 + i;
-                f32x4 R[4];                                                  // [output row]
-                {
-                    const f32x4 s12 = acc[1][jj][i] + acc[2][jj][i], d12 = acc[1][jj][i] - acc[2][jj][i];
-                    const f32x4 s34 = acc[3][jj][i] + acc[4][jj][i], d34 = acc[3][jj][i] - acc[4][jj][i];
-                    R[0] = (acc[0][jj][i] + s12) + s34;
-                    R[1] = d12 + 2.0f * d34;
-                    R[2] = s12 + 4.0f * s34;
-                    R[3] = (acc[5][jj][i] + d12) + 8.0f * d34;
-                }
-                W4_EPI_FENCE();
-                if constexpr (sb + 1 < 16) res_ld(sb + 1, rn_[(sb + 1) & 1]);
-                W4_EPI_FENCE();
-                const int le = lane_now();
-                const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4);
-                const int rel0 = opix(i, le & 15);
-                const bool ok = FULL ? !(WCONV4_DIAG & 16) : (c < p.N && rel0 >= 0 && !(WCONV4_DIAG & 16));
-                const unsigned o0 = (__umul24((unsigned)rel0, (unsigned)p.N) + (unsigned)c) * 4u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 rq = rn_[sb & 1][r];
-                    float4 v;
-                    v.x = __builtin_fmaf(R[r][0], sq.x, bq.x);               // (one fixed rounding order in every variant of the epilogue)
-                    v.y = __builtin_fmaf(R[r][1], sq.y, bq.y);
-                    v.z = __builtin_fmaf(R[r][2], sq.z, bq.z);
-                    v.w = __builtin_fmaf(R[r][3], sq.w, bq.w);
-                    if constexpr (MODE != 0) { v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w; }
-                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                    const u32x4_ vb = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(vb, rc, ok ? o0 + (unsigned)r * row_bytes : 0xFFFFFFF0u, 0, 0);
-                    if (FULL || ok) {
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq2.x = __builtin_fmaf(v.x, v.x, cq2.x); cq2.y = __builtin_fmaf(v.y, v.y, cq2.y);
-                        cq2.z = __builtin_fmaf(v.z, v.z, cq2.z); cq2.w = __builtin_fmaf(v.w, v.w, cq2.w);
-                    }
-                }
-            });
-            if (!(WCONV4_DIAG & 64)) {
-                // as below: the wave's 256 output pixels are four 64-pixel slots of the column-sum array of ONE image; the sums over
-                // the sixteen position lanes of a row (DPP row shifts: lane 15 of the row ends up with the total) go to the first slot
-                float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    t[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[u]), 0x111, 0xf, 0xf, false));       // row_shr:1
-                    t[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[u]), 0x112, 0xf, 0xf, false));       // row_shr:2
-                    t[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[u]), 0x114, 0xf, 0xf, false));       // row_shr:4
-                    t[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[u]), 0x118, 0xf, 0xf, false));       // row_shr:8
-                }
-                // (buffer stores that always issue - masked lanes and a null colsum go beyond the descriptor: straight-line code, and
-                // the compiler does not weave the four blocks' conditions into the FULL / masked dispatch)
-                const int le = lane_now();
-                const int c = n0 + wn * 64 + 16 * jj + 4 * (le >> 4), slot_e = 15 - (le & 15);
-                const bool okc = slot_e < 4 && c < p.N && pos0 < p.Mv;
-                const bool first = slot_e == 0;
-                const unsigned oc = (unsigned)((((pos0 >> 4) + slot_e) * 2 * p.N + c) * 4);
-                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                const u32x4_ z4 = {0u, 0u, 0u, 0u};
-                const u32x4_ s4 = {__float_as_uint(t[0]), __float_as_uint(t[1]), __float_as_uint(t[2]), __float_as_uint(t[3])};
-                const u32x4_ q4 = {__float_as_uint(t[4]), __float_as_uint(t[5]), __float_as_uint(t[6]), __float_as_uint(t[7])};
-                __builtin_amdgcn_raw_buffer_store_b128(first ? s4 : z4, rcs, okc ? oc : 0xFFFFFFF0u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(first ? q4 : z4, rcs, okc ? oc + (unsigned)p.N * 4u : 0xFFFFFFF0u, 0, 0);
-            }
-        });
-#else
         // column scale * 1 / v_scale and bias of both channel-block pairs (this lane's four channels of each), before any store goes out
         float4 sq_[2], bq_[2];
 #pragma unroll
@@ -645,7 +544,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             }
         });
-#endif
         };
         using EF = std::integral_constant<bool, false>;
         using ET = std::integral_constant<bool, true>;
