@@ -41,7 +41,10 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)
 // magnitude leaves fp16's range (|s| > 65504: hi saturates and the pair carries fewer than 22 bits - counter 0) and those below fp16's
 // smallest normal (0 < |s| < 2^-14: hi is subnormal; the pair is still exact to 2^-25 / scale absolutely - counter 1).  Each translation
 // unit holds its own copy of the device pointer (static: no relocatable device code needed); dua_range_check sets them all.
-static __device__ unsigned long long* dua_range_dev = nullptr;
+// __constant__: a scalar load the compiler may hoist and share.  As a plain __device__ variable the pointer was RE-LOADED in front of every
+// group of operands that followed a store (it might alias): 64 - 128 vector loads per tile in the epilogues of k_hgemm and in the plane writers
+// of k_flash_attn_x - each behind an s_waitcnt vmcnt that, retiring in order, drained every output store in flight (U-ViT fc1 -9 %).
+static __constant__ unsigned long long* dua_range_dev = nullptr;
 // (kernels load the pointer ONCE - dua_range_ctr() - and test it per group of operands: one uniform branch when the check is off)
 __device__ __forceinline__ unsigned long long* dua_range_ctr() {
 #ifdef DUA_NO_RANGE_CHECK                                             // (A/B build: prices the check in the plane writers)
