@@ -6,6 +6,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if os.environ.get("DUA_DIAG_LIB"):                     # A/B: an alternative build of the library (scripts/diag/build/...)
+    from diffusion_uncertainty_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["DUA_DIAG_LIB"])
 import bench  # noqa: E402
 
 ns = argparse.Namespace(uvit_mc_group=int(sys.argv[1]) if len(sys.argv) > 1 else 1, uvit_split_k=(len(sys.argv) > 2 and sys.argv[2] == "1"))
