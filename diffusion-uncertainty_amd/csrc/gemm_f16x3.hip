@@ -39,29 +39,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Exact GELU v * Phi(v) (uvit/timm.py:96-111, nn.GELU) without the two-branch erff: with x = |v| / sqrt(2), erfc(x) = exp(-x g(x)) and g a
 // degree-8 polynomial on [0, 4] (least-squares fit weighted by the sensitivity of erfc; beyond 4 erfc < 2e-8), so Phi(v) = erfc(x) / 2 for
-// v < 0 - no cancellation on the negative side, unlike 0.5 (1 + erf) - and 1 - erfc(x) / 2 otherwise.  Against fp64 over [-12, 12]:
-// max abs error 3.9e-7 (the fp32 erf formula: 4.5e-7), i.e. half an ulp of the result's magnitude; ~18 VALU operations, no divergence.
-__device__ __forceinline__ float hg_gelu(float v) {
-    if (HG_DIAG & 8) return v;
-    const float x = fminf(fabsf(v) * 0.70710678118654752f, 4.0f);
-    float g = -8.056373400e-06f;
-    g = fmaf(g, x, 1.061473860e-04f);
-    g = fmaf(g, x, -5.884277713e-04f);
-    g = fmaf(g, x, 1.577756018e-03f);
-    g = fmaf(g, x, -5.995723508e-05f);
-    g = fmaf(g, x, -1.921636361e-02f);
-    g = fmaf(g, x, 1.027989408e-01f);
-    g = fmaf(g, x, 6.366161475e-01f);
-    g = fmaf(g, x, 1.128379331e+00f);
-    const float he = 0.5f * __builtin_amdgcn_exp2f(x * g * -1.4426950408889634f);
-    return v * (v < 0.f ? he : 1.0f - he);
-}
-
-// Two elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32: the polynomial, the exponent and the final combination are
-// one instruction per pair): the epilogue of fc1 spent an eighth of the GEMM's time in 18 scalar operations per element (HG_DIAG 8).
-// Folded for that: -log2(e) into the coefficients, the 1/2 into the exponent (exp2(x g' - 1) = erfc(x) / 2 =: he), and
-// v Phi(v) = max(v, 0) - |v| he on both sides of zero (v >= 0: v - v he; v < 0: v he = -|v| he), so no select and no 1 - he.
-// Against fp64 over [-12, 12]: max abs error 2.4e-7 (the two-branch form above: 3.9e-7).
+// v < 0 - no cancellation on the negative side, unlike 0.5 (1 + erf) - and 1 - erfc(x) / 2 otherwise.
+// Two elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32: the polynomial, the exponent and the final combination are one
+// instruction per pair; as 18 scalar operations per element the GELU was an eighth of fc1's time, HG_DIAG 8).  Folded for that: -log2(e) into
+// the coefficients, the 1/2 into the exponent (exp2(x g' - 1) = erfc(x) / 2 =: he), and v Phi(v) = max(v, 0) - |v| he on both sides of zero
+// (v >= 0: v - v he; v < 0: v he = -|v| he): no select, no 1 - he.  Against fp64 over [-12, 12]: max abs error 2.4e-7 (the fp32 erf formula:
+// 4.5e-7), no divergence.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 hg_gelu2(f32x2 v) {
     if (HG_DIAG & 8) return v;
