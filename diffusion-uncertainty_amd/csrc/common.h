@@ -59,7 +59,7 @@ __device__ __forceinline__ void dua_range_note(unsigned long long* c, float s) {
     else if (a > 0.f && a < 6.103515625e-05f) atomicAdd(c + 1, 1ull);
 }
 #define DUA_RANGE_TU(NAME)                                                                                      \
-    void dua_range_set_##NAME(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(dua_range_dev), &p, sizeof(p)); }
+    int dua_range_set_##NAME(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(dua_range_dev), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
 
 // Four consecutive columns of one row as f16x3 planes: plane 0 fp16(x * scale) (saturating), plane 1 the fp16 remainder.
 __device__ __forceinline__ void dua_store_f16x3_quad(void* planes, long plane_elems, long o, float4 w, float scale) {

@@ -1001,16 +1001,17 @@ extern "C" int dua_transpose_batched(const float* in, float* out, int R, int Cc,
 DUA_RANGE_TU(denoiser)
 
 // ---- f16x3 range check: host side (see common.h).  Process-global debug facility; dua_range_check_read synchronises the device.
-void dua_range_set_conv_wino(unsigned long long*);
-void dua_range_set_conv_wino4(unsigned long long*);
-void dua_range_set_xtile(unsigned long long*);
-void dua_range_set_hgemm(unsigned long long*);
-void dua_range_set_sgemm(unsigned long long*);
-void dua_range_set_attention(unsigned long long*);
+int dua_range_set_conv_wino(unsigned long long*);
+int dua_range_set_conv_wino4(unsigned long long*);
+int dua_range_set_xtile(unsigned long long*);
+int dua_range_set_hgemm(unsigned long long*);
+int dua_range_set_sgemm(unsigned long long*);
+int dua_range_set_attention(unsigned long long*);
 static unsigned long long* g_range_buf = nullptr;
 static int g_range_on = 0;
-static void range_set_all(unsigned long long* p) {
-    dua_range_set_denoiser(p); dua_range_set_conv_wino(p); dua_range_set_conv_wino4(p); dua_range_set_xtile(p); dua_range_set_hgemm(p); dua_range_set_sgemm(p); dua_range_set_attention(p);
+static int range_set_all(unsigned long long* p) {              // every translation unit's copy of the pointer; non-zero: one of the copies failed
+    return dua_range_set_denoiser(p) | dua_range_set_conv_wino(p) | dua_range_set_conv_wino4(p) | dua_range_set_xtile(p) | dua_range_set_hgemm(p) |
+           dua_range_set_sgemm(p) | dua_range_set_attention(p);
 }
 extern "C" int dua_range_check(int on) {
     const int was = g_range_on;
@@ -1019,7 +1020,7 @@ extern "C" int dua_range_check(int on) {
     }
     if (on && hipMemset(g_range_buf, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { dua_set_error("dua_range_check: hipMemset failed"); return DUA_EHIP; }
     if (hipDeviceSynchronize() != hipSuccess) { dua_set_error("dua_range_check: device error"); return DUA_EHIP; }
-    range_set_all(on ? g_range_buf : nullptr);
+    if (range_set_all(on ? g_range_buf : nullptr)) { dua_set_error("dua_range_check: hipMemcpyToSymbol failed"); return DUA_EHIP; }
     g_range_on = on != 0;
     return was;
 }

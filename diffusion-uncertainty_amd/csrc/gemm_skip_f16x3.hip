@@ -489,4 +489,4 @@ int dua_launch_sgemm(SGemmP& p, hipStream_t st, const char* what) {
 }
 
 // (f16x3 range check, common.h: this translation unit keeps the counter pointer on the host and hands it to the kernel's checking instantiation)
-void dua_range_set_sgemm(unsigned long long* p) { sg_range_host = p; }
+int dua_range_set_sgemm(unsigned long long* p) { sg_range_host = p; return 0; }
