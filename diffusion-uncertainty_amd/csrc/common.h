@@ -36,6 +36,19 @@ static inline unsigned stream_grid(size_t work_items, unsigned block) {
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
+// A lane id formed where it is used (volatile: neither hoisted nor shared) and a lane ^ mask exchange built on it.  __shfl_xor's own
+// __lane_id() is hoisted to the start of the kernel, lives across the K loop, is spilled by the register-full kernels and comes back by
+// a scratch load behind s_waitcnt vmcnt(0) - which, retiring in order, drains every output store in flight: in k_wconv4 once per tile,
+// right after its 64 stores, in front of the column-sum fold (round 5).
+__device__ __forceinline__ int dua_lane_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+__device__ __forceinline__ float dua_xor_fresh(float v, int lane, int mask) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (lane ^ mask), __float_as_int(v)));
+}
+
 // ---- f16x3 range check (debug facility, off by default): with dua_range_check(1) every kernel that WRITES f16x3 operands (the GroupNorm /
 // LayerNorm / GELU / attention plane writers, the Winograd V writer, the on-the-fly split of raw operands) counts the operands whose scaled
 // magnitude leaves fp16's range (|s| > 65504: hi saturates and the pair carries fewer than 22 bits - counter 0) and those below fp16's

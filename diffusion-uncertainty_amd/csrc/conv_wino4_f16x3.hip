@@ -528,13 +528,13 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 // slots of the column-sum array: their sums go to the first, zeros to the other three.  The consumer
                 // (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
                 float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+                const int le = lane_now();                                   // (not __shfl_xor: its hoisted lane id came back from scratch behind a vmcnt(0))
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    t[u] += __shfl_xor(t[u], 8);
-                    t[u] += __shfl_xor(t[u], 16);
-                    t[u] += __shfl_xor(t[u], 32);
+                    t[u] += dua_xor_fresh(t[u], le, 8);
+                    t[u] += dua_xor_fresh(t[u], le, 16);
+                    t[u] += dua_xor_fresh(t[u], le, 32);
                 }
-                const int le = lane_now();
                 const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7), lp_e = le >> 3;
                 if (lp_e < 4 && c < p.N && pos0 < p.Mv) {
                     const float z = lp_e == 0 ? 1.0f : 0.0f;

@@ -147,11 +147,12 @@ __device__ __forceinline__ void w432_epilogue(const WConvP& p, f32x4 (&acc)[3][2
         // column-sum array: the first wave's sums (rows 0, 2) go to slot 0, the second's (rows 1, 3) to slot 1, zeros to slots 2 and 3.
         // The consumer (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
         float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+        const int lf_ = dua_lane_fresh();            // (not __shfl_xor: its hoisted lane id is spilled and reloaded behind a vmcnt(0), common.h)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            t[u] += __shfl_xor(t[u], 8);
-            t[u] += __shfl_xor(t[u], 16);
-            t[u] += __shfl_xor(t[u], 32);
+            t[u] += dua_xor_fresh(t[u], lf_, 8);
+            t[u] += dua_xor_fresh(t[u], lf_, 16);
+            t[u] += dua_xor_fresh(t[u], lf_, 32);
         }
         if (pr_e < 2 && cok && pos0 < p.Mv) {
             const float z = pr_e == 0 ? 1.0f : 0.0f;

@@ -197,11 +197,12 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
             if (t + 2 < T) patch_put(t + 2);     // (its patch was read for slot t: the LDS queue is in order)
             if (i == 3 && p.colsum) {            // GroupNorm statistics of the next layer: fold the 8 row lanes that share these channels
                 float u_[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+                const int lf_ = dua_lane_fresh();            // (not __shfl_xor: its hoisted lane id is spilled and reloaded behind a vmcnt(0), common.h)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    u_[u] += __shfl_xor(u_[u], 8);
-                    u_[u] += __shfl_xor(u_[u], 16);
-                    u_[u] += __shfl_xor(u_[u], 32);
+                    u_[u] += dua_xor_fresh(u_[u], lf_, 8);
+                    u_[u] += dua_xor_fresh(u_[u], lf_, 16);
+                    u_[u] += dua_xor_fresh(u_[u], lf_, 32);
                 }
                 if (pr_e == 0 && cok && row0 < p.M) {
                     float* o = p.colsum + (long)(row0 >> 6) * 2 * p.N + c;

@@ -158,11 +158,12 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
             // consecutive output pixels = two 64-pixel slots of the column-sum array; this wave fills the slot of its parity.
             // The consumer (dua_groupnorm_stats_from_colsums) folds all slots of an image, so only the per-image totals matter.
             float t[8] = {cs.x, cs.y, cs.z, cs.w, cq2.x, cq2.y, cq2.z, cq2.w};
+            const int lf_ = dua_lane_fresh();            // (not __shfl_xor: its hoisted lane id is spilled and reloaded behind a vmcnt(0), common.h)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                t[u] += __shfl_xor(t[u], 8);
-                t[u] += __shfl_xor(t[u], 16);
-                t[u] += __shfl_xor(t[u], 32);
+                t[u] += dua_xor_fresh(t[u], lf_, 8);
+                t[u] += dua_xor_fresh(t[u], lf_, 16);
+                t[u] += dua_xor_fresh(t[u], lf_, 32);
             }
             if (pr_e == 0 && cok && pos0 < p.Mv) {
                 float* o = p.colsum + ((long)(pos0 >> 5) + (odd ? 1 : 0)) * 2 * p.N + c;
