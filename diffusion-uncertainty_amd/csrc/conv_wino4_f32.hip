@@ -34,8 +34,7 @@ static_assert(W432_STORES <= 63, "vmcnt is a 6-bit counter");
 // 4 (lane >> 4) .. + 3 of position lane & 15.
 __device__ __forceinline__ void w432_epilogue(const WConvP& p, f32x4 (&acc)[3][2][4], char* ldsw, int slot0_bytes, int wave, int lane, int m0, int n0) {
     const int grp = wave >> 2, ph = (wave >> 1) & 1, wn = wave & 1;
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
+    const int lane_e = dua_lane_fresh();         // formed here: the kernel's own lane id, kept across the K loop, was spilled and came back behind a vmcnt(0)
     char* mine = ldsw + slot0_bytes + wave * 8192;
     char* theirs = ldsw + slot0_bytes + (wave ^ 4) * 8192;
     const bool second = grp == 1;                                          // rows 1, 3 (first group: rows 0, 2)

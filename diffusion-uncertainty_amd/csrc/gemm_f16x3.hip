@@ -79,8 +79,7 @@ __device__ __forceinline__ f32x2 hg_gelu2(f32x2 v) {
 template <int NT, int EPI>
 __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 * NT][4], char* pw, int wave, int lane, int m0, int n0) {
     static_assert(8 * NT >= HG_TAIL_WAIT, "the item-start wait counts on this many stores");
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));             // keep the epilogue's addresses out of the K loop's register budget
+    const int lane_e = dua_lane_fresh();         // formed here: the kernel's own lane id, kept across the K loop, was spilled and came back behind a vmcnt(0)
     const int wm = wave >> 1, wn = wave & 1;
     const int lr_e = lane_e & 15, lc_e = lane_e >> 4;
     const int row0 = m0 + wm * 64;
@@ -318,12 +317,16 @@ __global__ __launch_bounds__(512, 2) void k_hgemm(HGemmP p) {
     const int n_items = n_head + n_seg;
     // item idx -> (tile id, K range, workspace slot or -1 for a whole tile with the real epilogue)
     auto get_item = [&](int idx, int& tile, int& k0, int& k1, int& part) {
-        if (idx < n_head) { tile = chunk0 + slot + idx * nslot; k0 = 0; k1 = nk; part = -1; return; }
+        if (idx < n_head) { tile = __builtin_amdgcn_readfirstlane(chunk0 + slot + idx * nslot); k0 = 0; k1 = nk; part = -1; return; }
         const int j = idx - n_head;
         tile = p.n_full + seg_first + j;
         k0 = j == 0 ? seg_k0 : 0;
         k1 = j == n_seg - 1 ? seg_k1 : nk;
         part = (k0 == 0 && k1 == nk) ? -1 : 2 * cu + (j == 0 ? 0 : 1);
+        // (wave-uniform, and SAID so: `part` otherwise lives in a vector register, is spilled by the 256-column instantiations and comes
+        // back from scratch behind an s_waitcnt vmcnt(0) in front of the epilogue - a wait for the next item's prologue DMA, once per tile)
+        tile = __builtin_amdgcn_readfirstlane(tile); k0 = __builtin_amdgcn_readfirstlane(k0);
+        k1 = __builtin_amdgcn_readfirstlane(k1); part = __builtin_amdgcn_readfirstlane(part);
     };
 
     const int dl_row = lane >> 2;

@@ -39,8 +39,7 @@ __device__ __forceinline__ void wconv_epilogue(const WConvP& p, f32x4 (&acc0)[4]
                                                int m0, int n0) {
     constexpr int A1_BYTES = 3 * 32768 + 32768, B2_BYTES = 2 * 32768;       // activation stage 1, weight stage 2
     const int wm = wave >> 1, wn = wave & 1, grp_w = wave >> 2, ph = wm & 1;
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
+    const int lane_e = dua_lane_fresh();         // formed here: the kernel's own lane id, kept across the K loop, was spilled and came back behind a vmcnt(0)
     auto slot_of = [&](int w) -> char* { return ldsw + (w < 4 ? A1_BYTES + w * 8192 : B2_BYTES + (w - 4) * 8192); };
     char* mine = slot_of(wave);
     char* theirs = slot_of(wave ^ 4);
