@@ -35,7 +35,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # (inline-asm) MFMA write and any other instruction touching the register; `fences` = exact count of the `s_nop 15 / s_nop 3` blocks.
 SPECS = [
     dict(name="k_wconv4", obj="conv_wino4_f16x3.o", sym=r"^_Z8k_wconv4ILi[0-3]EEv6WConvP$", regs=512, scratch=128,
-         mfma=("v_mfma_f32_16x16x32_f16", {864}), loop_vmcnt={0, 4, 6, 8}, loop_vmcnt_need={6, 8}, tail_wait=63, hazard=18, fences=12),
+         mfma=("v_mfma_f32_16x16x32_f16", {864}), loop_vmcnt={0, 4, 6, 8}, loop_vmcnt_need={6, 8}, tail_wait=63, hazard=18, fences=12, tail_scratch_loads=0),
     dict(name="k_wconv", obj="conv_wino_f16x3.o", sym=r"^_Z7k_wconv6WConvP$", regs=512, scratch=0,
          mfma=("v_mfma_f32_16x16x32_f16", None), loop_vmcnt=None, loop_vmcnt_need=set(), tail_wait=16),
     dict(name="k_wconv1", obj="conv_wino_f16x3.o", sym=r"^_Z8k_wconv16WConvP$", regs=512, scratch=0,
@@ -45,9 +45,9 @@ SPECS = [
     # reload of a spilled LDS address, behind an s_waitcnt vmcnt(0), inside the K loop of the 256-column GELU -> planes instantiation
     # (U-ViT fc1); its epilogue now requests the column scales / biases one pair ahead instead of all 64 registers up front.)
     dict(name="k_hgemm", obj="gemm_f16x3.o", sym=r"^_Z7k_hgemmILi[234]ELi[01]EEv6HGemmP$", regs=256, scratch=64,
-         mfma=("v_mfma_f32_16x16x32_f16", {6 * 48, 6 * 72, 6 * 96}), loop_vmcnt={4, 6, 7}, loop_vmcnt_need=set(), tail_wait=None),
+         mfma=("v_mfma_f32_16x16x32_f16", {6 * 48, 6 * 72, 6 * 96}), loop_vmcnt={4, 6, 7}, loop_vmcnt_need=set(), tail_wait=None, tail_scratch_loads=2),
     dict(name="k_sgemm", obj="gemm_skip_f16x3.o", sym=r"^_Z7k_sgemmILi[24]ELb0EEv6SGemmP$", regs=256, scratch=0,
-         mfma=("v_mfma_f32_16x16x32_f16", {48, 96}), loop_vmcnt={4, 6}, loop_vmcnt_need=set(), tail_wait=8),
+         mfma=("v_mfma_f32_16x16x32_f16", {48, 96}), loop_vmcnt={4, 6}, loop_vmcnt_need=set(), tail_wait=8, tail_scratch_loads=0),
     dict(name="k_wconv432", obj="conv_wino4_f32.o", sym=r"^_Z10k_wconv4326WConvP$", regs=256, scratch=128,
          mfma=("v_mfma_f32_16x16x4_f32", {9 * 64}), loop_vmcnt={2, 4, 6}, loop_vmcnt_need={2, 4, 6}, tail_wait=16),
     dict(name="k_wconv32", obj="conv_wino_f32.o", sym=r"^_Z9k_wconv326WConvP$", regs=256, scratch=192,
@@ -261,6 +261,14 @@ def lint_kernel(spec, sym, insns, meta):
     missing = sorted(spec["loop_vmcnt_need"] - set(vm))
     if missing:
         errs.append(f"the K loop lacks its counted waits vmcnt({missing})")
+    if spec.get("tail_scratch_loads") is not None:
+        # a reload from scratch after the K loop waits on vmcnt - which retires in order: it drains the next item's prologue DMA and every
+        # output store in flight (round 5: a spilled lane id re-loaded after the 64 stores of every k_wconv4 tile)
+        last = max(k for k, i in enumerate(insns) if i.op == mfma_op)
+        n_sl = sum(1 for i in insns[last + 1:] if i.op.startswith("scratch_load"))
+        if n_sl > spec["tail_scratch_loads"]:
+            errs.append(f"{n_sl} scratch_load instruction(s) after the last {mfma_op} (allowed: {spec['tail_scratch_loads']}): a spill reload in the epilogue "
+                        "is an s_waitcnt vmcnt that drains the stores in flight")
     if spec.get("tail_wait") is not None:
         N = spec["tail_wait"]
         waits = [k for k, i in enumerate(insns) if i.op == "s_waitcnt" and re.search(rf"vmcnt\({N}\)", i.args) and not (lo <= k <= hi)]

@@ -138,3 +138,14 @@ def test_quantile_load_block_without_its_wait_is_caught(lint):
     split = lines[:last] + [f"\tv_mov_b32_e32 v1, v2                                        // {addr}: 00000000"] + lines[last:]
     errs = list(lint.lint_listing(spec, "\n".join(split), notes).values())[0]
     assert any("load block of 6" in e for e in errs), errs
+
+
+def test_scratch_reload_in_the_epilogue_is_caught(lint, wconv4_listing):
+    """A spill reload after the K loop (round 5: __shfl_xor's hoisted lane id came back from scratch behind vmcnt(0) after the 64 stores of every
+    k_wconv4 tile) is reported."""
+    lines, notes = wconv4_listing
+    last = max(k for k, ln in enumerate(lines) if "v_mfma_f32_16x16x32_f16" in ln)
+    addr = re.search(r"//\s*([0-9A-Fa-f]+):", lines[last + 5]).group(1)
+    doctored = lines[:last + 5] + [f"\tscratch_load_dword v144, off, off offset:32                // {addr}: DC504020"] + lines[last + 5:]
+    errs = list(lint.lint_listing(spec_of(lint, "k_wconv4"), "\n".join(doctored), notes).values())[0]
+    assert any("scratch_load instruction(s) after the last" in e for e in errs), errs
