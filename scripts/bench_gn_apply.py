@@ -5,6 +5,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from diffusion_uncertainty_amd import _lib, ops
+if os.environ.get("DUA_DIAG_LIB"):                     # A/B: an alternative build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["DUA_DIAG_LIB"])
 
 dev = "cuda"
 L = _lib.lib()
@@ -28,5 +30,5 @@ for H, C in ((128, 256), (64, 256), (64, 512), (32, 512), (32, 1024), (16, 768),
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
-            by = N * H * H * C * 8.0
+            by = N * H * H * C * (10.0 if split == "f16x3w4" else 8.0)          # F(4,3) images: 4 B read, 6 B written per element
             print(f"H={H:4d} C={C:4d} split={str(split):6s} wide={wide}: {ms:7.3f} ms  {by / ms / 1e9:6.2f} TB/s", flush=True)
