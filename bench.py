@@ -542,6 +542,8 @@ def main(argv=None):
     model, base, sd = build_model(dev)
     model.winograd = {"on": True, "off": False, "2": 2, "4": 4}[a.winograd]       # on = the library picks F(2,3) / F(4,3) per shape
     model.stream_split = int(os.environ.get("DUA_ADM_STREAMS", "1"))           # (A/B switch: the batch in chunks on HIP streams of their own)
+    if os.environ.get("DUA_ADM_HIP_GRAPH", "0") == "1":                        # (A/B switch: the forward captured once per shape, replayed)
+        model.enable_hip_graph()
     # synthetic inputs exactly as scripts/generate_diffusion_starting_data.py:27-49, sharded by rank like the script (:51)
     g = torch.Generator().manual_seed(49394 + 1)         # dataset index k = 1 (imagenet128), SURVEY 8(d)
     X_all = torch.randn(a.batch * world, 3, 128, 128, generator=g)
