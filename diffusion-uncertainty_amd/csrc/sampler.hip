@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
 //   1. every workgroup loads its stripes into registers as keys, and - all G of them the same - 768 scattered float4 of the
 //      whole sample (3072 keys: 1/16 of the [3,128,128] map, columns rotating from row to row);
 //   2. 2048-bin histogram levels over the SAMPLE bracket the target: bin edges A <= B such that the sample's ranks
-//      r - delta .. r + delta (r = lo scaled to the sample, delta = 5.7 sigma of a rank under independent draws) lie inside;
+//      r - delta .. r + delta (r = lo scaled to the sample, delta = 5 sigma of a rank under independent draws) lie inside;
 //      every workgroup computes the same A, B from the same keys - no exchange;
 //   3. one register pass counts the own keys below A and ballot-packs those in [A, B] (~6 - 10 % of them) into LDS; the counts
 //      and the packed keys go to the sample's slot of a global workspace (one reserving atomic per workgroup), then the G
@@ -533,34 +533,45 @@ struct QmSel { uint32_t klo, next; bool need_next; };
 // Exact selection of rank `rank` among the NK keys per thread of one QM_TH-thread workgroup (NONE = absent): the histogram
 // levels, candidate ranking and successor scan of k_quantile_mask_reg.  All threads return the same values.
 template <int NK>
-__device__ __forceinline__ QmSel qm_select(const uint32_t (&key)[NK], uint32_t rank, bool two, uint32_t* hist, uint32_t* cand,
-                                           uint32_t (*part)[QM_TH / 64], uint32_t* sv, uint64_t* stp) {
+__device__ __forceinline__ QmSel qm_select(const uint32_t (&key)[NK], uint32_t rank, bool two, bool have_range, uint32_t base0, uint32_t span0,
+                                           uint32_t* hist, uint32_t* cand, uint32_t (*part)[QM_TH / 64], uint32_t* sv, uint64_t* stp) {
+    // have_range (uniform): every key lies in [base0, base0 + span0] (the sample bracket) - no min / max pass; the caller has zeroed hist[]
+    // and a barrier has passed since.  Barriers are what this function costs (sixteen wavefronts): six on the usual path.
     (void)stp;
     constexpr int NW = QM_TH / 64, BPT = QBINS / QM_TH;
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QM_STAMP(16);
-    uint32_t kmin = NONE, kmax = 0;
+    if (tid == 0) { sv[6] = 0; sv[7] = NONE; }               // (candidate count, successor: read behind several barriers)
+    uint32_t base = base0, span = span0, shift, bsel, csel;
+    if (!have_range) {
+        uint32_t kmin = NONE, kmax = 0;
 #pragma unroll
-    for (int i = 0; i < NK; ++i) {
-        kmin = min(kmin, key[i]);
-        kmax = key[i] != NONE ? max(kmax, key[i]) : kmax;
+        for (int i = 0; i < NK; ++i) {
+            kmin = min(kmin, key[i]);
+            kmax = key[i] != NONE ? max(kmax, key[i]) : kmax;
+        }
+        kmin = qm_wave_min(kmin);
+        kmax = qm_wave_max(kmax);
+        __syncthreads();
+        if (lane == 0) { part[0][wave] = kmin; part[1][wave] = kmax; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { kmin = min(kmin, part[0][i]); kmax = max(kmax, part[1][i]); }
+        base = kmin;
+        span = kmax - kmin;
     }
-    kmin = qm_wave_min(kmin);
-    kmax = qm_wave_max(kmax);
-    __syncthreads();
-    if (lane == 0) { part[0][wave] = kmin; part[1][wave] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NW; ++i) { kmin = min(kmin, part[0][i]); kmax = max(kmax, part[1][i]); }
-    uint32_t base = kmin, span = kmax - kmin, shift, bsel, csel;
     QM_STAMP(17);
+    bool zeroed = true;
     for (;;) {
         shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
-        __syncthreads();
+        if (!zeroed) {
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
-        __syncthreads();
+            for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
+            __syncthreads();
+        }
+        zeroed = false;
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
             const uint32_t d = key[i] - base;              // (d <= span is base <= key <= base + span; NONE never passes)
@@ -592,12 +603,9 @@ __device__ __forceinline__ QmSel qm_select(const uint32_t (&key)[NK], uint32_t r
         base += bsel << shift;
         span = (1u << shift) - 1u;
     }
-    __syncthreads();
     if (shift == 0) {
         if (tid == 0) { sv[3] = base + bsel; sv[4] = csel; sv[5] = rank; }
     } else {
-        if (tid == 0) sv[6] = 0;
-        __syncthreads();
         // the bin's keys -> cand[] in any order (they are ranked by counting): usually a handful, so one exec-masked LDS atomic
         // per key position and no wavefront bookkeeping; positions without a member in the wavefront are skipped
 #pragma unroll
@@ -618,7 +626,6 @@ __device__ __forceinline__ QmSel qm_select(const uint32_t (&key)[NK], uint32_t r
             if (less <= rank && rank < less + eq) { sv[3] = k; sv[4] = eq; sv[5] = rank - less; }
         }
     }
-    if (tid == 0) sv[7] = NONE;
     __syncthreads();
     QM_STAMP(21);
     QmSel r;
@@ -667,6 +674,8 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
 
     // ---- 1. own stripes and the common sample -> keys
     QM_STAMP(0);
+#pragma unroll
+    for (int i = 0; i < QBINS / QM_TH; ++i) hist[tid + i * QM_TH] = 0;      // (for the first histogram level; a barrier follows before its atomics)
     // Every load in ONE asm statement together with its wait (V4 + 1 of 16 bytes in flight per lane): left to the compiler the
     // loads are sunk to their conversions one by one, each behind its own vmcnt(0); with the wait inside the statement no
     // compiler-placed copy can read a register before its data has arrived.  (Tried: the stripes by LDS-DMA, read back after
@@ -733,10 +742,12 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
     QM_STAMP(9);
     for (int level = 0; level < 4; ++level) {
         const uint32_t shift = span >= QBINS ? (uint32_t)(32 - __clz(span)) - 11u : 0u;
-        __syncthreads();
+        if (level > 0) {                                     // (level 0: zeroed at the kernel's start, under the loads)
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
-        __syncthreads();
+            for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
+            __syncthreads();
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t d = sk[e] - base;               // (d <= span is base <= key <= base + span; NONE never passes)
@@ -774,6 +785,9 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
         if (inB - exA <= cap_s || shift == 0 || stuck) break;
     }
     const uint32_t A = openA ? 0u : base, Bk = openB ? 0xFFFFFFFEu : base + span;
+    // (every thread is past its last read of hist[]: zeroed here for the select of step 4 - two barriers fewer there)
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) hist[tid + i * QM_TH] = 0;
 
     QM_STAMP(2);
     // ---- 3. own keys: count below A, pack [A, B] into the own region of the sample's candidate area, publish, meet.
@@ -853,7 +867,7 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
             if (at - r * RC < sv[16 + r]) ck[i] = __hip_atomic_load(gcand + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         QM_STAMP(15);
-        const QmSel r = qm_select<NKF>(ck, (uint32_t)lo - tot_below, hi != lo, hist, cand, part, sv, stp);
+        const QmSel r = qm_select<NKF>(ck, (uint32_t)lo - tot_below, hi != lo, !openA && !openB, A, Bk - A, hist, cand, part, sv, stp);
         if (tid == 0) {
             const float qv = qm_lerp(r.klo, r.next, r.need_next, w);
             s_q = qv;
@@ -986,12 +1000,12 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
     }
     const int mode = quantile_force_stream;
     if (vec && n > 16384 && n <= 65536 && (mode == 0 || mode == 3)) {
-        // two workgroups per sample; delta: 5.7 sigma of the sample rank of s[lo] under independent draws (+ 8)
+        // two workgroups per sample; delta: 5 sigma of the sample rank of s[lo] under independent draws (+ 8)
         constexpr int G = QM_G;
         uint32_t* ws = quantile_workspace(st, B);
         DUA_REQUIRE(ws, "dua_quantile_mask: no workspace (%d samples)", B);
         const double pr = (double)lo / (double)n;
-        const int delta = (int)ceil(5.7 * sqrt(pr * (1.0 - pr) * 4.0 * QM_S4)) + 8;
+        const int delta = (int)ceil(5.0 * sqrt(pr * (1.0 - pr) * 4.0 * QM_S4)) + 8;
         const int n4 = n / 4, force_miss = mode == 3;
 #define QMULTI(V) hipLaunchKernelGGL((k_quantile_mask_multi<V>), B * G, QM_TH, 0, st, u, n, lo, hi, w, mask, q, ws, delta, force_miss)
         if (n4 <= 3 * G * QM_TH) QMULTI(3);

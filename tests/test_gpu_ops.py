@@ -196,7 +196,7 @@ def test_quantile_mask_register_kernel_vs_streaming(ops, shape):
               f"streaming kernel {times[1]:.1f} us ({alg / times[1] / 1e6:.2f} TB/s)")
     if shape == (128, 3, 128, 128):
         # regression guard.  One workgroup per sample: 1.17 TB/s (r01: 0.53; its floor, constant input, is 3.0).  Round 5, two workgroups per
-        # sample bracketing the target from a common 3072-key sample (k_quantile_mask_multi): 2.6 - 2.7 TB/s measured (20.8 - 21.7 us, of
+        # sample bracketing the target from a common 3072-key sample (k_quantile_mask_multi): 2.9 TB/s measured (19.7 us, of
         # which ~3 us are the launch; scripts/diag/quantile_diag.py has the phases); VERDICT r04 item 9 asked for 3
         assert alg / report["chi2"][0] / 1e6 >= 2.0
         assert alg / report["chi2"][2] / 1e6 >= 0.9
