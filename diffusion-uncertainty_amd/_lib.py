@@ -115,6 +115,7 @@ SIGNATURES = {
     "dua_gemm_f16x3_presplit": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P]),
     "dua_gemm_f16x3_presplit2": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _F, _P]),
     "dua_set_hgemm_mode": (_I, [_I, _I]),
+    "dua_set_hgemm_concurrent": (_I, [_I]),
     "dua_set_sgemm_mode": (_I, [_I]),
     "dua_conv3x3_tap_gather": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "dua_f16x3_wino_act_bytes": (_Z, [_I, _I, _I, _I]),

@@ -631,6 +631,18 @@ extern "C" int dua_set_hgemm_mode(int nt, int streamk) {
     return DUA_OK;
 }
 
+// The caller runs several launches side by side on HIP streams of their own (UViT / UNetModel._forward_streams: the batch in chunks):
+// the CUs a launch's last, partly filled round leaves idle are taken by the other stream's workgroups, so the tile width is chosen by
+// work per column (width / loop efficiency, columns beyond N included) and not by whole rounds of tiles - U-ViT's fc1 at 32 images
+// (594 tiles of 256 columns) picked 128-column tiles for their five full rounds.  Returns the previous setting.  Results do not depend on
+// the tile width.
+static int hg_concurrent = 0;
+extern "C" int dua_set_hgemm_concurrent(int on) {
+    const int was = hg_concurrent;
+    hg_concurrent = on != 0;
+    return was;
+}
+
 template <int NT>
 static void hg_launch(const HGemmP& p, int grid, bool planes, hipStream_t st) {
     if (planes) {
@@ -655,7 +667,8 @@ int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what) {
         for (int c = 4; c >= 2; --c) {
             const int w = 64 * c, tn = (p.N + w - 1) / w;
             const long tiles = (long)p.ntm * tn;
-            const double t = (double)((tiles + 255) / 256) * (nk + 8) * c / (c == 4 ? 1.0 : (c == 3 ? 0.95 : 0.85));
+            const double rounds = hg_concurrent ? (double)tiles / 256.0 : (double)((tiles + 255) / 256);
+            const double t = rounds * (nk + 8) * c / (c == 4 ? 1.0 : (c == 3 ? 0.95 : 0.85));
             if (t < best) { best = t; nt = c; }
         }
     }

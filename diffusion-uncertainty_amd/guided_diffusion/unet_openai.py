@@ -15,7 +15,7 @@ dims=2, use_scale_shift_norm=True, resblock_updown=True.  There is no CPU path.
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
 from ..utils import params_generation
 from .nn import normalization
 
@@ -559,9 +559,11 @@ class UNetModel(nn.Module):
         # the split-K / stream-K workspace is ONE process-global buffer: concurrent chunks would fold each other's parts.  Force it off
         # here - also when the CALLER had registered it (ops.set_split_k(True)) - and restore the caller's setting afterwards.
         prev_splitk = ops.set_split_k(False, x.device)
+        prev_conc = _lib.lib().dua_set_hgemm_concurrent(1)       # tile widths by work: the other chunk's kernels fill partly empty rounds
         try:
             return self._forward_chunks(xs, ts, ys, cur, outs, out_channels_keep)
         finally:
+            _lib.lib().dua_set_hgemm_concurrent(prev_conc)
             ops.set_split_k(prev_splitk, x.device)
 
     def _forward_chunks(self, xs, ts, ys, cur, outs, out_channels_keep=None):

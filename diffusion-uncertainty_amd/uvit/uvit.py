@@ -11,7 +11,7 @@ fp32 attention (the reference upcasts qkv to fp32 and calls SDPA, :71-73).  No C
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
 
 
 class Mlp(nn.Module):
@@ -221,9 +221,11 @@ class UViT(nn.Module):
         # the split-K / stream-K workspace is ONE process-global buffer: concurrent chunks would fold each other's parts.  Force it off
         # here - also when the CALLER had registered it (ops.set_split_k(True)) - and restore the caller's setting afterwards.
         prev_splitk = ops.set_split_k(False, x.device)
+        prev_conc = _lib.lib().dua_set_hgemm_concurrent(1)       # tile widths by work: the other chunk's kernels fill partly empty rounds
         try:
             return self._forward_chunks(xs, ts, ys, cur, outs)
         finally:
+            _lib.lib().dua_set_hgemm_concurrent(prev_conc)
             ops.set_split_k(prev_splitk, x.device)
 
     def _forward_chunks(self, xs, ts, ys, cur, outs):

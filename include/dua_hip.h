@@ -370,6 +370,10 @@ int dua_gemm_f16x3_presplit2(const void* a1planes, int K1, const void* a2planes,
  * (k_xconv_dma<NT, 3> / k_hconv<NT, false>); bit 0 of streamk = 0 runs whole tiles only even when dua_set_splitk_workspace registered a
  * buffer; bits 1-2 are ignored; bits 3-4 the stream-K extent: 0 = per shape (default), 8 = the last partly filled round of tiles only, 16 = the whole launch (workgroups out of phase). */
 int dua_set_hgemm_mode(int nt, int streamk);
+/* The caller keeps several launches in flight on HIP streams of their own (the batch in chunks, uvit/uvit.py / unet_openai.py
+ * _forward_streams): the tile width is then chosen by work, not by whole rounds of tiles on the 256 CUs - the other stream's workgroups
+ * take the CUs a partly filled round leaves idle.  Process-global; returns the previous setting; results do not depend on it. */
+int dua_set_hgemm_concurrent(int on);
 /* ... the result as f16x3 planes of C * split_scale ([M][N] hi | lo) for the next presplit GEMM; act_out 2 = GELU
  * (U-ViT Mlp: fc1 -> GELU -> fc2, uvit/timm.py:96-111). */
 int dua_gemm_f16x3_presplit_planes(const void* aplanes, const void* packed, const float* bias, void* Cplanes, int M, int N, int K,
