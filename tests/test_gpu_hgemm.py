@@ -171,3 +171,28 @@ def test_hgemm_ab_switches_select_correct_kernels(ops, L, M, N, K, flags):
     assert e < 2e-6
     np.testing.assert_array_equal(c.cpu().numpy(), c2.cpu().numpy())
     check_colsums(c, M, N)
+
+
+def test_tile_width_rule_under_concurrent_streams_keeps_the_bits(ops, L):
+    """dua_set_hgemm_concurrent(1) (set by _forward_streams while the batch runs in chunks on HIP streams) lets the one-tap GEMM choose its
+    tile width by work instead of whole rounds of tiles: U-ViT's fc1 at 32 images (8256 rows, N = 4608: 594 tiles of 256 columns) moves from
+    128-column to 256-column tiles.  The result - fp32 output and GELU -> planes - must be the same bits either way, and the setter returns
+    the previous value."""
+    M, K, N = 32 * 258, 1152, 4608
+    x, w, b = rnd(31, M, K), rnd(32, N, K) / math.sqrt(K), rnd(33, N)
+    pl, _ = planes_of(ops, x, ops.F16X3_ACT_SCALE)
+    pk = ops.pack_weight_f16x3(w.to(dev))
+    out = {}
+    assert L.dua_set_hgemm_concurrent(0) == 0
+    try:
+        for conc in (0, 1):
+            was = L.dua_set_hgemm_concurrent(conc)
+            assert was == (0 if conc == 0 else 0)
+            c = ops.gemm_bf16x3_presplit(pl, pk, N, bias=b.to(dev))
+            g = ops.gemm_bf16x3_presplit(pl, pk, N, bias=b.to(dev), act_out=2, split_out=True)
+            out[conc] = (c.clone(), g.buf.clone())
+        assert L.dua_set_hgemm_concurrent(0) == 1
+    finally:
+        L.dua_set_hgemm_concurrent(0)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
