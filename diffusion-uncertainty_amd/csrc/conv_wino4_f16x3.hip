@@ -42,6 +42,9 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #else
 #define W4_EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef W4_EPI_PATCH
+#define W4_EPI_PATCH 1                             // 0: the lane transpose of the epilogue by DPP + ds_bpermute per register instead of the LDS patch
+#endif
 constexpr int W4_STORES = 2 * 4 * 2 * 4;          // channel-block pairs x position blocks x halves x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
@@ -454,6 +457,9 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         }
         float4 rn_[2][4];
         res_ld(0, rn_[0]);
+#if W4_EPI_PATCH
+        char* const pw_ = (char*)lds + (wave < 2 ? (BOFF + 2 * STG) * 2 + wave * 8192 : (AOFF + 2 * STG) * 2 + (wave - 2) * 8192);
+#endif
         w4_static_for<2>([&](auto jp_c) __attribute__((always_inline)) {
             constexpr int jp = decltype(jp_c)::value;
             float4 sq = sq_[jp];
@@ -473,6 +479,23 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     R[u][2] = s12 + 4.0f * s34;
                     R[u][3] = (acc[5][jj][i] + d12) + 8.0f * d34;
                 }
+#if W4_EPI_PATCH
+                // Lane transpose through the wave's 8-KB LDS patch (weight / activation ring slot 2: no wave reads the rings after the
+                // tile's last barrier, and the next tile's requests for slot 2 go out behind its opening barrier): eight 16-byte writes in the
+                // accumulator layout - row r, position lane & 15, 16-byte chunk (4 u + (lane >> 4)) ^ ((position >> 1) & 7) of the 128-byte
+                // line: conflict-free both ways (the patch of k_hgemm) - and eight reads in the row layout, instead of a DPP move and a
+                // ds_bpermute per REGISTER (64 instructions per block of 2 x 4 quads).
+                {
+                    const int le0 = lane_now();
+                    char* pp_ = pw_ + (le0 & 15) * 128;
+                    const int sw_ = ((le0 & 15) >> 1) & 7, lc0 = le0 >> 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        *(f32x4*)(pp_ + r * 2048 + 16 * (lc0 ^ sw_)) = R[0][r];
+                        *(f32x4*)(pp_ + r * 2048 + 16 * ((4 + lc0) ^ sw_)) = R[1][r];
+                    }
+                }
+#endif
                 w4_static_for<2>([&](auto h_c) __attribute__((always_inline)) {
                     constexpr int h = decltype(h_c)::value;
                     constexpr int sb = (jp * 4 + i) * 2 + h;
@@ -484,6 +507,18 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     const int rel0 = opix(i, pl);
                     const bool ok = FULL ? !(WCONV4_DIAG & 16) : (c < p.N && rel0 >= 0 && !(WCONV4_DIAG & 16));
                     const unsigned o0 = (__umul24((unsigned)rel0, (unsigned)p.N) + (unsigned)c) * 4u;
+#if W4_EPI_PATCH
+                    // the half block's four rows back from the wave's LDS patch in the row layout (put_patch above): four 16-byte reads
+                    float t4[4][4];
+                    {
+                        const char* pr_ = pw_ + pl * 128 + 16 * (q ^ ((pl >> 1) & 7));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const f32x4 tv = *(const f32x4*)(pr_ + r * 2048);
+                            t4[r][0] = tv[0]; t4[r][1] = tv[1]; t4[r][2] = tv[2]; t4[r][3] = tv[3];
+                        }
+                    }
+#else
                     // The 32 lanes whose accumulator-layout position (lane & 15) lies in half h hold the first block's quads of the 8 rows
                     // this instruction writes; the other 32 lanes are free to carry the second block's (a rotation by 8 inside the 16-lane
                     // row, one DPP move): then ONE ds_bpermute per register gathers a row's eight 16-byte pieces into adjacent lanes.
@@ -499,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                             const int y = __builtin_amdgcn_update_dpp(__float_as_int(R[0][r][e]), __float_as_int(R[1][r][e]), 0x128, 0xf, h == 0 ? 0xc : 0x3, false);
                             t4[r][e] = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, y));
                         }
+#endif
                     W4_EPI_FENCE();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
