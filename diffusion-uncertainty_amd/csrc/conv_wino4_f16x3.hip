@@ -42,9 +42,6 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #else
 #define W4_EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifndef W4_PRO3
-#define W4_PRO3 1                                  // 0: the prologue of a tile requests two slots of each ring, not all three
-#endif
 constexpr int W4_STORES = 2 * 4 * 2 * 4;          // channel-block pairs x position blocks x halves x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
@@ -147,11 +144,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             sboff += 16384;                                // the next K step's stage
         }
     };
-    // All THREE slots of both rings (W4_PRO3): the first request the K loop then makes is the weight stage of step 3, in step 1, needed at the
-    // end of step 2 - vmcnt retires in order, so that wait is where the previous tile's output stores (up to 63 per wave in flight, 256 KB per
-    // CU draining at the CU's ~20 GB/s) must have retired: two and a half steps into the tile instead of one and a half.  (The epilogue's
-    // 13 us are this drain, not its instructions: -15 % of them through an LDS-patch transpose bought 0.2 %.)
-    auto issue_prologue = [&]() {          // A(channel block 0, f = 0, 1 [, 2]) B(0) B(1) [B(2)]
+    auto issue_prologue = [&]() {          // A(channel block 0, f = 0) A(channel block 0, f = 1) B(0) B(1)
         toffReq = 0;
         a_setup(0);
 #pragma unroll
@@ -159,19 +152,10 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         a_setup(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_a(1, i);
-        if (W4_PRO3) {
-            a_setup(2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dma_a(2, i);
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_b(0, i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma_b(1, i);
-        if (W4_PRO3) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dma_b(2, i);
-        }
     };
 
     const char* ldsb = reinterpret_cast<const char*>(lds);
@@ -254,25 +238,23 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         // block: in the tile's final group (last channel block, f = 5) the requests that would run past the tile are skipped by uniform
         // branches around single instructions, so that no two regions of code hold the accumulators in different registers (the
         // copies between them would sit next to matrix-core instructions the compiler cannot see).
-        auto step = [&](auto fi_c, auto dxi_c, const bool last_cb, const bool first_cb) __attribute__((always_inline)) {
+        auto step = [&](auto fi_c, auto dxi_c, const bool last_cb) __attribute__((always_inline)) {
             constexpr int FI = decltype(fi_c)::value, DXI = decltype(dxi_c)::value;
             constexpr bool AG = FI < 4;
-            // the tile's first group with the three-stage prologue: activation stage of group 2 and weight stage of step 2 are there already
-            const bool firstg = W4_PRO3 && FI == 0 && first_cb;                 // (compile-time false for f > 0)
             const bool lastg = FI == 5 && last_cb;                              // (compile-time false for f < 5): no weight stage beyond the tile
             const bool lastA = FI >= 4 && last_cb;                              // group g + 2 lies beyond the tile: no activation request
             constexpr int FN = (FI + 1) % 6, F2 = (FI + 2) % 6;
             constexpr int sa_n = F2 % 3, sb_n = (DXI + 2) % 3;
             constexpr int sa_r = DXI == 2 ? (FN % 3) : (FI % 3), sb_r = (DXI + 1) % 3, dxn = DXI == 2 ? -1 : DXI;   // the NEXT step's fragments
             f32x4 (&A)[4][4] = acc[FI];
-            if (DXI == 0 && !lastA && !firstg) {                                // set up the activation stage of group g + 2 ...
+            if (DXI == 0 && !lastA) {                                           // set up the activation stage of group g + 2 ...
                 toffReq = toffA + (FI >= 4 ? 16384 : 0);                        // (f = 4, 5: it opens the next channel block)
                 a_setup(F2);
             }
             auto early_piece = [&](int q) {
                 if (WCONV4_DIAG & 4) return;
-                if (q < 4) { if ((!lastg || DXI == 0) && !(firstg && DXI == 0)) dma_b(sb_n, q); }          // the weight stage of step s + 2
-                else if (q < 6) { if (DXI < 2 && !lastA && !firstg) dma_a(sa_n, q - 4 + 2 * DXI); }    // ... requested half in this group's first, half in its second step
+                if (q < 4) { if (!lastg || DXI == 0) dma_b(sb_n, q); }          // the weight stage of step s + 2
+                else if (q < 6) { if (DXI < 2 && !lastA) dma_a(sa_n, q - 4 + 2 * DXI); }    // ... requested half in this group's first, half in its second step
             };
             WSB();
             // P1: w_hi * x_lo | the DMA pieces of this step
@@ -293,12 +275,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             // last two groups of the tile no activation pieces are requested, in the final one no weight stage beyond its last step.
             if (lastA) {
                 if (FI == 5 && DXI > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else if (firstg) {
-                // steps 0, 1: the stage read next came with the prologue (landed: the tile-start wait), nothing younger is needed - the
-                // previous tile's stores stay in flight; step 2: behind its own four weight pieces lie those of step 1 (no activation
-                // pieces were requested in this group), which must have landed
-                if (DXI < 2) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 if (DXI == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -337,16 +313,13 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
         using I3 = std::integral_constant<int, 3>;
         using I4 = std::integral_constant<int, 4>;
         using I5 = std::integral_constant<int, 5>;
-#define W4_GROUP(F) step(F{}, I0{}, last_cb, first_cb); step(F{}, I1{}, last_cb, first_cb); step(F{}, I2{}, last_cb, first_cb);
+#define W4_GROUP(F) step(F{}, I0{}, last_cb); step(F{}, I1{}, last_cb); step(F{}, I2{}, last_cb);
 #pragma nounroll
         for (int cbi = 0; cbi < ncb; ++cbi) {
             toffA = cbi * 16384;
             int last_i = __builtin_amdgcn_readfirstlane(cbi == ncb - 1 ? 1 : 0);
             asm volatile("" : "+s"(last_i));                                    // (opaque: the loop is neither peeled nor versioned on it)
             const bool last_cb = last_i != 0;
-            int first_i = __builtin_amdgcn_readfirstlane(cbi == 0 ? 1 : 0);
-            asm volatile("" : "+s"(first_i));
-            const bool first_cb = first_i != 0;
             W4_GROUP(I0) W4_GROUP(I1) W4_GROUP(I2) W4_GROUP(I3) W4_GROUP(I4) W4_GROUP(I5)
         }
 #undef W4_GROUP

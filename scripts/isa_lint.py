@@ -35,7 +35,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # (inline-asm) MFMA write and any other instruction touching the register; `fences` = exact count of the `s_nop 15 / s_nop 3` blocks.
 SPECS = [
     dict(name="k_wconv4", obj="conv_wino4_f16x3.o", sym=r"^_Z8k_wconv4ILi[0-3]EEv6WConvP$", regs=512, scratch=128,
-         mfma=("v_mfma_f32_16x16x32_f16", {864}), loop_vmcnt={0, 4, 6, 8, 63}, loop_vmcnt_need={6, 8}, tail_wait=63, hazard=18, fences=12, tail_scratch_loads=0),
+         mfma=("v_mfma_f32_16x16x32_f16", {864}), loop_vmcnt={0, 4, 6, 8}, loop_vmcnt_need={6, 8}, tail_wait=63, hazard=18, fences=12, tail_scratch_loads=0),
     dict(name="k_wconv", obj="conv_wino_f16x3.o", sym=r"^_Z7k_wconv6WConvP$", regs=512, scratch=0,
          mfma=("v_mfma_f32_16x16x32_f16", None), loop_vmcnt=None, loop_vmcnt_need=set(), tail_wait=16),
     dict(name="k_wconv1", obj="conv_wino_f16x3.o", sym=r"^_Z8k_wconv16WConvP$", regs=512, scratch=0,
