@@ -489,7 +489,9 @@ __global__ __launch_bounds__(NTH) void k_quantile_mask_reg(const float* __restri
 //      writes the whole mask.  Exact either way; the result never depends on the sample.
 //   5. mask from the registers; the last workgroup to leave zeroes the sample's counters for the next launch.
 // Deadlock freedom: every workgroup reaches the arrival counter unconditionally, and the G workgroups of a sample have
-// consecutive block indices, so with in-order dispatch a waiting workgroup's partners are resident or next to be placed.
+// consecutive block indices, so with in-order dispatch a waiting workgroup's partners are resident or next to be placed
+// (600 workgroups for 300 samples - more than the CUs hold at once - are a test).  The wait is bounded all the same: a
+// workgroup whose partner does not arrive within 2^18 polls takes the streaming fallback alone (exact, slow, no hang).
 #define QM_TH 1024
 #define QM_CAP 12288                         // candidate slots per sample (12 per thread in the final select)
 #define QM_S4 768                            // float4 of the common sample
@@ -841,8 +843,14 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
         uint64_t* word = (uint64_t*)(ctr + 2);
         const uint64_t add = (1ull << 60) | ((uint64_t)sv[9] << 28) | ((uint64_t)min(sv[8], RC + 1u) << (14 * g));
         __hip_atomic_fetch_add(word, add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // The wait is BOUNDED (2^18 polls, a few tenths of a second): should the partner never be placed beside this workgroup - a
+        // dispatch order this kernel does not expect - the workgroup stops waiting and takes the fallback of step 4 by itself (the
+        // streaming select needs nobody, and what this workgroup has published stays valid for a partner that arrives later): slow, exact,
+        // and no hang.
         uint64_t wv;
-        while (((wv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 60) < (uint64_t)QM_G) __builtin_amdgcn_s_sleep(1);
+        uint32_t polls = 0;
+        while (((wv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 60) < (uint64_t)QM_G && ++polls < (1u << 18))
+            __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const uint32_t c0 = (uint32_t)wv & 0x3FFFu, c1 = (uint32_t)(wv >> 14) & 0x3FFFu;
         sv[16] = c0;
@@ -850,11 +858,13 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
         sv[11] = (uint32_t)(wv >> 28) & 0x3FFFFu;
         sv[12] = c0 + c1;
         sv[13] = c0 <= RC && c1 <= RC ? 1u : 0u;
+        sv[14] = (wv >> 60) < (uint64_t)QM_G ? 1u : 0u;      // gave up waiting
     }
     __syncthreads();
     QM_STAMP(5);
     const uint32_t tot_below = sv[11], tot_in = sv[12];
-    const bool inside = !force_miss && sv[13] && tot_below <= (uint32_t)lo && (uint32_t)hi < tot_below + tot_in;
+    const bool alone = sv[14] != 0 || force_miss == 2;        // (force_miss 2: tests - as if the partner had never arrived)
+    const bool inside = !force_miss && !alone && sv[13] && tot_below <= (uint32_t)lo && (uint32_t)hi < tot_below + tot_in;
 
     // ---- 4. exact select among the candidates (or the streaming select of the whole sample by workgroup 0)
     bool write_own = true;
@@ -876,7 +886,7 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
         __syncthreads();
     } else {
         write_own = false;
-        if (g == 0) {                                        // (uniform) four radix passes + successor pass + mask pass over global memory
+        if (g == 0 || alone) {                               // (uniform) four radix passes + successor pass + mask pass over global memory
             uint32_t prefix = 0, rank = (uint32_t)lo, cnt_eq = 0;
             for (int pass = 0; pass < 4; ++pass) {
                 const int shift = 24 - 8 * pass;
@@ -957,7 +967,8 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
 }
 
 // A/B switch for tests: 0 = default dispatch, 1 = always the streaming (multi-pass) kernel, 2 = never the multi-workgroup
-// kernel, 3 = the multi-workgroup kernel with its bracket declared missed (the fallback inside it)
+// kernel, 3 = the multi-workgroup kernel with its bracket declared missed (the fallback inside it), 4 = ... with every workgroup
+// behaving as if its partner had never arrived (the bounded wait's way out: each runs the fallback alone)
 static int quantile_force_stream = 0;
 extern "C" int dua_set_quantile_stream(int on) { int o = quantile_force_stream; quantile_force_stream = on; return o; }
 
@@ -999,14 +1010,14 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
         else hipLaunchKernelGGL((k_quantile_mask_reg<V, TH, false>), B, TH, 0, st, u, n, lo, hi, w, mask, q);   \
     }
     const int mode = quantile_force_stream;
-    if (vec && n > 16384 && n <= 65536 && (mode == 0 || mode == 3)) {
+    if (vec && n > 16384 && n <= 65536 && (mode == 0 || mode == 3 || mode == 4)) {
         // two workgroups per sample; delta: 5 sigma of the sample rank of s[lo] under independent draws (+ 8)
         constexpr int G = QM_G;
         uint32_t* ws = quantile_workspace(st, B);
         DUA_REQUIRE(ws, "dua_quantile_mask: no workspace (%d samples)", B);
         const double pr = (double)lo / (double)n;
         const int delta = (int)ceil(5.0 * sqrt(pr * (1.0 - pr) * 4.0 * QM_S4)) + 8;
-        const int n4 = n / 4, force_miss = mode == 3;
+        const int n4 = n / 4, force_miss = mode == 3 ? 1 : (mode == 4 ? 2 : 0);
 #define QMULTI(V) hipLaunchKernelGGL((k_quantile_mask_multi<V>), B * G, QM_TH, 0, st, u, n, lo, hi, w, mask, q, ws, delta, force_miss)
         if (n4 <= 3 * G * QM_TH) QMULTI(3);
         else if (n4 <= 4 * G * QM_TH) QMULTI(4);

@@ -78,7 +78,8 @@ int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uin
 /* A/B switch (returns the previous value): 0 = default: samples of up to 65536 elements are held in registers (u read once) - by one
  * workgroup (min/max-ranged LDS histogram + wavefront scans), or, for 16384 < n <= 65536 and 16-byte aligned rows, by two workgroups
  * that bracket the target from a common sample and meet once through a per-stream workspace; 1 = always the streaming multi-pass kernel
- * (six passes over u); 2 = never the two-workgroup kernel; 3 = the two-workgroup kernel with its bracket declared missed (its fallback). */
+ * (six passes over u); 2 = never the two-workgroup kernel; 3 = the two-workgroup kernel with its bracket declared missed (its fallback);
+ * 4 = ... with every workgroup acting as if its partner had never arrived (the way out of its bounded wait). */
 int dua_set_quantile_stream(int on);
 
 /* y[p][h][w] = x[p][H-1-h][w] over `planes` = N*C image planes: torch.flip(x, dims=[2]) of an NCHW tensor, the input / output

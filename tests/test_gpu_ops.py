@@ -116,7 +116,8 @@ def test_quantile_mask_full_size_properties(ops):
 
 
 @pytest.mark.parametrize("shape", [(1, 4, 64, 64), (128, 3, 128, 128), (3, 3, 64, 64), (2, 4, 32, 32), (5, 1, 1, 4099), (2, 1, 1, 65536),
-                                   (2, 1, 1, 65537), (3, 1, 1, 7), (4, 1, 1, 40000), (3, 1, 1, 20000), (2, 2, 128, 128), (5, 1, 1, 16388)])
+                                   (2, 1, 1, 65537), (3, 1, 1, 7), (4, 1, 1, 40000), (3, 1, 1, 20000), (2, 2, 128, 128), (5, 1, 1, 16388),
+                                   (300, 3, 128, 128)])         # (600 workgroups of 1024 threads: more than the 256 CUs hold at once)
 def test_quantile_mask_register_kernel_vs_streaming(ops, shape):
     """The register-resident kernels (sample read once: one workgroup per sample with an LDS histogram over the sample's own key range; two
     workgroups per sample with a sample bracket for 16384 < n <= 65536) against the streaming six-pass kernel and the oracle's sort-based
@@ -150,8 +151,9 @@ def test_quantile_mask_register_kernel_vs_streaming(ops, shape):
             if 16384 < n <= 65536 and n % 4 == 0:
                 # the default above was the several-workgroups-per-sample kernel: also the one-workgroup register kernel (2) and the
                 # several-workgroups kernel with its sample bracket declared missed (3: workgroup 0 selects over global memory), twice
-                # in a row (each launch has to leave the workspace counters zeroed)
-                for mode in (2, 3, 3, 0):
+                # in a row (each launch has to leave the workspace counters zeroed), and with every workgroup acting as if its partner had
+                # never arrived (4: the way out of the bounded wait - each selects alone)
+                for mode in (2, 3, 3, 4, 0):
                     L.dua_set_quantile_stream(mode)
                     try:
                         mask_m, q_m = ops.quantile_mask(ud, p)
