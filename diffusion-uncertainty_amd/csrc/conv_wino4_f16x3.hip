@@ -33,7 +33,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #ifndef WCONV4_DIAG
 #define WCONV4_DIAG 0             // timing-only diagnostic builds (scripts/wconv_diag.py --kernel w4; WRONG results): bit 0 no in-loop barrier,
                                   // bit 1 no epilogue, bit 2 no in-loop DMA, bit 3 no in-loop fragment reads, bit 4 output stores dropped by the buffer unit,
-                                  // bit 5 no residual loads, bit 6 wave 0 writes s_memrealtime at the start and end of every epilogue into the colsum buffer
+                                  // bit 5 no residual loads, bit 6 wave 0 writes s_memrealtime at the start and end of every epilogue into the colsum buffer, bit 7 no scale / bias loads
 #endif
 
 // (A/B build -DW4_EPI_NOFENCE=1: the epilogue's sub-blocks without scheduling fences - the compiler may interleave their dependent chains)
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
             const int c = n0 + wn * 64 + 32 * jp + 4 * (lane_now() & 7);
+            if (WCONV4_DIAG & 128) { sq_[jp] = make_float4(1.f, 1.f, 1.f, 1.f); bq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }    // (timing only: no scale / bias loads)
             sq_[jp] = *(const float4*)(p.Cscale + c);                        // (padded to the tile grid)
             bq_[jp] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias && c < p.N) bq_[jp] = *(const float4*)(p.bias + c);

@@ -18,7 +18,7 @@ DIAG = os.path.join(ROOT, "scripts", "diag", "build")
 VARIANTS = (1, 2, 4, 6, 8, 15, 16, 32, 64)
 
 
-VARIANTS4 = (2, 16, 32, 48)          # k_wconv4 (csrc/conv_wino4_f16x3.hip, -DWCONV4_DIAG): 1 barrier, 2 epilogue, 4 in-loop DMA, 8 fragment reads
+VARIANTS4 = (2, 16, 32, 48, 128)          # k_wconv4 (csrc/conv_wino4_f16x3.hip, -DWCONV4_DIAG): 1 barrier, 2 epilogue, 4 in-loop DMA, 8 fragment reads
 
 
 def lib_of(v, k4=False):
