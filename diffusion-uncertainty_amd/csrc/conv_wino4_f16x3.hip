@@ -42,9 +42,6 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 #else
 #define W4_EPI_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifndef W4_RES_LDS
-#define W4_RES_LDS 1                               // 0: the residual rows of the plain / upsampled modes through registers, one sub-block ahead
-#endif
 constexpr int W4_STORES = 2 * 4 * 2 * 4;          // channel-block pairs x position blocks x halves x output rows: always-issued stores of a wave
 static_assert(W4_STORES >= 63, "the tile-start wait leaves the 63 youngest vector-memory operations in flight: all must be behind the prologue DMA");
 
@@ -446,38 +443,6 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                 }
             }
         };
-        // Plain and upsampled residual (MODE 1, 2) with W4_RES_LDS: the rows do not come through registers but by DMA into a two-slot ring in
-        // the wave's 8 KB of free LDS (slot 2 of the weight / activation ring: no wave reads the rings after the tile's last barrier, the next
-        // tile's requests for slot 2 go out behind its opening barrier), TWO sub-blocks ahead of their use instead of one - there are no
-        // registers for a deeper ring (every depth tried spills), and with one sub-block of lead the residual rows cost 7 us per tile
-        // (timing build without them).  Sub-block sb: wait for DMA(sb) (vmcnt counts the always-issued operations behind it), read its four
-        // rows, and only then request DMA(sb + 2) into the same slot.  `nt`: the rows are read once (and the lint tells these requests
-        // from the rings' by it).
-        constexpr bool RLDS = W4_RES_LDS && MODE == 1;        // (MODE 2: its 64-bit source arithmetic beside the ring spills three registers)
-        char* const pwr = (char*)lds + (wave < 2 ? (BOFF + 2 * STG) * 2 + wave * 8192 : (AOFF + 2 * STG) * 2 + (wave - 2) * 8192);
-        auto res_dma = [&](int sb) {
-            const int jp = sb >> 3, i = (sb >> 1) & 3, h = sb & 1;
-            const int le = lane_now();
-            const int c = n0 + wn * 64 + 32 * jp + 4 * (le & 7);
-            const int rel0 = opix(i, (le >> 3) + 8 * h);
-            const bool okl = FULL ? !(WCONV4_DIAG & 32) : (c < p.N && rel0 >= 0 && !(WCONV4_DIAG & 32));
-            char* dst = pwr + (sb & 1) * 4096;
-            if constexpr (MODE == 1) {
-                const unsigned o0 = (__umul24((unsigned)rel0, (unsigned)p.N) + (unsigned)c) * 4u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, dst + r * 1024, 16, okl ? o0 + (unsigned)r * row_bytes : 0xFFFFFFF0u, 0, 0, 2);
-            } else {
-                const long row0 = rel0 < 0 ? -1L : cpix0 + rel0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long row = row0 + (long)r * p.W;
-                    const unsigned t = (unsigned)row >> (31 - __clz(p.W)), xo = (unsigned)row & (p.W - 1), n = t / (unsigned)p.H, yo = t - n * p.H;
-                    const long src = ((long)(n - res_n0) * (p.H >> 1) + (yo >> 1)) * (p.W >> 1) + (xo >> 1);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rres, dst + r * 1024, 16, okl ? (unsigned)((src * p.N + c) * 4) : 0xFFFFFFF0u, 0, 0, 2);
-                }
-            }
-        };
         // column scale * 1 / v_scale and bias of both channel-block pairs (this lane's four channels of each), before any store goes out
         float4 sq_[2], bq_[2];
 #pragma unroll
@@ -489,8 +454,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
             if (p.bias && c < p.N) bq_[jp] = *(const float4*)(p.bias + c);
         }
         float4 rn_[2][4];
-        if constexpr (RLDS) { res_dma(0); res_dma(1); }
-        else res_ld(0, rn_[0]);
+        res_ld(0, rn_[0]);
         w4_static_for<2>([&](auto jp_c) __attribute__((always_inline)) {
             constexpr int jp = decltype(jp_c)::value;
             float4 sq = sq_[jp];
@@ -514,18 +478,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
                     constexpr int h = decltype(h_c)::value;
                     constexpr int sb = (jp * 4 + i) * 2 + h;
                     W4_EPI_FENCE();
-                    if constexpr (RLDS) {
-                        // operations always issued behind DMA(sb): [DMA(1)] | [DMA(2), stores(0)] | stores(sb - 2), DMA(sb + 1), stores(sb - 1)
-                        constexpr int NW_ = sb == 0 ? 4 : (sb == 1 ? 8 : (sb == 15 ? 8 : 12));
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_) : "memory");
-                        const char* src_ = pwr + (sb & 1) * 4096 + lane_now() * 16;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rn_[0][r] = *(const float4*)(src_ + r * 1024);
-                        if constexpr (sb + 2 < 16) {
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the slot has been read: it may be overwritten
-                            res_dma(sb + 2);
-                        }
-                    } else if constexpr (sb + 1 < 16) res_ld(sb + 1, rn_[(sb + 1) & 1]);
+                    if constexpr (sb + 1 < 16) res_ld(sb + 1, rn_[(sb + 1) & 1]);
                     W4_EPI_FENCE();
                     const int le = lane_now();
                     const int q = le & 7, c = n0 + wn * 64 + 32 * jp + 4 * q, pl = (le >> 3) + 8 * h;
@@ -551,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void k_wconv4(WConvP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float (&t)[4] = t4[r];
-                        const float4 rq = rn_[RLDS ? 0 : (sb & 1)][r];
+                        const float4 rq = rn_[sb & 1][r];
                         float4 v;
                         v.x = __builtin_fmaf(t[0], sq.x, bq.x);                   // (one fixed rounding order in every variant of the epilogue)
                         v.y = __builtin_fmaf(t[1], sq.y, bq.y);

@@ -191,8 +191,7 @@ def check_tail_wait(insns, w, N):
     instructions may sit closer than N stores - with none at all; every other DMA (the K loop's, the prefetch of the next tile in front of the
     epilogue) must have N stores on every path.  A branch around epilogue stores, or around the whole epilogue, adds a second such run."""
     found = min_stores_before(insns, w, lambda i: i.op.startswith("buffer_store") or i.op.startswith("global_store"),
-                              # (the rings' requests; the epilogue's own residual requests carry `nt` and are waited for inside the epilogue)
-                              lambda i: i.op.startswith("buffer_load") and i.args.rstrip().endswith("lds") and " nt" not in i.args)
+                              lambda i: i.op.startswith("buffer_load") and i.args.rstrip().endswith("lds"))
     short = sorted(k for k, d in found.items() if d < N)
     runs = []
     for k in short:
