@@ -597,6 +597,59 @@ def g13():
     save("g13_adm128_chain", **out)
 
 
+def g20():
+    """BASELINE configs[1]'s own schedule on one image: full-size ADM-128 through the REFERENCE driver and the reference scheduler
+    (uncertainty_zigzag_centered), B=1, 50 DDIM steps, M=5, num_zigzag=3, UC window (after_step 40, 10 steps) - 50 + 10 * 5 * 3 = 200
+    denoiser forwards - seeded weights, torch's CPU generator re-seeded before every scheduler.step() (seed 9000 + step index) as in G13.
+    Stored: the start, the final image, uncertainty maps and scores of the ten window steps, x_t at a few steps of the plain stretch
+    (how far a free-running chain has drifted by then), and the percentile-0.9 mask of the final map."""
+    m = build_adm(ADM128, 128)
+    X_T, y = randn(2031, 1, 3, 128, 128), torch.tensor([417])
+    rec = {"main": True, "calls": [], "n": 0}
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x, t, y=None):
+            o = self.inner(x, t, y=y)
+            rec["n"] += 1
+            if rec["main"]:
+                rec["calls"].append((x.clone(), int(t[0])))
+            return o
+
+    wrapped = Recorder(m)
+    with _quiet:
+        s = RefZigzag.from_config(CONFIGS["adm128"], M=5, after_step=40, num_steps_uc=10, unet=wrapped, num_zigzag=3)
+        s.set_timesteps(50)
+    ref_step, k = s.step, [0]
+
+    def seeded_step(*a, **kw):
+        torch.manual_seed(9000 + k[0])
+        k[0] += 1
+        rec["main"] = False
+        try:
+            return ref_step(*a, **kw)
+        finally:
+            rec["main"] = True
+
+    s.step = seeded_step
+    with _quiet, torch.no_grad():
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, 1, torch.device("cpu"), wrapped, s)
+    assert len(rec["calls"]) == 50 and rec["n"] == 50 + 10 * 5 * 3, (len(rec["calls"]), rec["n"])
+    out = dict(X_T=X_T, y=y, seed=128, timesteps=s.timesteps, gen_images=r["gen_images"], uncertainty=r["uncertainty"], score=r["score"],
+               kept=np.array([10, 25, 40, 49]), window=np.array([40, 10, s.timestep_after_step, s.timestep_end_step]))
+    for i in out["kept"]:
+        x, t = rec["calls"][int(i)]
+        assert t == int(s.timesteps[int(i)])
+        out[f"x{i}"] = x
+    u = r["uncertainty"][:, -1]
+    q = torch.quantile(u.flatten(1).float(), 0.9, dim=1)
+    out["final_mask"] = (u > q.reshape(-1, 1, 1, 1)).to(torch.uint8)
+    save("g20_adm128_headline_schedule", **out)
+
+
 def g17():
     """Full-size U-ViT-H/2 + full KL-VAE decoder through the REFERENCE latent driver (generate_samples.py:469-570) and the reference
     scheduler (uncertainty_zigzag_centered, U-ViT scheduler config): B=1, 10 DDIM steps, M=2, num_zigzag=3, UC window (after_step 6,
@@ -796,6 +849,6 @@ def g16():
 
 
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

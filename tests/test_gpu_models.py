@@ -817,6 +817,82 @@ def test_full_size_chain_vs_golden(golden, precision):
     assert es < tol_s and eu < tol_u and d.max() <= tol_lsb and agree >= tol_mask
 
 
+# BASELINE configs[1]'s own schedule against the reference's run of it (G20).  With SEEDED RANDOM weights the 50-step map is chaotic - the
+# exact-fp32 engine itself is 2e-5 from the reference's CPU run at step 10, 8e-4 at step 25, 0.1 at step 40 (different summation orders
+# only) - so the free-running part is held at steps 10 and 25, and the UC window is teacher-forced from the reference's own x_t:
+# (x_t drift at step 10, at step 25, teacher-forced eps, score, uncertainty (relative)).  The same bars for the exact-fp32 engine and f16x3.
+HEADLINE_CHAIN_TOL = {"fp32": (2e-4, 1e-2, 1e-3, 1e-3, 2.5e-2), "f16x3": (2e-4, 1e-2, 1e-3, 1e-3, 2.5e-2)}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_headline_schedule_chain_vs_golden(golden, precision):
+    """Full-size ADM-128 through the driver on the headline job's OWN schedule - 50 DDIM steps, M=5, num_zigzag=3, UC window (40, 10) -
+    for one image, against the reference driver's run of the same schedule (G20: reference UNet, scheduler and driver on the CPU, 200
+    forwards; same seeded weights, same noise tape).  Free-running: x_t at steps 10 and 25 of the plain stretch (later steps are printed,
+    not asserted: the map is chaotic with random weights).  Teacher-forced from the reference's x_t at the first and the last step of
+    the window (timesteps of the real schedule, M=5, three zig-zag passes): the denoiser's eps, then scheduler.step on it with the
+    reference's noise tape - score and uncertainty map against the reference's."""
+    from oracle import adm
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    g = golden("g20_adm128_headline_schedule")
+    m, _ = build_adm(dict(adm.ADM128), int(g["seed"]))
+    m.precision = precision
+    tol_x10, tol_x25, tol_tf, tol_s, tol_u = HEADLINE_CHAIN_TOL[precision]
+    after, num = int(g["window"][0]), int(g["window"][1])
+    a = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=5, start_step_uc=after, num_steps_uc=num, predict_next=True,
+                           eta=0.0, num_zigzag=3, uncertainty_distance=1)
+    ts = [int(t) for t in g["timesteps"]]
+    y = T(g["y"]).to(dev)
+    # ---- teacher-forced: first and last step of the window from the reference's own x_t
+    s = get_uncertainty_scheduler(a, None, m, init_scheduler_imagenet128())
+    s.set_timesteps(50)
+    s.prompt_embeds = y
+    assert s.timesteps.tolist() == ts and (s.timestep_after_step, s.timestep_end_step) == (int(g["window"][2]), int(g["window"][3]))
+    for i in (40, 49):
+        x = T(g[f"x{i}"]).to(dev)
+        eps = m(x, torch.full((1,), ts[i], dtype=torch.long, device=dev), y=y, out_channels_keep=3)
+        e_tf = np.abs(eps.cpu().numpy() - g["score"][:, i - after]).max()
+        torch.manual_seed(9000 + i)
+        o = s.step(eps, ts[i], x)
+        ref_u = g["uncertainty"][:, i - after]
+        e_s = np.abs(o.pred_epsilon.cpu().numpy() - g["score"][:, i - after]).max()
+        e_u = np.abs(o.uncertainty.cpu().numpy() - ref_u).max() / np.abs(ref_u).max()
+        print(f"{precision}: headline schedule, step {i} (t = {ts[i]}) teacher-forced: eps {e_tf:.2e}, score {e_s:.2e}, uncertainty rel {e_u:.2e}")
+        assert e_tf < tol_tf and e_s < tol_s and e_u < tol_u, (precision, i, e_tf, e_s, e_u)
+    # ---- free-running, same noise tape
+    s = get_uncertainty_scheduler(a, None, m, init_scheduler_imagenet128())
+    s.set_timesteps(50)
+    inner, k = s.step, [0]
+
+    def seeded_step(*aa, **kw):
+        torch.manual_seed(9000 + k[0])
+        k[0] += 1
+        return inner(*aa, **kw)
+
+    s.step = seeded_step
+    seen = {}                                             # timestep -> x of the FIRST forward at it (the main pass of that step)
+
+    def record(_mod, args, kwargs):
+        t = int((args[1] if len(args) > 1 else kwargs["timesteps"]).flatten()[0])
+        seen.setdefault(t, (args[0] if args else kwargs["x"]).detach().float().cpu().clone())
+
+    h = m.register_forward_pre_hook(record, with_kwargs=True)
+    try:
+        r = gen(T(g["X_T"]), T(g["y"]), 1, torch.device(dev), m, s)
+    finally:
+        h.remove()
+    drift = {}
+    for i in [int(v) for v in g["kept"]]:
+        ref = g[f"x{i}"]
+        drift[i] = float(np.abs(seen[ts[i]].numpy() - ref).max() / np.abs(ref).max())
+    d = np.abs(r["gen_images"].numpy().astype(int) - g["gen_images"].astype(int))
+    print(f"{precision}: headline schedule, free-running: x_t drift by step {({k_: float(f'{v:.1e}') for k_, v in drift.items()})}, final image: "
+          f"{100 * (d > 0).mean():.1f} % of the bytes differ (max {d.max()})")
+    assert drift[10] < tol_x10 and drift[25] < tol_x25, (precision, drift)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_uvit_full_size_chain_vs_golden(golden, precision):
     """BASELINE configs[2] end to end at full size: U-ViT-H/2 + the full KL-VAE decoder through the latent driver, 10 DDIM steps,
