@@ -470,14 +470,14 @@ def test_g16_flip(golden):
 
 
 def test_g13_g17_chain_fixtures_are_self_consistent(golden):
-    """The free-running full-size chain fixtures (G13 ADM-128, G17 U-ViT-H/2 + VAE; reference driver outputs): the timestep grid
+    """The free-running full-size chain fixtures (G13 ADM-128, G17 U-ViT-H/2 + VAE, G20 ADM-128 on the headline schedule; reference driver outputs): the timestep grid
     is the oracle's for the model's scheduler config, the UC window bounds follow from it, and the stored percentile-0.9 mask is the
     oracle's exact quantile mask of the last uncertainty map (the GPU tests compare against these fields)."""
     from oracle import guidance, schedule
-    for name, kw in (("g13_adm128_chain", {}), ("g17_uvit_h2_chain", dict(steps_offset=1))):
+    for name, steps, kw in (("g13_adm128_chain", 10, {}), ("g17_uvit_h2_chain", 10, dict(steps_offset=1)), ("g20_adm128_headline_schedule", 50, {})):
         g = golden(name)
         ts = [int(t) for t in g["timesteps"]]
-        assert ts == [int(t) for t in schedule.leading_timesteps(1000, 10, **kw)], name
+        assert ts == [int(t) for t in schedule.leading_timesteps(1000, steps, **kw)], name
         after, num = int(g["window"][0]), int(g["window"][1])
         assert (int(g["window"][2]), int(g["window"][3])) == schedule.uc_window(ts, after, num)
         u = np.ascontiguousarray(g["uncertainty"][:, -1]).astype(np.float32)
