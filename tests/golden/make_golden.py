@@ -696,6 +696,75 @@ def g17():
          final_mask=(u > q.reshape(-1, 1, 1, 1)).to(torch.uint8))
 
 
+def g21():
+    """BASELINE configs[2]'s own schedule on one image: full-size U-ViT-H/2 (+ the KL-VAE decode at the end) through the REFERENCE latent driver
+    and the reference scheduler, B=1, 50 DDIM steps, M=5, num_zigzag=3, UC window (after_step 40, 10 steps) - 200 denoiser forwards -
+    seeded weights, the CPU generator re-seeded before every scheduler.step() (seed 9500 + step index).  Stored like G20: start, window
+    scores / uncertainty maps, x_t (latents) at steps 10 / 25 / 40 / 49, the mask of the last map; the decoded image is NOT stored
+    (G17 covers the decoder)."""
+    with _quiet:
+        from diffusion_uncertainty.uvit import autoencoder as ref_ae
+        from diffusion_uncertainty.uvit.uvit_ae import UViTAE as RefUViTAE
+
+    class RefKL(ref_ae.FrozenAutoencoderKL):
+        def __init__(self, ddconfig, embed_dim, scale_factor):
+            torch.nn.Module.__init__(self)
+            self.encoder = ref_ae.Encoder(**ddconfig)
+            self.decoder = ref_ae.Decoder(**ddconfig)
+            self.quant_conv = torch.nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+            self.post_quant_conv = torch.nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+            self.embed_dim, self.scale_factor = embed_dim, scale_factor
+
+    uvit = build_uvit(UVIT_H2, 7)
+    dd = dict(double_z=True, z_channels=4, in_channels=3, out_ch=3, attn_resolutions=[], dropout=0.0, resolution=256, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2)
+    with _quiet:
+        ae = RefKL(dd, 4, 0.18215)
+    ae.load_state_dict(seeded_state_dict({k: v.shape for k, v in ae.state_dict().items()}, 9))
+    ae.eval()
+    model = RefUViTAE(uvit, ae)
+    X_T, y = randn(2171, 1, 4, 32, 32), torch.tensor([88])
+    rec = {"main": True, "calls": [], "n": 0}
+
+    def pre(_m, args, kwargs):
+        rec["n"] += 1
+        if rec["main"]:
+            x = args[0] if args else kwargs["x"]
+            t = args[1] if len(args) > 1 else kwargs["timesteps"]
+            rec["calls"].append((x.clone(), int(t.flatten()[0])))
+
+    hook = uvit.register_forward_pre_hook(pre, with_kwargs=True)
+    with _quiet:
+        s = RefZigzag.from_config(CONFIGS["uvit"], M=5, after_step=40, num_steps_uc=10, unet=model, num_zigzag=3)
+        s.set_timesteps(50)
+    ref_step, k = s.step, [0]
+
+    def seeded_step(*a, **kw):
+        torch.manual_seed(9500 + k[0])
+        k[0] += 1
+        rec["main"] = False
+        try:
+            return ref_step(*a, **kw)
+        finally:
+            rec["main"] = True
+
+    s.step = seeded_step
+    with _quiet, torch.no_grad():
+        r = ref_gs.generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(X_T, y, 1, model, s, "cpu")
+    hook.remove()
+    assert len(rec["calls"]) == 50 and rec["n"] == 50 + 10 * 5 * 3, (len(rec["calls"]), rec["n"])
+    out = dict(X_T=X_T, y=y, uvit_seed=7, vae_seed=9, timesteps=s.timesteps, uncertainty=r["uncertainty"], score=r["score"],
+               kept=np.array([10, 25, 40, 49]), window=np.array([40, 10, s.timestep_after_step, s.timestep_end_step]))
+    for i in out["kept"]:
+        x, t = rec["calls"][int(i)]
+        assert t == int(s.timesteps[int(i)]), (t, int(s.timesteps[int(i)]))
+        out[f"x{i}"] = x
+    u = r["uncertainty"][:, -1]
+    q = torch.quantile(u.flatten(1).float(), 0.9, dim=1)
+    out["final_mask"] = (u > q.reshape(-1, 1, 1, 1)).to(torch.uint8)
+    save("g21_uvit_h2_headline_schedule", **out)
+
+
 def g18():
     """BASELINE configs[0] as it stands ("ADM ImageNet-64, 10 DDIM steps, M=2, batch 4 on CPU reference path"),
     full-size ADM-64 (dropout 0.1) through the REFERENCE driver and schedulers, UC window = all 10 steps, synthetic starting points
@@ -849,6 +918,6 @@ def g16():
 
 
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20, g21=g21)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

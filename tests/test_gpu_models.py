@@ -940,6 +940,75 @@ def test_uvit_full_size_chain_vs_golden(golden, precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_uvit_headline_schedule_chain_vs_golden(golden, precision):
+    """BASELINE configs[2]'s own schedule for one image - full-size U-ViT-H/2, 50 DDIM steps, M=5, num_zigzag=3, UC window (40, 10) -
+    against the reference latent driver's run of it (G21; 200 forwards, same seeded weights, same noise tape), like the ADM test above:
+    free-running latents at steps 10, 25, 40 and 49 (observed 1e-6 throughout: unlike the ADM's, this random-weight chain is not
+    chaotic), and the window's first and last step teacher-forced from the reference's own x_t (the real timesteps, M=5, three zig-zag passes): eps, score, uncertainty map."""
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_uvit_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import load_autoencoder_uvit, load_uvit, load_uvit_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
+    g = golden("g21_uvit_h2_headline_schedule")
+    uvit = load_uvit(256, device="cpu", load_checkpoint=False)
+    uvit.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in uvit.state_dict().items()}, int(g["uvit_seed"])))
+    ae = load_autoencoder_uvit(device="cpu", load_checkpoint=False)
+    ae.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in ae.state_dict().items()}, int(g["vae_seed"])), strict=True)
+    uvit.precision, ae.precision = precision, precision
+    model = UViTAE(uvit, ae).to(dev)
+    tol_x10, tol_x25, tol_tf, tol_s, tol_u = HEADLINE_CHAIN_TOL[precision]
+    after, num = int(g["window"][0]), int(g["window"][1])
+    a = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=5, start_step_uc=after, num_steps_uc=num, predict_next=True,
+                           eta=0.0, num_zigzag=3, uncertainty_distance=1)
+    ts = [int(t) for t in g["timesteps"]]
+    y = T(g["y"]).to(dev)
+    s = get_uncertainty_scheduler(a, None, model, load_uvit_scheduler())
+    s.set_timesteps(50)
+    s.prompt_embeds = y
+    assert s.timesteps.tolist() == ts and (s.timestep_after_step, s.timestep_end_step) == (int(g["window"][2]), int(g["window"][3]))
+    for i in (40, 49):
+        x = T(g[f"x{i}"]).to(dev)
+        eps = s.predict_model(x, ts[i])
+        e_tf = np.abs(eps.cpu().numpy() - g["score"][:, i - after]).max()
+        torch.manual_seed(9500 + i)
+        o = s.step(eps, ts[i], x)
+        ref_u = g["uncertainty"][:, i - after]
+        e_s = np.abs(o.pred_epsilon.cpu().numpy() - g["score"][:, i - after]).max()
+        e_u = np.abs(o.uncertainty.cpu().numpy() - ref_u).max() / np.abs(ref_u).max()
+        print(f"uvit-h/2 {precision}: headline schedule, step {i} (t = {ts[i]}) teacher-forced: eps {e_tf:.2e}, score {e_s:.2e}, uncertainty rel {e_u:.2e}")
+        assert e_tf < tol_tf and e_s < tol_s and e_u < tol_u, (precision, i, e_tf, e_s, e_u)
+    s = get_uncertainty_scheduler(a, None, model, load_uvit_scheduler())
+    s.set_timesteps(50)
+    inner, k = s.step, [0]
+
+    def seeded_step(*aa, **kw):
+        torch.manual_seed(9500 + k[0])
+        k[0] += 1
+        return inner(*aa, **kw)
+
+    s.step = seeded_step
+    seen = {}
+
+    def record(_mod, args, kwargs):
+        t = int((args[1] if len(args) > 1 else kwargs["timesteps"]).flatten()[0])
+        seen.setdefault(t, (args[0] if args else kwargs["x"]).detach().float().cpu().clone())
+
+    h = uvit.register_forward_pre_hook(record, with_kwargs=True)
+    try:
+        gen(T(g["X_T"]), T(g["y"]), 1, model, s, device=dev)
+    finally:
+        h.remove()
+    drift = {}
+    for i in [int(v) for v in g["kept"]]:
+        ref = g[f"x{i}"]
+        drift[i] = float(np.abs(seen[ts[i]].numpy() - ref).max() / np.abs(ref).max())
+    print(f"uvit-h/2 {precision}: headline schedule, free-running: x_t drift by step {({k_: float(f'{v:.1e}') for k_, v in drift.items()})}")
+    # (this chain is not chaotic: the latents stay within 1e-6 of the reference's through all 50 steps, the window included - all four held)
+    assert max(drift.values()) < 1e-4, (precision, drift)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("kind", ["uncertainty_zigzag_centered", "mc_dropout"])
 def test_baseline_config0_vs_reference_driver(golden, kind, precision):
     """BASELINE configs[0] as it stands: full-size ADM-64, 10 DDIM steps, M=2, batch 4, UC window over all steps, the script's

@@ -474,7 +474,8 @@ def test_g13_g17_chain_fixtures_are_self_consistent(golden):
     is the oracle's for the model's scheduler config, the UC window bounds follow from it, and the stored percentile-0.9 mask is the
     oracle's exact quantile mask of the last uncertainty map (the GPU tests compare against these fields)."""
     from oracle import guidance, schedule
-    for name, steps, kw in (("g13_adm128_chain", 10, {}), ("g17_uvit_h2_chain", 10, dict(steps_offset=1)), ("g20_adm128_headline_schedule", 50, {})):
+    for name, steps, kw in (("g13_adm128_chain", 10, {}), ("g17_uvit_h2_chain", 10, dict(steps_offset=1)), ("g20_adm128_headline_schedule", 50, {}),
+                            ("g21_uvit_h2_headline_schedule", 50, dict(steps_offset=1))):
         g = golden(name)
         ts = [int(t) for t in g["timesteps"]]
         assert ts == [int(t) for t in schedule.leading_timesteps(1000, steps, **kw)], name
@@ -484,4 +485,4 @@ def test_g13_g17_chain_fixtures_are_self_consistent(golden):
         assert g["uncertainty"].shape[1] == num and np.isfinite(u).all() and (u >= 0).all()
         mask, _q = guidance.quantile_mask(u, 0.9)
         np.testing.assert_array_equal(mask, g["final_mask"])
-        assert g["gen_images"].dtype == np.uint8
+        assert "gen_images" not in g or g["gen_images"].dtype == np.uint8
