@@ -474,7 +474,7 @@ def test_g13_g17_chain_fixtures_are_self_consistent(golden):
     is the oracle's for the model's scheduler config, the UC window bounds follow from it, and the stored percentile-0.9 mask is the
     oracle's exact quantile mask of the last uncertainty map (the GPU tests compare against these fields)."""
     from oracle import guidance, schedule
-    for name, steps, kw in (("g13_adm128_chain", 10, {}), ("g17_uvit_h2_chain", 10, dict(steps_offset=1)), ("g20_adm128_headline_schedule", 50, {}),
+    for name, steps, kw in (("g13_adm128_chain", 10, {}), ("g17_uvit_h2_chain", 10, dict(steps_offset=1)), ("g20_adm128_headline_schedule", 50, {}), ("g22_adm128_headline_schedule_damped", 50, {}),
                             ("g21_uvit_h2_headline_schedule", 50, dict(steps_offset=1))):
         g = golden(name)
         ts = [int(t) for t in g["timesteps"]]
