@@ -835,7 +835,7 @@ __global__ __launch_bounds__(QM_TH) void k_quantile_mask_multi(const float* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     QM_STAMP(3);
-    QM_STAMP(4);
+    QM_STAMP(4);                                             // (3 -> 4: nothing left between them - the publish is the arrival add below)
     if (tid == 0) {
         // ONE 64-bit word per sample carries everything the workgroups tell each other: candidates of workgroup 0 / 1 (14 bits
         // each, saturated at RC + 1), keys below A (18 bits, summed), arrivals (bits 60..62).  The add that publishes the own
