@@ -7,3 +7,46 @@ There is no CPU fallback: every compute entry point raises if the HIP library
 or a GPU tensor is missing.
 """
 __version__ = "0.1.0"
+
+import importlib as _importlib
+import importlib.abc as _abc
+import importlib.machinery as _machinery
+import sys as _sys
+
+
+class _AliasFinder(_abc.MetaPathFinder, _abc.Loader):
+    """Resolves ``<alias>[.sub.module]`` to the SAME module object as ``<this package>[.sub.module]`` (one copy of every
+    class, so ``isinstance`` checks hold whichever name a caller imported it under)."""
+
+    def __init__(self, alias, real):
+        self.alias, self.real = alias, real
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname != self.alias and not fullname.startswith(self.alias + "."):
+            return None
+        real = self.real + fullname[len(self.alias):]
+        try:
+            module = _importlib.import_module(real)
+        except ModuleNotFoundError as e:
+            if e.name == real:
+                return None                                   # -> ModuleNotFoundError under the alias name
+            raise
+        spec = _machinery.ModuleSpec(fullname, self, is_package=hasattr(module, "__path__"))
+        spec._dua_module = module
+        return spec
+
+    def create_module(self, spec):
+        return spec._dua_module
+
+    def exec_module(self, module):
+        pass
+
+
+def alias_as_reference(name="diffusion_uncertainty"):
+    """Make ``import diffusion_uncertainty.<module>`` resolve to this package: the reference's
+    scripts keep their import blocks.  Idempotent; returns the package."""
+    this = _sys.modules[__name__]
+    if not any(isinstance(f, _AliasFinder) and f.alias == name for f in _sys.meta_path):
+        _sys.meta_path.insert(0, _AliasFinder(name, __name__))
+    _sys.modules[name] = this
+    return this

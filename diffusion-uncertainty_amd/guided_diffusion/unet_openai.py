@@ -15,7 +15,7 @@ dims=2, use_scale_shift_norm=True, resblock_updown=True.  There is no CPU path.
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, range_guard
 from ..utils import params_generation
 from .nn import normalization
 
@@ -110,12 +110,8 @@ class ResBlock(TimestepBlock):
                                         None if ident else self.skip_connection.bias, self.out_channels, updown=self.resample,
                                         dropmask=mask, precision=("f16w" if ctx.model.wino_single else ctx.model.precision),
                                         want_colsum=ctx.model.fuse_gn_stats, conv1_wino=w1, conv2_wino=w2, conv1_wino_m=m1, conv2_wino_m=m2)
-        if ctx.model.wino_single and not getattr(ctx.model, "_warned_f16w_composed", False):
-            # "f16w" (one fp16 product per tap) exists on the block-level C ABI only: this composed per-op path runs the THREE-product convs
-            ctx.model._warned_f16w_composed = True
-            import warnings
-            warnings.warn("precision 'f16w': a ResBlock runs on the composed per-op path (use_block_abi off, activation noise, or dropout on a "
-                          "resampling block) and uses the three-product f16x3 convolutions there", RuntimeWarning, stacklevel=2)
+        # (mode "f16w": ctx.conv_split hands the GroupNorm writer the hi-images-only operand here too, so this per-op composition runs the
+        # single-product Winograd conv exactly like the block-level call above)
         st = ops.groupnorm_stats(x, skip)
         Hc = H * 2 if self.resample > 0 else (H // 2 if self.resample < 0 else H)
         Wc = W * 2 if self.resample > 0 else (W // 2 if self.resample < 0 else W)
@@ -264,7 +260,11 @@ class _Ctx:
         the f16x3 mode pick the Winograd operand where the kernel takes the shape)."""
         m = self.wino_form(*conv_shape) if conv_shape is not None else 0
         if m:
-            return ("f16x3w4" if m == 4 else "f16x3w") if self.model.precision == "f16x3" else ("f32w4" if m == 4 else "f32w")
+            if self.model.precision == "f16x3":
+                # mode "f16w" (one fp16 product per tap, F(2,3) only): the hi-images-only operand on EVERY call path - the block-level
+                # C ABI (DUA_PREC_F16W) and this per-op composition run the same kernel on the same operand, bit for bit (ADVICE r04)
+                return "f16x3w4" if m == 4 else ("f16w" if self.model.wino_single else "f16x3w")
+            return "f32w4" if m == 4 else "f32w"
         return self.split_acts
 
     def packed(self, mod, kind):
@@ -338,7 +338,7 @@ class _Ctx:
     def conv3x3(self, h, conv, cout, residual=None, nchw_out=False, colsum=False):
         colsum = colsum and self.model.fuse_gn_stats
         if isinstance(h, ops.SplitPlanes) or (self.split_mode and h.shape[3] % 32 == 0):
-            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f16x3w4": "w3w4", "f32w": "w3wf", "f32w4": "w3w4f"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
+            kind = {"f16x3": "w3h", "f16x3w": "w3w", "f16w": "w3w", "f16x3w4": "w3w4", "f32w": "w3wf", "f32w4": "w3w4f"}.get(h.fmt, "w3x") if isinstance(h, ops.SplitPlanes) else "w3x"
             return ops.conv3x3_bf16x3(h, self.packed(conv, kind), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
         return ops.conv3x3(h, self.packed(conv, "w3"), conv.bias, cout, residual=residual, nchw_out=nchw_out, colsum=colsum)
 
@@ -455,6 +455,11 @@ class UNetModel(nn.Module):
         # activation_noise_source.draw(shape, device)
         self.activation_noise = None
         self.activation_noise_source = None
+        # f16x3: the first forward after the weights were loaded / edited runs with the library's range counters on and warns when
+        # an operand left fp16's range after its static plane scale (range_guard.py); False opts out
+        self.auto_range_check = True
+        self._range_checked = False
+        self._range_probe = None
 
     @property
     def precision(self):
@@ -473,6 +478,7 @@ class UNetModel(nn.Module):
     # ---- weight cache hygiene
     def invalidate_packed_weights(self):
         self._packed = {}
+        self._range_checked = False
         if getattr(self, "_graphs", None):
             self._graphs = {}
 
@@ -520,6 +526,9 @@ class UNetModel(nn.Module):
             if getattr(self, "_graphs", None):
                 self._graphs = {}
             self._packed_gen = gen
+            self._range_checked = False
+        if range_guard.due(self):
+            return range_guard.checked_forward(self, lambda: self._forward_impl(x, timesteps, y, out_channels_keep))
         graphs = getattr(self, "_graphs", None)
         n = int(getattr(self, "stream_split", 1))
         if n > 1 and graphs is None and not self.training and not self.activation_noise and x.shape[0] >= 2 * n:
@@ -602,12 +611,19 @@ class UNetModel(nn.Module):
         ctx.emb = emb
         h = ops.nchw_to_nhwc(x.float().contiguous(), 4)
         hs = []
+        probe = self._range_probe
         for i, module in enumerate(self.input_blocks):
             h = module.run(ctx, h, name=f"input_blocks.{i}")
             hs.append(h)
+            if probe is not None:
+                probe.note(f"input_blocks.{i}", module)
         h = self.middle_block.run(ctx, h, name="middle_block")
+        if probe is not None:
+            probe.note("middle_block", self.middle_block)
         for i, module in enumerate(self.output_blocks):
             h = module.run(ctx, h, hs.pop(), name=f"output_blocks.{i}")
+            if probe is not None:
+                probe.note(f"output_blocks.{i}", module)
         gn, conv = self.out[0], self.out[2]
         st = ops.groupnorm_stats(h)
         keep = self.out_channels if out_channels_keep is None else out_channels_keep

@@ -64,35 +64,8 @@ def init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=True, dropout
     return init_guided_diffusion_imagenet64(load_checkpoint=load_checkpoint, dropout=dropout), init_scheduler_imagenet64()
 
 
-# ---- U-ViT (uvit/load_pretrained_models.py)
-def load_uvit(image_size=256, device="cuda", load_checkpoint=True):
-    assert image_size in (256, 512)
-    patch_size = 2 if image_size == 256 else 4
-    nnet = UViT(img_size=image_size // 8, patch_size=patch_size, in_chans=4, embed_dim=1152, depth=28, num_heads=16,
-                num_classes=1001, conv=False)
-    if load_checkpoint:
-        nnet.load_state_dict(torch.load(MODELS / f"imagenet{image_size}_uvit_huge.pth", map_location="cpu"))
-    nnet.to(device)
-    nnet.eval()
-    return nnet
-
-
-def load_uvit_scheduler():
-    """load_pretrained_models.py:44-62: only the DDPM keys survive DDPMScheduler.from_config
-    (set_alpha_to_one / skip_prk_steps are dropped -> set_alpha_to_one defaults to True downstream)."""
-    scheduler_config = {"_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012,
-                        "beta_schedule": "scaled_linear", "beta_start": 0.00085, "num_train_timesteps": 1000,
-                        "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1, "trained_betas": None,
-                        "clip_sample": False}
-    return DDPMScheduler.from_config(scheduler_config)
-
-
-def load_autoencoder_uvit(device="cuda", load_checkpoint=True):
-    """load_pretrained_models.py:66-... : the f8 KL-VAE (uvit/autoencoder.py get_model), decoder on the HIP library."""
-    from .uvit.autoencoder import get_model
-    ae = get_model(str(MODELS / "autoencoder_kl_ema.pth") if load_checkpoint else None)
-    ae.to(device)
-    return ae
+# ---- U-ViT: the loaders live where the reference keeps them (uvit/load_pretrained_models.py:13,44,66); re-exported here
+from .uvit.load_pretrained_models import load_autoencoder_uvit, load_uvit, load_uvit_scheduler  # noqa: E402,F401
 
 
 __all__ = ["UNetModel", "UViT", "UViTAE", "DDPMScheduler"]

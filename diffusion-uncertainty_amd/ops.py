@@ -489,12 +489,22 @@ def set_split_k(on, device=None):
     return prev
 
 
+_RANGE_ON = False
+
+
 def range_check(on):
     """Switch the f16x3 range counters on / off (dua_range_check); returns the previous setting."""
+    global _RANGE_ON
     was = _lib.lib().dua_range_check(1 if on else 0)
     if was < 0:                       # DUA_EHIP: the counters could not be allocated / cleared - not "was on"
         check(was, "dua_range_check")
+    _RANGE_ON = bool(on)
     return bool(was)
+
+
+def range_check_is_on():
+    """Whether the counters are on (as last set through range_check; reading this has no side effect on the counters)."""
+    return _RANGE_ON
 
 
 def range_check_read(reset=True):

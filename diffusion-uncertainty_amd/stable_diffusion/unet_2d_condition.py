@@ -14,7 +14,7 @@ oracle/sd_unet.py (a restatement of the published architecture) only.  There is 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, range_guard
 from ..utils import params_generation
 
 
@@ -405,6 +405,9 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
         self._packed = {}
         self.precision = "fp32"          # "fp32" | "f16x3" | "bf16x3" (see guided_diffusion/unet_openai.py)
+        self.auto_range_check = True     # f16x3: first forward after a weight load runs with the range counters on (range_guard.py)
+        self._range_checked = False
+        self._range_probe = None
         # hipGraph replay of the forward (enable_hip_graph): at the CFG batch of 2 one forward is ~1000 launches of a few
         # microseconds each and the host cannot issue them fast enough; a captured graph removes the launch path.
         self._graphs = None
@@ -445,6 +448,7 @@ class UNet2DConditionModel(nn.Module):
     def invalidate_packed_weights(self):
         """Drop the packed weights (and the captured graphs that hold them); the next forward repacks."""
         self._packed = {}
+        self._range_checked = False
         self._kv_cache = []
         if getattr(self, "_graphs", None) is not None:
             self._graphs = {}
@@ -456,6 +460,7 @@ class UNet2DConditionModel(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = {}
+        self._range_checked = False
         self._kv_cache = []
         if getattr(self, "_graphs", None) is not None:
             self._graphs = {}
@@ -463,6 +468,7 @@ class UNet2DConditionModel(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._packed = {}
+        self._range_checked = False
         self._kv_cache = []
         if getattr(self, "_graphs", None) is not None:
             self._graphs = {}
@@ -497,7 +503,9 @@ class UNet2DConditionModel(nn.Module):
                 self.invalidate_packed_weights()
             self._packed_gen = gen
         kv = self._context_kv(enc)                                     # cross-attention keys / values of this context (cached), or None
-        if self._graphs is None:
+        if range_guard.due(self):                                      # first forward after a weight load: range counters on (range_guard.py)
+            out = range_guard.checked_forward(self, lambda: self._forward_impl(sample, t, enc, kv=kv))
+        elif self._graphs is None:
             out = self._forward_impl(sample, t, enc, kv=kv)
         else:
             key = (tuple(sample.shape), tuple(enc.shape), self.precision, ops.ATTENTION_MODE, bool(self.split_k), kv is not None, bool(self.fold_temb))
@@ -544,7 +552,10 @@ class UNet2DConditionModel(nn.Module):
         h = ops.conv3x3(h, ctx.packed((id(self.conv_in), "w3"), lambda: ops.pack_conv3x3_weight(self.conv_in.weight.detach().contiguous())),
                         self.conv_in.bias, self.conv_in.out_channels, colsum=True)
         res = [h]
-        for blk in self.down_blocks:
+        probe = getattr(self, "_range_probe", None)
+        for i, blk in enumerate(self.down_blocks):
+            if probe is not None and i:
+                probe.note(f"down_blocks.{i - 1}", self.down_blocks[i - 1])
             for j, r in enumerate(blk.resnets):
                 h = r.run(ctx, h, tape=tape)
                 if hasattr(blk, "attentions"):
@@ -554,10 +565,16 @@ class UNet2DConditionModel(nn.Module):
                 conv = blk.downsamplers[0].conv
                 h = ops.pick_even(ctx.conv3x3(ctx.raw_planes(h), conv, conv.out_channels))      # stride 2 / pad 1 = stride 1 at the even pixels
                 res.append(h)
+        if probe is not None:
+            probe.note(f"down_blocks.{len(self.down_blocks) - 1}", self.down_blocks[-1])
         h = self.mid_block.resnets[0].run(ctx, h, tape=tape)
         h = self.mid_block.attentions[0].run(ctx, h, enc, tape=tape)
         h = self.mid_block.resnets[1].run(ctx, h, tape=tape)
-        for blk in self.up_blocks:
+        if probe is not None:
+            probe.note("mid_block", self.mid_block)
+        for i, blk in enumerate(self.up_blocks):
+            if probe is not None and i:
+                probe.note(f"up_blocks.{i - 1}", self.up_blocks[i - 1])
             for j, r in enumerate(blk.resnets):
                 h = r.run(ctx, h, res.pop(), tape=tape)
                 if hasattr(blk, "attentions"):
@@ -565,6 +582,8 @@ class UNet2DConditionModel(nn.Module):
             if hasattr(blk, "upsamplers"):
                 conv = blk.upsamplers[0].conv
                 h = ctx.conv3x3(ctx.raw_planes(h, resample=1), conv, conv.out_channels, colsum=True)
+        if probe is not None:
+            probe.note(f"up_blocks.{len(self.up_blocks) - 1}", self.up_blocks[-1])
         G = self.conv_norm_out.num_groups
         st = ops.groupnorm_stats(h, groups=G, eps=self.conv_norm_out.eps)
         if tape is not None:

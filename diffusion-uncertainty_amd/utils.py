@@ -8,12 +8,37 @@ per-tensor seed derived from its *name*, so the same weights can be rebuilt on
 any box from (names, shapes, seed) alone - that is how the golden vectors of
 ``tests/golden`` and the random-init weights of ``bench.py`` are defined.
 """
+import argparse
 import math
+import os
 import random
 import zlib
 
 import numpy as np
 import torch
+import yaml
+
+DATASET_IMAGE_SIZE = {"imagenet64": 64, "imagenet128": 128, "imagenet256": 256, "lsun-churches": 256, "imagenet512": 512,
+                      "cifar10": 32}                                   # reference utils.py:23-30
+
+
+def load_config(folder_path, config_name):
+    """Flat key -> value YAML file as an ``argparse.Namespace`` (reference utils.py:42-62: a leading ``configs/`` folder is
+    stripped from the name, ``.yaml`` appended when missing; the callers feed the result to ``argparser.set_defaults``)."""
+    config_name = str(config_name)
+    if config_name.startswith("configs/"):
+        config_name = os.path.basename(config_name)
+    if not config_name.endswith(".yaml"):
+        config_name = config_name + ".yaml"
+    with open(os.path.join(str(folder_path), config_name)) as f:
+        config = yaml.safe_load(f)
+    return argparse.Namespace(**config)
+
+
+def get_generation_configs(folder_name):
+    """Names (without extension) of the YAML files of ``CONFIG/<folder_name>`` (reference utils.py:65-68)."""
+    from .paths import CONFIG
+    return [x.basename().replace(".yaml", "") for x in CONFIG.joinpath(folder_name).files("*.yaml")]
 
 
 def seeded_tensor(name, shape, seed=0):

@@ -11,7 +11,7 @@ fp32 attention (the reference upcasts qkv to fp32 and calls SDPA, :71-73).  No C
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, range_guard
 
 
 class Mlp(nn.Module):
@@ -151,15 +151,20 @@ class UViT(nn.Module):
         self.stream_split = 1            # > 1: the batch in that many chunks on HIP streams of their own (see _forward_streams)
         self.stream_split_max_batch = 1 << 30
         self._streams = []
+        self.auto_range_check = True     # f16x3: first forward after a weight load runs with the range counters on (range_guard.py)
+        self._range_checked = False
+        self._range_probe = None
         self.skip_planes = True          # f16x3: block outputs that feed a skip_linear also leave the fc2 epilogue as f16x3 planes (A/B switch)
         self._planes = {}
 
     def _apply(self, fn, *a, **k):
         self._planes = {}
+        self._range_checked = False
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._planes = {}
+        self._range_checked = False
         return super().load_state_dict(*a, **k)
 
     def _lin(self, a, mod, a2=None, residual=None, act_out=0, split_out=False):
@@ -195,9 +200,14 @@ class UViT(nn.Module):
     def forward(self, x, timesteps, y=None):
         if not x.is_cuda:
             raise RuntimeError("UViT.forward: the HIP path needs GPU tensors; this package has no CPU fallback")
+        if range_guard.due(self):
+            return range_guard.checked_forward(self, lambda: self._forward_single(x, timesteps, y))
         n = int(self.stream_split)
         if n > 1 and 2 * n <= x.shape[0] <= self.stream_split_max_batch:
             return self._forward_streams(x, timesteps, y, n)
+        return self._forward_single(x, timesteps, y)
+
+    def _forward_single(self, x, timesteps, y):
         if not (self.split_k and self.precision == "f16x3"):
             return self._forward_body(x, timesteps, y)
         prev = ops.set_split_k(True, x.device)
@@ -264,13 +274,20 @@ class UViT(nn.Module):
         # f16x3: a block whose output is the x or the long skip of a skip_linear also leaves it as f16x3 planes (the epilogue of fc2 writes
         # them beside the fp32 tokens), so that skip_linear(cat([x, skip])) runs on the presplit two-source GEMM
         wp = self.precision == "f16x3" and self.skip_planes and bool(self.out_blocks) and self.out_blocks[0].skip_linear is not None
-        for blk in self.in_blocks:
+        probe = self._range_probe
+        for i, blk in enumerate(self.in_blocks):
             h = blk.run(self._lin, h, B, T, precision=self.precision, block_cache=bc, want_planes=wp)
             skips.append(h)
+            if probe is not None:
+                probe.note(f"in_blocks.{i}", blk)
         h = self.mid_block.run(self._lin, h, B, T, precision=self.precision, block_cache=bc, want_planes=wp)
+        if probe is not None:
+            probe.note("mid_block", self.mid_block)
         for i, blk in enumerate(self.out_blocks):
             h = blk.run(self._lin, h, B, T, skips.pop(), precision=self.precision, block_cache=bc,
                         want_planes=wp and i + 1 < len(self.out_blocks))
+            if probe is not None:
+                probe.note(f"out_blocks.{i}", blk)
         h = ops.layernorm(h, self.norm.weight, self.norm.bias, self.norm.eps)
         h = self._lin(h, self.decoder_pred)                                                # [B*T, P*P*C]
         return ops.unpatchify(h, B, L, self.extras, C, P)                                  # :228-229

@@ -4,10 +4,12 @@ scripts/generate_dataset_score_uncertainty_imagenet.py on the MI355X engine).
 
 Same flags and defaults as the reference's ``parse_args`` (:147-196) and the same flow as ``generate_and_save``
 (:33-93): one process per GPU (``torch.multiprocessing.spawn``), rank r samples
-``X_T[start + r*n : start + (r+1)*n]``, per-rank output files ``uncertainty_{scheduler}_{rank}.pth`` /
-``gen_images_{rank}.pth`` / ``timesteps.pth`` (+ ``args.yaml``).  Deviations: ``score_{rank}.pth`` carries the rank
-suffix (the reference's shared ``score.pth`` is a last-writer-wins race, :91); ``--synthetic`` / ``--random-weights``
-run without the starting-point files / checkpoints; ``--precision`` and ``--noise`` select the engine modes.
+``X_T[start + r*n : start + (r+1)*n]`` read from ``DIFFUSION_STARTING_POINTS/imagenet{size}{suffix}/{X_T,y}.pth``, per-rank
+output files ``timestep_{rank}.pth`` / ``uncertainty_{scheduler}_{rank}.pth`` / ``gen_images_{rank}.pth`` (+ ``args.yaml``), :90-93.
+Deviations: the score maps go to ``score_{rank}.pth`` (the reference's shared ``score.pth`` is a last-writer-wins race,
+:91; rank 0 also writes ``score.pth`` and ``timesteps.pth`` under the shared names); missing starting-point files are an
+ERROR unless ``--synthetic`` asks for generated ones; ``--random-weights`` runs without checkpoints; ``--precision`` and
+``--noise`` select the engine modes.  The import block below names the same modules and symbols as the reference's :14-27.
 """
 import argparse
 import datetime
@@ -25,15 +27,18 @@ from diffusion_uncertainty_amd.generate_samples import (  # noqa: E402
     generate_samples_model_scheduler_class_conditioned_from_tensor,
     generate_samples_model_scheduler_class_conditioned_uvit_from_tensor)
 from diffusion_uncertainty_amd.init_model import (  # noqa: E402
-    init_guided_diffusion_imagenet64_and_scheduler, init_guided_diffusion_imagenet128_and_scheduler, load_autoencoder_uvit,
-    load_uvit, load_uvit_scheduler)
-from diffusion_uncertainty_amd.paths import DIFFUSION_STARTING_POINTS, RESULTS  # noqa: E402
+    init_guided_diffusion_imagenet64_and_scheduler, init_guided_diffusion_imagenet128_and_scheduler)
+from diffusion_uncertainty_amd.paths import CONFIG, DIFFUSION_STARTING_POINTS, RESULTS  # noqa: E402
 from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler  # noqa: E402
 from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise  # noqa: E402
-from diffusion_uncertainty_amd.utils import randomize_parameters_, seed_everything, starting_points  # noqa: E402
+from diffusion_uncertainty_amd.utils import load_config, randomize_parameters_, seed_everything, starting_points  # noqa: E402
+from diffusion_uncertainty_amd.uvit.load_pretrained_models import load_autoencoder_uvit, load_uvit, load_uvit_scheduler  # noqa: E402
 from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE  # noqa: E402
 
-CONFIG = ROOT / "config"
+
+def index_range(gpu_idx, args, num_samples):
+    """The rank's slice of the starting points (reference :51): rank r owns ``[start + r*n, start + (r+1)*n)``."""
+    return slice(args.start_index + gpu_idx * num_samples, args.start_index + (gpu_idx + 1) * num_samples)
 
 
 @torch.no_grad()
@@ -42,13 +47,19 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
     device = torch.device("cuda", gpu_idx)
     torch.cuda.set_device(device)
     suffix = "_uvit" if (args.image_size == 128 and args.model_type == "uvit") else ""
-    lo, hi = args.start_index + gpu_idx * num_samples, args.start_index + (gpu_idx + 1) * num_samples
+    rng = index_range(gpu_idx, args, num_samples)
+    lo, hi = rng.start, rng.stop
     folder = DIFFUSION_STARTING_POINTS / f"imagenet{args.image_size}{suffix}"
-    if args.synthetic or not (folder / "X_T.pth").exists():
+    if args.synthetic:
         shape = (4, args.image_size // 8, args.image_size // 8) if args.model_type == "uvit" else (3, args.image_size, args.image_size)
         X_T, y = starting_points(hi, shape)
         X_T, y = X_T[lo:hi], y[lo:hi]
     else:
+        for name in ("y.pth", "X_T.pth"):
+            if not (folder / name).exists():
+                raise FileNotFoundError(f"{folder / name}: starting points not found (the reference's "
+                                        f"scripts/generate_diffusion_starting_data.py writes them); pass --synthetic to "
+                                        f"generate them the same way instead")
         y = torch.load(folder / "y.pth", map_location="cpu")[lo:hi]
         X_T = torch.load(folder / "X_T.pth", map_location="cpu")[lo:hi]
     ckpt = not args.random_weights
@@ -110,15 +121,14 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
     if args.measure_time:
         print(f"[rank {gpu_idx}] {X_T.shape[0]} images in {elapsed:.2f} s -> {X_T.shape[0] / elapsed:.3f} images/s "
               f"({uc_scheduler.denoiser_calls} UC forwards + {args.generation_steps} main forwards per batch)")
-    torch.save(uc_scheduler.timesteps, dest / "timesteps.pth")
+    dest = Path(dest)
+    torch.save(uc_scheduler.timesteps, dest / f"timestep_{gpu_idx}.pth")
     torch.save(results["score"], dest / f"score_{gpu_idx}.pth")
+    if gpu_idx == 0:
+        torch.save(uc_scheduler.timesteps, dest / "timesteps.pth")
+        torch.save(results["score"], dest / "score.pth")
     torch.save(results["uncertainty"], dest / f"uncertainty_{args.scheduler_type}_{gpu_idx}.pth")
     torch.save(results["gen_images"], dest / f"gen_images_{gpu_idx}.pth")
-
-
-def load_config(folder, name):
-    with open(folder / f"{name}.yaml") as f:
-        return argparse.Namespace(**yaml.safe_load(f))
 
 
 def parse_args(argv=None):
@@ -135,7 +145,9 @@ def parse_args(argv=None):
     p.add_argument("--class-condition")
     p.add_argument("--image-size", type=int, choices=[64, 128, 256, 512], dest="image_size", default=None)
     p.add_argument("--scheduler-type", "--scheduler", type=str, default=None, dest="scheduler_type",
-                   choices=["mc_dropout", "uncertainty_centered", "uncertainty_zigzag_centered"])
+                   choices=["mc_dropout", "flip", "uncertainty", "flip_grad", "uncertainty_single", "uncertainty_single_score",
+                            "uncertainty_centered", "uncertainty_centered_d", "uncertainty_image", "uncertainty_original",
+                            "uncertainty_zigzag_centered", "uncertainty_fisher", "dpm_2_uncertainty_centered"])     # reference :161
     p.add_argument("--start-index", type=int, default=None, dest="start_index")
     p.add_argument("--multi-gpu", action="store_true", default=False)
     p.add_argument("--model-type", type=str, default=None, choices=["unet", "uvit"], dest="model_type")
@@ -165,7 +177,7 @@ def parse_args(argv=None):
     p.add_argument("--synthetic", action="store_true", help="generate X_T / y like scripts/generate_diffusion_starting_data.py")
     p.add_argument("--random-weights", action="store_true", help="seeded random weights instead of checkpoints")
     p.add_argument("--dest", type=str, default=None)
-    options = sorted(x.stem for x in (CONFIG / "generation").glob("*.yaml"))
+    options = [x.basename().replace(".yaml", "") for x in CONFIG.joinpath("generation").files("*.yaml")]
     p.add_argument("--config", type=str, default=None, choices=options, help="name of a config/generation/*.yaml file")
     args = p.parse_args(argv)
     if args.config is not None:

@@ -305,6 +305,68 @@ def g7():
     save("g7_guidance", **out)
 
 
+class FakeCFGUNetNL(torch.nn.Module):
+    """conv3x3(4 -> 32) -> SiLU -> conv3x3(32 -> 4) with the diffusers call signature: a denoiser whose Monte-Carlo variance DOES depend
+    on pred_epsilon (through a linear model - FakeCFGUNet - every sample shifts alike and d var / d eps is zero up to rounding)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w1, self.w2 = randn(171, 32, 4, 3, 3) * 0.35, randn(172, 4, 32, 3, 3) * 0.12
+
+    def forward(self, sample, timestep, encoder_hidden_states, **kw):
+        h = torch.nn.functional.silu(torch.nn.functional.conv2d(sample, self.w1, padding=1))
+        h = torch.nn.functional.conv2d(h, self.w2, padding=1)
+        return (h + encoder_hidden_states.mean(dim=(1, 2))[:, None, None, None],)
+
+
+def g7b():
+    """Gradient-mode guidance (use_posterior = False, uncertainty_guidance.py:79-108,121-129; the default of
+    scripts/generate_with_uncertainty_threshold_stable_diffusion.py:17,88): the reference function itself, plain autograd through the
+    same FakeCFGUNet, latents, seeds and percentiles as g7, lr 1.0 and 0.5.  Stored: final_epsilon, pred_epsilon.grad, and the variance map /
+    quantile the function computed (captured at its torch.quantile call, :112) with the mask they give."""
+    out = {}
+    eps, lat = randn(76, 1, 4, 64, 64), randn(77, 1, 4, 64, 64)
+    inp = torch.cat([lat, lat])
+    ctx = randn(78, 2, 5, 8)
+    lin, nl = FakeCFGUNet(), FakeCFGUNetNL()
+    out["sd_eps"], out["sd_input"], out["sd_ctx"], out["sd_w"], out["nl_w1"], out["nl_w2"] = eps, inp, ctx, lin.w, nl.w1, nl.w2
+    seen = {}
+    real_quantile = torch.quantile
+
+    def spy(u, *a, **k):
+        q = real_quantile(u, *a, **k)
+        seen["u"], seen["q"] = u.detach().clone(), q.detach().clone()
+        return q
+
+    ref_ug.use_posterior = False
+    try:
+        torch.quantile = spy
+        for tag, model, percentiles in (("sd", lin, (0.85, 0.9, 0.95, 0.99)), ("nl", nl, (0.9, 0.95))):
+            for lr in (1.0, 0.5):
+                for i, p in enumerate(percentiles):
+                    torch.manual_seed(700 + i)
+                    pe = eps.clone()
+                    with _quiet:
+                        fe = ref_ug.get_uncertainty_guided_score_with_percentile(
+                            pe, inp, torch.tensor([500]), ctx, model, torch.tensor(0.3), p, "stable-diffusion",
+                            num_uncertainty_samples=5, guidance_scale=7.5, lr=lr)
+                    u = seen["u"].reshape(eps.shape)
+                    out[f"{tag}_final_{p}_lr{lr}"] = fe.detach()
+                    if lr != 1.0:                                       # grad / u / q do not depend on lr: stored once per percentile
+                        assert torch.equal(out[f"{tag}_grad_{p}"], pe.grad) and torch.equal(out[f"{tag}_u_{p}"], u)
+                        continue
+                    out[f"{tag}_grad_{p}"] = pe.grad.detach().clone()
+                    out[f"{tag}_u_{p}"] = u
+                    out[f"{tag}_q_{p}"] = seen["q"].reshape(-1)
+                    out[f"{tag}_mask_{p}"] = (u > seen["q"].view(-1, 1, 1, 1)).to(torch.uint8)
+    finally:
+        torch.quantile = real_quantile
+        ref_ug.use_posterior = True
+    out["sd_alpha"], out["lrs"], out["ps"], out["nl_ps"] = np.float32(0.3), np.array([1.0, 0.5]), np.array([0.85, 0.9, 0.95, 0.99]), np.array([0.9, 0.95])
+    out["guidance_scale"], out["M"], out["seed_base"] = np.float32(7.5), np.int64(5), np.int64(700)
+    save("g7b_guidance_gradient", **out)
+
+
 def g8():
     out = {}
     cfg = dict(TINY_ADM, dropout=0.1)
@@ -935,6 +997,6 @@ def g16():
 
 
 if __name__ == "__main__":
-    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20, g21=g21, g22=g22)
+    groups = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g7b=g7b, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14, g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20, g21=g21, g22=g22)
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()

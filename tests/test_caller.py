@@ -1,0 +1,223 @@
+"""The caller of the hot path: scripts/generate_dataset_score_uncertainty_imagenet.py against the reference script
+(/root/reference/scripts/generate_dataset_score_uncertainty_imagenet.py: import block :14-27, generate_and_save :33-93,
+main :137-144) - the import surface on the CPU, ``generate_and_save`` itself under ``-m gpu``."""
+import argparse
+import ast
+import importlib
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "scripts", "generate_dataset_score_uncertainty_imagenet.py")
+REF_SCRIPT = "/root/reference/scripts/generate_dataset_score_uncertainty_imagenet.py"
+
+# the reference script's lines 14-27, as (module, symbol) pairs
+REFERENCE_IMPORTS = [
+    ("diffusion_uncertainty.utils", "load_config"),
+    ("diffusion_uncertainty.uvit.autoencoder", "FrozenAutoencoderKL"),
+    ("diffusion_uncertainty.uvit.load_pretrained_models", "load_autoencoder_uvit"),
+    ("diffusion_uncertainty.uvit.load_pretrained_models", "load_uvit"),
+    ("diffusion_uncertainty.uvit.load_pretrained_models", "load_uvit_scheduler"),
+    ("diffusion_uncertainty.uvit.uvit", "UViT"),
+    ("diffusion_uncertainty.uvit.uvit_ae", "UViTAE"),
+    ("diffusion_uncertainty.schedulers_uncertainty.get_uncertainty_scheduler", "get_uncertainty_scheduler"),
+    ("diffusion_uncertainty.generate_samples", "generate_samples_model_scheduler_class_conditioned"),
+    ("diffusion_uncertainty.generate_samples", "generate_samples_model_scheduler_class_conditioned_from_tensor"),
+    ("diffusion_uncertainty.generate_samples", "generate_samples_model_scheduler_class_conditioned_uvit"),
+    ("diffusion_uncertainty.generate_samples", "generate_samples_model_scheduler_class_conditioned_uvit_from_tensor"),
+    ("diffusion_uncertainty.init_model", "init_guided_diffusion_imagenet64_and_scheduler"),
+    ("diffusion_uncertainty.init_model", "init_guided_diffusion_imagenet128_and_scheduler"),
+    ("diffusion_uncertainty.paths", "CONFIG"),
+    ("diffusion_uncertainty.paths", "DIFFUSION_STARTING_POINTS"),
+    ("diffusion_uncertainty.paths", "RESULTS"),
+]
+
+
+@pytest.fixture
+def aliased():
+    """the package under the reference's name."""
+    import diffusion_uncertainty_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "diffusion_uncertainty" or k.startswith("diffusion_uncertainty.")}
+    meta = list(sys.meta_path)
+    yield diffusion_uncertainty_amd.alias_as_reference()
+    sys.meta_path[:] = meta
+    for k in [k for k in sys.modules if k == "diffusion_uncertainty" or k.startswith("diffusion_uncertainty.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def _cli():
+    spec = importlib.util.spec_from_file_location("gen_cli", SCRIPT)
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    return cli
+
+
+def test_reference_import_block_resolves(aliased):
+    for module, symbol in REFERENCE_IMPORTS:
+        m = importlib.import_module(module)
+        assert hasattr(m, symbol), f"from {module} import {symbol}"
+        # one copy of every module: the alias and the package name give the same object (isinstance checks hold across them)
+        assert m is importlib.import_module(module.replace("diffusion_uncertainty", "diffusion_uncertainty_amd", 1))
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("diffusion_uncertainty.no_such_module")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not present (GPU box)")
+def test_import_table_is_the_reference_scripts(aliased):
+    """The table above is what the reference script imports from its own package: parsed from its text, nothing executed."""
+    tree = ast.parse(open(REF_SCRIPT).read())
+    pairs = [(n.module, a.name) for n in ast.walk(tree) if isinstance(n, ast.ImportFrom) and n.module
+             and n.module.startswith("diffusion_uncertainty") for a in n.names]
+    assert sorted(pairs) == sorted(REFERENCE_IMPORTS)
+
+
+def test_paths_follow_the_reference_layout():
+    from diffusion_uncertainty_amd import paths
+    assert paths.RESULTS == paths.ROOT / "results"                                        # paths.py:12
+    assert paths.DIFFUSION_STARTING_POINTS == paths.RESULTS / "diffusion_starting_points"  # paths.py:36
+    assert paths.MODELS == paths.ROOT / "models"                                           # paths.py:172
+    assert paths.SCORE_UNCERTAINTY == paths.RESULTS / "score-uncertainty" and paths.THRESHOLD == paths.RESULTS / "thresholds"
+    files = paths.CONFIG.joinpath("generation").files("*.yaml")                            # the calls of script :174-175
+    names = [x.basename().replace(".yaml", "") for x in files]
+    assert "imagenet128_readme_example" in names
+    assert not paths.RESULTS.joinpath("no-such-folder").files("*.yaml")
+
+
+def test_load_config_semantics(tmp_path):
+    from diffusion_uncertainty_amd.paths import CONFIG
+    from diffusion_uncertainty_amd.utils import get_generation_configs, load_config
+    a = load_config(CONFIG / "generation", "imagenet128_readme_example")
+    b = load_config(CONFIG / "generation", "configs/imagenet128_readme_example.yaml")      # utils.py:53-56
+    assert isinstance(a, argparse.Namespace) and a == b and (a.M, a.image_size, a.model_type) == (5, 128, "unet")
+    assert "imagenet128_readme_example" in get_generation_configs("generation")
+    with pytest.raises(FileNotFoundError):
+        load_config(tmp_path, "missing")
+
+
+def test_uvit_loaders_signatures_and_errors():
+    from diffusion_uncertainty_amd import init_model
+    from diffusion_uncertainty_amd.configuration import DDPMScheduler
+    from diffusion_uncertainty_amd.uvit import load_pretrained_models as lpm
+    assert init_model.load_uvit is lpm.load_uvit and init_model.load_autoencoder_uvit is lpm.load_autoencoder_uvit
+    s = lpm.load_uvit_scheduler()
+    assert isinstance(s, DDPMScheduler)
+    assert (s.config.beta_start, s.config.beta_end, s.config.beta_schedule, s.config.steps_offset, s.config.clip_sample) == \
+        (0.00085, 0.012, "scaled_linear", 1, False)                                        # load_pretrained_models.py:45-57
+    with pytest.raises(TypeError):
+        lpm.load_uvit(128, "cpu")
+    with pytest.raises(FileNotFoundError, match="imagenet256_uvit_huge.pth"):              # no download: a named missing file
+        lpm.load_uvit(256, "cpu")
+    with pytest.raises(FileNotFoundError, match="autoencoder_kl_ema.pth"):
+        lpm.load_autoencoder_uvit("cpu")
+
+
+def test_rank_slices_and_spawn_arguments(monkeypatch, tmp_path):
+    """main() with two visible GPUs: two processes, n = num_samples // 2 each, rank r on [start + r n, start + (r+1) n)
+    (reference :51,137-144)."""
+    cli = _cli()
+    seen = {}
+
+    def fake_spawn(fn, args, nprocs, join):
+        seen.update(fn=fn, args=args, nprocs=nprocs, join=join)
+
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.multiprocessing, "spawn", fake_spawn)
+    monkeypatch.setattr(sys, "argv", ["x", "--image-size", "128", "--scheduler-type", "uncertainty_zigzag_centered", "--model-type", "unet",
+                                      "--start-index", "10", "--num-samples", "301", "--dest", str(tmp_path / "out")])
+    cli.main()
+    assert seen["fn"] is cli.generate_and_save and seen["nprocs"] == 2 and seen["join"] is True
+    args, n, dest = seen["args"]
+    assert n == 150 and str(dest) == str(tmp_path / "out") and (tmp_path / "out" / "args.yaml").exists()
+    r0, r1 = cli.index_range(0, args, n), cli.index_range(1, args, n)
+    assert (r0.start, r0.stop, r1.start, r1.stop) == (10, 160, 160, 310)                   # the remainder image is dropped by //
+    assert args.dataset == "imagenet128"                                                   # :128
+
+
+def test_missing_starting_points_is_an_error(monkeypatch, tmp_path):
+    """No silent synthetic fallback: without --synthetic the starting-point files must exist (checked before any GPU work)."""
+    cli = _cli()
+    args = cli.parse_args(["--image-size", "64", "--scheduler-type", "mc_dropout", "--model-type", "unet", "--start-index", "0"])
+    assert not args.synthetic
+    monkeypatch.setattr(cli, "DIFFUSION_STARTING_POINTS", cli.Path(tmp_path))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    with pytest.raises(FileNotFoundError, match="y.pth"):
+        cli.generate_and_save(0, args, 4, tmp_path)
+
+
+def test_scheduler_choices_are_the_references():
+    cli = _cli()
+    for name in ("mc_dropout", "flip", "uncertainty", "uncertainty_centered", "uncertainty_centered_d", "uncertainty_image",
+                 "uncertainty_original", "uncertainty_zigzag_centered", "dpm_2_uncertainty_centered", "flip_grad"):
+        a = cli.parse_args(["--image-size", "64", "--scheduler-type", name, "--model-type", "unet", "--start-index", "0"])
+        assert a.scheduler_type == name
+    with pytest.raises(SystemExit):
+        cli.parse_args(["--image-size", "64", "--scheduler-type", "nope", "--model-type", "unet", "--start-index", "0"])
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _direct(cli, args, n):
+    """The same job through the driver API, built the way generate_and_save builds it."""
+    from diffusion_uncertainty_amd.generate_samples import (generate_samples_model_scheduler_class_conditioned_from_tensor,
+                                                            generate_samples_model_scheduler_class_conditioned_uvit_from_tensor)
+    from diffusion_uncertainty_amd.init_model import init_guided_diffusion_imagenet64_and_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.utils import randomize_parameters_, seed_everything, starting_points
+    from diffusion_uncertainty_amd.uvit.load_pretrained_models import load_autoencoder_uvit, load_uvit, load_uvit_scheduler
+    from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
+    device = torch.device("cuda", 0)
+    seed_everything(args.seed)
+    if args.model_type == "unet":
+        X_T, y = starting_points(n, (3, 64, 64))
+        unet, scheduler = init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=False, dropout=args.dropout)
+        randomize_parameters_(unet, seed=64)
+        unet.eval().to(device)
+        unet.precision, unet.split_k, unet.winograd = "f16x3", True, True
+        model = unet
+    else:
+        X_T, y = starting_points(n, (4, 32, 32))
+        uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
+        ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
+        uvit.precision, uvit.split_k, ae.precision = "f16x3", True, "f16x3"
+        model = UViTAE(uvit, ae).to(device)
+        scheduler = load_uvit_scheduler()
+    s = get_uncertainty_scheduler(args, y.to(device), model, scheduler)
+    s.set_timesteps(args.generation_steps)
+    if args.model_type == "unet":
+        out = generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, args.batch_size, device, model, s)
+    else:
+        out = generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(X_T, y, args.batch_size, model, s, device)
+    return s, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_type,image_size,scheduler_type", [("unet", 64, "uncertainty_zigzag_centered"), ("unet", 64, "mc_dropout"),
+                                                                  ("uvit", 256, "uncertainty_zigzag_centered")])
+def test_generate_and_save_writes_the_reference_files(tmp_path, model_type, image_size, scheduler_type):
+    cli = _cli()
+    n, steps, window = 4, 4, 2
+    args = cli.parse_args(["--image-size", str(image_size), "--scheduler-type", scheduler_type, "--model-type", model_type,
+                           "--start-index", "0", "--num-samples", str(n), "--batch-size", "3", "--generation-steps", str(steps), "-M", "2",
+                           "--start-step-uc", "1", "--num-steps-uc", str(window), "--random-weights", "--synthetic"])
+    cli.generate_and_save(0, args, n, tmp_path)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["timestep_0.pth", "timesteps.pth", "score_0.pth", "score.pth", f"uncertainty_{scheduler_type}_0.pth",
+                            "gen_images_0.pth"])
+    t = torch.load(tmp_path / "timestep_0.pth")
+    score = torch.load(tmp_path / "score_0.pth")
+    unc = torch.load(tmp_path / f"uncertainty_{scheduler_type}_0.pth")
+    img = torch.load(tmp_path / "gen_images_0.pth")
+    lat = (4, 32, 32) if model_type == "uvit" else (3, 64, 64)
+    assert t.shape == (steps,) and t.dtype == torch.int64
+    assert score.shape == (n, window) + lat and score.dtype == torch.float32 and score.device.type == "cpu"
+    assert unc.shape == (n, window) + lat and unc.dtype == torch.float32
+    assert img.shape == (n, 3, image_size, image_size) and img.dtype == torch.uint8
+    assert torch.isfinite(score).all() and torch.isfinite(unc).all() and (unc >= 0).all() and unc.max() > 0
+    assert torch.equal(torch.load(tmp_path / "score.pth"), score) and torch.equal(torch.load(tmp_path / "timesteps.pth"), t)
+    s, out = _direct(cli, args, n)
+    assert torch.equal(s.timesteps.cpu(), t)
+    assert torch.equal(out["gen_images"], img) and torch.equal(out["score"], score) and torch.equal(out["uncertainty"], unc)

@@ -4,7 +4,9 @@
 Checkers: torch autograd in fp32 on the CPU for the single kernels (a floating-point kernel vs the plain PyTorch op it
 differentiates), oracle/sd_unet.input_vjp and oracle/guidance.guided_score_percentile_gradient (torch autograd through the
 CPU restatement, exactly what the reference does with the diffusers UNet) for the network and the guidance step.
-PARITY UNPINNED for the network itself (un-vendored diffusers), as in tests/test_gpu_sd.py."""
+PARITY UNPINNED for the network itself (un-vendored diffusers), as in tests/test_gpu_sd.py; the guidance step itself - everything
+uncertainty_guidance.py computes around the denoiser calls - is pinned to the reference's own run by G7b
+(test_gradient_mode_guidance_vs_reference_g7b)."""
 import numpy as np
 import pytest
 import torch
@@ -176,6 +178,85 @@ def test_gradient_mode_guidance_vs_oracle():
     print(f"gradient-mode guidance: max|hip - oracle| = {d.max().item():.3e}, update size {upd:.3e}, mask px {int(ref_mask.sum())}")
     # a pixel whose variance sits at the quantile may flip side of the hard threshold: allow a handful, hold the rest to the bar
     assert upd > 1e-3 and (d > 1e-3 * max(1.0, upd)).float().mean().item() < 5e-3 and d.median().item() < 1e-5 * max(1.0, upd)
+
+
+class _FakeCFGUNetHIP:
+    """The fake CFG denoisers of tests/golden/make_golden.py (g7 / g7b) on the HIP library, with the forward_with_tape / backward_sample
+    protocol gradient-mode guidance asks of a denoiser: conv3x3 [-> SiLU -> conv3x3] + the context's mean, convolutions forward and
+    backward (flipped, transposed weights) on dua_conv3x3.  Test-side model: only the activation and the scalar shift are torch ops."""
+
+    def __init__(self, ws, ctx_ndim=3):
+        from diffusion_uncertainty_amd import ops
+        self.ops = ops
+        self.w = [w.to(dev) for w in ws]
+        self.fwd = [ops.pack_conv3x3_weight(w.contiguous()) for w in self.w]
+        self.bwd = [ops.pack_conv3x3_weight(w.transpose(0, 1).flip(2, 3).contiguous()) for w in self.w]
+
+    def _conv(self, x, wp, cout):
+        return self.ops.conv3x3(x, wp, None, cout)
+
+    def forward_with_tape(self, sample, timestep, encoder_hidden_states):
+        h = self.ops.nchw_to_nhwc(sample.float().contiguous(), 4)
+        pre = []
+        for i, w in enumerate(self.w):
+            h = self._conv(h, self.fwd[i], w.shape[0])
+            if i + 1 < len(self.w):
+                pre.append(h)
+                h = F.silu(h)
+        out = self.ops.nhwc_to_nchw(h) + encoder_hidden_states.mean(dim=(1, 2))[:, None, None, None]
+        return out.contiguous(), pre
+
+    def backward_sample(self, tape, grad_out):
+        g = self.ops.nchw_to_nhwc(grad_out.float().contiguous(), 4)
+        for i in reversed(range(len(self.w))):
+            if i + 1 < len(self.w):
+                z = tape[i]
+                sg = torch.sigmoid(z)
+                g = (g * (sg * (1 + z * (1 - sg)))).contiguous()
+            g = self._conv(g, self.bwd[i], self.w[i].shape[1])
+        return self.ops.nhwc_to_nchw(g).contiguous()
+
+
+@pytest.mark.parametrize("tag", ["sd", "nl"])
+def test_gradient_mode_guidance_vs_reference_g7b(golden, tag):
+    """use_posterior = False against the REFERENCE's own run of uncertainty_guidance.py:79-108,121-129 (G7b, plain autograd on the CPU):
+    the product function - re-noising, CFG combine, variance over the M samples, its gradient (csrc/backward.hip dua_mc_var_grad), the batch
+    sum, the quantile mask and the masked update, all on the HIP library - with the fixture's fake CFG denoisers, same noise tape.
+    Bars: pred_epsilon.grad-sized update within 1e-3 (relative to the gradient's scale) outside a handful of pixels that sit on the
+    quantile; the mask kernel bit-exact on the fixture's own variance map."""
+    from conftest import T
+    from diffusion_uncertainty_amd import ops
+    from diffusion_uncertainty_amd import uncertainty_guidance as ug
+    from diffusion_uncertainty_amd.schedulers_uncertainty.noise import HostNoise
+    g = golden("g7b_guidance_gradient")
+    model = _FakeCFGUNetHIP([T(g["sd_w"])] if tag == "sd" else [T(g["nl_w1"]), T(g["nl_w2"])])
+    eps, inp, ctx = T(g["sd_eps"]), T(g["sd_input"]), T(g["sd_ctx"])
+    old = ug.use_posterior, ug.noise_source
+    try:
+        ug.use_posterior, ug.noise_source = False, HostNoise()
+        for lr in g["lrs"]:
+            for i, p in enumerate(g["ps"] if tag == "sd" else g["nl_ps"]):
+                ref, ref_grad, ref_u, ref_mask = (T(g[f"{tag}_final_{p}_lr{lr}"]), T(g[f"{tag}_grad_{p}"]), T(g[f"{tag}_u_{p}"]),
+                                                  T(g[f"{tag}_mask_{p}"]))
+                torch.manual_seed(int(g["seed_base"]) + i)
+                out = ug.get_uncertainty_guided_score_with_percentile(
+                    eps.to(dev), inp.to(dev), torch.tensor([500]), ctx.to(dev), model, torch.tensor(float(g["sd_alpha"])), float(p),
+                    "stable-diffusion", num_uncertainty_samples=int(g["M"]), guidance_scale=float(g["guidance_scale"]), lr=float(lr)).cpu()
+                scale = max(1.0, ref_grad.abs().max().item())
+                d = (out - ref).abs()
+                flips = (d > 1e-3 * scale).float().mean().item()
+                print(f"g7b {tag} p={p} lr={lr}: max|hip - reference| = {d.max().item():.3e} (gradient scale {scale:.3g}), "
+                      f"{int((d > 1e-3 * scale).sum())} px over the bar, median {d.median().item():.2e}")
+                assert flips < 5e-4 and d.median().item() < 1e-5 * scale
+                # the mask on the fixture's own variance map: bit-exact (a14), and the quantile itself
+                mask, q = ops.quantile_mask(ref_u.to(dev), float(p))
+                np.testing.assert_array_equal(mask.cpu().numpy().astype(np.uint8), ref_mask.numpy())
+                np.testing.assert_array_equal(q.cpu().numpy().reshape(-1), g[f"{tag}_q_{p}"])
+                # outside the reference's mask the score is untouched, bit for bit (final = eps + lr * grad * 0)
+                same = (out == eps)[ref_mask == 0].float().mean().item()
+                assert same > 0.999
+    finally:
+        ug.use_posterior, ug.noise_source = old
 
 
 def test_gradient_mode_pipeline_vs_oracle():

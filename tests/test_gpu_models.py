@@ -1241,11 +1241,13 @@ def test_flip_estimator_vs_golden(golden):
     assert bool((r["uncertainty"] >= 0).all())
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16w"])
 def test_block_level_abi_bit_identical(precision):
     """dua_adm_resblock_fwd / dua_adm_attnblock_fwd (one C-ABI call per block) against the per-op composition in
     Python: same kernels in the same order, so the UNet output must be bit-identical - eval and train (dropout masks) mode,
-    batch sizes that leave partial tiles, the up / down / channel-changing / attention blocks of the tiny ADM."""
+    batch sizes that leave partial tiles, the up / down / channel-changing / attention blocks of the tiny ADM.  "f16w": the
+    single-product Winograd conv on BOTH paths (the mode's arithmetic does not depend on the call path) - and it is
+    not the three-product conv under another name: the f16w output differs from f16x3's."""
     from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise
     m, _ = build_adm(dict(TINY_ADM, dropout=0.1), 5)
     m.precision = precision
@@ -1260,6 +1262,11 @@ def test_block_level_abi_bit_identical(precision):
             outs[(train, blk)] = m(x, t, y=y)
         assert torch.equal(outs[(train, True)], outs[(train, False)]), (precision, train)
     assert not torch.equal(outs[(True, True)], outs[(False, True)])           # dropout was live
+    if precision == "f16w":
+        m.train(False)
+        m.use_block_abi = False
+        m.precision = "f16x3"
+        assert not torch.equal(m(x, t, y=y), outs[(False, False)])
     # argument validation happens on the host, before any launch
     from diffusion_uncertainty_amd import _lib
     import ctypes

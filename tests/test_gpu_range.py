@@ -147,3 +147,100 @@ def test_model_with_checkpoint_like_statistics(ops):
     assert sat > 0 and torch.isfinite(out).all()
     # (a saturated hi half keeps ~11 bits up to twice the range, then clips - observed here: 0.36 of the output scale.  There is no bound to
     # assert once operands clip: the non-zero count IS the signal, and the remedy is precision "fp32")
+
+
+# ---- the default-on check of a model's first forward (range_guard.py)
+def test_first_forward_is_range_checked_once(ops):
+    """f16x3: the first forward after a weight load runs with the counters on and leaves model.range_report; clean weights: no warning,
+    no second check; the checked forward returns the bits of an unchecked one; a reload re-arms the check; fp32 never checks."""
+    import warnings
+
+    from diffusion_uncertainty_amd.range_guard import F16RangeWarning
+    from diffusion_uncertainty_amd.utils import randomize_parameters_
+    from diffusion_uncertainty_amd.uvit.uvit import UViT
+    from test_gpu_models import TINY_ADM, TINY_UVIT, build_adm
+    x = rnd(7, 3, 3, 16, 16).to(dev)
+    t, y = torch.tensor([900, 400, 20]).to(dev), torch.tensor([1, 5, 9]).to(dev)
+    m, sd = build_adm(dict(TINY_ADM), 5)
+    m.precision = "f16x3"
+    assert not m._range_checked and not ops.range_check_is_on()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", F16RangeWarning)
+        a = m(x, t, y=y)
+    assert m._range_checked and m.range_report["saturated"] == 0 and not ops.range_check_is_on()
+    m.range_report = None
+    b = m(x, t, y=y)                                                   # not checked again
+    assert m.range_report is None and torch.equal(a, b)
+    m.load_state_dict(sd)
+    assert not m._range_checked
+    m.auto_range_check = False
+    c = m(x, t, y=y)
+    assert not m._range_checked and torch.equal(a, c)
+    m.precision = "fp32"
+    m.auto_range_check = True
+    m(x, t, y=y)
+    assert not m._range_checked                                        # the exact-fp32 engines have no plane scales to leave
+    # U-ViT: same contract, LayerNorm planes
+    u = randomize_parameters_(UViT(**TINY_UVIT), 3).eval().to(dev)
+    u.precision = "f16x3"
+    xl = rnd(8, 3, 4, 8, 8).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", F16RangeWarning)
+        u(xl, t, y)
+    assert u._range_checked and u.range_report["saturated"] == 0
+    with torch.no_grad():
+        u.in_blocks[1].norm2.weight.mul_(40000.0)                      # LayerNorm output * 64 beyond 65504
+    u.load_state_dict(u.state_dict())
+    with pytest.warns(F16RangeWarning, match=r"in_blocks\.1 \[Block\]"):
+        u(xl, t, y)
+    assert u.range_report["saturated"] > 0
+
+
+def test_first_forward_warns_on_a_saturating_groupnorm(ops):
+    """One GroupNorm gamma scaled x2000 (activations ~ +-6000 against the 1023 the plane scale 64 leaves room for): the default path
+    - no flag, no call of range_check - warns once, names the block and its layer classes, and still returns finite values."""
+    from diffusion_uncertainty_amd.range_guard import F16RangeWarning
+    from test_gpu_models import TINY_ADM, build_adm
+    m, _ = build_adm(dict(TINY_ADM), 5)
+    m.precision = "f16x3"
+    with torch.no_grad():
+        m.input_blocks[1][0].in_layers[0].weight.mul_(2000.0)
+    x = rnd(7, 3, 3, 16, 16).to(dev)
+    t, y = torch.tensor([900, 400, 20]).to(dev), torch.tensor([1, 5, 9]).to(dev)
+    with pytest.warns(F16RangeWarning, match=r"input_blocks\.1 \[ResBlock\]") as rec:
+        out = m(x, t, y=y)
+    assert len([w for w in rec if issubclass(w.category, F16RangeWarning)]) == 1 and torch.isfinite(out).all()
+    rep = m.range_report
+    assert rep["saturated"] > 0 and rep["blocks"][0][0] == "input_blocks.1" and not ops.range_check_is_on()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", F16RangeWarning)
+        m(x, t, y=y)                                                   # once per weight load
+
+
+def test_default_cli_warns_on_saturating_weights(tmp_path, monkeypatch):
+    """The caller script with its default flags (no --check-range): a model whose first GroupNorm gamma is x2000 triggers the warning."""
+    import importlib.util
+    import os
+
+    from diffusion_uncertainty_amd.range_guard import F16RangeWarning
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_cli", os.path.join(root, "scripts", "generate_dataset_score_uncertainty_imagenet.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    seeded = cli.randomize_parameters_
+
+    def checkpoint_with_a_hot_layer(module, seed=0):
+        seeded(module, seed)
+        with torch.no_grad():
+            module.input_blocks[1][0].in_layers[0].weight.mul_(2000.0)
+        return module
+
+    monkeypatch.setattr(cli, "randomize_parameters_", checkpoint_with_a_hot_layer)
+    args = cli.parse_args(["--image-size", "64", "--scheduler-type", "uncertainty_zigzag_centered", "--model-type", "unet", "--start-index", "0",
+                           "--num-samples", "2", "--batch-size", "2", "--generation-steps", "2", "-M", "1", "--start-step-uc", "1",
+                           "--num-steps-uc", "1", "--random-weights", "--synthetic"])
+    assert not args.check_range
+    with pytest.warns(F16RangeWarning, match="input_blocks.1"):
+        cli.generate_and_save(0, args, 2, tmp_path)
+    assert (tmp_path / "gen_images_0.pth").exists()

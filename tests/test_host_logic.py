@@ -231,11 +231,30 @@ def test_precision_modes_pick_operand_formats():
     m = UNetModel(image_size=16, in_channels=3, model_channels=32, out_channels=6, num_res_blocks=1, attention_resolutions=(2,),
                   channel_mult=(1, 2), num_classes=10, num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)
     want = {"fp32": (False, False, False), "f16x3": ("f16x3", "f16x3", "f16x3"), "bf16x3": (True, True, True),
-            "f16w": ("f16x3", "f16x3", "f16x3")}
+            "f16w": ("f16x3", "f16x3", "f16x3")}                 # (no conv shape given: the direct form's operand)
     for mode, (w16, w24, gemm) in want.items():
         m.precision = mode
         ctx = _Ctx(m)
         assert (ctx.conv_split(16), ctx.conv_split(24), ctx.gemm_split) == (w16, w24, gemm), mode
+    # with a conv shape the Winograd operand of the mode: f16w is the ONE-product format on every call path (block ABI or not), never the
+    # three-product one under the f16w name; the form rule is host logic, the shape test is the library's
+    from diffusion_uncertainty_amd import ops
+    orig = ops.conv3x3_wino_supported, ops.conv3x3_wino4_supported, ops.conv3x3_wino_pick
+    try:
+        ops.conv3x3_wino_supported = ops.conv3x3_wino4_supported = lambda *a: True
+        ops.conv3x3_wino_pick = lambda *a: 4
+        shape = (2, 16, 16, 64, 64)
+        got = {}
+        for mode in ("fp32", "f16x3", "f16w", "bf16x3"):
+            m.precision = mode
+            for abi in (True, False):
+                m.use_block_abi = abi
+                got[(mode, abi)] = _Ctx(m).conv_split(16, shape)
+        assert got == {("fp32", True): "f32w4", ("fp32", False): "f32w4", ("f16x3", True): "f16x3w4", ("f16x3", False): "f16x3w4",
+                       ("f16w", True): "f16w", ("f16w", False): "f16w", ("bf16x3", True): True, ("bf16x3", False): True}
+    finally:
+        ops.conv3x3_wino_supported, ops.conv3x3_wino4_supported, ops.conv3x3_wino_pick = orig
+        m.use_block_abi = True
     m.precision = "int8"
     with pytest.raises(AssertionError):
         _Ctx(m)

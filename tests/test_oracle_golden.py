@@ -205,6 +205,32 @@ def test_g7_posterior_guidance(golden):
         np.testing.assert_allclose(fe, g[f"sd_final_{p}"], rtol=2e-4, atol=1e-5)
 
 
+def test_g7b_gradient_guidance(golden):
+    """oracle/guidance.py's gradient branch (use_posterior = False) against the reference function's own run (G7b): the linear fake UNet of
+    g7 (d var / d eps is zero up to rounding there: the update must vanish against the scores) and the non-linear one (gradients up to ~20)."""
+    g = golden("g7b_guidance_gradient")
+    ctx, eps, inp = T(g["sd_ctx"]), T(g["sd_eps"]), T(g["sd_input"])
+    w, w1, w2 = T(g["sd_w"]), T(g["nl_w1"]), T(g["nl_w2"])
+    F = torch.nn.functional
+    shift = ctx.mean(dim=(1, 2))[:, None, None, None]
+    models = {"sd": lambda x, t, y: F.conv2d(x, w, padding=1) + shift,
+              "nl": lambda x, t, y: F.conv2d(F.silu(F.conv2d(x, w1, padding=1)), w2, padding=1) + shift}
+    for tag, ps in (("sd", g["ps"]), ("nl", g["nl_ps"])):
+        for lr in g["lrs"]:
+            for i, p in enumerate(ps):
+                torch.manual_seed(int(g["seed_base"]) + i)
+                fe, grad, u, mask = guidance.guided_score_percentile_gradient(
+                    eps, inp, models[tag], torch.tensor([500]), ctx, float(g["guidance_scale"]), float(g["sd_alpha"]), float(p), int(g["M"]),
+                    torch.randn_like, lr=float(lr))
+                ref_grad, ref_u = g[f"{tag}_grad_{p}"], g[f"{tag}_u_{p}"]
+                scale = max(1.0, float(np.abs(ref_grad).max()))
+                np.testing.assert_array_equal(mask.numpy().astype(np.uint8), g[f"{tag}_mask_{p}"])                  # bit-exact
+                np.testing.assert_allclose(u.numpy(), ref_u, rtol=0, atol=1e-6 * max(1.0, float(ref_u.max())))
+                np.testing.assert_allclose(grad.numpy(), ref_grad, rtol=0, atol=1e-6 * scale)
+                np.testing.assert_allclose(fe.numpy(), g[f"{tag}_final_{p}_lr{lr}"], rtol=0, atol=1e-6 * scale)
+    assert float(np.abs(g["sd_grad_0.9"]).max()) < 1e-4 < 1.0 < float(np.abs(g["nl_grad_0.9"]).max())
+
+
 def test_g8_mc_dropout(golden):
     g = golden("g8_mc_dropout")
     assert float(g["dropout_equiv_maxdiff"]) < 1e-6      # same Bernoulli mask; 1-ulp scale rounding only
