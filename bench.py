@@ -58,10 +58,12 @@ MODES = {
               "f16x3 (fp32 operands scaled by a power of two and split into fp16 hi + fp16 lo = 22 significant bits; three fp16 MFMA "
               "products, fp32 accumulate: fp32-equivalent, 2^-22 per product; 3x3 convs, qkv, proj_out, 1x1 skip convs and attention "
               "(head dims <= 256) in this format, embedding GEMMs exact fp32 MFMA; norms / softmax / sampler fp32)"),
-    "fp32": ("k_wconv432 / k_wconv32 (csrc/conv_wino4_f32.hip, conv_wino_f32.hip): exact-fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd "
+    "fp32": ("k_wconv432 / k_wconv32 (csrc/conv_wino4_f32.hip, conv_wino_f32.hip): fp32 LDS-DMA implicit-GEMM conv3x3 in the Winograd "
              "F(4,3)-along-y form on v_mfma_f32_16x16x4_f32 (4.5 instead of 9 taps per pixel, products and sums in fp32; tile 128 positions x 64 "
              "channels x 6 frequencies on eight waves) wherever its kernel takes the shape, F(2,3) (6 taps) elsewhere; in / out convs on the "
-             "direct fp32 MFMA kernel k_tile<MODE_CONV>", 1.0, "f32"),
+             "direct fp32 MFMA kernel k_tile<MODE_CONV>.  fp32 products, NOT the reference's summation order: F(4,3) amplifies fp32 rounding "
+             "(a layer up to ~4x the direct engine's error vs fp64; the full UNet up to 5e-5 from the direct form, 7.9e-6 from the reference's "
+             "output); --winograd off runs the direct kernels", 1.0, "f32"),
     "f16w": ("k_wconv1 (csrc/conv_wino_f16x3.hip): the Winograd F(2,3)-along-y LDS-DMA conv3x3 with ONE fp16 MFMA per tap on the hi images "
              "of the transformed operands (fp16 x fp16 products, fp32 accumulate; half the DMA pieces and a third of the MFMAs of k_wconv)", 1.0,
              "f16w (3x3 convs of the ResBlocks: fp16 operands, one product per tap, fp32 accumulation - the arithmetic class of the "
@@ -161,6 +163,62 @@ class ConvProfile:
                           f"Winograd form), so frac <= 1/{eff:.2f} against the {peak:g} TFLOP/s peak by construction"
                           + (" (fewer executed than algorithmic products: frac reports executed_frac, the pipe's share)" if eff < 1 else ""))
         return r
+
+
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 TB/s achievable)
+
+
+def kernel_profile(run, sync):
+    """Run `run()` with the library's per-entry-point launch timing on (dua_kernel_profile: HIP events on the launch stream around the sampler
+    kernels, the operand writers, the GEMMs, the attention and the Winograd conv launches, tagged with the launch's ALGORITHMIC bytes / FLOPs)
+    and return (per-kind sums, wall seconds).  Untimed side job: the events are never inside a timed region."""
+    import ctypes
+    from diffusion_uncertainty_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(1 << 16)
+    L.dua_kernel_profile_collect(buf, len(buf))          # drop whatever an earlier, aborted pass left
+    sync()
+    L.dua_kernel_profile(1)
+    t0 = time.perf_counter()
+    try:
+        run()
+        sync()
+    finally:
+        L.dua_kernel_profile(0)
+    wall = time.perf_counter() - t0
+    n = L.dua_kernel_profile_collect(buf, len(buf))
+    return (json.loads(buf.value.decode()) if n > 0 else {}), wall
+
+
+def kernel_tables(kp, wall_s, mfma_peak=BF16_MFMA_PEAK_TFLOPS):
+    """-> (hbm_kernels, mfma_kernels): one row per kind, HBM-bound kinds (no FLOPs attached) with bytes per launch and GB/s against the
+    8 TB/s peak, matrix-core kinds with algorithmic FLOPs per launch and TFLOP/s against the dense fp16 MFMA peak."""
+    hbm, mfma = [], []
+    for kind, v in sorted(kp.items(), key=lambda kv: -kv[1]["ms"]):
+        n, ms = v["launches"], v["ms"]
+        if not n or ms <= 0:
+            continue
+        row = dict(kernel=kind, launches=n, us_per_launch=round(ms / n * 1e3, 2), share_of_job=round(ms * 1e-3 / wall_s, 4))
+        if v["flops"] > 0:
+            tf = v["flops"] / (ms * 1e-3) / 1e12
+            row.update(bound="mfma", flops_per_launch=v["flops"] / n, achieved=round(tf, 1), peak=mfma_peak, unit="TFLOP/s", frac=round(tf / mfma_peak, 4),
+                       bytes_per_launch=v["bytes"] / n, gbytes_per_s=round(v["bytes"] / (ms * 1e-3) / 1e9, 1))
+            mfma.append(row)
+        else:
+            gbs = v["bytes"] / (ms * 1e-3) / 1e9
+            row.update(bound="hbm", bytes_per_launch=v["bytes"] / n, achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4))
+            hbm.append(row)
+    return hbm, mfma
+
+
+def leg_roofline(mfma_rows, what):
+    """`roofline` block of a side leg: its dominant matrix-core kernel (largest share of the profiled job) - algorithmic FLOPs per launch /
+    mean launch duration (HIP events on the launch stream) / dense fp16 MFMA peak."""
+    if not mfma_rows:
+        return None
+    r = max(mfma_rows, key=lambda x: x["share_of_job"])
+    return dict(bound="mfma", achieved=r["achieved"], peak=r["peak"], unit="TFLOP/s", frac=r["frac"], traffic=None, kernel=r["kernel"], launches=r["launches"],
+                flops_per_launch=r["flops_per_launch"], ms_per_launch=round(r["us_per_launch"] / 1e3, 4), share_of_job=r["share_of_job"], measured_on=what)
 
 
 def build_model(device, seed=128):
@@ -271,7 +329,23 @@ def cpu_baseline(sd, M, nz, gen_steps, n_uc):
     s_per_img_fwd = min(reps)
     s_median = sorted(reps)[len(reps) // 2]
     ref_forwards = gen_steps + n_uc * M * nz             # the reference executes every zig-zag forward (W10, M=5: 200 / image)
-    return dict(value=1.0 / (ref_forwards * s_per_img_fwd), value_at_median=round(1.0 / (ref_forwards * s_median), 5), unit="images/sec", cores=threads, kind="port",
+    # BASELINE.md 4.5's own sample beside the best-of-sweep one: batch 8, three DDIM timesteps = two plain steps + one UC step (M=1, nz=1:
+    # 4 forwards x 8 images), three repeats, at the sweep's best thread count
+    reps8 = []
+    if not os.environ.get("DUA_BENCH_NO_CPU_BS8"):
+        for r in range(3):
+            nfwd[0] = 0
+            torch.manual_seed(100 + r)
+            t0 = time.perf_counter()
+            driver.generate(X8, y8, 8, model, schedule.Tables(), 3, "zigzag_centered", M=1, after_step=2, num_steps_uc=1, num_zigzag=1)
+            reps8.append((time.perf_counter() - t0) / (nfwd[0] * 8))
+    bs8 = None
+    if reps8:
+        med8 = sorted(reps8)[len(reps8) // 2]
+        bs8 = dict(value=round(1.0 / (ref_forwards * med8), 5), unit="images/sec", threads=threads,
+                   sample=f"bs=8, 3 DDIM timesteps (2 plain + 1 UC step with M=1, nz=1) = {nfwd[0]} forwards x 8 images, 3 repeats: "
+                          f"{', '.join(f'{v:.3f}' for v in reps8)} s/forward/image, median {med8:.3f}; extrapolated to {ref_forwards} forwards/image (BASELINE.md 4.5)")
+    return dict(sample_bs8=bs8, value=1.0 / (ref_forwards * s_per_img_fwd), value_at_median=round(1.0 / (ref_forwards * s_median), 5), unit="images/sec", cores=threads, kind="port",
                 cpu_model=cpu_model, physical_cores=phys, logical_cpus_available=avail, cgroup_cpu_quota=quota,
                 torch_cpu_backend=f"torch {torch.__version__} aten conv2d -> oneDNN (mkldnn available {torch.backends.mkldnn.is_available()}, "
                                   f"enabled {torch.backends.mkldnn.enabled}), OpenMP intra-op pool; fp32",
@@ -321,10 +395,22 @@ def other_config_uvit(dev, a):
     job(5, 4, 1, 1)
     dt, uc = job(50, 40, 10, 0)
     uvit_streams, uvit_splitk = int(uvit.stream_split), bool(uvit.split_k)
+    # the leg's roofline: one more job on ONE stream (concurrent chunks would stretch each other's event brackets) with the library's launch
+    # timing on - the dominant kernel of this configuration is the one-tap GEMM k_hgemm (linears = 96.7 % of U-ViT-H/2's FLOPs)
+    roof = hbm = mfma = None
+    if not a.no_profile:
+        try:
+            uvit.stream_split = 1
+            kp, wall = kernel_profile(lambda: job(50, 40, 10, 0), torch.cuda.synchronize)
+            hbm, mfma = kernel_tables(kp, wall)
+            roof = leg_roofline(mfma, "one untimed job of this leg on a single stream (stream_split = 1), dua_kernel_profile on")
+        except Exception as e:
+            roof = dict(error=f"{type(e).__name__}: {e}"[:300])
     del model, uvit, ae
     torch.cuda.empty_cache()
     return dict(config="BASELINE configs[2]: U-ViT-H/2 ImageNet-256, 50 steps, M=5, uncertainty_zigzag_centered (W10), batch 64, + KL-VAE decode",
                 value=round(64 / dt, 3), unit="images/sec", seconds_per_job=round(dt, 2), executed_forwards_per_image=50 + uc,
+                end_to_end_tflops=round((50 + uc) * 2.664e11 * 64 / dt / 1e12, 1), roofline=roof, hbm_kernels=hbm, mfma_kernels=mfma,
                 mc_group=int(getattr(a, "uvit_mc_group", 5)), stream_split=uvit_streams, split_k=uvit_splitk,
                 dtype="f16x3 (the fp32-equivalent split: LayerNorm / GELU / attention outputs as fp16 hi + lo planes, 22 significant bits); "
                       "KL-VAE decoder in the same format (its single-head attention, head dim 512, exact fp32)", data="synthetic, random-init weights")
@@ -377,16 +463,121 @@ def other_config_sd(dev, a):
             res["grad_" + bwd] = times
     finally:
         uncertainty_guidance.use_posterior = True
+    # the leg's roofline: one more image, eager (no graph replay: events cannot be recorded into a captured graph), with the conv3x3 launches
+    # bracketed by HIP events (ops.PROFILE) and the library's launch timing on for the rest.  At the CFG batch of 2 an eager forward is
+    # launch-bound, so the brackets include the host's launch gaps: a LOWER bound of the kernels' own rate
+    roof = mfma = hbm = None
+    if not a.no_profile:
+        from diffusion_uncertainty_amd import ops
+        try:
+            unet.enable_hip_graph(False)
+            cp = ConvProfile()
+            ops.PROFILE = cp
+            kp, wall = kernel_profile(lambda: pipe(generator=torch.Generator().manual_seed(491), **kw), torch.cuda.synchronize)
+            ops.PROFILE = None
+            hbm, mfma = kernel_tables(kp, wall)
+            cs = cp.summary(3.0)
+            if cs:
+                mfma = (mfma or []) + [dict(kernel="conv3x3 (k_hconv / k_xconv_dma, direct f16x3 form)", launches=cs["launches"], us_per_launch=round(cs["ms_per_launch"] * 1e3, 2),
+                                            share_of_job=round(cs["launches"] * cs["ms_per_launch"] * 1e-3 / wall, 4), bound="mfma", flops_per_launch=cs["flops_per_launch"],
+                                            achieved=round(cs["tflops"], 1), peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(cs["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4))]
+            roof = leg_roofline(mfma, "one untimed EAGER image of this leg (launch-bound at the CFG batch of 2: the event brackets include launch gaps)")
+        except Exception as e:
+            roof = dict(error=f"{type(e).__name__}: {e}"[:300])
+        finally:
+            ops.PROFILE = None
+    mc_batched = bool(uncertainty_guidance.batch_mc_samples)
     del unet, pipe
     torch.cuda.empty_cache()
     return dict(config="BASELINE configs[4]: SD-1.5 latent UNet 512x512, percentile-0.9 uncertainty guidance (posterior mode), 20 steps, M=5, 2 guided steps",
-                value=round(min(res["f16x3"][1:]), 3), unit="seconds/image", higher_is_better=False,
+                value=round(min(res["f16x3"][1:]), 3), unit="seconds/image", higher_is_better=False, roofline=roof, mfma_kernels=mfma, hbm_kernels=hbm,
+                note=("the M = 5 Monte-Carlo CFG denoiser calls of a guided step are issued as ONE forward of batch 10 (uncertainty_guidance.batch_mc_samples = True: "
+                      "rows [uncond x5 | text x5], same noise draws in the same order)" if mc_batched else
+                      "the M = 5 Monte-Carlo CFG denoiser calls of a guided step run one by one at batch 2 (uncertainty_guidance.batch_mc_samples = False)")
+                     + "; 22 + 10 denoiser forwards per image: 20 PLMS steps of batch 2 (+ 1 PLMS warm-up) and 2 guided steps x 5 samples",
                 dtype="f16x3 (fp32-equivalent split, as the headline); parity of the UNet itself unpinned (un-vendored diffusers), the guidance function is pinned (G7)",
                 data="synthetic prompt embeddings, random-init weights", first_run_incl_packing_s=round(res["f16x3"][0], 2),
                 gradient_update_seconds_per_image=round(min(res["grad_fp32"][1:]), 3),
                 gradient_update_bf16x3_backward_seconds_per_image=round(min(res["grad_bf16x3"][1:]), 3),
                 gradient_update_note="use_posterior=False (the reference script's default): taped forward of batch 2M in f16x3 + input-gradient "
                                      "pass (exact fp32 MFMA, or convs / linears on the split-bf16 engine) per guided step")
+
+
+def config0_leg(dev, a, cpu_full):
+    """BASELINE configs[0] (SURVEY 8(d) "Config 1"): ADM ImageNet-64, 10 DDIM steps, M=2, batch 4, both estimators the reference script offers
+    for it - uncertainty_zigzag_centered (num_zigzag=3, UC window = all 10 steps: 70 forwards per image) and mc_dropout (p=0.1: 30 forwards) -
+    the driver call timed on the GPU (best of two after one untimed call; the forward replayed from a HIP graph, split-K on: the CLI's
+    defaults for small batches; noise and dropout masks drawn in HBM like the headline job's noise) and, when cpu_full, the oracle's driver timed IN FULL on the host cores ("Config 1 is timed
+    in full"; the span of scripts/measure_times_imagenet.py:88-98).  Synthetic X_T / y (dataset index 0), seeded random weights."""
+    import torch
+    from diffusion_uncertainty_amd.generate_samples import generate_samples_model_scheduler_class_conditioned_from_tensor as gen
+    from diffusion_uncertainty_amd.init_model import ADM64_PARAMS, init_guided_diffusion_imagenet64_and_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise
+    from diffusion_uncertainty_amd.utils import seeded_state_dict, starting_points
+    model, base = init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=False, dropout=0.1)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 64)
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    model.precision, model.split_k = a.precision, True
+    X_T, y = starting_points(4, (3, 64, 64))
+    legs = []
+    for kind, fwd in (("uncertainty_zigzag_centered", 10 + 10 * 2 * 3), ("mc_dropout", 10 + 10 * 2)):
+        args = argparse.Namespace(scheduler_type=kind, M=2, start_step_uc=0, num_steps_uc=10, predict_next=True, eta=0.0, num_zigzag=3,
+                                  uncertainty_distance=1)
+        if kind == "mc_dropout":
+            model.enable_hip_graph(False)                      # train-mode forwards draw a fresh dropout tape per call: eager
+            model.dropout_mask_source = DeviceNoise(seed=1064).dropout_mask      # masks drawn in HBM (the CLI's --noise device), like the job's noise
+        else:
+            model.enable_hip_graph()
+        times = []
+        for rep in range(3):
+            s_ = get_uncertainty_scheduler(args, None, model, base)
+            s_.noise_source = DeviceNoise(seed=64 + rep)
+            s_.set_timesteps(10)
+            torch.manual_seed(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = gen(X_T, y, 4, dev, model, s_)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        assert r["uncertainty"].shape == (4, 10, 3, 64, 64)
+        dt = min(times[1:])
+        executed = 10 + s_.denoiser_calls
+        legs.append(dict(estimator=kind, value=round(4 / dt, 3), unit="images/sec", seconds_per_job=round(dt, 4), executed_forwards_per_image=executed,
+                         reference_forwards_per_image=fwd, value_at_reference_forward_count=round(4 / dt * executed / fwd, 3),
+                         first_call_incl_packing_s=round(times[0], 2)))
+    model.enable_hip_graph(False)
+    del model
+    torch.cuda.empty_cache()
+    cpu = None
+    if cpu_full:
+        from oracle import adm, driver, schedule
+        cfg = dict(adm.ADM64)
+        _, _, avail = cpu_info()
+        quota = cgroup_cpu_quota()
+        threads = max(1, min(avail, int(quota) if quota else avail))
+        torch.set_num_threads(threads)
+        tab = schedule.Tables(trained_betas=schedule.cosine_trained_betas())
+        cpu = []
+        with torch.no_grad():
+            adm.forward(sd, cfg, X_T[:1], torch.tensor([500]), y[:1])          # untimed: first touch of the weights, thread pool start
+        for kind, okind, fwd in (("uncertainty_zigzag_centered", "zigzag_centered", 70), ("mc_dropout", "mc_dropout", 30)):
+            torch.manual_seed(0)
+            t0 = time.perf_counter()
+            o = driver.generate(X_T, y, 4, lambda x, t, yy, train=False: adm.forward(sd, cfg, x, t, yy, train=train), tab, 10, okind, M=2,
+                                after_step=0, num_steps_uc=10, num_zigzag=3)
+            dt = time.perf_counter() - t0
+            assert o["uncertainty"].shape == (4, 10, 3, 64, 64)
+            cpu.append(dict(estimator=kind, value=round(4 / dt, 5), unit="images/sec", seconds_per_job=round(dt, 1), forwards_per_image=fwd, cores=threads,
+                            kind="port", sample="timed in full: the oracle's driver over all 10 steps of the 4-image batch"))
+        for g_, c_ in zip(legs, cpu):
+            g_["gpu_over_cpu_same_forward_count"] = round(g_["value_at_reference_forward_count"] / c_["value"], 1)
+    return dict(config="BASELINE configs[0]: ADM ImageNet-64, 10 DDIM steps, M=2, batch 4 (UC window = all 10 steps)", gpu=legs, cpu_baseline=cpu,
+                value=legs[0]["value"], unit="images/sec", dtype=a.precision, data="synthetic, random-init weights",
+                note="GPU: hip-graph replay of the eval forward + split-K (the small-batch defaults of the CLI); mc_dropout eager (fresh dropout tape per call). "
+                     + ("CPU: the oracle timed in full on the host cores (BASELINE.md section 2 measured 0.0263 / 0.0570 images/s for the reference itself on 8 cores)"
+                        if cpu_full else "CPU leg not run (--cpu-config0 off: fewer than 16 host CPUs, or --no-cpu-baseline)"))
 
 
 def dispatch_check(model, X, y, dev, samples=(0, 77, 127)):
@@ -440,6 +631,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the one-job runs of BASELINE configs[2] (U-ViT) and configs[4] (SD) at N=1")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-config0", choices=["auto", "on", "off"], default="auto",
+                    help="BASELINE configs[0] leg: time the CPU oracle IN FULL (ADM-64, 10 steps, M=2, batch 4, both estimators; ~1-3 min of host time). "
+                         "auto: on when the box gives at least 16 CPUs")
     ap.add_argument("--no-check", action="store_true", help="skip the post-timing check of the timed dispatch (batch forward vs batch-1 forwards)")
     ap.add_argument("--legs-file", default=os.environ.get("DUA_BENCH_LEGS", ""), help="where the long legs (other modes / configs, full roofline and "
                     "CPU-baseline records) are written as JSON; default gpurun_out/bench_legs.json when that directory exists, else bench_legs.json")
@@ -617,60 +811,28 @@ def main(argv=None):
         except Exception as e:                               # (reported, never fatal for the line)
             checked = dict(ok=False, error=f"{type(e).__name__}: {e}"[:300])
     fwd_per_img = a.generation_steps + uc_calls / jobs
-    others = []
-    if world == 1 and not a.no_secondary:
-        for other in [m for m in a.secondary.split(",") if m and m != a.precision]:
-            dt2, uc2, prof2 = timed(other, 1, 1)
-            others.append(dict(precision=other, value=round(a.batch / dt2, 4), unit="images/sec", steps=steps_per_job,
-                               ms_per_step=round(dt2 / steps_per_job * 1e3, 1), dtype=MODES[other][2],
-                               end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
-                               roofline=(prof2.roofline(other) if prof2 is not None else None)))
+    # One more job of the same configuration, untimed, with the library's per-entry-point launch timing on: the GB/s of the HBM-bound
+    # kernels (V writers, GroupNorm, sampler, quantile mask) against 8 TB/s and the TFLOP/s of every matrix-core kernel
+    hbm_kernels = mfma_kernels = None
+    if world == 1 and not a.no_profile:
+        try:
+            model.precision = a.precision
+            kp, wall = kernel_profile(lambda: job(a.generation_steps, a.start_step_uc, a.num_steps_uc, 4242), sync)
+            hbm_kernels, mfma_kernels = kernel_tables(kp, wall, FP32_MFMA_PEAK_TFLOPS if a.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS)
+        except Exception as e:
+            hbm_kernels = [dict(error=f"{type(e).__name__}: {e}"[:300])]
+    images = a.batch * world * jobs
+    ref_fwd = a.generation_steps + a.num_steps_uc * a.M * a.num_zigzag
+    cb = None
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        cb = cpu_baseline(sd, a.M, a.num_zigzag, a.generation_steps, a.num_steps_uc)
+        at_ref = images / dt * fwd_per_img / ref_fwd
+        cb["gpu_over_cpu_same_forward_count"] = round(at_ref / cb["value"], 1)
+        cb["gpu_over_cpu_same_forward_count_at_cpu_median"] = round(at_ref / cb["value_at_median"], 1)
+        cb["ratio_note"] = "gpu_over_cpu_same_forward_count divides by the CPU's BEST repeat (conservative); ..._at_cpu_median by its median repeat"
 
-    other_configs = []
-    if world == 1 and not a.no_other_configs and not a.no_secondary:
-        # the same model in the headline precision, one whole job each (weights are packed, code is paged in): the reference's second
-        # wall-clock number `time_normal` (scripts/measure_times_imagenet.py:109-118: the same driver with the plain DDIM scheduler), the
-        # UC window over all 50 steps (W50, BASELINE.md section 3), every zig-zag forward executed, and BASELINE configs[3] on one GPU
-        model.precision = a.precision
-        ops.PROFILE = None
-
-        def adm_leg(name, start, num, M, faithful, ref_fwd, note):
-            sync()
-            t0 = time.perf_counter()
-            uc = job(a.generation_steps, start, num, 77, M=M, faithful=faithful, plain=(num == 0))
-            sync()
-            dt_ = time.perf_counter() - t0
-            fwd = a.generation_steps + uc
-            return dict(config=name, value=round(a.batch / dt_, 4), unit="images/sec", seconds_per_job=round(dt_, 2),
-                        executed_forwards_per_image=fwd, reference_forwards_per_image=ref_fwd,
-                        end_to_end_tflops=round(fwd * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt_ / 1e12, 1), dtype=a.precision, note=note)
-
-        gs, nzz = a.generation_steps, a.num_zigzag
-        for spec in (("time_normal: ADM ImageNet-128, 50 plain DDIM steps (no uncertainty window), batch 128", gs - 1, 0, a.M, False, gs,
-                      "measure_times_imagenet.py:109-118; time_uc of the same script = the headline job: seconds_per_job "
-                      f"{dt / jobs:.2f} (skip_dead_zigzag) - the uncertainty window costs time_uc - time_normal"),
-                     ("W50: BASELINE configs[1] with the UC window over all 50 steps (--start-step-uc 0 --num-steps-uc 50)", 0, gs, a.M, False,
-                      gs + gs * a.M * nzz, "skip_dead_zigzag"),
-                     ("BASELINE configs[1], W10, every zig-zag forward executed (--faithful-zigzag: the reference's forward count)",
-                      a.start_step_uc, a.num_steps_uc, a.M, True, gs + a.num_steps_uc * a.M * nzz, "faithful"),
-                     ("BASELINE configs[3] on one GPU: ADM ImageNet-128, 50 steps, M=10, W10, 128 images (the 8-GPU job is 8 such ranks)",
-                      a.start_step_uc, a.num_steps_uc, 10, False, gs + a.num_steps_uc * 10 * nzz, "skip_dead_zigzag")):
-            try:
-                other_configs.append(adm_leg(*spec))
-            except Exception as e:
-                other_configs.append(dict(config=spec[0], error=f"{type(e).__name__}: {e}"[:300]))
-        del model                                   # the ADM-128 weights and packed planes (3 GB) are not needed any more
-        torch.cuda.empty_cache()
-        for leg in (other_config_uvit, other_config_sd):
-            try:
-                other_configs.append(leg(dev, a))
-            except Exception as e:                   # a side leg must never take the headline line down
-                other_configs.append(dict(config=leg.__name__, error=f"{type(e).__name__}: {e}"[:300]))
-
-    if rank == 0:
-        images = a.batch * world * jobs
+    def headline_record():
         exec_flops = fwd_per_img * ADM128_FLOPS_PER_FWD_IMG * images
-        ref_fwd = a.generation_steps + a.num_steps_uc * a.M * a.num_zigzag
         line = {
             "metric": "images/sec @ ADM ImageNet-128, 50 steps, M=5, bs=128; 1/2/4/8 GPU",
             "value": round(images / dt, 4), "unit": "images/sec", "n_gpus": world, "steps": steps_run, "warmup": a.warmup,
@@ -693,16 +855,103 @@ def main(argv=None):
             "value_at_reference_forward_count": round(images / dt * fwd_per_img / ref_fwd, 4),
             "roofline": prof.roofline(a.precision) if prof is not None else None,
         }
+        if hbm_kernels is not None:
+            line["hbm_kernels"] = hbm_kernels
+            line["mfma_kernels"] = mfma_kernels
+            line["kernel_profile_note"] = ("one extra, untimed job of the headline configuration with dua_kernel_profile on: HIP events on the launch stream around "
+                                           "every instrumented entry point; bytes / FLOPs are ALGORITHMIC per launch (SURVEY 8(d)); share_of_job = summed launch time / "
+                                           "wall time of that job")
+        if cb is not None:
+            line["cpu_baseline"] = cb
+        if checked is not None:
+            line["checked"] = checked
+        return line
+
+    if rank == 0 and world == 1 and not a.no_secondary:
+        # the contract record BEFORE the side legs (several minutes): should the run be cut short during a leg, the last JSON line on stdout
+        # is still the complete headline record (contract fields, roofline, cpu_baseline, checked); the final line below replaces it
+        pre = short_line(headline_record(), None)
+        pre["preliminary"] = "side legs (other precision modes / configs) still to run; the final line follows"
+        print(json.dumps(pre), flush=True)
+
+    others = []
+    if world == 1 and not a.no_secondary:
+        for other in [m for m in a.secondary.split(",") if m and m != a.precision]:
+            dt2, uc2, prof2 = timed(other, 1, 1)
+            from diffusion_uncertainty_amd.guided_diffusion.unet_openai import _Ctx
+            ctx_ = _Ctx(model)
+            forms_ = {f"{H}^2:{cin}->{cout}": f"F({ctx_.wino_form(a.batch, H, H, cin, cout)},3)" for H, cin, cout in
+                      ((128, 256, 256), (64, 256, 256), (32, 512, 512), (16, 768, 768), (8, 1024, 1024))}
+            others.append(dict(precision=other, conv3x3_forms=forms_, value=round(a.batch / dt2, 4), unit="images/sec", steps=steps_per_job,
+                               ms_per_step=round(dt2 / steps_per_job * 1e3, 1), dtype=MODES[other][2],
+                               end_to_end_tflops=round((a.generation_steps + uc2) * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt2 / 1e12, 2),
+                               roofline=(prof2.roofline(other) if prof2 is not None else None)))
+
+    other_configs = []
+    if world == 1 and not a.no_other_configs and not a.no_secondary:
+        # the same model in the headline precision, one whole job each (weights are packed, code is paged in): the reference's second
+        # wall-clock number `time_normal` (scripts/measure_times_imagenet.py:109-118: the same driver with the plain DDIM scheduler), the
+        # UC window over all 50 steps (W50, BASELINE.md section 3), every zig-zag forward executed, and BASELINE configs[3] on one GPU
+        model.precision = a.precision
+        ops.PROFILE = None
+
+        def adm_leg(name, start, num, M, faithful, ref_fwd, note):
+            prof_ = ConvProfile() if (M != a.M and not a.no_profile) else None          # configs[3]: its own roofline block (conv3x3 launches of THIS job)
+            ops.PROFILE = prof_
+            if prof_ is not None:
+                prof_.start()
+            sync()
+            t0 = time.perf_counter()
+            uc = job(a.generation_steps, start, num, 77, M=M, faithful=faithful, plain=(num == 0))
+            sync()
+            dt_ = time.perf_counter() - t0
+            ops.PROFILE = None
+            if prof_ is not None:
+                prof_.stop()
+            fwd = a.generation_steps + uc
+            leg = dict(config=name, value=round(a.batch / dt_, 4), unit="images/sec", seconds_per_job=round(dt_, 2),
+                       executed_forwards_per_image=fwd, reference_forwards_per_image=ref_fwd,
+                       end_to_end_tflops=round(fwd * ADM128_FLOPS_PER_FWD_IMG * a.batch / dt_ / 1e12, 1), dtype=a.precision, note=note)
+            if prof_ is not None:
+                leg["roofline"] = prof_.roofline(a.precision)
+            return leg
+
+        gs, nzz = a.generation_steps, a.num_zigzag
+        for spec in (("time_normal: ADM ImageNet-128, 50 plain DDIM steps (no uncertainty window), batch 128", gs - 1, 0, a.M, False, gs,
+                      "measure_times_imagenet.py:109-118; time_uc of the same script = the headline job: seconds_per_job "
+                      f"{dt / jobs:.2f} (skip_dead_zigzag) - the uncertainty window costs time_uc - time_normal"),
+                     ("W50: BASELINE configs[1] with the UC window over all 50 steps (--start-step-uc 0 --num-steps-uc 50)", 0, gs, a.M, False,
+                      gs + gs * a.M * nzz, "skip_dead_zigzag"),
+                     ("BASELINE configs[1], W10, every zig-zag forward executed (--faithful-zigzag: the reference's forward count)",
+                      a.start_step_uc, a.num_steps_uc, a.M, True, gs + a.num_steps_uc * a.M * nzz, "faithful"),
+                     ("BASELINE configs[3] on one GPU: ADM ImageNet-128, 50 steps, M=10, W10, 128 images (the 8-GPU job is 8 such ranks)",
+                      a.start_step_uc, a.num_steps_uc, 10, False, gs + a.num_steps_uc * 10 * nzz, "skip_dead_zigzag")):
+            try:
+                other_configs.append(adm_leg(*spec))
+            except Exception as e:
+                other_configs.append(dict(config=spec[0], error=f"{type(e).__name__}: {e}"[:300]))
+        del model                                   # the ADM-128 weights and packed planes (3 GB) are not needed any more
+        torch.cuda.empty_cache()
+        for leg in (other_config_uvit, other_config_sd):
+            try:
+                other_configs.append(leg(dev, a))
+            except Exception as e:                   # a side leg must never take the headline line down
+                other_configs.append(dict(config=leg.__name__, error=f"{type(e).__name__}: {e}"[:300]))
+        try:
+            _, _, avail_cpus = cpu_info()
+            quota_ = cgroup_cpu_quota()
+            cpus_ = min(avail_cpus, int(quota_)) if quota_ else avail_cpus
+            cpu_full = (not a.no_cpu_baseline) and (a.cpu_config0 == "on" or (a.cpu_config0 == "auto" and cpus_ >= 16))
+            other_configs.append(config0_leg(dev, a, cpu_full))
+        except Exception as e:
+            other_configs.append(dict(config="BASELINE configs[0]", error=f"{type(e).__name__}: {e}"[:300]))
+
+    if rank == 0:
+        line = headline_record()
         if others:
             line["other_precision_modes"] = others
         if other_configs:
             line["other_configs"] = other_configs
-        if not a.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(sd, a.M, a.num_zigzag, a.generation_steps, a.num_steps_uc)
-            cb["gpu_over_cpu_same_forward_count"] = round(line["value_at_reference_forward_count"] / cb["value"], 1)
-            line["cpu_baseline"] = cb
-        if checked is not None:
-            line["checked"] = checked
         # The full record (every leg) goes to a side file and to stdout as a line of its own; the LAST line is the short headline record
         # (contract fields + roofline + cpu_baseline + checked, < 2 KB) so that a tail-truncating reader never cuts it.
         legs = a.legs_file or os.path.join(ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "bench_legs.json")
@@ -739,6 +988,9 @@ def short_line(line, legs_path):
     if c:
         out["cpu_baseline"] = {k: c.get(k) for k in ("value", "value_at_median", "unit", "cores", "kind", "gpu_over_cpu_same_forward_count")}
         out["cpu_baseline"]["sample"] = c["sample"].split(":")[0] + " (full text in the legs file)"
+    hk = [r for r in (line.get("hbm_kernels") or []) if "kernel" in r]
+    if hk:
+        out["hbm_kernels_gbs"] = {r["kernel"].split(" (")[0][:24]: r["achieved"] for r in hk[:6]}
     ch = line.get("checked")
     if ch:
         out["checked"] = {k: ch.get(k) for k in ("ok", "max_abs_diff", "bit_identical", "of", "error") if k in ch}

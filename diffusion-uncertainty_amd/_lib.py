@@ -60,6 +60,7 @@ SIGNATURES = {
     "dua_mc_reduce_var": (_I, [_P, _P, _Z, _I, _P]),
     "dua_quantile_mask": (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "dua_set_quantile_stream": (_I, [_I]),
+    "dua_quantile_workspace_release": (_I, [_P, _I]),
     "dua_flip_h": (_I, [_P, _P, _Z, _I, _I, _P]),
     "dua_posterior_blend": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "dua_threshold_map": (_I, [_P, _P, _P, _I, _Z, _I, _I, _P]),
@@ -154,6 +155,8 @@ SIGNATURES = {
     "dua_uvit_block_fwd": (_I, [_c.POINTER(UViTBlockArgs), _P]),
     "dua_conv_profile": (_I, [_I]),
     "dua_conv_profile_collect": (_I, [_c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_long), _c.POINTER(_c.c_double)]),
+    "dua_kernel_profile": (_I, [_I]),
+    "dua_kernel_profile_collect": (_c.c_long, [_c.c_char_p, _Z]),
     "dua_set_dma_conv": (_I, [_I]),
     "dua_set_gn_apply_wide": (_I, [_I]),
     "dua_set_conv_stagger": (_I, [_I, _I, _I]),

@@ -468,7 +468,12 @@ static int launch_attn_x(const AttnP& p, int B, hipStream_t s) {
             raised = true;
         }
     }
+    DuaKTimer kt((void*)s);
     hipLaunchKernelGGL((k_flash_attn_x<CT16, QW, F16>), grid, 64 * QW, qlds, s, p);
+    {   // algorithmic: 4 B H Tq Tk ch FLOPs; bytes: q, k, v rows read once + the output (fp32 and / or planes)
+        const double Tk = p.Tk > 0 ? (double)p.Tk : (double)p.T, BH = (double)B * p.heads;
+        kt.done(F16 ? "k_flash_attn_x (f16x3)" : "k_flash_attn_x (bf16x3)", 4.0 * BH * p.ch * ((double)p.T * 2.0 + 2.0 * Tk), 4.0 * BH * (double)p.T * Tk * p.ch);
+    }
     return dua_check_launch("dua_attention_bf16x3");
 }
 

@@ -4,6 +4,10 @@
 // composition in guided_diffusion/unet_openai.py (ResBlock.run / AttentionBlock.run), so the results are bit-identical to it.
 // Precisions: DUA_PREC_FP32 (exact fp32 MFMA) and DUA_PREC_F16X3 (the fp32-equivalent split) - the two parity modes.
 #include "common.h"
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
 #include <vector>
 
 namespace {
@@ -306,6 +310,57 @@ int check_attnblock(const dua_attnblock_args* a) {
 }
 
 }  // namespace
+
+// ---- per-entry-point launch timing (DuaKTimer of common.h): bench facility, off by default, not thread-safe
+namespace {
+struct KRec { hipEvent_t a, b; const char* kind; double bytes, flops; };
+bool g_kprof = false;
+std::vector<KRec> g_krecs;
+}  // namespace
+extern "C" void* dua_kprof_begin_(void* stream) {
+    if (!g_kprof) return nullptr;
+    hipEvent_t a;
+    if (hipEventCreate(&a) != hipSuccess) return nullptr;
+    (void)hipEventRecord(a, as_stream(stream));
+    return (void*)a;
+}
+extern "C" void dua_kprof_end_(void* h, void* stream, const char* kind, double bytes, double flops) {
+    hipEvent_t b;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy((hipEvent_t)h); return; }
+    (void)hipEventRecord(b, as_stream(stream));
+    g_krecs.push_back({(hipEvent_t)h, b, kind, bytes, flops});
+}
+extern "C" int dua_kernel_profile(int on) {
+    const int was = g_kprof ? 1 : 0;
+    g_kprof = on != 0;
+    return was;
+}
+extern "C" long dua_kernel_profile_collect(char* buf, size_t cap) {
+    struct Sum { long n = 0; double ms = 0, bytes = 0, flops = 0, min_ms = 1e30; };
+    std::map<std::string, Sum> sums;
+    for (KRec& r : g_krecs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            Sum& s = sums[r.kind];
+            s.n += 1; s.ms += t; s.bytes += r.bytes; s.flops += r.flops;
+            if (t < s.min_ms) s.min_ms = t;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_krecs.clear();
+    std::string out = "{";
+    char line[512];
+    for (auto& kv : sums) {
+        snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"min_ms\": %.6f, \"bytes\": %.6e, \"flops\": %.6e}", out.size() > 1 ? ", " : "",
+                 kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.min_ms, kv.second.bytes, kv.second.flops);
+        out += line;
+    }
+    out += "}";
+    if (!buf || cap < out.size() + 1) { dua_set_error("dua_kernel_profile_collect: buffer of %zu bytes, %zu needed", cap, out.size() + 1); return DUA_EINVAL; }
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return (long)out.size();
+}
 
 extern "C" int dua_conv_profile(int on) {
     const int was = g_prof ? 1 : 0;

@@ -26,6 +26,18 @@ static inline int dua_check_launch(const char* what) {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- bench facility: per-entry-point launch timing (dua_kernel_profile, csrc/blocks.hip).  An entry point that wants to appear in
+// bench.py's `hbm_kernels` / per-leg roofline brackets its launches with a DuaKTimer: HIP events on the LAUNCH stream, tagged with a
+// kind and the launch's ALGORITHMIC bytes / FLOPs.  Off (the default): one load and one branch per entry point.
+extern "C" void* dua_kprof_begin_(void* stream);
+extern "C" void dua_kprof_end_(void* h, void* stream, const char* kind, double bytes, double flops);
+struct DuaKTimer {
+    void* h;
+    void* st;
+    explicit DuaKTimer(void* stream) : h(dua_kprof_begin_(stream)), st(stream) {}
+    void done(const char* kind, double bytes, double flops = 0.0) { if (h) dua_kprof_end_(h, st, kind, bytes, flops); }
+};
+
 // Memory-bound grids: cap at 256 CUs x 8 blocks and grid-stride the rest.
 static inline unsigned stream_grid(size_t work_items, unsigned block) {
     size_t g = (work_items + block - 1) / block;

@@ -679,10 +679,15 @@ extern "C" int dua_conv3x3_f16x3_wino4(const void* vplanes, const void* packed, 
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
     p.out_scale = 1.0f / v_scale;
     const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    DuaKTimer kt(stream);
     if (!residual) hipLaunchKernelGGL(k_wconv4<0>, dim3(grid), 256, 0, as_stream(stream), p);
     else if (p.res_mode == 0) hipLaunchKernelGGL(k_wconv4<1>, dim3(grid), 256, 0, as_stream(stream), p);
     else if (p.res_mode > 0) hipLaunchKernelGGL(k_wconv4<2>, dim3(grid), 256, 0, as_stream(stream), p);
     else hipLaunchKernelGGL(k_wconv4<3>, dim3(grid), 256, 0, as_stream(stream), p);
+    {   // algorithmic: 2 N H W 9 Cin Cout FLOPs; bytes: the V images once (6 B per input element) + the packed weights + the fp32 output (+ residual)
+        const double px = (double)N * H * W;
+        kt.done(residual ? "k_wconv4 (residual)" : "k_wconv4", 6.0 * px * Cin + 4.0 * 18.0 * Cin * Cout + 4.0 * px * Cout * (residual ? 2.0 : 1.0), 2.0 * px * 9.0 * Cin * Cout);
+    }
     return dua_check_launch("dua_conv3x3_f16x3_wino4");
 }
 
@@ -920,6 +925,7 @@ static int gn_apply_wino4_impl(const float* x1, int C1, const float* x2, int C2,
     p.JC = JC;
     const dim3 grid(nxb * ((P + JC - 1) / JC), N);
     const bool strm = resample >= 0 && !dropmask && Wo >= 16;
+    DuaKTimer kt(stream);
     if (f32_planes) {
         if (strm) hipLaunchKernelGGL((k_gn_apply_wino4<true, true>), grid, 256, 0, as_stream(stream), p);
         else hipLaunchKernelGGL((k_gn_apply_wino4<false, true>), grid, 256, 0, as_stream(stream), p);
@@ -927,6 +933,8 @@ static int gn_apply_wino4_impl(const float* x1, int C1, const float* x2, int C2,
         if (strm) hipLaunchKernelGGL((k_gn_apply_wino4<true>), grid, 256, 0, as_stream(stream), p);
         else hipLaunchKernelGGL((k_gn_apply_wino4<false>), grid, 256, 0, as_stream(stream), p);
     }
+    // algorithmic bytes: the fp32 input once + the six V images of the conv's input positions (24 B per group of four rows = 6 B per element)
+    kt.done(f32_planes ? "k_gn_apply_wino4 (fp32 V images)" : "k_gn_apply_wino4", 4.0 * N * H * W * C + 6.0 * N * Ho * Wo * C);
     return dua_check_launch(f32_planes ? "dua_groupnorm_apply_wino4_f32" : "dua_groupnorm_apply_wino4_f16x3");
 }
 

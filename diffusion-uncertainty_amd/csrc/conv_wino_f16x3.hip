@@ -625,8 +625,14 @@ static int conv3x3_wino_impl(const void* vplanes, const void* packed, const floa
     p.Cscale = (const float*)((const _Float16*)packed + 2 * p.b_plane);
     p.out_scale = 1.0f / v_scale;
     const int ntiles = p.ntm * p.ntn, grid = ntiles < 256 ? ntiles : 256;
+    DuaKTimer kt(stream);
     if (single) hipLaunchKernelGGL(k_wconv1, dim3(grid), 512, 0, as_stream(stream), p);
     else hipLaunchKernelGGL(k_wconv, dim3(grid), 512, 0, as_stream(stream), p);
+    {   // algorithmic: 2 N H W 9 Cin Cout FLOPs; bytes: the V images once (8 B per input element, hi images: 4) + the packed weights + the output (+ residual)
+        const double px = (double)N * H * W;
+        kt.done(single ? "k_wconv1" : "k_wconv", (single ? 4.0 : 8.0) * px * Cin + (single ? 2.0 : 4.0) * 12.0 * Cin * Cout + 4.0 * px * Cout * (residual ? 2.0 : 1.0),
+                2.0 * px * 9.0 * Cin * Cout);
+    }
     return dua_check_launch("dua_conv3x3_f16x3_wino");
 }
 extern "C" int dua_conv3x3_f16x3_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
@@ -876,12 +882,15 @@ static int gn_apply_wino_impl(const float* x1, int C1, const float* x2, int C2, 
     p.JC = JC;
     const dim3 grid(nxb * ((P + JC - 1) / JC), N);
     const bool strm = resample >= 0 && !dropmask && Wo >= 16;
+    DuaKTimer kt(stream);
     if (hi_only && strm) hipLaunchKernelGGL((k_gn_apply_wino<false, true, true>), grid, BLK, 0, as_stream(stream), p);
     else if (hi_only) hipLaunchKernelGGL((k_gn_apply_wino<false, false, true>), grid, BLK, 0, as_stream(stream), p);
     else if (f32 && strm) hipLaunchKernelGGL((k_gn_apply_wino<true, true>), grid, BLK, 0, as_stream(stream), p);
     else if (f32) hipLaunchKernelGGL((k_gn_apply_wino<true, false>), grid, BLK, 0, as_stream(stream), p);
     else if (strm) hipLaunchKernelGGL((k_gn_apply_wino<false, true>), grid, BLK, 0, as_stream(stream), p);
     else hipLaunchKernelGGL((k_gn_apply_wino<false, false>), grid, BLK, 0, as_stream(stream), p);
+    // algorithmic bytes: the fp32 input once + the four V images of the conv's input positions (8 B per element; hi images only: 4 B)
+    kt.done(hi_only ? "k_gn_apply_wino (hi images)" : (f32 ? "k_gn_apply_wino (fp32 V images)" : "k_gn_apply_wino"), 4.0 * N * H * W * C + (hi_only ? 4.0 : 8.0) * N * Ho * Wo * C);
     return dua_check_launch("dua_groupnorm_apply_wino");
 }
 extern "C" int dua_groupnorm_apply_wino_f16x3(const float* x1, int C1, const float* x2, int C2, int N, int H, int W, int G,

@@ -140,10 +140,12 @@ extern "C" int dua_groupnorm_stats(const float* x1, int C1, const float* x2, int
     DUA_REQUIRE(((uintptr_t)ws & 7) == 0, "dua_groupnorm_stats: ws must be 8-byte aligned");
     int cp, nc;
     gn_chunking(N, HW, &cp, &nc);
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_gn_partial, dim3(nc, N), BLK, 4096 * sizeof(float), as_stream(stream), x1, C1, x2, C2, HW, G, cp, nc, (double*)ws);
     int NG = N * G;
     hipLaunchKernelGGL(k_gn_finalize, (NG + 3) / 4, 256, 0, as_stream(stream), (const double*)ws, NG, G, nc,
                        (double)HW * (double)(C / G), eps, stats);
+    kt.done("k_gn_partial + k_gn_finalize", 4.0 * N * HW * C);             // the activation read once
     return dua_check_launch("dua_groupnorm_stats");
 }
 
@@ -538,10 +540,13 @@ static int gn_apply_impl(const float* x1, int C1, const float* x2, int C2, int N
     // fewer, fatter lanes leave part of a workgroup idle
     const bool wide = C1 % 8 == 0 && C2 % 8 == 0 && (C / 8) % 2 == 0 && C / 8 <= BLK && 
                       (long)Ho * Wo >= 4096 && BLK % (C / 8) == 0;
+    DuaKTimer kt(stream);
     if (wide && gn_apply_wide) hipLaunchKernelGGL(k_gn_apply8, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= BLK) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else if (C / 4 <= 2 * BLK) hipLaunchKernelGGL(k_gn_apply<2>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);
     else hipLaunchKernelGGL(k_gn_apply<3>, dim3(nc, N), BLK, 0, as_stream(stream), p, cp);    // SD-1.5 up blocks: 1280 + 1280
+    // algorithmic bytes: the fp32 input once + 4 B per output element (fp32, or hi + lo halves of a split format)
+    kt.done(split ? "k_gn_apply (operand planes)" : "k_gn_apply (fp32)", 4.0 * N * H * W * C + 4.0 * (double)p.plane);
     return dua_check_launch("dua_groupnorm_apply");
 }
 
@@ -842,15 +847,15 @@ static int layernorm_impl(const float* x, const float* gamma, const float* beta,
     DUA_REQUIRE(x && gamma && beta && y && D >= 1 && D <= 2048, "dua_layernorm: D must be in [1, 2048]");
     if (rows == 0) return DUA_OK;
     unsigned grid = (unsigned)((rows + 3) / 4);
+    DuaKTimer kt(stream);
     if (D % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
         if (D <= 256) hipLaunchKernelGGL(k_layernorm4<1>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
         else if (D <= 1024) hipLaunchKernelGGL(k_layernorm4<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
         else hipLaunchKernelGGL(k_layernorm4<8>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
-        return dua_check_launch("dua_layernorm");
-    }
-    if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
+    } else if (D <= 256) hipLaunchKernelGGL(k_layernorm<4>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
     else if (D <= 1024) hipLaunchKernelGGL(k_layernorm<16>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
     else hipLaunchKernelGGL(k_layernorm<32>, grid, BLK, 0, as_stream(stream), x, gamma, beta, y, rows, D, eps, split, oscale);
+    kt.done(split ? "k_layernorm (operand planes)" : "k_layernorm (fp32)", 8.0 * (double)rows * D);      // 4 B read + 4 B written per element
     return dua_check_launch("dua_layernorm");
 }
 extern "C" int dua_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int D, float eps, void* stream) {

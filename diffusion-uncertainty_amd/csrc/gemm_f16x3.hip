@@ -35,6 +35,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef HG_DIAG
 #define HG_DIAG 0
 #endif
+#ifndef HG_COND_LOADS
+#define HG_COND_LOADS 0              // 1: the round-5 epilogue loads (conditional global loads) - A/B builds only (scripts/diag/hgemm_condloads_build.py)
+#endif
 #define HG_TAIL_WAIT 8               // vector-memory operations an epilogue ALWAYS issues after the next item's prologue DMA (stores)
 
 // Exact GELU v * Phi(v) (uvit/timm.py:96-111, nn.GELU) without the two-branch erff: with x = |v| / sqrt(2), erfc(x) = exp(-x g(x)) and g a
@@ -42,9 +45,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // v < 0 - no cancellation on the negative side, unlike 0.5 (1 + erf) - and 1 - erfc(x) / 2 otherwise.
 // Two elements at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma_f32: the polynomial, the exponent and the final combination are one
 // instruction per pair; as 18 scalar operations per element the GELU was an eighth of fc1's time, HG_DIAG 8).  Folded for that: -log2(e) into
-// the coefficients, the 1/2 into the exponent (exp2(x g' - 1) = erfc(x) / 2 =: he), and v Phi(v) = max(v, 0) - |v| he on both sides of zero
-// (v >= 0: v - v he; v < 0: v he = -|v| he): no select, no 1 - he.  Against fp64 over [-12, 12]: max abs error 2.4e-7 (the fp32 erf formula:
-// 4.5e-7), no divergence.
+// the coefficients, the 1/2 and a sqrt(2) into the exponent (exp2(x g' - 1/2) = sqrt(2) erfc(x) / 2 =: hs), and
+// v Phi(v) = max(v, 0) - |v| he = (v + |v|) / 2 - x hs on both sides of zero (v >= 0: v - v he; v < 0: v he = -|v| he): no select, no 1 - he.
+// The product uses the CLAMPED x (not |v|): beyond |v| = 4 sqrt(2) the tail term stays below 4.5e-8 instead of growing with |v|
+// (|v| he reached -7.9e21 at v = -1e30 and inf - inf = NaN at v = +inf), and (v + |v|) / 2 - formed as v/2 + |v|/2, exact, no
+// overflow - propagates NaN and gives +inf -> +inf, -inf -> NaN like torch's v Phi(v).  Against fp64 over [-12, 12]: max abs error 2.4e-7
+// (the fp32 erf formula: 4.5e-7), no divergence.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 hg_gelu2(f32x2 v) {
     if (HG_DIAG & 8) return v;
@@ -61,10 +67,10 @@ __device__ __forceinline__ f32x2 hg_gelu2(f32x2 v) {
     g = __builtin_elementwise_fma(g, x, (f32x2){1.027989408e-01f * L, 1.027989408e-01f * L});
     g = __builtin_elementwise_fma(g, x, (f32x2){6.366161475e-01f * L, 6.366161475e-01f * L});
     g = __builtin_elementwise_fma(g, x, (f32x2){1.128379331e+00f * L, 1.128379331e+00f * L});
-    const f32x2 e = __builtin_elementwise_fma(x, g, (f32x2){-1.0f, -1.0f});
-    const f32x2 he = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-    const f32x2 r = {fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
-    return __builtin_elementwise_fma(-a, he, r);
+    const f32x2 e = __builtin_elementwise_fma(x, g, (f32x2){-0.5f, -0.5f});
+    const f32x2 hs = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    const f32x2 r = __builtin_elementwise_fma(v, (f32x2){0.5f, 0.5f}, a * 0.5f);
+    return __builtin_elementwise_fma(-x, hs, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -103,25 +109,48 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         // latency instead of two per pair; the residual rows of slot t + 2 are requested while slot t is stored
         constexpr int RR = NT == 4 ? 2 : 3;                      // residual ring: slots ahead + 1 (the 256-column kernel has no registers for three)
         float4 rres[RR][2];
+        // Residual rows, column scales and biases through buffer loads that ALWAYS issue (a lane outside the tensor - or every lane when
+        // there is no residual / bias: a descriptor of zero records - reads zeros): the epilogue is then straight-line code between its
+        // stores and the compiler's vector-memory waits count the loads exactly.  Behind a conditional load it has to assume the load
+        // did not issue and waits vmcnt(0) at the next use - draining, in order, every output store in flight: four to seven times per
+        // tile in the round-5 code (the fix that paid in k_wconv4)
+        const long rrem = ((long)p.M - m0) * p.N * 4;
+        const auto rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res + (long)m0 * p.N : nullptr), 0,
+                                                           p.res ? (int)(rrem < 0x7FFFFFF0L ? rrem : 0x7FFFFFF0L) : 0, 0x00020000);
+        const auto rsc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Cscale, 0, p.N * 4, 0x00020000);
+        const auto rbi = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
+        auto ldq = [&](const auto& rs, unsigned off) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            return make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
+        };
         auto res_ld = [&](int t, float4 (&dst)[2]) {
             const int c = n0 + wn * 32 * NT + 32 * (t >> 2) + 4 * pc_e;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int row = row0 + 16 * (t & 3) + 8 * h + pr_e;
+#if HG_COND_LOADS
                 dst[h] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.res && c < p.N && row < p.M) dst[h] = *(const float4*)(p.res + (long)row * p.N + c);
+#else
+                dst[h] = ldq(rrs, (c < p.N && row < p.M) ? (unsigned)(((long)(row - m0) * p.N + c) * 4) : OOB);
+#endif
             }
         };
         // (column scale and bias of a pair are requested one pair ahead: all NT pairs up front cost 32 registers at NT = 4)
         float4 sqn, bqn;
         auto sb_ld = [&](int jp) {
             const int c = n0 + wn * 32 * NT + 32 * jp + 4 * pc_e;
+#if HG_COND_LOADS
             sqn = make_float4(0.f, 0.f, 0.f, 0.f);
             bqn = sqn;
             if (c < p.N) {
                 sqn = *(const float4*)(p.Cscale + c);
                 if (p.bias) bqn = *(const float4*)(p.bias + c);
             }
+#else
+            sqn = ldq(rsc, c < p.N ? (unsigned)c * 4u : OOB);
+            bqn = ldq(rbi, c < p.N ? (unsigned)c * 4u : OOB);
+#endif
         };
         sb_ld(0);
         float4 sq_cur = sqn, bq_cur = bqn;
@@ -220,14 +249,27 @@ __device__ __forceinline__ void hgemm_epilogue(const HGemmP& p, f32x4 (&acc)[2 *
         // column scales and biases of a pair (this lane's eight channels), requested ONE pair ahead (all NT pairs up front are 64 registers
         // at NT = 4: the K loop of that instantiation then reloaded a spilled LDS address behind an s_waitcnt vmcnt(0) - scripts/isa_lint.py)
         float4 s0n, s1n, b0n, b1n;
+        // (always-issued buffer loads, as in the fp32 epilogue above: no conditional load between the plane stores)
+        const auto rsc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Cscale, 0, p.N * 4, 0x00020000);
+        const auto rbi = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
+        auto ldq = [&](const auto& rs, unsigned off) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            return make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
+        };
         auto sb_ld8 = [&](int jp) {
             const int c = n0 + wn * 32 * NT + 32 * jp + 8 * ch8;
+#if HG_COND_LOADS
             s0n = make_float4(0.f, 0.f, 0.f, 0.f);
             s1n = s0n; b0n = s0n; b1n = s0n;
             if (c < p.N) {
                 s0n = *(const float4*)(p.Cscale + c); s1n = *(const float4*)(p.Cscale + c + 4);
                 if (p.bias) { b0n = *(const float4*)(p.bias + c); b1n = *(const float4*)(p.bias + c + 4); }
             }
+#else
+            const unsigned o = c < p.N ? (unsigned)c * 4u : OOB;             // (N % 8 == 0 on this path: the second chunk is in range with the first)
+            s0n = ldq(rsc, o); s1n = ldq(rsc, o == OOB ? OOB : o + 16u);
+            b0n = ldq(rbi, o); b1n = ldq(rbi, o == OOB ? OOB : o + 16u);
+#endif
         };
         sb_ld8(0);
         float4 s0c = s0n, s1c = s1n, b0c = b0n, b1c = b1n;
@@ -695,9 +737,14 @@ int dua_launch_hgemm(HGemmP& p, hipStream_t st, const char* what) {
         }
     }
     const bool planes = p.Cplanes != nullptr;
+    DuaKTimer kt((void*)st);
     if (nt == 4) hg_launch<4>(p, grid, planes, st);
     else if (nt == 3) hg_launch<3>(p, grid, planes, st);
     else hg_launch<2>(p, grid, planes, st);
+    {   // algorithmic: 2 M N K FLOPs; bytes = the operand planes (4 B per element, A once per launch, the packed weights once) + the outputs
+        const double K = (double)(p.K1 + p.K2), M = (double)p.M, N = (double)p.N;
+        kt.done("k_hgemm", 4.0 * M * K + 4.0 * N * K + (p.C ? 4.0 * M * N : 0.0) + ((p.Cplanes || p.Cextra) ? 4.0 * M * N : 0.0) + (p.res ? 4.0 * M * N : 0.0), 2.0 * M * N * K);
+    }
     return dua_check_launch(what);
 }
 

@@ -478,12 +478,17 @@ int dua_launch_sgemm(SGemmP& p, hipStream_t st, const char* what) {
     const int ntiles = p.ntm * p.ntn;
     const int grid = ntiles < 256 ? ntiles : 256;
     p.range_ctr = sg_range_host;
+    DuaKTimer kt((void*)st);
     if (p.range_ctr) {
         if (nt == 4) hipLaunchKernelGGL((k_sgemm<4, true>), dim3(grid), 512, 0, st, p);
         else hipLaunchKernelGGL((k_sgemm<2, true>), dim3(grid), 512, 0, st, p);
     } else {
         if (nt == 4) hipLaunchKernelGGL((k_sgemm<4, false>), dim3(grid), 512, 0, st, p);
         else hipLaunchKernelGGL((k_sgemm<2, false>), dim3(grid), 512, 0, st, p);
+    }
+    {   // algorithmic: 2 M N K FLOPs; bytes = the raw fp32 operand once + the packed weights + the fp32 output
+        const double K = (double)(p.K1 + p.K2), M = (double)p.M, N = (double)p.N;
+        kt.done("k_sgemm", 4.0 * M * K + 4.0 * N * K + 4.0 * M * N, 2.0 * M * N * K);
     }
     return dua_check_launch(what);
 }

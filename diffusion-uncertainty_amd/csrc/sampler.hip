@@ -59,11 +59,13 @@ extern "C" int dua_ddim_step(const float* eps, const float* x, const float* nois
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(eps && x && prev && x0, "dua_ddim_step: null pointer");
     if (sigma == 0.f) noise = nullptr;
+    DuaKTimer kt(stream);
     bool vec = (n % 4 == 0) && aligned16(eps) && aligned16(x) && aligned16(prev) && aligned16(x0) && (!noise || aligned16(noise));
     if (vec)
         hipLaunchKernelGGL(k_ddim_step<true>, stream_grid(n / 4, BLK), BLK, 0, as_stream(stream), eps, x, noise, prev, x0, n, sb, sa, sap, dc, sigma, clip, cr);
     else
         hipLaunchKernelGGL(k_ddim_step<false>, stream_grid(n, BLK), BLK, 0, as_stream(stream), eps, x, noise, prev, x0, n, sb, sa, sap, dc, sigma, clip, cr);
+    kt.done("k_ddim_step", (noise ? 20.0 : 16.0) * (double)n);         // read eps, x (+ noise), write prev, x0: 4 P
     return dua_check_launch("dua_ddim_step");
 }
 
@@ -85,7 +87,9 @@ extern "C" int dua_axpby(const float* src, const float* noise, float* out, size_
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(src && noise && out, "dua_axpby: null pointer");
     int vec = (n % 4 == 0) && aligned16(src) && aligned16(noise) && aligned16(out);
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_axpby, stream_grid(vec ? n / 4 : n, BLK), BLK, 0, as_stream(stream), src, noise, out, n, a, b, vec);
+    kt.done("k_axpby", 12.0 * (double)n);                               // re-noising: 3 P per call
     return dua_check_launch("dua_axpby");
 }
 
@@ -156,7 +160,9 @@ __global__ __launch_bounds__(BLK) void k_mc_accum(const float* __restrict__ em, 
 extern "C" int dua_mc_centered_accum(const float* eps_m, const float* eps, float* acc, size_t n, int m, int M, void* stream) {
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(eps_m && eps && acc && M >= 1 && m >= 0 && m < M, "dua_mc_centered_accum: bad arguments");
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_mc_accum, stream_grid(n, BLK), BLK, 0, as_stream(stream), eps_m, eps, acc, n, m == 0, m == M - 1, (float)M);
+    kt.done("k_mc_accum", (m == 0 ? 12.0 : 16.0) * (double)n);         // read eps_m, eps (+ acc), write acc: streaming form of the (M + 2) P reduce
     return dua_check_launch("dua_mc_centered_accum");
 }
 
@@ -175,7 +181,9 @@ __global__ __launch_bounds__(BLK) void k_mc_centered(const float* __restrict__ s
 extern "C" int dua_mc_reduce_centered(const float* stack, const float* eps, float* u, size_t n, int M, void* stream) {
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(stack && eps && u && M >= 1, "dua_mc_reduce_centered: bad arguments");
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_mc_centered, stream_grid(n, BLK), BLK, 0, as_stream(stream), stack, eps, u, n, M);
+    kt.done("k_mc_centered", 4.0 * (M + 2) * (double)n);
     return dua_check_launch("dua_mc_reduce_centered");
 }
 
@@ -196,7 +204,9 @@ extern "C" int dua_mc_reduce_var(const float* stack, float* u, size_t n, int M, 
     DUA_REQUIRE(M >= 2, "dua_mc_reduce_var: need M >= 2");
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(stack && u, "dua_mc_reduce_var: null pointer");
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_mc_var, stream_grid(n, BLK), BLK, 0, as_stream(stream), stack, u, n, M);
+    kt.done("k_mc_var", 4.0 * (M + 1) * (double)n);
     return dua_check_launch("dua_mc_reduce_var");
 }
 
@@ -973,27 +983,57 @@ static int quantile_force_stream = 0;
 extern "C" int dua_set_quantile_stream(int on) { int o = quantile_force_stream; quantile_force_stream = on; return o; }
 
 // Workspace of the multi-workgroup kernel: per (device, stream) so that launches on different streams never share counters;
-// zeroed once when allocated, left zeroed by every launch.
+// zeroed once when allocated, left zeroed by every launch that completes.  A launch that is rejected marks the buffer dirty and the
+// next use re-zeroes it on the stream before launching (stale arrival words would read as "both arrived");
+// dua_quantile_workspace_release frees the entries of a stream that is about to be destroyed (a recycled stream handle would otherwise
+// inherit them) or all of them.
+struct QmBuf { uint32_t* p; int cap; bool dirty; };
+static std::map<std::pair<int, hipStream_t>, QmBuf>& quantile_bufs() { static std::map<std::pair<int, hipStream_t>, QmBuf> m; return m; }
+static std::mutex& quantile_mu() { static std::mutex m; return m; }
 static uint32_t* quantile_workspace(hipStream_t st, int B);
 #ifdef QM_DIAG
 extern "C" void* dua_quantile_diag_workspace(void* stream, int B) { return quantile_workspace(as_stream(stream), B); }
 #endif
 static uint32_t* quantile_workspace(hipStream_t st, int B) {
-    struct Buf { uint32_t* p; int cap; };
-    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
-    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    Buf& b = bufs[std::make_pair(dev, st)];
+    std::lock_guard<std::mutex> lk(quantile_mu());
+    QmBuf& b = quantile_bufs()[std::make_pair(dev, st)];
     if (b.cap < B) {
         if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
         const size_t bytes = (size_t)B * (QM_CTR + QM_CAP) * sizeof(uint32_t);
         if (hipMalloc((void**)&b.p, bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
         if (hipMemset(b.p, 0, bytes) != hipSuccess) { (void)hipFree(b.p); b.p = nullptr; return nullptr; }
         b.cap = B;
+        b.dirty = false;
+    } else if (b.dirty) {
+        if (hipMemsetAsync(b.p, 0, (size_t)b.cap * (QM_CTR + QM_CAP) * sizeof(uint32_t), st) != hipSuccess) return nullptr;
+        b.dirty = false;
     }
     return b.p;
+}
+static void quantile_workspace_mark_dirty(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(quantile_mu());
+    auto it = quantile_bufs().find(std::make_pair(dev, st));
+    if (it != quantile_bufs().end()) it->second.dirty = true;
+}
+extern "C" int dua_quantile_workspace_release(void* stream, int all) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { dua_set_error("dua_quantile_workspace_release: no device"); return DUA_EHIP; }
+    std::lock_guard<std::mutex> lk(quantile_mu());
+    int freed = 0;
+    // (all: the recorded stream handles may be gone - wait for the device, never for a handle; one stream: the caller's, still alive)
+    if ((all ? hipDeviceSynchronize() : hipStreamSynchronize(as_stream(stream))) != hipSuccess) { dua_set_error("dua_quantile_workspace_release: synchronize failed"); return DUA_EHIP; }
+    for (auto it = quantile_bufs().begin(); it != quantile_bufs().end();) {
+        if (it->first.first == dev && (all || it->first.second == as_stream(stream))) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            it = quantile_bufs().erase(it);
+            ++freed;
+        } else ++it;
+    }
+    return freed;
 }
 
 extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uint8_t* mask, float* q, void* stream) {
@@ -1001,6 +1041,8 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
     DUA_REQUIRE(B >= 0 && n >= 1 && lo >= 0 && hi >= lo && hi <= lo + 1 && hi < n, "dua_quantile_mask: bad rank split (n=%d lo=%d hi=%d)", n, lo, hi);
     if (B == 0) return DUA_OK;
     hipStream_t st = as_stream(stream);
+    DuaKTimer kt(stream);
+    const double qbytes = 9.0 * (double)B * (double)n;                  // read u twice (select + mask) + the uint8 mask: 2.25 P
     // small samples: 1024 threads x <= 16 keys (128-register budget); up to 65536 elements: 512 threads x <= 128 keys (two
     // waves per SIMD, 256-register budget); beyond that the streaming kernel
     const bool vec = n % 4 == 0 && (((uintptr_t)u | (uintptr_t)mask) & 15) == 0;
@@ -1024,7 +1066,10 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
         else if (n4 <= 6 * G * QM_TH) QMULTI(6);
         else QMULTI(8);
 #undef QMULTI
-        return dua_check_launch("dua_quantile_mask");
+        kt.done("k_quantile_mask_multi", qbytes);
+        const int rc = dua_check_launch("dua_quantile_mask");
+        if (rc != DUA_OK) quantile_workspace_mark_dirty(st);
+        return rc;
     }
     if (mode == 1 || n > 65536 || n < 4) hipLaunchKernelGGL(k_quantile_mask, B, QT, 0, st, u, n, lo, hi, w, mask, q);
     else if (n <= 4096) QREG(1, 1024)
@@ -1034,6 +1079,7 @@ extern "C" int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, f
     else if (n <= 49152) QREG(24, 512)
     else QREG(32, 512)
 #undef QREG
+    kt.done((mode == 1 || n > 65536 || n < 4) ? "k_quantile_mask (streaming)" : "k_quantile_mask_reg", qbytes);
     return dua_check_launch("dua_quantile_mask");
 }
 
@@ -1159,7 +1205,9 @@ __global__ __launch_bounds__(BLK) void k_to_uint8(const float* __restrict__ x, u
 extern "C" int dua_to_uint8(const float* x, uint8_t* out, size_t n, void* stream) {
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(x && out, "dua_to_uint8: null pointer");
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_to_uint8, stream_grid(n, BLK), BLK, 0, as_stream(stream), x, out, n);
+    kt.done("k_to_uint8", 5.0 * (double)n);
     return dua_check_launch("dua_to_uint8");
 }
 
@@ -1198,7 +1246,9 @@ __global__ __launch_bounds__(BLK) void k_randn(float* __restrict__ out, size_t n
 extern "C" int dua_randn(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
     if (n == 0) return DUA_OK;
     DUA_REQUIRE(out, "dua_randn: null pointer");
+    DuaKTimer kt(stream);
     hipLaunchKernelGGL(k_randn, stream_grid((n + 3) / 4, BLK), BLK, 0, as_stream(stream), out, n, seed, offset);
+    kt.done("k_randn", 4.0 * (double)n);
     return dua_check_launch("dua_randn");
 }
 

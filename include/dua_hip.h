@@ -81,6 +81,11 @@ int dua_quantile_mask(const float* u, int B, int n, int lo, int hi, float w, uin
  * (six passes over u); 2 = never the two-workgroup kernel; 3 = the two-workgroup kernel with its bracket declared missed (its fallback);
  * 4 = ... with every workgroup acting as if its partner had never arrived (the way out of its bounded wait). */
 int dua_set_quantile_stream(int on);
+/* The two-workgroup kernel keeps one small counter workspace per (device, stream), zeroed when allocated and left zeroed by every launch
+ * that completes (a rejected launch marks it for re-zeroing before the next use).  Releases the current device's workspace of `stream`
+ * (call before destroying a stream: a recycled handle must not inherit it) or, with all != 0, of every stream; returns the number of
+ * workspaces freed, or a negative DUA_E* code. */
+int dua_quantile_workspace_release(void* stream, int all);
 
 /* y[p][h][w] = x[p][H-1-h][w] over `planes` = N*C image planes: torch.flip(x, dims=[2]) of an NCHW tensor, the input / output
  * mirroring of the `flip` estimator (schedulers_uncertainty/scheduling_ddim_flip.py:486,491).  Out of place. */
@@ -345,8 +350,12 @@ int dua_groupnorm_apply_wino_f32(const float* x1, int C1, const float* x2, int C
                                  int resample, const float* dropmask, void* vplanes, void* stream);
 int dua_conv3x3_f32_wino(const void* vplanes, const void* packed, const float* bias, const float* residual, int res_resample, float* y,
                          int N, int H, int W, int Cin, int Cout, float* colsum, void* stream);
-/* The F(4,3)-along-y form in EXACT fp32 (csrc/conv_wino4_f32.hip: k_wconv432 on v_mfma_f32_16x16x4_f32, 4.5 of 9 taps per pixel - the
- * best form of `precision = "fp32"`, the one mode whose products are the reference's own arithmetic, unet_openai.py:186,212).  The six
+/* The F(4,3)-along-y form with fp32 products and sums (csrc/conv_wino4_f32.hip: k_wconv432 on v_mfma_f32_16x16x4_f32, 4.5 of 9 taps per
+ * pixel - the fastest form of `precision = "fp32"`).  Every product is an fp32 product, but the Winograd transforms re-associate the
+ * reference's sums (unet_openai.py:186,212) and F(4,3)'s transform matrices amplify rounding: a single layer carries up to ~4 x the direct
+ * fp32 engine's error against fp64, and the full-size ADM UNets differ from the direct form by up to 5e-5 (7.9e-6 against the reference's
+ * output, bar 1e-3).  `model.winograd = False` runs the direct fp32 kernel - the reference's own summation order - and `2` the milder
+ * F(2,3) form; use those when the closest possible fp32 arithmetic matters more than throughput.  The six
  * transformed images hold floats in the stage-block layout of dua_groupnorm_apply_wino4_f16x3 (same bytes: dua_f16x3_wino4_act_bytes),
  * the packed weights [column tile of 64][K step = (channel block, fi, dx)][group * 64 + channel][32] floats; shapes as
  * dua_conv3x3_f16x3_wino4_supported; colsum needs H * W % 256 == 0. */
@@ -515,6 +524,14 @@ int dua_uvit_block_fwd(const dua_uvitblock_args* args_host, void* stream);
  * FLOPs those launches executed (3 fp16 products per tap in f16x3, 6 of 9 taps in the Winograd form), and frees the events. */
 int dua_conv_profile(int on);
 int dua_conv_profile_collect(double* total_ms, double* total_flops, long* launches, double* total_mfma_flops);
+/* Bench facility for the kernels OUTSIDE the conv3x3 launches (bench.py's `hbm_kernels` list and the per-leg rooflines):
+ * dua_kernel_profile(1) makes the sampler kernels (DDIM step, re-noising, Monte-Carlo accumulation, quantile mask, uint8 conversion), the
+ * GroupNorm / LayerNorm operand writers (V writers of the Winograd forms, plane writers), the one-tap / skip GEMMs and the attention kernels
+ * bracket their launches with HIP events on the launch stream, tagged with a kind and the launch's ALGORITHMIC bytes / FLOPs (returns the
+ * previous setting).  dua_kernel_profile_collect synchronises on the events and writes one JSON object
+ * {"kind": {"launches", "ms", "min_ms", "bytes", "flops"}, ...} (sums per kind) into buf; returns its length or DUA_EINVAL when cap is too small. */
+int dua_kernel_profile(int on);
+long dua_kernel_profile_collect(char* buf, size_t cap);
 int dua_adm_attnblock_fwd(const dua_attnblock_args* args_host, void* stream);
 
 /* ---------------- U-ViT token plumbing (uvit/uvit.py) ---------------- */

@@ -124,6 +124,25 @@ def test_presplit_gemm_planes_epilogue(ops, L, M, N, K, act):
         outs.append(o)
 
 
+def test_gelu_epilogue_tails(ops, L):
+    """The GELU epilogue far outside the fitted range: a pre-activation of -1e6 or -1e30 gives ~0 (the tail term uses the
+    clamped argument: it does not grow with |v|), +1e30 and +inf saturate the planes at their largest value instead of turning into
+    inf - inf = NaN, moderate values keep the 4e-6 bar."""
+    M, N, K = 600, 256, 96
+    a, w = rnd(5, M, K), rnd(6, N, K) / math.sqrt(K)
+    b = rnd(7, N) * 0.5
+    b[0], b[1], b[2], b[3], b[4], b[5] = -1e6, -1e30, 1e30, float("inf"), 40.0, -40.0
+    pl, dec = planes_of(ops, a, ops.F16X3_ACT_SCALE)
+    o = ops.gemm_bf16x3_presplit(pl, ops.pack_weight_f16x3(w.to(dev)), N, bias=b.to(dev), act_out=2, split_out=True)
+    got = decode_planes(o)
+    assert torch.isfinite(got).all()                                               # no NaN, and the planes saturate instead of overflowing
+    assert got[:, 0].abs().max().item() < 1e-6 and got[:, 1].abs().max().item() < 1e-6 and got[:, 5].abs().max().item() < 1e-6
+    top = 65504.0 / o.scale
+    assert (got[:, 2] > 0.99 * top).all() and (got[:, 3] > 0.99 * top).all()
+    ref = gelu64(dec @ w.double().t() + b.double())
+    assert (got[:, 4:] - ref[:, 4:]).abs().max().item() < 4e-6 * 41.0
+
+
 @pytest.mark.parametrize("M,K1,K2,N", [(1000, 256, 256, 256), (16512, 1152, 1152, 1152), (4100, 512, 256, 512), (900, 64, 32, 96), (2048, 768, 0, 1024)])
 def test_two_source_presplit_gemm(ops, L, M, K1, K2, N):
     """1x1 skip convolution / skip_linear on a virtual concatenation of two plane sets, with the f16x3 planes of the result beside it."""
