@@ -26,8 +26,16 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  launch duration, HIP events on the launch stream, over the timed region; peak = 2.5 PFLOP/s (fp16 / bf16 MFMA)
                  for the split modes, 157.3 TFLOP/s (fp32-input MFMA) for --precision fp32; `traffic` = HBM-side bytes per
                  launch from the rocprofv3 --pmc passes committed under profiles/ (read at run time, null if absent).
-  cpu_baseline - the CPU oracle (port of the reference path, fp32) timed on rank 0 at N=1 on a bounded sample (bs=8, two DDIM
-                 timesteps, one of them a UC step, 3 repeats, median) and extrapolated with the reference's exact forward count.
+  cpu_baseline - the CPU oracle (port of the reference path, fp32) timed on rank 0 at N=1 on a bounded sample: the best setting of a
+                 threads x batch sweep (two DDIM timesteps, one of them a UC step; five repeats, best = `value`, median beside it) and
+                 BASELINE.md 4.5's own sample (`sample_bs8`: batch 8, two plain steps + one UC step, three repeats, median), both
+                 extrapolated with the reference's exact forward count.
+  hbm_kernels / mfma_kernels (full record) - one extra untimed job with the library's per-entry-point launch timing on: bytes per launch
+                 and GB/s against 8 TB/s for the HBM-bound kernels (V writers, GroupNorm, sampler), FLOPs per launch and TFLOP/s for
+                 every matrix-core kernel; the configs[2] / [3] / [4] legs carry a `roofline` block of their own dominant kernel, the
+                 configs[0] leg (ADM-64, 10 steps, M=2, batch 4, both estimators) the CPU oracle timed IN FULL beside the GPU time.
+The contract record is printed twice: once (`"preliminary"`) right after the headline measurement, its roofline and the CPU baseline,
+before the side legs run, and again as the LAST line with the legs' summaries.
 """
 import argparse
 import json
