@@ -338,6 +338,13 @@ extern "C" int dua_kernel_profile(int on) {
 extern "C" long dua_kernel_profile_collect(char* buf, size_t cap) {
     struct Sum { long n = 0; double ms = 0, bytes = 0, flops = 0, min_ms = 1e30; };
     std::map<std::string, Sum> sums;
+    {   // the buffer is checked BEFORE the records are consumed: a too-small buffer loses nothing
+        size_t need = 3;
+        std::map<std::string, int> kinds;
+        for (KRec& r : g_krecs) kinds[r.kind] = 1;
+        for (auto& kv : kinds) need += kv.first.size() + 192;
+        if (!buf || cap < need) { dua_set_error("dua_kernel_profile_collect: buffer of %zu bytes, %zu needed", cap, need); return DUA_EINVAL; }
+    }
     for (KRec& r : g_krecs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
@@ -352,12 +359,11 @@ extern "C" long dua_kernel_profile_collect(char* buf, size_t cap) {
     std::string out = "{";
     char line[512];
     for (auto& kv : sums) {
-        snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"min_ms\": %.6f, \"bytes\": %.6e, \"flops\": %.6e}", out.size() > 1 ? ", " : "",
+        snprintf(line, sizeof(line), "%s\"%s\": {\"launches\": %ld, \"ms\": %.6f, \"min_ms\": %.6f, \"bytes\": %.9e, \"flops\": %.9e}", out.size() > 1 ? ", " : "",
                  kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.min_ms, kv.second.bytes, kv.second.flops);
         out += line;
     }
     out += "}";
-    if (!buf || cap < out.size() + 1) { dua_set_error("dua_kernel_profile_collect: buffer of %zu bytes, %zu needed", cap, out.size() + 1); return DUA_EINVAL; }
     std::memcpy(buf, out.c_str(), out.size() + 1);
     return (long)out.size();
 }

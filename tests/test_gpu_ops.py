@@ -760,3 +760,64 @@ def test_epilogue_colsums_feed_groupnorm(ops, N, H, Cin, Cout, x3):
     fused = ops.groupnorm_stats(y, y2)
     plain = ops.groupnorm_stats(y.clone(), y2.clone())
     np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_quantile_workspace_release_and_reuse(ops):
+    """dua_quantile_workspace_release: the two-workgroup kernel's per-(device, stream) counter workspace can be freed - for one
+    stream (before it is destroyed) or for all - and the next launch allocates a fresh, zeroed one: masks stay bit-exact against
+    torch.quantile before and after, on the default stream and on a side stream."""
+    from diffusion_uncertainty_amd import _lib
+    L = _lib.lib()
+    u = (rnd(11, 6, 3, 128, 128) ** 2).to(dev)                           # n = 49152: the two-workgroup kernel's range
+
+    def check():
+        mask, q = ops.quantile_mask(u, 0.9)
+        want_q = torch.quantile(u.flatten(1), 0.9, dim=1)
+        assert torch.equal(q, want_q) and torch.equal(mask.bool(), u > want_q.view(-1, 1, 1, 1))
+
+    check()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        check()
+    side.synchronize()
+    assert L.dua_quantile_workspace_release(side.cuda_stream, 0) == 1    # that stream's workspace only
+    assert L.dua_quantile_workspace_release(side.cuda_stream, 0) == 0
+    check()
+    assert L.dua_quantile_workspace_release(None, 1) >= 1                # everything of this device
+    check()
+    with torch.cuda.stream(side):
+        check()
+    side.synchronize()
+
+
+def test_kernel_profile_facility(ops):
+    """dua_kernel_profile / dua_kernel_profile_collect (bench.py's hbm_kernels / leg rooflines): off by default (nothing recorded), on:
+    one record per instrumented launch with the launch's ALGORITHMIC bytes, summed per kind, as JSON; a too-small buffer is an error."""
+    import ctypes
+    import json
+
+    from diffusion_uncertainty_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(1 << 14)
+    L.dua_kernel_profile_collect(buf, len(buf))
+    n = 3 * 64 * 64 * 8
+    a, b = rnd(1, n).to(dev), rnd(2, n).to(dev)
+    ops.axpby(a, b, 1.0, 2.0)
+    assert L.dua_kernel_profile_collect(buf, len(buf)) == 2 and buf.value == b"{}"            # off: nothing
+    assert L.dua_kernel_profile(1) == 0
+    try:
+        for _ in range(3):
+            ops.axpby(a, b, 1.0, 2.0)
+        ops.to_uint8(a.reshape(8, 3, 64, 64))
+        torch.cuda.synchronize()
+    finally:
+        assert L.dua_kernel_profile(0) == 1
+    small = ctypes.create_string_buffer(8)
+    assert L.dua_kernel_profile_collect(small, len(small)) == -1 and b"buffer" in L.dua_last_error()        # (nothing is lost: checked first)
+    ops.axpby(a, b, 1.0, 2.0)                                              # off again: not recorded
+    ln = L.dua_kernel_profile_collect(buf, len(buf))
+    rec = json.loads(buf.value.decode())
+    assert ln == len(buf.value) and set(rec) == {"k_axpby", "k_to_uint8"}
+    assert rec["k_axpby"]["launches"] == 3 and rec["k_axpby"]["bytes"] == 3 * 12.0 * n and rec["k_axpby"]["flops"] == 0
+    assert rec["k_to_uint8"]["launches"] == 1 and rec["k_to_uint8"]["bytes"] == 5.0 * n
+    assert 0 < rec["k_axpby"]["min_ms"] <= rec["k_axpby"]["ms"] < 50
