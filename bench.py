@@ -406,7 +406,7 @@ def other_config_uvit(dev, a):
     # the leg's roofline: one more job on ONE stream (concurrent chunks would stretch each other's event brackets) with the library's launch
     # timing on - the dominant kernel of this configuration is the one-tap GEMM k_hgemm (linears = 96.7 % of U-ViT-H/2's FLOPs)
     roof = hbm = mfma = None
-    if not a.no_profile:
+    if not getattr(a, "no_profile", False):
         try:
             uvit.stream_split = 1
             kp, wall = kernel_profile(lambda: job(50, 40, 10, 0), torch.cuda.synchronize)
@@ -475,7 +475,7 @@ def other_config_sd(dev, a):
     # bracketed by HIP events (ops.PROFILE) and the library's launch timing on for the rest.  At the CFG batch of 2 an eager forward is
     # launch-bound, so the brackets include the host's launch gaps: a LOWER bound of the kernels' own rate
     roof = mfma = hbm = None
-    if not a.no_profile:
+    if not getattr(a, "no_profile", False):
         from diffusion_uncertainty_amd import ops
         try:
             unet.enable_hip_graph(False)

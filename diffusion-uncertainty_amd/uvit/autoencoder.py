@@ -11,7 +11,7 @@ The encoder modules only hold parameters (encoding is not on the path).  No CPU 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, range_guard
 
 
 def Normalize(in_channels, num_groups=32):
@@ -158,6 +158,9 @@ class FrozenAutoencoderKL(nn.Module):
         self.embed_dim = embed_dim
         self.scale_factor = scale_factor
         self.precision = "fp32"          # or "f16x3" (fp32-equivalent fp16 hi + lo split) or "bf16x3"
+        self.auto_range_check = True     # f16x3: the first decode after a weight load runs with the range counters on (range_guard.py)
+        self._range_checked = False
+        self._range_probe = None
         self._packed = {}
         if pretrained_path is not None:
             m, u = self.load_state_dict(torch.load(pretrained_path, map_location="cpu"))
@@ -167,10 +170,12 @@ class FrozenAutoencoderKL(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = {}
+        self._range_checked = False
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = {}
+        self._range_checked = False
         return super().load_state_dict(*a, **k)
 
     # ---- precision-aware FLOP carriers (same contract as guided_diffusion.unet_openai._Ctx)
@@ -241,7 +246,13 @@ class FrozenAutoencoderKL(nn.Module):
         """uvit/autoencoder.py:446-450 + Decoder.forward :380-407."""
         if not z.is_cuda:
             raise RuntimeError("FrozenAutoencoderKL.decode: the HIP path needs GPU tensors; this package has no CPU fallback")
+        if range_guard.due(self):
+            return range_guard.checked_forward(self, lambda: self._decode(z))
+        return self._decode(z)
+
+    def _decode(self, z):
         d = self.decoder
+        probe = self._range_probe
         B, Cz, H, W = z.shape
         zz = ops.nchw_to_nhwc(z.float().contiguous(), 4 if Cz <= 4 else Cz)                       # NHWC (padded to 4)
         w = self._pack("pq", lambda: torch.nn.functional.pad(self.post_quant_conv.weight.detach().reshape(self.post_quant_conv.out_channels, Cz),
@@ -255,12 +266,16 @@ class FrozenAutoencoderKL(nn.Module):
         h = d.mid.block_1.run(self, h)
         h = d.mid.attn_1.run(self, h)
         h = d.mid.block_2.run(self, h)
+        if probe is not None:
+            probe.note("decoder.mid", d.mid.block_1)
         for i_level in reversed(range(d.num_resolutions)):
             for blk in d.up[i_level].block:
                 h = blk.run(self, h)
             if i_level != 0:
                 up = d.up[i_level].upsample.conv                                                 # nearest x2 (:38)
                 h = self.conv3x3(self.raw_planes(h, resample=1), up, up.out_channels)
+            if probe is not None:
+                probe.note(f"decoder.up.{i_level}", d.up[i_level].block[0])
         st = ops.groupnorm_stats(h, eps=1e-6)
         h = ops.groupnorm_apply(h, st, d.norm_out.weight, d.norm_out.bias, act=1, split=self.split_acts)
         return self.conv3x3(h, d.conv_out, d.conv_out.out_channels, nchw_out=True)

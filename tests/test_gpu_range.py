@@ -194,6 +194,21 @@ def test_first_forward_is_range_checked_once(ops):
     with pytest.warns(F16RangeWarning, match=r"in_blocks\.1 \[Block\]"):
         u(xl, t, y)
     assert u.range_report["saturated"] > 0
+    # KL-VAE decoder: same contract on decode()
+    from diffusion_uncertainty_amd.uvit.autoencoder import FrozenAutoencoderKL
+    tiny = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    v = randomize_parameters_(FrozenAutoencoderKL(tiny, 4), 9).to(dev)
+    v.precision = "f16x3"
+    z = rnd(9, 2, 4, 16, 16).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", F16RangeWarning)
+        img = v.decode(z)
+    assert v._range_checked and v.range_report["saturated"] == 0 and torch.equal(v.decode(z), img)
+    with torch.no_grad():
+        v.decoder.norm_out.weight.mul_(50000.0)
+    v.load_state_dict(v.state_dict())
+    with pytest.warns(F16RangeWarning, match="FrozenAutoencoderKL"):
+        v.decode(z)
 
 
 def test_first_forward_warns_on_a_saturating_groupnorm(ops):
