@@ -221,3 +221,48 @@ def test_generate_and_save_writes_the_reference_files(tmp_path, model_type, imag
     s, out = _direct(cli, args, n)
     assert torch.equal(s.timesteps.cpu(), t)
     assert torch.equal(out["gen_images"], img) and torch.equal(out["score"], score) and torch.equal(out["uncertainty"], unc)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_subprocess(tmp_path):
+    """The caller as a user starts it: `python scripts/generate_dataset_score_uncertainty_imagenet.py ...` in a fresh process (argument
+    parsing, args.yaml, the one-GPU path of main(), the output files), ADM-64, 3 images, 3 steps."""
+    import subprocess
+
+    import yaml
+    dest = tmp_path / "out"
+    cmd = [sys.executable, SCRIPT, "--image-size", "64", "--scheduler-type", "uncertainty_zigzag_centered", "--model-type", "unet", "--start-index", "1",
+           "--num-samples", "3", "--batch-size", "2", "--generation-steps", "3", "-M", "1", "--start-step-uc", "1", "--num-steps-uc", "2",
+           "--random-weights", "--synthetic", "--measure-time", "--dest", str(dest)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Done:" in r.stdout and "images/s" in r.stdout
+    a = yaml.safe_load(open(dest / "args.yaml"))
+    assert a["dataset"] == "imagenet64" and a["M"] == 1 and a["num_samples"] == 3
+    img = torch.load(dest / "gen_images_0.pth")
+    unc = torch.load(dest / "uncertainty_uncertainty_zigzag_centered_0.pth")
+    assert img.shape == (3, 3, 64, 64) and img.dtype == torch.uint8 and unc.shape == (3, 2, 3, 64, 64) and torch.isfinite(unc).all()
+    # a run without --synthetic and without the starting-point files fails loudly, naming the file
+    r = subprocess.run([c for c in cmd if c != "--synthetic"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, DIFFUSION_UNCERTAINTY_ROOT=str(tmp_path / "empty_root")))
+    assert r.returncode != 0 and "y.pth" in r.stderr and "starting points not found" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("update", ["posterior", "gradient"])
+def test_sd_cli_end_to_end_subprocess(tmp_path, update):
+    """The second caller (reference scripts/generate_with_uncertainty_threshold_stable_diffusion.py: percentile-thresholded guidance on the
+    SD-1.5 latent UNet) in a fresh process, both updates - gradient mode is the script's default, as upstream (:16-17,88): 4 PLMS steps,
+    1 guided step, M = 2; the saved latents are finite and the two updates differ."""
+    import subprocess
+    script = os.path.join(ROOT, "scripts", "generate_with_uncertainty_threshold_stable_diffusion.py")
+    out = tmp_path / f"latents_{update}.pth"
+    cmd = [sys.executable, script, "--num-steps", "4", "--num-steps-threshold", "1", "-M", "2", "--repeats", "0", "--no-graph", "--out", str(out)]
+    if update == "posterior":
+        cmd.append("--use-posterior")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"{update} update" in r.stdout
+    lat = torch.load(out)
+    assert lat.shape == (1, 4, 64, 64) and torch.isfinite(lat).all() and lat.abs().max() > 0
