@@ -107,6 +107,20 @@ def pmc_traffic(precision):
     return best
 
 
+def power_capped_ceiling():
+    """What BARE fp16 MFMAs of the kernels' shape sustain under the part's power cap on random operands (scripts/diag/mfma_power_ceiling.hip,
+    measured once per round and kept under profiles/): the attainable ceiling of an MFMA-bound kernel, below the datasheet peak the
+    contract's `frac` divides by.  None when no such record is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_power_ceiling.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            return float(d["f16x3_mix_sustained_tflops"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None
+
+
 class ConvProfile:
     def __init__(self):
         self.items = []
@@ -162,6 +176,12 @@ class ConvProfile:
                  traffic=(tr[0] if tr else None), traffic_source=(tr[1] if tr else None), traffic_by_kernel=((tr[2] or None) if tr else None),
                  kernel=kernel, launches=cs["launches"],
                  flops_per_launch=cs["flops_per_launch"], ms_per_launch=round(cs["ms_per_launch"], 4))
+        cap = power_capped_ceiling() if precision != "fp32" else None
+        if mult and cap:
+            # informational: the executed matrix-core rate against what bare MFMAs sustain under the 1 400 W cap (not the contract's frac)
+            r.update(power_capped_mfma_ceiling=dict(value=cap[0], unit="TFLOP/s executed", source=cap[1], executed_over_ceiling=round(cs["mfma_tflops"] / cap[0], 4),
+                                                   note="bare v_mfma_f32_16x16x32_f16 on random operands, no LDS / memory traffic, at the part's power cap: 0.79 of the datasheet "
+                                                        "peak; the headline job runs at 1 359 W of the 1 400 W cap (profiles/r06_power_trace_headline_job.txt)"))
         if mult:
             eff = cs["mfma_tflops"] / cs["tflops"]                 # executed matrix-core products per algorithmic product (measured mix)
             r.update(executed_mfma_tflops=round(cs["mfma_tflops"], 1), executed_frac=round(cs["mfma_tflops"] / peak, 4),
