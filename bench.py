@@ -1010,21 +1010,22 @@ def short_line(line, legs_path):
     r = line.get("roofline")
     if r:
         out["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches", "flops_per_launch",
-                                                  "ms_per_launch", "executed_frac", "executed_products_per_algorithmic_product")}
+                                                  "ms_per_launch", "executed_frac")}
+        out["roofline"]["flops_per_launch"] = round(out["roofline"]["flops_per_launch"] or 0.0)
         out["roofline"]["kernel"] = r["kernel"].split(":")[0]
     c = line.get("cpu_baseline")
     if c:
         out["cpu_baseline"] = {k: c.get(k) for k in ("value", "value_at_median", "unit", "cores", "kind", "gpu_over_cpu_same_forward_count")}
-        out["cpu_baseline"]["sample"] = c["sample"].split(":")[0] + " (full text in the legs file)"
+        out["cpu_baseline"]["sample"] = c["sample"].split(":")[0].replace(" at the sweep's best setting", "") + " (full text: legs file)"
     hk = [r for r in (line.get("hbm_kernels") or []) if "kernel" in r]
     if hk:
-        out["hbm_kernels_gbs"] = {r["kernel"].split(" (")[0][:24]: r["achieved"] for r in hk[:6]}
+        out["hbm_kernels_gbs"] = {r["kernel"].split(" (")[0][:20]: r["achieved"] for r in hk[:4]}
     ch = line.get("checked")
     if ch:
         out["checked"] = {k: ch.get(k) for k in ("ok", "max_abs_diff", "bit_identical", "of", "error") if k in ch}
     for k, name in (("other_precision_modes", "precision"), ("other_configs", "config")):
         if line.get(k):
-            out[k + "_summary"] = {str(o.get(name, "?"))[:28]: o.get("value", o.get("error")) for o in line[k]}
+            out[k + "_summary"] = {str(o.get(name, "?")).replace("BASELINE ", "")[:22]: o.get("value", o.get("error")) for o in line[k]}
     out["full_record"] = legs_path and os.path.relpath(legs_path, ROOT)
     return out
 
