@@ -186,6 +186,11 @@ def _direct(cli, args, n):
         model = UViTAE(uvit, ae).to(device)
         scheduler = load_uvit_scheduler()
     s = get_uncertainty_scheduler(args, y.to(device), model, scheduler)
+    if args.noise == "device":                                   # the script's --noise device branch: Philox noise / dropout masks drawn in HBM
+        from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise
+        s.noise_source = DeviceNoise(seed=args.seed)
+        if args.model_type == "unet":
+            model.dropout_mask_source = DeviceNoise(seed=args.seed + 1000).dropout_mask
     s.set_timesteps(args.generation_steps)
     if args.model_type == "unet":
         out = generate_samples_model_scheduler_class_conditioned_from_tensor(X_T, y, args.batch_size, device, model, s)
@@ -202,7 +207,8 @@ def test_generate_and_save_writes_the_reference_files(tmp_path, model_type, imag
     n, steps, window = 4, 4, 2
     args = cli.parse_args(["--image-size", str(image_size), "--scheduler-type", scheduler_type, "--model-type", model_type,
                            "--start-index", "0", "--num-samples", str(n), "--batch-size", "3", "--generation-steps", str(steps), "-M", "2",
-                           "--start-step-uc", "1", "--num-steps-uc", str(window), "--random-weights", "--synthetic"])
+                           "--start-step-uc", "1", "--num-steps-uc", str(window), "--random-weights", "--synthetic"]
+                          + (["--noise", "device"] if scheduler_type == "mc_dropout" else []))       # (host dropout tapes of ADM-64: 30 s on the CPU)
     cli.generate_and_save(0, args, n, tmp_path)
     names = sorted(os.listdir(tmp_path))
     assert names == sorted(["timestep_0.pth", "timesteps.pth", "score_0.pth", "score.pth", f"uncertainty_{scheduler_type}_0.pth",
