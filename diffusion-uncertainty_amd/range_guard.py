@@ -8,7 +8,9 @@ executes with the library's counters on (``dua_range_check``), block by block, a
 once as an ``F16RangeWarning`` naming the blocks and their layer classes; the counters are then switched off again (their
 cost when on is ~0.6 % of a forward, and one forward in hundreds pays it).  The checked forward computes the same bits as an
 unchecked one.  ``model.auto_range_check = False`` opts out; a caller that has the counters on itself (``--check-range``)
-is left alone.
+is left alone.  ``model.on_range_violation`` chooses what a non-zero count does: ``"warn"`` (default), ``"raise"``
+(``F16RangeError``: a batch job that must not produce silently degraded maps) or ``"fp32"`` (warn, switch the model to the
+fp32 engines - 2.5x slower, no plane scales to leave - and re-run this forward there).
 """
 import warnings
 
@@ -19,6 +21,10 @@ from . import ops
 
 class F16RangeWarning(RuntimeWarning):
     """Operands of an f16x3 forward left fp16's range after their static scale: the run is not fp32-equivalent."""
+
+
+class F16RangeError(RuntimeError):
+    """Raised instead of the warning when ``model.on_range_violation == "raise"``."""
 
 
 class RangeProbe:
@@ -57,7 +63,16 @@ def checked_forward(model, run):
     if sat:
         worst = sorted((r for r in probe.rows if r[2]), key=lambda r: -r[2])[:6]
         where = ", ".join(f"{n} [{k}]: {s}" for n, k, s, _ in worst)
-        warnings.warn(f"{type(model).__name__} (precision f16x3): {sat} operand(s) left fp16's range after the static plane scale in the "
-                      f"first forward after the weights were loaded ({where}); the fp32-equivalent claim does NOT hold for these weights - "
-                      f"use precision 'fp32'", F16RangeWarning, stacklevel=3)
+        policy = getattr(model, "on_range_violation", "warn")
+        msg = (f"{type(model).__name__} (precision f16x3): {sat} operand(s) left fp16's range after the static plane scale in the "
+               f"first forward after the weights were loaded ({where}); the fp32-equivalent claim does NOT hold for these weights")
+        if policy == "raise":
+            model._range_checked = False                                # stays armed: every attempt on these weights raises
+            raise F16RangeError(msg + " - use precision 'fp32'")
+        if policy == "fp32":
+            warnings.warn(msg + " - switching this model to precision 'fp32' (on_range_violation = 'fp32') and re-running the forward there",
+                          F16RangeWarning, stacklevel=3)
+            model.precision = "fp32"
+            return run()
+        warnings.warn(msg + " - use precision 'fp32'", F16RangeWarning, stacklevel=3)
     return out

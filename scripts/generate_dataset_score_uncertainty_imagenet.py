@@ -74,6 +74,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
             randomize_parameters_(unet, seed=args.image_size)
         unet.eval().to(device)
         unet.precision = args.precision
+        unet.on_range_violation = args.on_range_violation
         unet.split_k = args.split_k == "on" or (args.split_k == "auto" and args.batch_size <= 32)
         unet.winograd = args.winograd == "on"
         if args.hip_graph and args.scheduler_type != "mc_dropout":
@@ -87,6 +88,7 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         if not ckpt:
             randomize_parameters_(ae, seed=9)
         uvit.precision = "f16x3" if args.precision == "f16w" else args.precision             # f16w is a 3x3-conv mode: ADM only
+        uvit.on_range_violation = ae.on_range_violation = args.on_range_violation
         uvit.split_k = args.split_k != "off"                                                 # (tail split of under-filled GEMM rounds)
         ae.precision = args.precision if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch)
         model = UViTAE(uvit, ae).to(device)
@@ -169,6 +171,9 @@ def parse_args(argv=None):
     p.add_argument("--check-range", action="store_true", dest="check_range",
                    help="f16x3: count the operands that leave fp16's range after their static power-of-two scale (dua_range_check); "
                         "a non-zero saturation count means the run is not fp32-equivalent")
+    p.add_argument("--on-range-violation", choices=["warn", "raise", "fp32"], default="warn", dest="on_range_violation",
+                   help="f16x3: what happens when the first forward after the weight load finds operands beyond fp16's range after their static "
+                        "scale (the default-on range check): warn, raise, or switch the denoiser to --precision fp32 and go on")
     p.add_argument("--precision", choices=["f16x3", "fp32", "f16w", "bf16x3"], default="f16x3",
                    help="f16x3 (default): the fp32-equivalent split - trajectories match the reference CPU path like the exact fp32 mode's; "
                         "fp32: exact fp32 MFMA; bf16x3: split-bf16 (16 operand bits); f16w: one fp16 product per tap in the Winograd convs (the "

@@ -233,6 +233,28 @@ def test_first_forward_warns_on_a_saturating_groupnorm(ops):
         m(x, t, y=y)                                                   # once per weight load
 
 
+def test_range_violation_policies(ops):
+    """model.on_range_violation: "raise" turns the first-forward finding into an F16RangeError; "fp32" warns, switches the model to the
+    fp32 engines and returns THEIR result for this forward (and every later one)."""
+    from diffusion_uncertainty_amd.range_guard import F16RangeError, F16RangeWarning
+    from test_gpu_models import TINY_ADM, build_adm
+    x = rnd(7, 3, 3, 16, 16).to(dev)
+    t, y = torch.tensor([900, 400, 20]).to(dev), torch.tensor([1, 5, 9]).to(dev)
+    m, _ = build_adm(dict(TINY_ADM), 5)
+    with torch.no_grad():
+        m.input_blocks[1][0].in_layers[0].weight.mul_(2000.0)
+    m.precision = "fp32"
+    want = m(x, t, y=y)
+    m.precision, m.on_range_violation = "f16x3", "raise"
+    with pytest.raises(F16RangeError, match=r"input_blocks\.1"):
+        m(x, t, y=y)
+    m.invalidate_packed_weights()                                  # re-arm the check
+    m.on_range_violation = "fp32"
+    with pytest.warns(F16RangeWarning, match="switching this model to precision 'fp32'"):
+        got = m(x, t, y=y)
+    assert m.precision == "fp32" and torch.equal(got, want) and torch.equal(m(x, t, y=y), want) and not ops.range_check_is_on()
+
+
 def test_default_cli_warns_on_saturating_weights(tmp_path, monkeypatch):
     """The caller script with its default flags (no --check-range): a model whose first GroupNorm gamma is x2000 triggers the warning."""
     import importlib.util
