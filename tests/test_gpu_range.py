@@ -246,9 +246,9 @@ def test_range_violation_policies(ops):
     m.precision = "fp32"
     want = m(x, t, y=y)
     m.precision, m.on_range_violation = "f16x3", "raise"
-    with pytest.raises(F16RangeError, match=r"input_blocks\.1"):
-        m(x, t, y=y)
-    m.invalidate_packed_weights()                                  # re-arm the check
+    for _ in range(2):                                             # stays armed: not a one-shot
+        with pytest.raises(F16RangeError, match=r"input_blocks\.1"):
+            m(x, t, y=y)
     m.on_range_violation = "fp32"
     with pytest.warns(F16RangeWarning, match="switching this model to precision 'fp32'"):
         got = m(x, t, y=y)
