@@ -7,7 +7,7 @@ Same flags and defaults as the reference's ``parse_args`` (:147-196) and the sam
 ``X_T[start + r*n : start + (r+1)*n]`` read from ``DIFFUSION_STARTING_POINTS/imagenet{size}{suffix}/{X_T,y}.pth``, per-rank
 output files ``timestep_{rank}.pth`` / ``uncertainty_{scheduler}_{rank}.pth`` / ``gen_images_{rank}.pth`` (+ ``args.yaml``), :90-93.
 Deviations: the score maps go to ``score_{rank}.pth`` (the reference's shared ``score.pth`` is a last-writer-wins race,
-:91; rank 0 also writes ``score.pth`` and ``timesteps.pth`` under the shared names); missing starting-point files are an
+:91; rank 0 also provides ``score.pth`` and ``timesteps.pth``, the shared names, as links to its own files); missing starting-point files are an
 ERROR unless ``--synthetic`` asks for generated ones; ``--random-weights`` runs without checkpoints; ``--precision`` and
 ``--noise`` select the engine modes.  The import block below names the same modules and symbols as the reference's :14-27.
 """
@@ -126,9 +126,15 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
     dest = Path(dest)
     torch.save(uc_scheduler.timesteps, dest / f"timestep_{gpu_idx}.pth")
     torch.save(results["score"], dest / f"score_{gpu_idx}.pth")
-    if gpu_idx == 0:
-        torch.save(uc_scheduler.timesteps, dest / "timesteps.pth")
-        torch.save(results["score"], dest / "score.pth")
+    if gpu_idx == 0:                    # the reference's shared names, as links to rank 0's files (no second copy of the score maps)
+        for shared, own in (("timesteps.pth", f"timestep_{gpu_idx}.pth"), ("score.pth", f"score_{gpu_idx}.pth")):
+            link = dest / shared
+            if link.is_symlink() or link.exists():
+                link.unlink()
+            try:
+                link.symlink_to(own)
+            except OSError:             # a file system without symlinks: a plain second file
+                torch.save(uc_scheduler.timesteps if shared.startswith("timesteps") else results["score"], link)
     torch.save(results["uncertainty"], dest / f"uncertainty_{args.scheduler_type}_{gpu_idx}.pth")
     torch.save(results["gen_images"], dest / f"gen_images_{gpu_idx}.pth")
 
