@@ -68,4 +68,29 @@ def init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=True, dropout
 from .uvit.load_pretrained_models import load_autoencoder_uvit, load_uvit, load_uvit_scheduler  # noqa: E402,F401
 
 
+def instantiate_model_scheduler(args, load_checkpoint=True, device="cuda"):
+    """(model, base scheduler) by dataset name - or by the ``args.yaml`` of ``args.dataset_folders[0]`` when given a Namespace
+    (reference init_model.py:222-262, a ``singledispatch`` pair; the CIFAR-10 branch is the diffusers UNet2DModel path: not built)."""
+    if not isinstance(args, str):
+        import os
+
+        import yaml
+        with open(os.path.join(str(args.dataset_folders[0]), "args.yaml")) as f:
+            args = yaml.safe_load(f)["dataset"]
+    dataset_name = args
+    if dataset_name == "imagenet64":
+        return init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=load_checkpoint)
+    if dataset_name == "imagenet128":
+        return init_guided_diffusion_imagenet128_and_scheduler(load_checkpoint=load_checkpoint)
+    if dataset_name in ("imagenet256", "imagenet512"):
+        size = int(dataset_name[len("imagenet"):])
+        return (UViTAE(load_uvit(size, device, load_checkpoint=load_checkpoint), load_autoencoder_uvit(device, load_checkpoint=load_checkpoint)),
+                load_uvit_scheduler())
+    if dataset_name == "cifar10":
+        raise NotImplementedError("cifar10: the diffusers UNet2DModel path is outside the accelerated hot path (SURVEY 8f)")
+    raise ValueError(f"invalid dataset name {dataset_name}")
+
+
+init_model_scheduler = instantiate_model_scheduler
+
 __all__ = ["UNetModel", "UViT", "UViTAE", "DDPMScheduler"]

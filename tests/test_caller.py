@@ -5,6 +5,7 @@ import argparse
 import ast
 import importlib
 import importlib.util
+import json
 import os
 import sys
 
@@ -272,3 +273,104 @@ def test_sd_cli_end_to_end_subprocess(tmp_path, update):
     assert f"{update} update" in r.stdout
     lat = torch.load(out)
     assert lat.shape == (1, 4, 64, 64) and torch.isfinite(lat).all() and lat.abs().max() > 0
+
+
+def test_threshold_cli_arguments_and_folder_checks(tmp_path):
+    """scripts/compute_threshold_pixel_wise.py (reference :21-40,167-186): flags and defaults, and the folder validation that runs before
+    any GPU work - a missing args.yaml, folders that disagree on the scheduler type, a folder without uncertainty files."""
+    import yaml
+    spec = importlib.util.spec_from_file_location("thr_cli", os.path.join(ROOT, "scripts", "compute_threshold_pixel_wise.py"))
+    thr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(thr)
+    a = thr.parse_args(["--dataset-folders", "x", "y"])
+    assert (a.perc, a.batch_size, a.on_cpu, a.dataset_folders) == (0.15, 128, False, ["x", "y"])
+    with pytest.raises(AssertionError):
+        thr.parse_args([])
+    f1, f2 = tmp_path / "a", tmp_path / "b"
+    for f, st in ((f1, "uncertainty_zigzag_centered"), (f2, "mc_dropout")):
+        f.mkdir()
+        yaml.safe_dump({"dataset": "imagenet64", "scheduler_type": st}, open(f / "args.yaml", "w"))
+        torch.save(torch.zeros(1), f / "gen_images_0.pth")
+        torch.save(torch.zeros(1), f / f"uncertainty_{st}_0.pth")
+    thr.assert_validity_folders_(argparse.Namespace(dataset_folders=[f1]))
+    with pytest.raises(AssertionError, match="scheduler types do not match"):
+        thr.assert_validity_folders_(argparse.Namespace(dataset_folders=[f1, f2]))
+    (f1 / "uncertainty_uncertainty_zigzag_centered_0.pth").unlink()
+    with pytest.raises(AssertionError, match="no uncertainty files"):
+        thr.assert_validity_folders_(argparse.Namespace(dataset_folders=[f1]))
+    (f2 / "args.yaml").unlink()
+    with pytest.raises(AssertionError, match="args.yaml not found"):
+        thr.assert_validity_folders_(argparse.Namespace(dataset_folders=[f2]))
+
+
+def test_guided_generation_cli_arguments():
+    """scripts/generate_images_with_uncertainty_threshold.py: the reference's flags (:85-109) with its defaults - except --guidance-type,
+    whose upstream default (gradient) is not built - and config files with terminal arguments taking priority (:113-118)."""
+    spec = importlib.util.spec_from_file_location("gen_thr_cli", os.path.join(ROOT, "scripts", "generate_images_with_uncertainty_threshold.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    a = g.parse_args(["--dataset", "imagenet64"])
+    assert (a.num_samples, a.batch_size, a.scheduler_type, a.num_steps, a.start_step_guidance, a.num_steps_guidance, a.start_index, a.seed, a.percentile,
+            a.use_percentile, a.skip_ddim, a.threshold_type, a.lambda_update) == (1000, 128, "uncertainty", 20, 0, 20, 0, 491, 0.95, False, False, "higher", 0.1)
+    assert a.guidance_type == "posterior"
+    b = g.parse_args(["--config", "imagenet128_0_95", "--num-samples", "7"])
+    assert (b.dataset_name, b.num_samples, b.scheduler_type, b.num_steps_guidance, b.use_percentile, b.seed) == ("imagenet128", 7, "uncertainty_centered", 3, True, 853983298)
+    with pytest.raises(AssertionError):
+        g.parse_args([])
+
+
+@pytest.mark.gpu
+def test_maps_to_thresholds_to_guided_sampling_cli_chain(tmp_path, monkeypatch):
+    """SURVEY 8f rank 2 end to end through the three CLIs, ADM-64 with seeded random weights and synthetic starting points: (1) a dataset of
+    104 uncertainty maps (4 steps, UC window = all 4), (2) pixel-wise thresholds at perc 0.5 - equal, bit for bit, to torch's argsort +
+    gather on the fp16 maps (the reference's arithmetic, :143-165), (3) posterior-guided sampling on 16 // 4 = 4 timesteps with those
+    thresholds: the guided images differ from the plain DDIM images of the same starting points, both are valid uint8 batches, and the
+    run with --use-percentile works without the threshold files."""
+    import subprocess
+
+    import yaml
+    root = tmp_path / "root"
+    env = dict(os.environ, DIFFUSION_UNCERTAINTY_ROOT=str(root))
+    ds = tmp_path / "dataset"
+    gen = [sys.executable, SCRIPT, "--image-size", "64", "--scheduler-type", "uncertainty_zigzag_centered", "--model-type", "unet", "--start-index", "0",
+           "--num-samples", "104", "--batch-size", "52", "--generation-steps", "4", "-M", "1", "--start-step-uc", "0", "--num-steps-uc", "4",
+           "--random-weights", "--synthetic", "--noise", "device", "--dest", str(ds)]
+    r = subprocess.run(gen, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    thr_cmd = [sys.executable, os.path.join(ROOT, "scripts", "compute_threshold_pixel_wise.py"), "--dataset-folders", str(ds), "--perc", "0.5"]
+    r = subprocess.run(thr_cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    thr_file = root / "results" / "thresholds" / "imagenet64" / "thresholds_uncertainty_zigzag_centered_perc=0.5.pth"
+    cfg_file = root / "results" / "thresholds" / "imagenet64" / "config_uncertainty_zigzag_centered_perc=0.5.yaml"
+    thr = torch.load(thr_file)
+    u = torch.load(ds / "uncertainty_uncertainty_zigzag_centered_0.pth").half()
+    want = torch.stack([u[:, i].gather(0, u[:, i].argsort(dim=0)[int(104 * 0.5)].unsqueeze(0)).squeeze(0) for i in range(4)])
+    assert thr.dtype == torch.float16 and thr.shape == (4, 3, 64, 64) and torch.equal(thr.view(torch.int16), want.view(torch.int16))
+    cfg = yaml.safe_load(open(cfg_file))
+    assert cfg["perc"] == 0.5 and cfg["dataset_config"]["dataset"] == "imagenet64" and cfg["dataset_config"]["generation_steps"] == 4
+    out = tmp_path / "guided"
+    g_cmd = [sys.executable, os.path.join(ROOT, "scripts", "generate_images_with_uncertainty_threshold.py"), "--dataset", "imagenet64", "--scheduler-type",
+             "uncertainty_zigzag_centered", "--percentile", "0.5", "--num-samples", "6", "--batch-size", "4", "--num-steps", "16", "--start-step-guidance", "1",
+             "--num-steps-guidance", "1", "--random-weights", "--synthetic", "--dest", str(out)]
+    r = subprocess.run(g_cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = [p for p in (out / "imagenet64_uncertainty_zigzag_centered_perc=0.5").iterdir()][0]
+    plain, guided = torch.load(run / "gen_images.pth"), torch.load(run / "gen_images_threshold.pth")
+    assert plain.shape == guided.shape == (6, 3, 64, 64) and plain.dtype == guided.dtype == torch.uint8
+    # 'higher' touches the pixels whose Monte-Carlo variance exceeds the dataset's threshold, 'lower' the others: between them every pixel
+    # of the guided window is revised once, so at least one of the two runs must leave the plain trajectory (which one is data)
+    r = subprocess.run(g_cmd + ["--threshold-type", "lower", "--dest", str(tmp_path / "guided_lower")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run_l = [p for p in (tmp_path / "guided_lower" / "imagenet64_uncertainty_zigzag_centered_perc=0.5").iterdir()][0]
+    guided_l = torch.load(run_l / "gen_images_threshold.pth")
+    assert torch.equal(torch.load(run_l / "gen_images.pth"), plain)                              # same plain run (same seed, same starting points)
+    changed = [(plain != g_).float().mean().item() for g_ in (guided, guided_l)]
+    print("fraction of bytes changed by the guided window: higher", changed[0], "lower", changed[1])
+    assert max(changed) > 0.01 and not torch.equal(guided, guided_l)
+    rec = json.load(open(out / "results.json"))
+    assert rec[-1]["guidance_type"] == "posterior" and rec[-1]["fid_score"] is None and rec[-1]["use_percentile"] is False
+    r = subprocess.run(g_cmd + ["--use-percentile", "--skip-save"], capture_output=True, text=True, timeout=900,
+                       env=dict(env, DIFFUSION_UNCERTAINTY_ROOT=str(tmp_path / "no_thresholds_here")))
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(g_cmd + ["--guidance-type", "gradient"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0 and "NotImplementedError" in r.stderr
