@@ -775,27 +775,9 @@ def main(argv=None):
 
     ranks_seen = [world]
 
-    class PlainDDIM:
-        """The scheduler's plain DDIM steps behind an object that is NOT a SchedulerUncertaintyMixin (a runtime-checkable Protocol: the
-        two window attributes must be absent): what the reference times as `time_normal` (measure_times_imagenet.py:109-118 builds a
-        diffusers DDIMScheduler from the same config; the driver then collects no uncertainty maps).  The wrapped scheduler's window
-        is empty, so every step() is the plain update (k_ddim_step)."""
-
-        def __init__(self, inner):
-            self._inner = inner
-            self.config, self.timesteps = inner.config, inner.timesteps
-
-        prompt_embeds = property(lambda self: self._inner.prompt_embeds, lambda self, v: setattr(self._inner, "prompt_embeds", v))
-
-        def set_timesteps(self, *a_, **k_):
-            self._inner.set_timesteps(*a_, **k_)
-            self.timesteps = self._inner.timesteps
-
-        def scale_model_input(self, x, t):
-            return self._inner.scale_model_input(x, t)
-
-        def step(self, *a_, **k_):
-            return self._inner.step(*a_, **k_)
+    # what the reference times as `time_normal` (measure_times_imagenet.py:109-118): the scheduler with an EMPTY window behind a wrapper
+    # that is not a SchedulerUncertaintyMixin, so the driver collects no maps and every step() is the plain update (k_ddim_step)
+    from diffusion_uncertainty_amd.schedulers_uncertainty.plain import PlainScheduler as PlainDDIM
 
     def job(n_steps, start, num, seed, M=None, faithful=None, plain=False):
         s = make_scheduler(model, base, a.M if M is None else M, start, num, a.num_zigzag, seed,

@@ -41,11 +41,9 @@ def index_range(gpu_idx, args, num_samples):
     return slice(args.start_index + gpu_idx * num_samples, args.start_index + (gpu_idx + 1) * num_samples)
 
 
-@torch.no_grad()
-def generate_and_save(gpu_idx, args, num_samples, dest):
-    seed_everything(args.seed)
-    device = torch.device("cuda", gpu_idx)
-    torch.cuda.set_device(device)
+def load_starting_points(gpu_idx, args, num_samples):
+    """The rank's X_T / y (reference :45-57): the files under DIFFUSION_STARTING_POINTS, or - with --synthetic - generated the way the
+    reference's scripts/generate_diffusion_starting_data.py generates them.  Missing files are an error that names them."""
     suffix = "_uvit" if (args.image_size == 128 and args.model_type == "uvit") else ""
     rng = index_range(gpu_idx, args, num_samples)
     lo, hi = rng.start, rng.stop
@@ -53,15 +51,19 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
     if args.synthetic:
         shape = (4, args.image_size // 8, args.image_size // 8) if args.model_type == "uvit" else (3, args.image_size, args.image_size)
         X_T, y = starting_points(hi, shape)
-        X_T, y = X_T[lo:hi], y[lo:hi]
-    else:
-        for name in ("y.pth", "X_T.pth"):
-            if not (folder / name).exists():
-                raise FileNotFoundError(f"{folder / name}: starting points not found (the reference's "
-                                        f"scripts/generate_diffusion_starting_data.py writes them); pass --synthetic to "
-                                        f"generate them the same way instead")
-        y = torch.load(folder / "y.pth", map_location="cpu")[lo:hi]
-        X_T = torch.load(folder / "X_T.pth", map_location="cpu")[lo:hi]
+        return X_T[lo:hi], y[lo:hi]
+    for name in ("y.pth", "X_T.pth"):
+        if not (folder / name).exists():
+            raise FileNotFoundError(f"{folder / name}: starting points not found (the reference's "
+                                    f"scripts/generate_diffusion_starting_data.py writes them); pass --synthetic to "
+                                    f"generate them the same way instead")
+    y = torch.load(folder / "y.pth", map_location="cpu")[lo:hi]
+    X_T = torch.load(folder / "X_T.pth", map_location="cpu")[lo:hi]
+    return X_T, y
+
+
+def build_denoiser(args, device):
+    """(denoiser on the device, base scheduler) by --model-type / --image-size (reference :59-78), engine options applied."""
     ckpt = not args.random_weights
     if args.model_type == "unet":
         if args.image_size == 64:
@@ -79,20 +81,27 @@ def generate_and_save(gpu_idx, args, num_samples, dest):
         unet.winograd = args.winograd == "on"
         if args.hip_graph and args.scheduler_type != "mc_dropout":
             unet.enable_hip_graph()
-        model = unet
-    else:
-        uvit = load_uvit(args.image_size, device="cpu", load_checkpoint=ckpt)
-        if not ckpt:
-            randomize_parameters_(uvit, seed=7)
-        ae = load_autoencoder_uvit(device="cpu", load_checkpoint=ckpt)
-        if not ckpt:
-            randomize_parameters_(ae, seed=9)
-        uvit.precision = "f16x3" if args.precision == "f16w" else args.precision             # f16w is a 3x3-conv mode: ADM only
-        uvit.on_range_violation = ae.on_range_violation = args.on_range_violation
-        uvit.split_k = args.split_k != "off"                                                 # (tail split of under-filled GEMM rounds)
-        ae.precision = args.precision if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch)
-        model = UViTAE(uvit, ae).to(device)
-        scheduler = load_uvit_scheduler()
+        return unet, scheduler
+    uvit = load_uvit(args.image_size, device="cpu", load_checkpoint=ckpt)
+    if not ckpt:
+        randomize_parameters_(uvit, seed=7)
+    ae = load_autoencoder_uvit(device="cpu", load_checkpoint=ckpt)
+    if not ckpt:
+        randomize_parameters_(ae, seed=9)
+    uvit.precision = "f16x3" if args.precision == "f16w" else args.precision             # f16w is a 3x3-conv mode: ADM only
+    uvit.on_range_violation = ae.on_range_violation = args.on_range_violation
+    uvit.split_k = args.split_k != "off"                                                 # (tail split of under-filled GEMM rounds)
+    ae.precision = args.precision if args.precision in ("fp32", "f16x3") else "bf16x3"   # VAE decoder (one call per batch)
+    return UViTAE(uvit, ae).to(device), load_uvit_scheduler()
+
+
+@torch.no_grad()
+def generate_and_save(gpu_idx, args, num_samples, dest):
+    seed_everything(args.seed)
+    device = torch.device("cuda", gpu_idx)
+    torch.cuda.set_device(device)
+    X_T, y = load_starting_points(gpu_idx, args, num_samples)
+    model, scheduler = build_denoiser(args, device)
     uc_scheduler = get_uncertainty_scheduler(args, y.to(device), model, scheduler)
     if args.noise == "device":
         uc_scheduler.noise_source = DeviceNoise(seed=args.seed + gpu_idx)

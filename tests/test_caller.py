@@ -374,3 +374,30 @@ def test_maps_to_thresholds_to_guided_sampling_cli_chain(tmp_path, monkeypatch):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run(g_cmd + ["--guidance-type", "gradient"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode != 0 and "NotImplementedError" in r.stderr
+
+
+@pytest.mark.gpu
+def test_measure_times_cli_subprocess(tmp_path):
+    """scripts/measure_times_imagenet.py (the reference script the metric's span is taken from, :88-118): time_uc and time_normal of the
+    driver on ADM-64, one record appended to the times file; the uncertainty window costs time (time_uc > time_normal)."""
+    import subprocess
+    times = tmp_path / "times.json"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "measure_times_imagenet.py"), "--image-size", "64", "--scheduler-type", "uncertainty_zigzag_centered",
+           "--model-type", "unet", "--start-index", "0", "--num-samples", "8", "--batch-size", "8", "--generation-steps", "6", "-M", "2", "--start-step-uc", "2",
+           "--num-steps-uc", "3", "--random-weights", "--synthetic", "--noise", "device", "--times-file", str(times)]
+    for n in (1, 2):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.load(open(times))
+        assert len(rec) == n
+    last = rec[-1]
+    assert (last["dataset"], last["image_size"], last["model_type"], last["scheduler_type"]) == ("imagenet", 64, "adm", "uncertainty_zigzag_centered")
+    assert last["time_uc"] > last["time_normal"] > 0 and last["executed_forwards_per_batch_uc"] == 6 + 3 * 2
+    # U-ViT: the plain run is DPM-Solver-2 (reference :103-104), the uncertainty run the zig-zag DDIM estimator
+    cmd_u = [sys.executable, os.path.join(ROOT, "scripts", "measure_times_imagenet.py"), "--image-size", "256", "--scheduler-type", "uncertainty_zigzag_centered",
+             "--model-type", "uvit", "--start-index", "0", "--num-samples", "2", "--batch-size", "2", "--generation-steps", "4", "-M", "1", "--start-step-uc", "1",
+             "--num-steps-uc", "2", "--random-weights", "--synthetic", "--noise", "device", "--warmup", "0", "--times-file", str(times)]
+    r = subprocess.run(cmd_u, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = json.load(open(times))[-1]
+    assert (last["image_size"], last["model_type"]) == (256, "uvit") and last["time_uc"] > 0 and last["time_normal"] > 0
