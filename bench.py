@@ -403,7 +403,7 @@ def other_config_uvit(dev, a):
     uvit.split_k = bool(getattr(a, "uvit_split_k", True)) and uvit.stream_split <= 1
     uvit.precision, ae.precision = "f16x3", "f16x3"           # the fp32-equivalent split for the U-ViT and the VAE decode (once per batch)
     model = UViTAE(uvit, ae).to(dev)
-    X_T, y = starting_points(64, (4, 32, 32))
+    X_T, y = starting_points(64, (4, 32, 32), dataset_index=3)         # imagenet256: k = 3 of scripts/generate_diffusion_starting_data.py
 
     def job(n_steps, start, num, seed):
         args = argparse.Namespace(scheduler_type="uncertainty_zigzag_centered", M=5, start_step_uc=start, num_steps_uc=num,
@@ -548,7 +548,7 @@ def config0_leg(dev, a, cpu_full):
     model.load_state_dict(sd)
     model.eval().to(dev)
     model.precision, model.split_k = a.precision, True
-    X_T, y = starting_points(4, (3, 64, 64))
+    X_T, y = starting_points(4, (3, 64, 64), dataset_index=0)          # imagenet64: k = 0
     legs = []
     for kind, fwd in (("uncertainty_zigzag_centered", 10 + 10 * 2 * 3), ("mc_dropout", 10 + 10 * 2)):
         args = argparse.Namespace(scheduler_type=kind, M=2, start_step_uc=0, num_steps_uc=10, predict_next=True, eta=0.0, num_zigzag=3,

@@ -73,10 +73,23 @@ def seed_everything(seed):
     return seed
 
 
+# The datasets of reference scripts/generate_diffusion_starting_data.py:33-40, in its order: name -> (channels, height, width, classes).
+# The script seeds the generator of the k-th dataset with 49394 + k (:31,67).
+STARTING_POINT_DATASETS = {"imagenet64": (3, 64, 64, 1000), "imagenet128": (3, 128, 128, 1000), "imagenet128_uvit": (4, 16, 16, 1000),
+                           "imagenet256": (4, 32, 32, 1000), "imagenet512": (4, 64, 64, 1000), "cifar10": (3, 32, 32, 10)}
+
+
+def starting_point_dataset_index(name):
+    return list(STARTING_POINT_DATASETS).index(name)
+
+
 def starting_points(n, shape, num_classes=1000, dataset_index=0):
-    """X_T / y exactly as reference scripts/generate_diffusion_starting_data.py:27-49
-    (fresh generator seeded 49394 per dataset; ``dataset_index`` kept for bookkeeping only)."""
-    g = torch.Generator(device="cpu").manual_seed(49394)
+    """n starting points X_T and labels y drawn the way reference scripts/generate_diffusion_starting_data.py:43-47 draws them: one CPU
+    generator seeded 49394 + dataset_index (k-th dataset of the script: imagenet64 0, imagenet128 1, imagenet128_uvit 2, imagenet256 3,
+    imagenet512 4), ``randn(n, *shape)`` then ``randint(0, num_classes, (n,))``.  X_T is a prefix of the reference's
+    61 000-sample file; its y follows the FULL draw, so labels equal the file's only when n is the script's own count
+    (scripts/generate_diffusion_starting_data.py here writes those files)."""
+    g = torch.Generator(device="cpu").manual_seed(49394 + int(dataset_index))
     x = torch.randn(n, *shape, generator=g)
     y = torch.randint(0, num_classes, (n,), generator=g)
     return x, y

@@ -31,7 +31,8 @@ from diffusion_uncertainty_amd.init_model import (  # noqa: E402
 from diffusion_uncertainty_amd.paths import CONFIG, DIFFUSION_STARTING_POINTS, RESULTS  # noqa: E402
 from diffusion_uncertainty_amd.schedulers_uncertainty.get_uncertainty_scheduler import get_uncertainty_scheduler  # noqa: E402
 from diffusion_uncertainty_amd.schedulers_uncertainty.noise import DeviceNoise  # noqa: E402
-from diffusion_uncertainty_amd.utils import load_config, randomize_parameters_, seed_everything, starting_points  # noqa: E402
+from diffusion_uncertainty_amd.utils import (load_config, randomize_parameters_, seed_everything, starting_point_dataset_index,  # noqa: E402
+                                             starting_points)
 from diffusion_uncertainty_amd.uvit.load_pretrained_models import load_autoencoder_uvit, load_uvit, load_uvit_scheduler  # noqa: E402
 from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE  # noqa: E402
 
@@ -50,7 +51,7 @@ def load_starting_points(gpu_idx, args, num_samples):
     folder = DIFFUSION_STARTING_POINTS / f"imagenet{args.image_size}{suffix}"
     if args.synthetic:
         shape = (4, args.image_size // 8, args.image_size // 8) if args.model_type == "uvit" else (3, args.image_size, args.image_size)
-        X_T, y = starting_points(hi, shape)
+        X_T, y = starting_points(hi, shape, dataset_index=starting_point_dataset_index(f"imagenet{args.image_size}{suffix}"))
         return X_T[lo:hi], y[lo:hi]
     for name in ("y.pth", "X_T.pth"):
         if not (folder / name).exists():

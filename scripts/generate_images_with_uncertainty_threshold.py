@@ -32,7 +32,8 @@ from diffusion_uncertainty_amd.pipeline_uncertainty.pipeline_sampler_class_condi
 from diffusion_uncertainty_amd.pipeline_uncertainty.pipeline_sampler_class_conditional_uncertainty_guided_posterior_distribution import \
     DiffusionClassConditionalGuidedPosteriorDistribution  # noqa: E402
 from diffusion_uncertainty_amd.schedulers_uncertainty.scheduling_ddim import DDIMScheduler  # noqa: E402
-from diffusion_uncertainty_amd.utils import load_config, randomize_parameters_, seed_everything, starting_points  # noqa: E402
+from diffusion_uncertainty_amd.utils import (load_config, randomize_parameters_, seed_everything, starting_point_dataset_index,  # noqa: E402
+                                             starting_points)
 
 
 def parse_args(argv=None):
@@ -109,7 +110,8 @@ def main(argv=None):
     generation_steps = args.num_steps
     lo, hi = args.start_index, args.start_index + args.num_samples
     if args.synthetic:
-        x_T, y = starting_points(hi, (4, image_size // 8, image_size // 8) if latent else (3, image_size, image_size))
+        x_T, y = starting_points(hi, (4, image_size // 8, image_size // 8) if latent else (3, image_size, image_size),
+                                 dataset_index=starting_point_dataset_index(args.dataset_name))
         x_T, y = x_T[lo:hi], y[lo:hi]
     else:
         folder = DIFFUSION_STARTING_POINTS / args.dataset_name

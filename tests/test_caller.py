@@ -173,14 +173,14 @@ def _direct(cli, args, n):
     device = torch.device("cuda", 0)
     seed_everything(args.seed)
     if args.model_type == "unet":
-        X_T, y = starting_points(n, (3, 64, 64))
+        X_T, y = starting_points(n, (3, 64, 64), dataset_index=0)                       # imagenet64: the script's first dataset
         unet, scheduler = init_guided_diffusion_imagenet64_and_scheduler(load_checkpoint=False, dropout=args.dropout)
         randomize_parameters_(unet, seed=64)
         unet.eval().to(device)
         unet.precision, unet.split_k, unet.winograd = "f16x3", True, True
         model = unet
     else:
-        X_T, y = starting_points(n, (4, 32, 32))
+        X_T, y = starting_points(n, (4, 32, 32), dataset_index=3)                       # imagenet256: its fourth
         uvit = randomize_parameters_(load_uvit(256, device="cpu", load_checkpoint=False), seed=7)
         ae = randomize_parameters_(load_autoencoder_uvit(device="cpu", load_checkpoint=False), seed=9)
         uvit.precision, uvit.split_k, ae.precision = "f16x3", True, "f16x3"
@@ -401,3 +401,25 @@ def test_measure_times_cli_subprocess(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     last = json.load(open(times))[-1]
     assert (last["image_size"], last["model_type"]) == (256, "uvit") and last["time_uc"] > 0 and last["time_normal"] > 0
+
+
+def test_starting_data_script_draws_like_the_reference(tmp_path, monkeypatch):
+    """scripts/generate_diffusion_starting_data.py (reference :25-69): the k-th dataset's generator is seeded 49394 + k, noise first, labels
+    after it from the same generator; files land under DIFFUSION_STARTING_POINTS/<name>."""
+    monkeypatch.setenv("DIFFUSION_UNCERTAINTY_ROOT", str(tmp_path))
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "generate_diffusion_starting_data.py"), "--datasets", "imagenet128_uvit", "cifar10",
+                        "--num-samples", "9"], capture_output=True, text=True, timeout=300, env=dict(os.environ, DIFFUSION_UNCERTAINTY_ROOT=str(tmp_path)))
+    assert r.returncode == 0, r.stderr[-1500:]
+    base = tmp_path / "results" / "diffusion_starting_points"
+    for name, k, shape, classes in (("imagenet128_uvit", 2, (4, 16, 16), 1000), ("cifar10", 5, (3, 32, 32), 10)):
+        g = torch.Generator().manual_seed(49394 + k)
+        x = torch.randn(9, *shape, generator=g)
+        y = torch.randint(0, classes, (9,), generator=g)
+        assert torch.equal(torch.load(base / name / "X_T.pth"), x) and torch.equal(torch.load(base / name / "y.pth"), y)
+    from diffusion_uncertainty_amd.utils import STARTING_POINT_DATASETS, starting_points
+    assert list(STARTING_POINT_DATASETS) == ["imagenet64", "imagenet128", "imagenet128_uvit", "imagenet256", "imagenet512", "cifar10"]
+    # X_T of a short draw is a prefix of a longer one (the labels are not: they follow the noise in the same stream)
+    a, _ = starting_points(5, (3, 8, 8), dataset_index=1)
+    b, _ = starting_points(40, (3, 8, 8), dataset_index=1)
+    assert torch.equal(a, b[:5])
