@@ -310,10 +310,11 @@ def cgroup_cpu_quota():
 
 def cpu_baseline(sd, M, nz, gen_steps, n_uc):
     """the oracle (CPU port of the reference path, fp32) on the GPU box's host cores.  First a sweep of the oracle's ADM-128
-    forward over intra-op threads {8, 16, 32, 64, 128} at batch 1, then the two best thread counts at batch 8 (one timed forward each
-    after one untimed): the best setting is the baseline's configuration - the host is given its best case, not a fixed guess.  Then the
-    bounded sample itself at that setting: two DDIM timesteps of which one is a UC step (M=1, num_zigzag=1: 3 forwards, every forward
-    executed like the reference) -> s / forward / image, extrapolated with the reference's exact forward count."""
+    forward over intra-op threads {8, 16, 32, 64, 128} at batch 1; at the best thread count BASELINE.md 4.5's own sample (batch 8, two plain
+    steps + one UC step, three repeats), which is also the sweep's batch-8 point; the faster of the two batch sizes is the baseline's
+    configuration - the host is given its best case, not a fixed guess.  At batch 1 the bounded sample is two DDIM timesteps of which one
+    is a UC step (M=1, num_zigzag=1: 3 forwards, every forward executed like the reference), five repeats -> s / forward / image (best and
+    median), extrapolated with the reference's exact forward count."""
     import torch
     from oracle import adm, driver, schedule
     cpu_model, phys, avail = cpu_info()
@@ -341,44 +342,47 @@ def cpu_baseline(sd, M, nz, gen_steps, n_uc):
     sweep = {}
     for t in cand:
         sweep[(t, 1)] = one_forward(t, 1)
-    for t in sorted(cand, key=lambda t: sweep[(t, 1)])[:2]:
-        one_forward(t, 8)                                       # (untimed: oneDNN primitive cache of the batch-8 shapes)
-        sweep[(t, 8)] = one_forward(t, 8)
-    (threads, bs), _ = min(sweep.items(), key=lambda kv: kv[1])
+    threads = min(cand, key=lambda t: sweep[(t, 1)])
     torch.set_num_threads(threads)
-    X_T, y = X8[:bs], y8[:bs]
-    reps = []
-    for r in range(5):                                   # (a shared host: five repeats, min AND median reported - VERDICT r04 weak 9)
-        nfwd[0] = 0
-        torch.manual_seed(r)
-        t0 = time.perf_counter()
-        driver.generate(X_T, y, bs, model, schedule.Tables(), 2, "zigzag_centered", M=1, after_step=1, num_steps_uc=1, num_zigzag=1)
-        reps.append((time.perf_counter() - t0) / (nfwd[0] * bs))
-    s_per_img_fwd = min(reps)
-    s_median = sorted(reps)[len(reps) // 2]
     ref_forwards = gen_steps + n_uc * M * nz             # the reference executes every zig-zag forward (W10, M=5: 200 / image)
-    # BASELINE.md 4.5's own sample beside the best-of-sweep one: batch 8, three DDIM timesteps = two plain steps + one UC step (M=1, nz=1:
-    # 4 forwards x 8 images), three repeats, at the sweep's best thread count
+    # BASELINE.md 4.5's own sample: batch 8, three DDIM timesteps = two plain steps + one UC step (M=1, nz=1: 4 forwards x 8 images), three
+    # repeats, at the sweep's best thread count.  It doubles as the sweep's batch-8 point (one untimed batch-8 forward first: oneDNN's
+    # primitive cache of those shapes)
     reps8 = []
     if not os.environ.get("DUA_BENCH_NO_CPU_BS8"):
+        one_forward(threads, 8)
         for r in range(3):
             nfwd[0] = 0
             torch.manual_seed(100 + r)
             t0 = time.perf_counter()
             driver.generate(X8, y8, 8, model, schedule.Tables(), 3, "zigzag_centered", M=1, after_step=2, num_steps_uc=1, num_zigzag=1)
             reps8.append((time.perf_counter() - t0) / (nfwd[0] * 8))
+        sweep[(threads, 8)] = min(reps8)
     bs8 = None
     if reps8:
         med8 = sorted(reps8)[len(reps8) // 2]
         bs8 = dict(value=round(1.0 / (ref_forwards * med8), 5), unit="images/sec", threads=threads,
                    sample=f"bs=8, 3 DDIM timesteps (2 plain + 1 UC step with M=1, nz=1) = {nfwd[0]} forwards x 8 images, 3 repeats: "
                           f"{', '.join(f'{v:.3f}' for v in reps8)} s/forward/image, median {med8:.3f}; extrapolated to {ref_forwards} forwards/image (BASELINE.md 4.5)")
+    if reps8 and min(reps8) < sweep[(threads, 1)]:       # the host is given its best case: batch 8 where it is the faster setting
+        bs, reps = 8, list(reps8)
+    else:
+        bs, reps = 1, []
+        X_T, y = X8[:1], y8[:1]
+        for r in range(5):                               # (a shared host: five repeats, min AND median reported - VERDICT r04 weak 9)
+            nfwd[0] = 0
+            torch.manual_seed(r)
+            t0 = time.perf_counter()
+            driver.generate(X_T, y, 1, model, schedule.Tables(), 2, "zigzag_centered", M=1, after_step=1, num_steps_uc=1, num_zigzag=1)
+            reps.append((time.perf_counter() - t0) / nfwd[0])
+    s_per_img_fwd = min(reps)
+    s_median = sorted(reps)[len(reps) // 2]
     return dict(sample_bs8=bs8, value=1.0 / (ref_forwards * s_per_img_fwd), value_at_median=round(1.0 / (ref_forwards * s_median), 5), unit="images/sec", cores=threads, kind="port",
                 cpu_model=cpu_model, physical_cores=phys, logical_cpus_available=avail, cgroup_cpu_quota=quota,
                 torch_cpu_backend=f"torch {torch.__version__} aten conv2d -> oneDNN (mkldnn available {torch.backends.mkldnn.is_available()}, "
                                   f"enabled {torch.backends.mkldnn.enabled}), OpenMP intra-op pool; fp32",
                 thread_batch_sweep_s_per_forward_image={f"{t}thr_bs{b}": round(v, 3) for (t, b), v in sorted(sweep.items())},
-                sample=f"oracle ADM-128 fp32 at the sweep's best setting ({threads} threads, bs={bs}): 2 DDIM timesteps (1 in the UC window, "
+                sample=f"oracle ADM-128 fp32 at the sweep's best setting ({threads} threads, bs={bs}): {'2' if bs == 1 else '3'} DDIM timesteps (1 in the UC window, "
                        f"M=1, nz=1) = {nfwd[0]} forwards x {bs} image(s), {len(reps)} repeats: {', '.join(f'{v:.3f}' for v in reps)} s/forward/image, "
                        f"min {s_per_img_fwd:.3f} (value), median {s_median:.3f} (value_at_median); extrapolated to the reference's {ref_forwards} forwards/image")
 
