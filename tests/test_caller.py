@@ -407,3 +407,40 @@ def test_starting_data_script_draws_like_the_reference(tmp_path, monkeypatch):
     a, _ = starting_points(5, (3, 8, 8), dataset_index=1)
     b, _ = starting_points(40, (3, 8, 8), dataset_index=1)
     assert torch.equal(a, b[:5])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not present (GPU box)")
+def test_reference_caller_source_runs_against_this_package():
+    """The reference's OWN script text, unmodified, against this package (BASELINE.json north_star: "scripts/generate_dataset_score_uncertainty_
+    imagenet.py runs unchanged"): in a fresh process the package is aliased as `diffusion_uncertainty`, the script's two third-party imports
+    that this image lacks get stand-ins (`path.Path` -> the Path of paths.py, `pytorch_lightning.seed_everything` -> utils.seed_everything),
+    and the script file is executed as a module: its whole import block (:14-31) resolves against this package, its `parse_args` (:147-196)
+    lists this checkout's config/generation/*.yaml through `CONFIG.joinpath(..).files(..)` / `.basename()`, loads one through `load_config` and
+    applies the terminal overrides.  (Everything after that point needs a GPU, which this container does not have and where the
+    reference checkout does not travel: tests/test_caller.py's -m gpu tests run this package's own copy of the flow.)"""
+    import subprocess
+    code = f"""
+import sys, types, importlib.util
+sys.path.insert(0, {ROOT!r})
+import diffusion_uncertainty_amd
+diffusion_uncertainty_amd.alias_as_reference()
+from diffusion_uncertainty_amd import paths, utils
+sys.modules["path"] = types.SimpleNamespace(Path=paths.Path)
+sys.modules["pytorch_lightning"] = types.SimpleNamespace(seed_everything=utils.seed_everything)
+spec = importlib.util.spec_from_file_location("reference_caller", {REF_SCRIPT!r})
+mod = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mod)                                   # the import block and the function definitions, as written upstream
+import diffusion_uncertainty.generate_samples as gs, diffusion_uncertainty_amd.generate_samples as ours
+assert gs is ours and mod.generate_samples_model_scheduler_class_conditioned_from_tensor is ours.generate_samples_model_scheduler_class_conditioned_from_tensor
+assert mod.get_uncertainty_scheduler.__module__.startswith("diffusion_uncertainty_amd")
+sys.argv = ["x", "--config", "imagenet128_readme_example", "-M", "7", "--batch-size", "16"]
+a = mod.parse_args()
+assert (a.M, a.batch_size, a.generation_steps, a.start_step_uc, a.num_steps_uc, a.image_size, a.scheduler_type, a.model_type, a.num_zigzag) == \\
+    (7, 16, 50, 40, 10, 128, "uncertainty_zigzag_centered", "unet", 3), a
+sys.argv = ["x", "--image-size", "64", "--scheduler-type", "mc_dropout", "--model-type", "unet", "--start-index", "5"]
+b = mod.parse_args()
+assert (b.num_samples, b.batch_size, b.generation_steps, b.M, b.dropout, b.start_index) == (300, 32, 20, 30, 0.1, 5)
+print("REFERENCE_CALLER_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REFERENCE_CALLER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
