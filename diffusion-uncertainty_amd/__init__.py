@@ -42,11 +42,16 @@ class _AliasFinder(_abc.MetaPathFinder, _abc.Loader):
         pass
 
 
-def alias_as_reference(name="diffusion_uncertainty"):
+def alias_as_reference(name="diffusion_uncertainty", create_dirs=False):
     """Make ``import diffusion_uncertainty.<module>`` resolve to this package: the reference's
-    scripts keep their import blocks.  Idempotent; returns the package."""
+    scripts keep their import blocks.  ``create_dirs=True`` also creates the results / models folders under ``paths.ROOT`` that the
+    reference creates when its ``paths`` module is imported (``paths.make_dirs``): its scripts ``mkdir()`` their output folders
+    non-recursively and rely on them.  Off by default - importing or aliasing this package writes nothing.  Idempotent; returns the package."""
     this = _sys.modules[__name__]
     if not any(isinstance(f, _AliasFinder) and f.alias == name for f in _sys.meta_path):
         _sys.meta_path.insert(0, _AliasFinder(name, __name__))
     _sys.modules[name] = this
+    if create_dirs:                                   # the reference's paths.py creates its folders at import; its scripts rely on them
+        from . import paths as _paths
+        _paths.make_dirs()
     return this

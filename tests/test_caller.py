@@ -444,3 +444,49 @@ print("REFERENCE_CALLER_OK")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "REFERENCE_CALLER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scripts/compute_threshold_pixel_wise.py"), reason="reference checkout not present (GPU box)")
+def test_reference_threshold_script_source_runs_against_this_package(tmp_path):
+    """The reference's scripts/compute_threshold_pixel_wise.py, unmodified, in a fresh process against the aliased package (its imports:
+    `utils.load_config`, `paths.{CONFIG, FID, RESULTS, ROOT}`): it finds a dataset folder written in this package's output format
+    (args.yaml, uncertainty_*_0.pth, gen_images_0.pth), runs its own CPU selection and writes thresholds + config under
+    RESULTS/thresholds/<dataset>; `thresholds.compute_threshold_pixel_wise` - this package's GPU path - must produce the same bits, which the
+    -m gpu chain test asserts against the same torch arithmetic."""
+    import subprocess
+
+    import yaml
+    root = tmp_path / "root"
+    ds = tmp_path / "dataset"
+    ds.mkdir()
+    u = torch.randn(120, 2, 3, 8, 8, generator=torch.Generator().manual_seed(5)).square()
+    torch.save(u, ds / "uncertainty_uncertainty_zigzag_centered_0.pth")
+    torch.save(torch.zeros(120, 3, 8, 8, dtype=torch.uint8), ds / "gen_images_0.pth")
+    yaml.safe_dump({"dataset": "imagenet64", "scheduler_type": "uncertainty_zigzag_centered", "generation_steps": 2}, open(ds / "args.yaml", "w"))
+    code = f"""
+import sys, types, importlib.util
+sys.path.insert(0, {ROOT!r})
+import diffusion_uncertainty_amd
+diffusion_uncertainty_amd.alias_as_reference()
+from diffusion_uncertainty_amd import paths
+diffusion_uncertainty_amd.alias_as_reference(create_dirs=True)     # (ROOT is this test's scratch folder: DIFFUSION_UNCERTAINTY_ROOT)
+class P(paths.Path):                                           # the two further path.Path methods this script calls (:33-35,111)
+    def relpath(self, start):
+        import os
+        return os.path.relpath(str(self), str(start))
+sys.modules["path"] = types.SimpleNamespace(Path=P)
+spec = importlib.util.spec_from_file_location("reference_threshold", "/root/reference/scripts/compute_threshold_pixel_wise.py")
+mod = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mod)
+sys.argv = ["x", "--dataset-folders", {str(ds)!r}, "--perc", "0.25", "--on-cpu"]
+mod.main()
+print("REFERENCE_THRESHOLD_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, DIFFUSION_UNCERTAINTY_ROOT=str(root)))
+    assert r.returncode == 0 and "REFERENCE_THRESHOLD_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+    thr = torch.load(root / "results" / "thresholds" / "imagenet64" / "thresholds_uncertainty_zigzag_centered_perc=0.25.pth")
+    h = u.half()
+    want = torch.stack([h[:, i].gather(0, h[:, i].argsort(dim=0)[int(120 * 0.25)].unsqueeze(0)).squeeze(0) for i in range(2)])
+    assert thr.dtype == torch.float16 and torch.equal(thr, want)
+    cfg = yaml.safe_load(open(root / "results" / "thresholds" / "imagenet64" / "config_uncertainty_zigzag_centered_perc=0.25.yaml"))
+    assert cfg["dataset_config"]["dataset"] == "imagenet64" and cfg["perc"] == 0.25
