@@ -153,6 +153,24 @@ def test_g5_full_size(golden, name):
     np.testing.assert_allclose(o.numpy(), g["out"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.slow
+def test_g23_checkpoint_like_full_size(golden):
+    """G23: the reference's forward on full-size ADM-128 with checkpoint-like magnitudes (gamma up to 10, FiLM scale +-5, stream ~1.6e3):
+    the oracle restatement on the same re-scaled weights."""
+    from tests_support import adm_state_shapes, checkpoint_like_state_dict
+    g = golden("g23_adm128_checkpoint_like")
+    cfg = dict(adm.ADM128)
+    sd = seeded_state_dict(adm_state_shapes(cfg), int(g["seed"]))
+    sd, peak = checkpoint_like_state_dict(sd, T(g["t"]), T(g["y"]), adm.timestep_embedding, float(g["gamma_max"]), float(g["film_gain"]),
+                                          float(g["stream_gain"]), int(g["like_seed"]))
+    assert abs(peak - float(g["film_peak"])) < 1e-4
+    with torch.no_grad():
+        o = adm.forward(sd, cfg, T(g["x"]), T(g["t"]), T(g["y"]))
+    scale = float(np.abs(g["out"]).max())
+    assert scale > 10 and float(g["stream_max"].max()) > 1000
+    np.testing.assert_allclose(o.numpy(), g["out"], rtol=0, atol=1e-4 * scale)
+
+
 def test_g6_uvit(golden):
     from tests_support import uvit_state_shapes
     g = golden("g6_uvit")

@@ -65,3 +65,41 @@ def uvit_state_shapes(cfg):
     s.update(blk("mid_block", False))
     s.update({"norm.weight": (D,), "norm.bias": (D,), "decoder_pred.weight": (P * P * C, D), "decoder_pred.bias": (P * P * C,)})
     return s
+
+
+def checkpoint_like_state_dict(sd, t, y, timestep_embedding, gamma_max=10.0, film_gain=5.0, stream_gain=1000.0, seed=3):
+    """Give a seeded random ADM state dict the magnitudes of a trained checkpoint - a pure function of (names, values, t, y, seed), so the
+    reference side (tests/golden/make_golden.py g23) and the HIP side build the SAME weights: every GroupNorm gamma uniform in
+    [0.3, gamma_max] (per-tensor generator seeded from its name); every ResBlock's FiLM projection rescaled so that, for THESE timesteps /
+    labels, its `scale` half peaks at +-film_gain and its `shift` half at film_gain / 2 (unet_openai.py:249-253 applies `1 + scale`); the
+    input convolution rescaled so that the residual stream peaks at ~stream_gain.  ``timestep_embedding(t, dim)`` is nn.py:103-121 (the
+    reference's own function on its side, the oracle's restatement on ours: G5 pins them to each other).  Returns (new state dict, FiLM peak)."""
+    import math
+    import zlib
+
+    import torch
+    import torch.nn.functional as F
+    out = {k: v.detach().clone().float() for k, v in sd.items()}
+    mc = out["time_embed.0.weight"].shape[1]
+    emb = timestep_embedding(t, mc).float()
+    emb = F.linear(F.silu(F.linear(emb, out["time_embed.0.weight"], out["time_embed.0.bias"])), out["time_embed.2.weight"], out["time_embed.2.bias"])
+    emb = emb + out["label_emb.weight"][y]
+    peak = 0.0
+    for name in sorted(out):
+        p = out[name]
+        if name.endswith("in_layers.0.weight") or name.endswith("out_layers.0.weight") or name.endswith("norm.weight") or name == "out.0.weight":
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 62))
+            out[name] = 0.3 + (gamma_max - 0.3) * torch.rand(p.shape, generator=g)
+        elif name.endswith("emb_layers.1.weight"):
+            bname = name[:-6] + "bias"
+            film = F.linear(F.silu(emb), p, out[bname])
+            C = film.shape[1] // 2
+            ks, kh = film_gain / film[:, :C].abs().max().item(), 0.5 * film_gain / film[:, C:].abs().max().item()
+            w, b = p.clone(), out[bname].clone()
+            w[:C] *= ks; b[:C] *= ks
+            w[C:] *= kh; b[C:] *= kh
+            out[name], out[bname] = w, b
+            peak = max(peak, (film[:, :C] * ks).abs().max().item())
+        elif name == "input_blocks.0.0.weight":
+            out[name] = p * (0.25 * stream_gain / max(1e-6, p.std().item() * math.sqrt(27.0)))       # std ~ gain / 4: peaks at ~gain
+    return out, peak
