@@ -313,3 +313,32 @@ def test_full_size_adm128_with_checkpoint_like_magnitudes_vs_reference(golden, o
     print(f"checkpoint-like ADM-128 {precision}: max|hip - reference| = {err:.3e} at output scale {scale:.1f} (stream max {float(g['stream_max'].max()):.0f})"
           + (f", range report {m.range_report['saturated']} saturated / {m.range_report['subnormal']} subnormal" if precision == "f16x3" else ""))
     assert err < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_full_size_uvit_with_checkpoint_like_magnitudes_vs_reference(golden, ops, precision):
+    """G24: U-ViT-H/2 with LayerNorm gammas up to 3 and a 3 x positional table (token magnitudes up to ~34) against the
+    REFERENCE's forward on the same weights: no operand of the LayerNorm / GELU / attention planes leaves fp16's range, and f16x3 is as
+    close to the reference as the exact-fp32 engines."""
+    import warnings
+
+    from conftest import T
+    from diffusion_uncertainty_amd.init_model import load_uvit
+    from diffusion_uncertainty_amd.range_guard import F16RangeWarning
+    from diffusion_uncertainty_amd.utils import seeded_state_dict
+    from tests_support import uvit_checkpoint_like_state_dict
+    g = golden("g24_uvit_h2_checkpoint_like")
+    m = load_uvit(256, device="cpu", load_checkpoint=False)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, int(g["seed"]))
+    m.load_state_dict(uvit_checkpoint_like_state_dict(sd, float(g["gamma_max"]), float(g["qkv_gain"]), int(g["like_seed"])))
+    m.to(dev)
+    m.precision = precision
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", F16RangeWarning)
+        out = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["y"]).to(dev))
+    if precision == "f16x3":
+        assert m._range_checked and m.range_report["saturated"] == 0, m.range_report
+    err = np.abs(out.cpu().numpy() - g["out"]).max()
+    scale = float(np.abs(g["out"]).max())
+    print(f"checkpoint-like U-ViT-H/2 {precision}: max|hip - reference| = {err:.3e} at output scale {scale:.1f} (token max {float(g['token_max'].max()):.0f})")
+    assert err < 1e-3

@@ -196,6 +196,21 @@ def test_g6_uvit_full(golden):
     np.testing.assert_allclose(o.numpy(), g["out"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.slow
+def test_g24_uvit_checkpoint_like_full_size(golden):
+    """G24: the reference's U-ViT-H/2 forward at checkpoint-like magnitudes (LayerNorm gammas up to 3, positional table x 3)."""
+    from tests_support import uvit_checkpoint_like_state_dict, uvit_state_shapes
+    g = golden("g24_uvit_h2_checkpoint_like")
+    cfg = dict(uvit.UVIT_H2_256)
+    sd = uvit_checkpoint_like_state_dict(seeded_state_dict(uvit_state_shapes(cfg), int(g["seed"])), float(g["gamma_max"]), float(g["qkv_gain"]),
+                                         int(g["like_seed"]))
+    with torch.no_grad():
+        o = uvit.forward(sd, cfg, T(g["x"]), T(g["t"]), T(g["y"]))
+    scale = float(np.abs(g["out"]).max())
+    assert scale > 5 and float(g["token_max"].max()) > 30
+    np.testing.assert_allclose(o.numpy(), g["out"], rtol=0, atol=1e-4 * scale)
+
+
 def test_g7_quantile_mask_bit_exact(golden):
     g = golden("g7_guidance")
     for name in ("rand", "ties", "const", "adm128_like", "odd_n"):

@@ -103,3 +103,23 @@ def checkpoint_like_state_dict(sd, t, y, timestep_embedding, gamma_max=10.0, fil
         elif name == "input_blocks.0.0.weight":
             out[name] = p * (0.25 * stream_gain / max(1e-6, p.std().item() * math.sqrt(27.0)))       # std ~ gain / 4: peaks at ~gain
     return out, peak
+
+
+def uvit_checkpoint_like_state_dict(sd, gamma_max=3.0, qkv_gain=1.0, seed=4):
+    """The U-ViT counterpart of checkpoint_like_state_dict: LayerNorm gammas uniform in [0.3, gamma_max] (per-tensor generator seeded from
+    the name), optionally sharper attention (qkv weights x qkv_gain) and a stronger positional table (x 3).  Pure function of names, values
+    and the seed.  (Keep the gains modest: see tests/golden/make_golden.py g24 - the network amplifies rounding chaotically beyond them.)"""
+    import zlib
+
+    import torch
+    out = {k: v.detach().clone().float() for k, v in sd.items()}
+    for name in sorted(out):
+        p = out[name]
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name == "norm.weight":
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 62))
+            out[name] = 0.3 + (gamma_max - 0.3) * torch.rand(p.shape, generator=g)
+        elif name.endswith("attn.qkv.weight"):
+            out[name] = p * qkv_gain
+        elif name == "pos_embed":
+            out[name] = p * 3.0
+    return out
