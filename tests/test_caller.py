@@ -377,14 +377,49 @@ def test_measure_times_cli_subprocess(tmp_path):
     last = rec[-1]
     assert (last["dataset"], last["image_size"], last["model_type"], last["scheduler_type"]) == ("imagenet", 64, "adm", "uncertainty_zigzag_centered")
     assert last["time_uc"] > last["time_normal"] > 0 and last["executed_forwards_per_batch_uc"] == 6 + 3 * 2
-    # U-ViT: the plain run is DPM-Solver-2 (reference :103-104), the uncertainty run the zig-zag DDIM estimator
-    cmd_u = [sys.executable, os.path.join(ROOT, "scripts", "measure_times_imagenet.py"), "--image-size", "256", "--scheduler-type", "uncertainty_zigzag_centered",
-             "--model-type", "uvit", "--start-index", "0", "--num-samples", "2", "--batch-size", "2", "--generation-steps", "4", "-M", "1", "--start-step-uc", "1",
-             "--num-steps-uc", "2", "--random-weights", "--synthetic", "--noise", "device", "--warmup", "0", "--times-file", str(times)]
-    r = subprocess.run(cmd_u, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    last = json.load(open(times))[-1]
-    assert (last["image_size"], last["model_type"]) == (256, "uvit") and last["time_uc"] > 0 and last["time_normal"] > 0
+
+
+@pytest.mark.gpu
+def test_measure_times_plain_scheduler_families():
+    """The plain schedulers scripts/measure_times_imagenet.py times (reference :103-107): DDIM for the ADM models, DPM-Solver-2 for the U-ViT
+    ones - the uncertainty scheduler of the family with an EMPTY window behind PlainScheduler: the driver collects no maps, the images are
+    valid, and for DDIM the result equals the plain DDIMScheduler's, bit for bit (tiny models, in process)."""
+    spec = importlib.util.spec_from_file_location("measure_cli", os.path.join(ROOT, "scripts", "measure_times_imagenet.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    from diffusion_uncertainty_amd.generate_samples import (generate_samples_model_scheduler_class_conditioned_from_tensor,
+                                                            generate_samples_model_scheduler_class_conditioned_uvit_from_tensor)
+    from diffusion_uncertainty_amd.init_model import init_scheduler_imagenet128, load_uvit_scheduler
+    from diffusion_uncertainty_amd.schedulers_uncertainty.mixin import SchedulerUncertaintyMixin
+    from diffusion_uncertainty_amd.schedulers_uncertainty.scheduling_ddim import DDIMScheduler
+    from diffusion_uncertainty_amd.utils import randomize_parameters_
+    from diffusion_uncertainty_amd.uvit.autoencoder import FrozenAutoencoderKL
+    from diffusion_uncertainty_amd.uvit.uvit import UViT
+    from diffusion_uncertainty_amd.uvit.uvit_ae import UViTAE
+    from test_gpu_models import TINY_ADM, TINY_UVIT, build_adm
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    base = argparse.Namespace(generation_steps=6, M=2, start_step_uc=0, num_steps_uc=6, predict_next=True, eta=0.0, num_zigzag=3, uncertainty_distance=1, seed=0)
+    # ADM: DDIM
+    m, _ = build_adm(dict(TINY_ADM), 5)
+    X, y = torch.randn(3, 3, 16, 16, generator=g), torch.tensor([1, 5, 9])
+    a = argparse.Namespace(**dict(base.__dict__, image_size=64, model_type="unet", scheduler_type="uncertainty_zigzag_centered"))
+    s = mt.plain_scheduler(a, y.to(dev), m, init_scheduler_imagenet128())
+    assert not isinstance(s, SchedulerUncertaintyMixin)
+    r = generate_samples_model_scheduler_class_conditioned_from_tensor(X, y, 3, dev, m, s)
+    assert set(r) == {"gen_images"} and r["gen_images"].dtype == torch.uint8
+    d = DDIMScheduler.from_config(init_scheduler_imagenet128().config)
+    d.set_timesteps(6)
+    assert torch.equal(generate_samples_model_scheduler_class_conditioned_from_tensor(X, y, 3, dev, m, d)["gen_images"], r["gen_images"])
+    # U-ViT: DPM-Solver-2
+    tiny_vae = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    u = UViTAE(randomize_parameters_(UViT(**TINY_UVIT), 3).eval(), randomize_parameters_(FrozenAutoencoderKL(tiny_vae, 4), 9)).to(dev)
+    Xl, yl = torch.randn(2, 4, 8, 8, generator=g), torch.tensor([2, 7])
+    a = argparse.Namespace(**dict(base.__dict__, image_size=256, model_type="uvit", scheduler_type="uncertainty_zigzag_centered"))
+    s = mt.plain_scheduler(a, yl.to(dev), u, load_uvit_scheduler())
+    assert type(s._inner).__name__.startswith("KDPM2") and not isinstance(s, SchedulerUncertaintyMixin)
+    r = generate_samples_model_scheduler_class_conditioned_uvit_from_tensor(Xl, yl, 2, u, s, dev)
+    assert "uncertainty" not in r and r["gen_images"].shape == (2, 3, 16, 16) and r["gen_images"].dtype == torch.uint8
 
 
 def test_starting_data_script_draws_like_the_reference(tmp_path, monkeypatch):
