@@ -997,25 +997,30 @@ def g16():
 
 
 def g23():
-    """Full-size ADM-128 with CHECKPOINT-LIKE magnitudes (all other fixtures use seeded random weights, whose activations sit
-    far inside the f16x3 plane scales): the seeded weights re-scaled by tests/tests_support.checkpoint_like_state_dict - GroupNorm gammas up
-    to 10, FiLM `scale` peaking at +-5 for these timesteps / labels, a residual stream peaking at ~1e3 - and the REFERENCE's forward on them."""
+    """Full-size ADM-128 and ADM-64 with CHECKPOINT-LIKE magnitudes (all other fixtures use seeded random weights, whose
+    activations sit far inside the f16x3 plane scales): the seeded weights re-scaled by tests/tests_support.checkpoint_like_state_dict -
+    GroupNorm gammas up to 10, FiLM `scale` peaking at +-5 for these timesteps / labels, a residual stream peaking at ~1e3 - and the
+    REFERENCE's forward on them."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from tests_support import checkpoint_like_state_dict
-    m = build_adm(ADM128, 128)
-    x, t, y = randn(2301, 2, 3, 128, 128), torch.tensor([900, 20]), torch.tensor([7, 421])
-    sd, peak = checkpoint_like_state_dict(m.state_dict(), t, y, ref_temb, gamma_max=10.0, film_gain=5.0, stream_gain=1000.0, seed=3)
-    m.load_state_dict(sd)
-    acts = {}
-    hooks = [mod.register_forward_hook(lambda _m, _i, o, n=name: acts.__setitem__(n, float(o.abs().max()))) for name, mod in m.named_modules()
-             if name in ("input_blocks.0", "input_blocks.3", "input_blocks.9", "middle_block", "output_blocks.14")]
-    with torch.no_grad():
-        o = m(x, t, y=y)
-    for h in hooks:
-        h.remove()
-    print("g23: FiLM peak", peak, "stream maxima", acts, "output max", float(o.abs().max()))
-    save("g23_adm128_checkpoint_like", x=x, t=t, y=y, out=o, seed=128, like_seed=3, gamma_max=10.0, film_gain=5.0, stream_gain=1000.0, film_peak=peak,
-         stream_max=np.array([acts[k] for k in sorted(acts)]), stream_names=np.array(sorted(acts)))
+    for tag, cfg, seed, probes in (("adm128", ADM128, 128, ("input_blocks.0", "input_blocks.3", "input_blocks.9", "middle_block", "output_blocks.14")),
+                                   ("adm64", ADM64, 64, ("input_blocks.0", "input_blocks.4", "input_blocks.12", "middle_block", "output_blocks.15"))):
+        m = build_adm(cfg, seed)
+        H = cfg["image_size"]
+        x, t, y = randn(2301, 2, 3, H, H), torch.tensor([900, 20]), torch.tensor([7, 421])
+        sd, peak = checkpoint_like_state_dict(m.state_dict(), t, y, ref_temb, gamma_max=10.0, film_gain=5.0, stream_gain=1000.0, seed=3)
+        m.load_state_dict(sd)
+        acts = {}
+        hooks = [mod.register_forward_hook(lambda _m, _i, o, n=name: acts.__setitem__(n, float(o.abs().max()))) for name, mod in m.named_modules()
+                 if name in probes]
+        with torch.no_grad():
+            o = m(x, t, y=y)
+        for h in hooks:
+            h.remove()
+        print(f"g23 {tag}: FiLM peak", peak, "stream maxima", acts, "output max", float(o.abs().max()))
+        save(f"g23_{tag}_checkpoint_like", x=x, t=t, y=y, out=o, seed=seed, like_seed=3, gamma_max=10.0, film_gain=5.0, stream_gain=1000.0, film_peak=peak,
+             stream_max=np.array([acts[k] for k in sorted(acts)]), stream_names=np.array(sorted(acts)))
+        del m
 
 
 def g24():

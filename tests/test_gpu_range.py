@@ -283,9 +283,10 @@ def test_default_cli_warns_on_saturating_weights(tmp_path, monkeypatch):
     assert (tmp_path / "gen_images_0.pth").exists()
 
 
-def test_full_size_adm128_with_checkpoint_like_magnitudes_vs_reference(golden, ops):
-    """G23: full-size ADM-128 whose weights carry checkpoint-like magnitudes - GroupNorm gammas up to 10, FiLM scale +-5,
-    a residual stream peaking at 1.6e3 - against the REFERENCE's own forward on the same weights.  The default first-forward range check
+@pytest.mark.parametrize("name", ["adm128", "adm64"])
+def test_full_size_adm_with_checkpoint_like_magnitudes_vs_reference(golden, ops, name):
+    """G23: full-size ADM-128 / ADM-64 whose weights carry checkpoint-like magnitudes - GroupNorm gammas up to 10, FiLM
+    scale +-5, a residual stream peaking at 1.6e3 - 2e3 - against the REFERENCE's own forward on the same weights.  The default first-forward range check
     finds NO operand outside fp16's range (the static plane scales hold at these magnitudes) and the f16x3 output stays inside the north
     star's 1e-3 per pixel at an output scale of 18 - as close to the reference as the exact-fp32 engines."""
     import warnings
@@ -295,8 +296,8 @@ def test_full_size_adm128_with_checkpoint_like_magnitudes_vs_reference(golden, o
     from test_gpu_models import build_adm
     from tests_support import checkpoint_like_state_dict
     from conftest import T
-    g = golden("g23_adm128_checkpoint_like")
-    m, sd = build_adm(dict(adm.ADM128), int(g["seed"]))
+    g = golden(f"g23_{name}_checkpoint_like")
+    m, sd = build_adm(dict(adm.ADM128 if name == "adm128" else adm.ADM64), int(g["seed"]))
     sd, _ = checkpoint_like_state_dict(sd, T(g["t"]), T(g["y"]), adm.timestep_embedding, float(g["gamma_max"]), float(g["film_gain"]),
                                        float(g["stream_gain"]), int(g["like_seed"]))
     m.load_state_dict(sd)
@@ -310,7 +311,7 @@ def test_full_size_adm128_with_checkpoint_like_magnitudes_vs_reference(golden, o
         if precision == "f16x3":
             assert m._range_checked and m.range_report["saturated"] == 0, m.range_report
         err = np.abs(out.cpu().numpy() - g["out"]).max()
-        print(f"checkpoint-like ADM-128 {precision}: max|hip - reference| = {err:.3e} at output scale {scale:.1f} (stream max {float(g['stream_max'].max()):.0f})"
+        print(f"checkpoint-like {name} {precision}: max|hip - reference| = {err:.3e} at output scale {scale:.1f} (stream max {float(g['stream_max'].max()):.0f})"
               + (f", range report {m.range_report['saturated']} saturated / {m.range_report['subnormal']} subnormal" if precision == "f16x3" else ""))
         assert err < 1e-3
 

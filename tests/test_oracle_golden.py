@@ -154,12 +154,13 @@ def test_g5_full_size(golden, name):
 
 
 @pytest.mark.slow
-def test_g23_checkpoint_like_full_size(golden):
-    """G23: the reference's forward on full-size ADM-128 with checkpoint-like magnitudes (gamma up to 10, FiLM scale +-5, stream ~1.6e3):
-    the oracle restatement on the same re-scaled weights."""
+@pytest.mark.parametrize("name", ["adm128", "adm64"])
+def test_g23_checkpoint_like_full_size(golden, name):
+    """G23: the reference's forward on full-size ADM-128 / ADM-64 with checkpoint-like magnitudes (gamma up to 10, FiLM scale +-5, stream
+    1.6e3 - 2e3): the oracle restatement on the same re-scaled weights."""
     from tests_support import adm_state_shapes, checkpoint_like_state_dict
-    g = golden("g23_adm128_checkpoint_like")
-    cfg = dict(adm.ADM128)
+    g = golden(f"g23_{name}_checkpoint_like")
+    cfg = dict(adm.ADM128 if name == "adm128" else adm.ADM64)
     sd = seeded_state_dict(adm_state_shapes(cfg), int(g["seed"]))
     sd, peak = checkpoint_like_state_dict(sd, T(g["t"]), T(g["y"]), adm.timestep_embedding, float(g["gamma_max"]), float(g["film_gain"]),
                                           float(g["stream_gain"]), int(g["like_seed"]))
